@@ -1,0 +1,100 @@
+"""Deterministic synthetic inputs and weight fills shared by tests, bench and
+the golden-vector generator.
+
+Everything here is numpy ``default_rng`` based so that the GPU box can
+regenerate bit-identical weights and batches from a seed: decoder weights are
+39 MB - 2.5 GB, so fixtures carry seed + formula + outputs, never weights.
+"""
+import math
+
+import numpy as np
+import torch
+
+
+def fill_tensor_like(name: str, shape, seed: int, index: int) -> np.ndarray:
+    """Documented fill formula.  ``index`` is the position in state_dict order.
+
+    * ``num_batches_tracked``            -> 0
+    * ``running_var``                    -> U(0.5, 1.5)
+    * ``running_mean``                   -> 0.1 * N(0,1)
+    * 1-D ``weight`` (BatchNorm gamma)   -> 1 + 0.1 * N(0,1)
+    * 1-D ``bias``                       -> 0.05 * N(0,1)
+    * >=2-D ``weight``                   -> N(0,1) / sqrt(fan_in), fan_in = prod(shape[1:])
+    """
+    rng = np.random.default_rng([int(seed), int(index)])
+    shape = tuple(int(s) for s in shape)
+    if name.endswith("num_batches_tracked"):
+        return np.zeros(shape, dtype=np.int64)
+    if name.endswith("running_var"):
+        return (0.5 + rng.random(shape)).astype(np.float32)
+    if name.endswith("running_mean"):
+        return (0.1 * rng.standard_normal(shape)).astype(np.float32)
+    if len(shape) == 1:
+        if name.endswith("weight"):
+            return (1.0 + 0.1 * rng.standard_normal(shape)).astype(np.float32)
+        return (0.05 * rng.standard_normal(shape)).astype(np.float32)
+    fan_in = int(np.prod(shape[1:]))
+    out = rng.standard_normal(shape, dtype=np.float32)
+    out *= np.float32(1.0 / math.sqrt(fan_in))
+    return out
+
+
+@torch.no_grad()
+def deterministic_fill_(module_or_state_dict, seed: int):
+    """In-place fill of every entry of a module's ``state_dict`` (reference
+    modules and this package's drop-in modules share key order, so the same
+    seed gives the same weights on both sides)."""
+    sd = module_or_state_dict
+    if isinstance(sd, torch.nn.Module):
+        sd = sd.state_dict()
+    for i, (name, t) in enumerate(sd.items()):
+        v = fill_tensor_like(name, t.shape, seed, i)
+        t.copy_(torch.from_numpy(v).to(t.dtype).reshape(t.shape))
+    return module_or_state_dict
+
+
+FEATURE_SCALE = (1.0, 1.0, 0.5, 1.0, 10.0)
+
+
+def synthetic_pcs(B, T, N, C, seed=1234) -> torch.Tensor:
+    """Point-major ``[B,T,N,C]`` float32 batch: standard normal, scaled per
+    feature, centred per frame over the N points (mimics the reference's
+    per-frame centring, ``datasets.py:142-146``).  Modules consume the
+    zero-copy ``permute(0,3,1,2)`` view ``[B,C,T,N]``."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, T, N, C), dtype=np.float32)
+    x *= np.asarray(FEATURE_SCALE[:C], dtype=np.float32)
+    x -= x.mean(axis=2, keepdims=True)
+    return torch.from_numpy(x)
+
+
+def synthetic_labels(B, K, seed=1235) -> torch.Tensor:
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy(rng.integers(0, K, size=(B,), dtype=np.int64))
+
+
+def synthetic_z0(B, D=32, seed=1236) -> torch.Tensor:
+    """Stand-in for the reference's host ``np.random.normal`` draw
+    (``PCAA_ablation.py:915-925``): float64 normal cast to float32."""
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy(rng.normal(0.0, 1.0, (B, D))).float()
+
+
+def synthetic_alphas(B, seed=1237) -> torch.Tensor:
+    """Stand-in for ``torch.rand((B,1))`` (``PCAA_ablation.py:944``)."""
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy(rng.random((B, 1), dtype=np.float32))
+
+
+def checksum(t: torch.Tensor, nsample: int = 16) -> dict:
+    """sum / L2 / first-and-strided samples of a tensor, float64."""
+    f = t.detach().double().reshape(-1).cpu()
+    n = f.numel()
+    k = min(nsample, n)
+    idx = (torch.arange(k, dtype=torch.int64) * (n - 1)) // max(k - 1, 1)
+    return {
+        "sum": float(f.sum()),
+        "l2": float(f.norm()),
+        "samples": f[idx].numpy().copy(),
+        "sample_idx": idx.numpy().copy(),
+    }
