@@ -1,0 +1,186 @@
+/*
+ * pcaa_hip.h -- C ABI of the MI355X (gfx950) PCAA hot path.
+ *
+ * The reference (rmazzier/OpenSetGaitRecognition_PCAA) has no FFI: its operator
+ * boundary is Python nn.Module.forward + autograd, below which sits PyTorch
+ * ATen.  Each entry point here replaces the ATen work behind one reference call
+ * site (cited per function as reference file:line).  The Python side
+ * (opensetgaitrecognition_pcaa_amd/functional.py) binds them with ctypes and
+ * wraps them in torch.autograd.Functions; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named host_*; nothing is
+ *     allocated, freed or synchronised inside a call (graph-capture safe);
+ *   - `stream` is a hipStream_t passed as void*;
+ *   - return value: PCAA_OK, or an error code with a message retrievable from
+ *     pcaa_last_error() (thread-local);
+ *   - activations are ROW-MAJOR [rows, channels] ("point-major": one row per
+ *     point / per (batch,time) step, channels fastest);
+ *   - dtype arguments: PCAA_F32 or PCAA_BF16 (storage type of an activation
+ *     tensor); parameters, statistics, losses and optimizer state are fp32
+ *     (BatchNorm statistics accumulate in fp64).
+ */
+#ifndef PCAA_HIP_H
+#define PCAA_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCAA_OK 0
+#define PCAA_ERR_INVALID_ARG 1
+#define PCAA_ERR_LAUNCH 2
+
+#define PCAA_F32 0
+#define PCAA_BF16 1
+
+/* operand storage order for pcaa_gemm */
+#define PCAA_LAYOUT_KC 0 /* contraction index contiguous: A[m*ld + k], B[n*ld + k] */
+#define PCAA_LAYOUT_RC 1 /* row index contiguous:         A[k*ld + m], B[k*ld + n] */
+
+#define PCAA_ACT_NONE 0
+#define PCAA_ACT_ELU 1
+
+const char* pcaa_last_error(void);
+int pcaa_abi_version(void);
+
+/* ------------------------------------------------------------------ GEMM
+ * C[M,N] (=|+=) A(M,K) . B(K,N) (+ bias[N]) on the MFMA pipe.
+ *   math = PCAA_F32 : v_mfma_f32_32x32x2_f32 (exact fp32), any operand dtype/layout
+ *   math = PCAA_BF16: v_mfma_f32_32x32x16_bf16, fp32 accumulate; operands KC
+ * colstats != NULL: per-column sum and sum-of-squares of the bias-free
+ *   accumulator over the M rows are added (fp64 atomics) into
+ *   colstats[(tile_m % nrep)][2][N] -- the BatchNorm batch statistics of the
+ *   layer this GEMM produces.
+ * split_k > 1 or accumulate != 0: fp32 atomic accumulation into C (C must be
+ *   fp32 and pre-initialised); bias is added by split 0 only.
+ * Replaces: Conv2d(1x1) models.py:20-27, Conv1d via im2col models.py:59-68,
+ *   Linear models.py:252-277, 346-371, 409-416, and their autograd backward.
+ */
+int pcaa_gemm(int math,
+              const void* A, int a_dtype, int a_layout, long lda,
+              const void* B, int b_dtype, int b_layout, long ldb,
+              void* C, int c_dtype, long ldc,
+              int M, int N, int K,
+              const float* bias, double* colstats, int nrep,
+              int split_k, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ BatchNorm (+ELU) pieces
+ * Training-mode BatchNorm2d/1d + ELU of PointNetModule (models.py:28-29) and
+ * DilTempConv1d (models.py:71,77-78), split around the grid-wide statistics
+ * dependency.  stats = [nrep][2][ch] fp64 (sum, sumsq of the bias-free linear
+ * output); count = rows reduced over.
+ */
+int pcaa_bn_finalize(const double* stats, int nrep, long count, const float* lin_bias,
+                     const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, long long* num_batches_tracked,
+                     float momentum, float eps,
+                     float* scale, float* shift, float* mean, float* rstd, int ch, void* stream);
+/* eval mode: scale/shift from the running statistics */
+int pcaa_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, float* scale, float* shift,
+                        int ch, void* stream);
+/* a = ELU(y*scale + shift) */
+int pcaa_bn_act_fwd(const void* y, void* a, int dtype, const float* scale, const float* shift,
+                    long rows, int ch, void* stream);
+/* pooled[g][c] = mean_{r in group g} ELU(y[g*group_rows + r][c]*scale[c] + shift[c])
+ * (AvgPool2d over the N points, models.py:242-243,282; AvgPool1d over T, :249,284) */
+int pcaa_bn_act_meanpool_fwd(const void* y, int dtype, const float* scale, const float* shift,
+                             float* pooled, long groups, int group_rows, int ch, void* stream);
+/* backward through ELU (+ the mean-pool broadcast when dpool != NULL):
+ *   da = (dpool ? dpool[row / group_rows][c] * pool_scale : da[row][c])
+ *   dz = da * ELU'(y*scale + shift);   stats += { sum dz, sum dz * yhat }  (fp64) */
+int pcaa_bn_act_bwd_dz(const void* da, const float* dpool, int group_rows, float pool_scale,
+                       const void* y, void* dz, int dtype,
+                       const float* scale, const float* shift, const float* mean, const float* rstd,
+                       double* stats, int nrep, long rows, int ch, void* stream);
+/* coef[3][ch] such that dy = coef0*dz + coef1*y + coef2; dgamma, dbeta */
+int pcaa_bn_bwd_finalize(const double* stats, int nrep, long count, const float* gamma,
+                         const float* mean, const float* rstd,
+                         float* coef, float* dgamma, float* dbeta, int ch, void* stream);
+int pcaa_bn_bwd_dy(const void* dz, const void* y, void* dy, int dtype, const float* coef,
+                   long rows, int ch, void* stream);
+
+/* ------------------------------------------------------------------ small fp32 helpers */
+/* y = act(y + bias[col])  (Linear bias + ELU of the decoder / MLP heads, models.py:373-382) */
+int pcaa_bias_act(float* y, const float* bias, int act, long rows, int cols, void* stream);
+/* dz = da * ELU'(z) computed from the saved output a = ELU(z) */
+int pcaa_elu_bwd_from_out(const float* da, const float* a, float* dz, long n, void* stream);
+/* out[c] = sum_r x[r][c]   (bias gradients) */
+int pcaa_colsum(const float* x, float* out, long rows, int cols, void* stream);
+/* out[0] = scale * sum(x[0..n)) -- deterministic single-block reduction */
+int pcaa_sum(const float* x, long n, float scale, float* out, void* stream);
+/* out[r] = scale * sum_c x[r][c] */
+int pcaa_rowsum(const float* x, float* out, long rows, int cols, float scale, void* stream);
+/* out[i] = x[i] * s[0]   (s is a DEVICE scalar: chain-rule scaling without a host sync) */
+int pcaa_scale_by_device_scalar(const float* x, const float* s, float* out, long n, void* stream);
+/* out[r][c] = x[r][c] * s[r] */
+int pcaa_scale_rows(const float* x, const float* s, float* out, long rows, int cols, void* stream);
+/* Prior sampling of the D-step (PCAA_ablation.py:904-931): onehot[b][k] = (k == gt[b]),
+ * z[b] = z0[b] + means[gt[b]] */
+int pcaa_prior_sample(const float* z0, const float* means, const long long* gt, int B, int K, int D,
+                      float* z, float* onehot, void* stream);
+/* dst[b,t,n,c] (contiguous) = src[b,c,t,n] (given element strides) */
+int pcaa_pack_points(const float* src, long sb, long sc, long st, long sn,
+                     float* dst, int B, int C, int T, int N, void* stream);
+
+/* causal dilated Conv1d (k=3) as a GEMM: col[(b,t)][ci*3+tap] = a[b][t-(2-tap)*d][ci] or 0
+ * (models.py:59-68,75-76) and its adjoint */
+int pcaa_dtc_im2col(const float* a, float* col, int B, int T, int Cin, int dilation, void* stream);
+int pcaa_dtc_col2im(const float* dcol, float* da, int B, int T, int Cin, int dilation, void* stream);
+
+/* ------------------------------------------------------------------ losses
+ * SeqChamferLoss (utils.py:88-132) forward + analytic backward w.r.t. preds.
+ * preds/gts/dpreds are logical [B,C,T,N] tensors with element strides.
+ * frame_loss[b*T+t] = sum_j min_i P + sum_i min_j P;
+ * dpreds (nullable) = d/dpreds of sum_{b,t} w_b * frame_loss, w_b = grad_scale
+ *   * (grad_per_b ? grad_per_b[b] : 1). */
+int pcaa_chamfer_fwd_bwd(const float* preds, long p_sb, long p_sc, long p_st, long p_sn,
+                         const float* gts, long g_sb, long g_sc, long g_st, long g_sn,
+                         int B, int T, int N, int C, float* frame_loss,
+                         float* dpreds, long d_sb, long d_sc, long d_st, long d_sn,
+                         float grad_scale, const float* grad_per_b, void* stream);
+/* CrossEntropyLoss(mean) (PCAA_ablation.py:1008) + argmax(softmax) (:891-893).
+ * loss, dlogits, preds are each nullable. dlogits = grad_scale*(softmax - onehot)/B */
+int pcaa_cross_entropy(const float* logits, const long long* target, int B, int K,
+                       float* loss, float* dlogits, float grad_scale, long long* preds,
+                       void* stream);
+
+/* ------------------------------------------------------------------ CGDiscriminator (models.py:405-421)
+ * u = [x(32) ; label(K)] -> 64 ELU -> 32 ELU -> 1.  Parameters in PyTorch layout. */
+int pcaa_disc_forward(const float* x, const float* label, int B, int K,
+                      const float* W1, const float* b1, const float* W2, const float* b2,
+                      const float* W3, const float* b3, float* out, void* stream);
+/* first-order backward: gout[B] -> dx[B,32], dlabel[B,K], parameter grads (each nullable;
+ * parameter grads are OVERWRITTEN) */
+int pcaa_disc_backward(const float* x, const float* label, int B, int K,
+                       const float* W1, const float* b1, const float* W2, const float* b2,
+                       const float* W3, const float* b3, const float* gout,
+                       float* dx, float* dlabel,
+                       float* dW1, float* db1, float* dW2, float* db2, float* dW3, float* db3,
+                       float* workspace, size_t workspace_bytes, void* stream);
+/* WGAN-GP critic step (PCAA_ablation.py:939-976): d_loss = mean D(fv) - mean D(z)
+ * + gp_weight * mean (|dD/dx(z + alpha (fv - z))| - 1)^2 with the closed-form
+ * second-order gradient.  losses[0]=d_loss, losses[1]=gp.
+ * Parameter grads are OVERWRITTEN. */
+size_t pcaa_disc_workspace_bytes(int B, int K);
+int pcaa_disc_wgan_gp(const float* z, const float* fv, const float* label, const float* alphas,
+                      int B, int K,
+                      const float* W1, const float* b1, const float* W2, const float* b2,
+                      const float* W3, const float* b3, float gp_weight, float* losses,
+                      float* dW1, float* db1, float* dW2, float* db2, float* dW3, float* db3,
+                      float* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ optimizer
+ * torch.optim.Adam (no weight decay, no amsgrad; PCAA_ablation.py:820-833) on a
+ * flat fp32 buffer. `step` is the 1-based step count after this update. */
+int pcaa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                   float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCAA_HIP_H */

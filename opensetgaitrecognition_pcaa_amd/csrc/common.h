@@ -1,0 +1,79 @@
+// Shared device/host helpers for the PCAA HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/pcaa_hip.h"
+
+typedef __bf16 bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------- errors
+void pcaa_set_error(const char* fmt, ...);
+
+#define PCAA_CHECK_ARG(cond, ...)                 \
+  do {                                            \
+    if (!(cond)) {                                \
+      pcaa_set_error(__VA_ARGS__);                \
+      return PCAA_ERR_INVALID_ARG;                \
+    }                                             \
+  } while (0)
+
+#define PCAA_RETURN_LAUNCH_STATUS(name)                                        \
+  do {                                                                         \
+    hipError_t e__ = hipGetLastError();                                        \
+    if (e__ != hipSuccess) {                                                   \
+      pcaa_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));   \
+      return PCAA_ERR_LAUNCH;                                                  \
+    }                                                                          \
+    return PCAA_OK;                                                            \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- math
+__device__ __forceinline__ float elu_f(float z) { return z > 0.f ? z : expm1f(z); }
+// derivative of ELU evaluated from the pre-activation
+__device__ __forceinline__ float elu_grad_from_pre(float z) { return z > 0.f ? 1.f : expf(z); }
+// derivative of ELU evaluated from the OUTPUT a = ELU(z):  z<=0 -> e^z = a + 1
+__device__ __forceinline__ float elu_grad_from_out(float a) { return a > 0.f ? 1.f : a + 1.f; }
+
+// ---------------------------------------------------------------- 4-wide typed access
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4(const bf16_t* p) {
+  uint2 raw = *reinterpret_cast<const uint2*>(p);
+  f32x4 r;
+  r.x = __uint_as_float(raw.x << 16);
+  r.y = __uint_as_float(raw.x & 0xffff0000u);
+  r.z = __uint_as_float(raw.y << 16);
+  r.w = __uint_as_float(raw.y & 0xffff0000u);
+  return r;
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
+  bf16x4 b;
+  b.x = (bf16_t)v.x; b.y = (bf16_t)v.y; b.z = (bf16_t)v.z; b.w = (bf16_t)v.w;
+  *reinterpret_cast<bf16x4*>(p) = b;
+}
+__device__ __forceinline__ float load1(const float* p) { return *p; }
+__device__ __forceinline__ float load1(const bf16_t* p) { return (float)*p; }
+__device__ __forceinline__ void store1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store1(bf16_t* p, float v) { *p = (bf16_t)v; }
+
+// block-wide sum of one float (blockDim.x multiple of 64, <= 1024); result valid in thread 0
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

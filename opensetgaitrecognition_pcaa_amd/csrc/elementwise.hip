@@ -1,0 +1,574 @@
+// BatchNorm(+ELU) forward/backward pieces, pooling, bias/activation helpers,
+// im2col for the causal dilated convolutions, Adam.  All HBM-bound: every
+// thread moves 4 consecutive channels (16 B fp32 / 8 B bf16) of one row, rows
+// of a tile are walked by the workgroup so per-channel partial sums stay in
+// registers and leave through one fp64 atomic per channel per workgroup.
+#include <stdarg.h>
+
+#include "common.h"
+
+// ---------------------------------------------------------------- error string
+static thread_local char g_err[512] = "";
+void pcaa_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* pcaa_last_error(void) { return g_err; }
+extern "C" int pcaa_abi_version(void) { return 1; }
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 128;  // rows of a [rows, ch] tensor one workgroup reduces
+
+inline bool ch_ok(int ch) {
+  // ch/4 lanes per row must tile a 256-thread workgroup
+  if (ch < 4 || ch > 1024 || (ch & 3)) return false;
+  const int q = ch >> 2;
+  return (256 % q) == 0;
+}
+
+// ---------------------------------------------------------------- BN finalize (forward)
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int nrep, double inv_count,
+                                   double unbias, const float* __restrict__ lin_bias,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* running_mean, float* running_var, long long* nbt,
+                                   float momentum, float eps, float* scale, float* shift,
+                                   float* mean_out, float* rstd_out, int ch) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= ch) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < nrep; ++r) {
+    s1 += stats[((long)r * 2 + 0) * ch + c];
+    s2 += stats[((long)r * 2 + 1) * ch + c];
+  }
+  const double m0 = s1 * inv_count;                 // mean of the bias-free linear output
+  double var = s2 * inv_count - m0 * m0;            // biased variance
+  if (var < 0.0) var = 0.0;
+  const double mean = m0 + (lin_bias ? (double)lin_bias[c] : 0.0);
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  const float sc = (float)((double)gamma[c] * rstd);
+  scale[c] = sc;
+  shift[c] = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
+  mean_out[c] = (float)mean;
+  rstd_out[c] = (float)rstd;
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+  }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm,
+                                      const float* rv, float eps, float* scale, float* shift, int ch) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ch) return;
+  const float rstd = 1.f / sqrtf(rv[c] + eps);
+  const float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+// ---------------------------------------------------------------- a = ELU(y*scale+shift)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, T* __restrict__ a,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         long nquads, int qpr) {
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (long)gridDim.x * 256) {
+    const int c = (int)(q % qpr) << 2;
+    const f32x4 v = load4(y + q * 4);
+    const f32x4 sc = load4(scale + c), sh = load4(shift + c);
+    f32x4 o;
+    o.x = elu_f(v.x * sc.x + sh.x);
+    o.y = elu_f(v.y * sc.y + sh.y);
+    o.z = elu_f(v.z * sc.z + sh.z);
+    o.w = elu_f(v.w * sc.w + sh.w);
+    store4(a + q * 4, o);
+  }
+}
+
+// ---------------------------------------------------------------- mean-pool of ELU(BN(y)) over group_rows
+// one workgroup per (group, 1024-channel slab): thread = channel quad x row lane
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_meanpool_kernel(const T* __restrict__ y,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              float* __restrict__ pooled,
+                                                              int group_rows, int ch) {
+  __shared__ f32x4 red[256];
+  const int qpr = ch >> 2;              // quads per row
+  const int rl = 256 / qpr;             // row lanes
+  const int cq = threadIdx.x % qpr, rlane = threadIdx.x / qpr;
+  const long g = blockIdx.x;
+  const T* base = y + g * (long)group_rows * ch + cq * 4;
+  const f32x4 sc = load4(scale + cq * 4), sh = load4(shift + cq * 4);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int r = rlane; r < group_rows; r += rl) {
+    const f32x4 v = load4(base + (long)r * ch);
+    acc.x += elu_f(v.x * sc.x + sh.x);
+    acc.y += elu_f(v.y * sc.y + sh.y);
+    acc.z += elu_f(v.z * sc.z + sh.z);
+    acc.w += elu_f(v.w * sc.w + sh.w);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (rlane == 0) {
+    for (int l = 1; l < rl; ++l) {
+      const f32x4 o = red[l * qpr + cq];
+      acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+    const float inv = 1.f / (float)group_rows;
+    acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+    store4(pooled + g * (long)ch + cq * 4, acc);
+  }
+}
+
+// ---------------------------------------------------------------- dz = da * ELU'(z) + BN-backward statistics
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(const T* __restrict__ da,
+                                                            const float* __restrict__ dpool,
+                                                            int group_rows, float pool_scale,
+                                                            const T* __restrict__ y, T* __restrict__ dz,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            double* __restrict__ stats, int nrep,
+                                                            long rows, int ch) {
+  __shared__ f32x4 red[2][256];
+  const int qpr = ch >> 2;
+  const int rl = 256 / qpr;
+  const int cq = threadIdx.x % qpr, rlane = threadIdx.x / qpr;
+  const int c = cq * 4;
+  const f32x4 sc = load4(scale + c), sh = load4(shift + c), mu = load4(mean + c), rs = load4(rstd + c);
+  const long r0 = (long)blockIdx.x * ROWS_PER_BLOCK;
+  const long r1 = min(rows, r0 + ROWS_PER_BLOCK);
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  for (long r = r0 + rlane; r < r1; r += rl) {
+    const f32x4 yv = load4(y + r * ch + c);
+    f32x4 g;
+    if (POOL) {
+      g = load4(dpool + (r / group_rows) * ch + c);
+      g.x *= pool_scale; g.y *= pool_scale; g.z *= pool_scale; g.w *= pool_scale;
+    } else {
+      g = load4(da + r * ch + c);
+    }
+    f32x4 d;
+    d.x = g.x * elu_grad_from_pre(yv.x * sc.x + sh.x);
+    d.y = g.y * elu_grad_from_pre(yv.y * sc.y + sh.y);
+    d.z = g.z * elu_grad_from_pre(yv.z * sc.z + sh.z);
+    d.w = g.w * elu_grad_from_pre(yv.w * sc.w + sh.w);
+    store4(dz + r * ch + c, d);
+    s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+    s2.x += d.x * ((yv.x - mu.x) * rs.x);
+    s2.y += d.y * ((yv.y - mu.y) * rs.y);
+    s2.z += d.z * ((yv.z - mu.z) * rs.z);
+    s2.w += d.w * ((yv.w - mu.w) * rs.w);
+  }
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  // 2*ch outputs; thread t handles stat = t / (ch/... ) -- walk all (stat, channel) pairs
+  for (int o = threadIdx.x; o < 2 * ch; o += 256) {
+    const int stat = o / ch, cc = o - stat * ch;
+    const int q = cc >> 2, e = cc & 3;
+    double v = 0.0;
+    for (int l = 0; l < rl; ++l) v += (double)red[stat][l * qpr + q][e];
+    unsafeAtomicAdd(&stats[((long)(blockIdx.x % nrep) * 2 + stat) * ch + cc], v);
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ stats, int nrep, double inv_count,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ rstd, float* coef, float* dgamma,
+                                       float* dbeta, int ch) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ch) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < nrep; ++r) {
+    s1 += stats[((long)r * 2 + 0) * ch + c];
+    s2 += stats[((long)r * 2 + 1) * ch + c];
+  }
+  if (dbeta) dbeta[c] = (float)s1;
+  if (dgamma) dgamma[c] = (float)s2;
+  const double c1 = s1 * inv_count, c2 = s2 * inv_count;
+  const double rs = rstd[c], mu = mean[c];
+  const double g = (double)gamma[c] * rs;
+  coef[0 * ch + c] = (float)g;
+  coef[1 * ch + c] = (float)(-g * c2 * rs);
+  coef[2 * ch + c] = (float)(-g * c1 + g * c2 * rs * mu);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_dy_kernel(const T* __restrict__ dz, const T* __restrict__ y,
+                                                        T* __restrict__ dy, const float* __restrict__ coef,
+                                                        long nquads, int qpr, int ch) {
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (long)gridDim.x * 256) {
+    const int c = (int)(q % qpr) << 2;
+    const f32x4 d = load4(dz + q * 4), yv = load4(y + q * 4);
+    const f32x4 k0 = load4(coef + c), k1 = load4(coef + ch + c), k2 = load4(coef + 2 * ch + c);
+    f32x4 o;
+    o.x = k0.x * d.x + k1.x * yv.x + k2.x;
+    o.y = k0.y * d.y + k1.y * yv.y + k2.y;
+    o.z = k0.z * d.z + k1.z * yv.z + k2.z;
+    o.w = k0.w * d.w + k1.w * yv.w + k2.w;
+    store4(dy + q * 4, o);
+  }
+}
+
+// ---------------------------------------------------------------- small fp32 helpers
+__global__ void bias_act_kernel(float* y, const float* __restrict__ bias, int act, long n, int cols) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = y[i] + (bias ? bias[i % cols] : 0.f);
+    y[i] = act == PCAA_ACT_ELU ? elu_f(v) : v;
+  }
+}
+
+__global__ void elu_bwd_from_out_kernel(const float* __restrict__ da, const float* __restrict__ a,
+                                        float* dz, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dz[i] = da[i] * elu_grad_from_out(a[i]);
+}
+
+// out[c] = sum_r x[r][c]; block = 256 threads = 64 columns x 4 row lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* out, long rows, int cols) {
+  __shared__ float red[256];
+  const int cl = threadIdx.x & 63, rlane = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float acc = 0.f;
+  if (c < cols)
+    for (long r = rlane; r < rows; r += 4) acc += x[r * cols + c];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (rlane == 0 && c < cols) out[c] = red[cl] + red[64 + cl] + red[128 + cl] + red[192 + cl];
+}
+
+__global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, long n, float scale, float* out) {
+  __shared__ double red[16];
+  double acc = 0.0;
+  for (long i = threadIdx.x; i < n; i += 1024) acc += (double)x[i];
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += red[i];
+    out[0] = (float)(t * (double)scale);
+  }
+}
+
+__global__ __launch_bounds__(64) void rowsum_kernel(const float* __restrict__ x, float* out, int cols, float scale) {
+  const long r = blockIdx.x;
+  double acc = 0.0;
+  for (int c = threadIdx.x; c < cols; c += 64) acc += (double)x[r * cols + c];
+  acc = wave_sum_d(acc);
+  if (threadIdx.x == 0) out[r] = (float)(acc * (double)scale);
+}
+
+__global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ s, float* out, long n) {
+  const float f = s[0];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = x[i] * f;
+}
+
+__global__ void scale_rows_kernel(const float* __restrict__ x, const float* __restrict__ s, float* out,
+                                  long n, int cols) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = x[i] * s[i / cols];
+}
+
+__global__ void prior_sample_kernel(const float* __restrict__ z0, const float* __restrict__ means,
+                                    const long long* __restrict__ gt, int B, int K, int D, float* z,
+                                    float* onehot) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * D) {
+    const int b = i / D, d = i - b * D;
+    z[i] = z0[i] + means[gt[b] * D + d];
+  }
+  if (i < B * K) {
+    const int b = i / K, k = i - b * K;
+    onehot[i] = (gt[b] == k) ? 1.f : 0.f;
+  }
+}
+
+__global__ void pack_points_kernel(const float* __restrict__ src, long sb, long sc, long st, long sn,
+                                   float* __restrict__ dst, int B, int C, int T, int N) {
+  const long total = (long)B * T * N * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int n = (int)(r % N); r /= N;
+    const int t = (int)(r % T);
+    const long b = r / T;
+    dst[i] = src[b * sb + c * sc + t * st + n * sn];
+  }
+}
+
+// col[(b,t)][ci*3+tap] = a[b][t-(2-tap)*d][ci]  (zero for negative time)
+__global__ void dtc_im2col_kernel(const float* __restrict__ a, float* __restrict__ col, int B, int T,
+                                  int Cin, int d) {
+  const long total = (long)B * T * Cin * 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % 3);
+    long r = i / 3;
+    const int ci = (int)(r % Cin); r /= Cin;
+    const int t = (int)(r % T);
+    const long b = r / T;
+    const int ts = t - (2 - tap) * d;
+    col[i] = ts >= 0 ? a[(b * T + ts) * Cin + ci] : 0.f;
+  }
+}
+
+// da[b][t][ci] = sum_tap dcol[b][t+(2-tap)*d][ci*3+tap]  (while t+(2-tap)*d < T)
+__global__ void dtc_col2im_kernel(const float* __restrict__ dcol, float* __restrict__ da, int B, int T,
+                                  int Cin, int d) {
+  const long total = (long)B * T * Cin;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin);
+    long r = i / Cin;
+    const int t = (int)(r % T);
+    const long b = r / T;
+    float acc = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+      const int tt = t + (2 - tap) * d;
+      if (tt < T) acc += dcol[((b * T + tt) * Cin + ci) * 3 + tap];
+    }
+    da[i] = acc;
+  }
+}
+
+// ---------------------------------------------------------------- Adam
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n,
+                                                   float b1, float b2, float eps, float step_size,
+                                                   float inv_bc2_sqrt, float grad_scale) {
+  const long nq = n >> 2;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+    f32x4 pv = load4(p + q * 4), gv = load4(g + q * 4), mv = load4(m + q * 4), vv = load4(v + q * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gg = gv[e] * grad_scale;
+      mv[e] = b1 * mv[e] + (1.f - b1) * gg;
+      vv[e] = b2 * vv[e] + (1.f - b2) * gg * gg;
+      const float denom = sqrtf(vv[e]) * inv_bc2_sqrt + eps;
+      pv[e] -= step_size * (mv[e] / denom);
+    }
+    store4(p + q * 4, pv);
+    store4(m + q * 4, mv);
+    store4(v + q * 4, vv);
+  }
+  // tail (n % 4)
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = (nq << 2) + threadIdx.x;
+    const float gg = g[i] * grad_scale;
+    const float mm = b1 * m[i] + (1.f - b1) * gg;
+    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    m[i] = mm;
+    v[i] = vv;
+    p[i] -= step_size * (mm / (sqrtf(vv) * inv_bc2_sqrt + eps));
+  }
+}
+
+inline int grid_for(long work_items, int per_block = 256, int cap = 256 * 8) {
+  long g = cdiv(work_items, per_block);
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- C ABI
+extern "C" int pcaa_bn_finalize(const double* stats, int nrep, long count, const float* lin_bias,
+                                const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, long long* num_batches_tracked, float momentum,
+                                float eps, float* scale, float* shift, float* mean, float* rstd,
+                                int ch, void* stream) {
+  PCAA_CHECK_ARG(stats && gamma && beta && scale && shift && mean && rstd, "pcaa_bn_finalize: null pointer");
+  PCAA_CHECK_ARG(nrep >= 1 && count >= 1 && ch >= 1, "pcaa_bn_finalize: bad sizes");
+  PCAA_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "pcaa_bn_finalize: running stats must come together");
+  const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(ch, 256)), dim3(256), 0, as_stream(stream),
+                     stats, nrep, 1.0 / (double)count, unbias, lin_bias, gamma, beta, running_mean,
+                     running_var, num_batches_tracked, momentum, eps, scale, shift, mean, rstd, ch);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_finalize");
+}
+
+extern "C" int pcaa_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                   const float* running_var, float eps, float* scale, float* shift,
+                                   int ch, void* stream) {
+  PCAA_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && ch >= 1, "pcaa_bn_eval_coeffs: bad args");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((unsigned)cdiv(ch, 256)), dim3(256), 0, as_stream(stream),
+                     gamma, beta, running_mean, running_var, eps, scale, shift, ch);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_eval_coeffs");
+}
+
+extern "C" int pcaa_bn_act_fwd(const void* y, void* a, int dtype, const float* scale, const float* shift,
+                               long rows, int ch, void* stream) {
+  PCAA_CHECK_ARG(y && a && scale && shift, "pcaa_bn_act_fwd: null pointer");
+  PCAA_CHECK_ARG(rows >= 1 && ch >= 4 && (ch & 3) == 0, "pcaa_bn_act_fwd: ch must be a multiple of 4");
+  const long nq = rows * (ch >> 2);
+  const int grid = grid_for(nq);
+  if (dtype == PCAA_F32)
+    hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream),
+                       (const float*)y, (float*)a, scale, shift, nq, ch >> 2);
+  else if (dtype == PCAA_BF16)
+    hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream),
+                       (const bf16_t*)y, (bf16_t*)a, scale, shift, nq, ch >> 2);
+  else { pcaa_set_error("pcaa_bn_act_fwd: bad dtype"); return PCAA_ERR_INVALID_ARG; }
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_act_fwd");
+}
+
+extern "C" int pcaa_bn_act_meanpool_fwd(const void* y, int dtype, const float* scale, const float* shift,
+                                        float* pooled, long groups, int group_rows, int ch, void* stream) {
+  PCAA_CHECK_ARG(y && scale && shift && pooled, "pcaa_bn_act_meanpool_fwd: null pointer");
+  PCAA_CHECK_ARG(groups >= 1 && group_rows >= 1 && ch_ok(ch), "pcaa_bn_act_meanpool_fwd: ch/4 must divide 256 (ch=%d)", ch);
+  if (dtype == PCAA_F32)
+    hipLaunchKernelGGL(bn_act_meanpool_kernel<float>, dim3((unsigned)groups), dim3(256), 0, as_stream(stream),
+                       (const float*)y, scale, shift, pooled, group_rows, ch);
+  else if (dtype == PCAA_BF16)
+    hipLaunchKernelGGL(bn_act_meanpool_kernel<bf16_t>, dim3((unsigned)groups), dim3(256), 0, as_stream(stream),
+                       (const bf16_t*)y, scale, shift, pooled, group_rows, ch);
+  else { pcaa_set_error("pcaa_bn_act_meanpool_fwd: bad dtype"); return PCAA_ERR_INVALID_ARG; }
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_act_meanpool_fwd");
+}
+
+extern "C" int pcaa_bn_act_bwd_dz(const void* da, const float* dpool, int group_rows, float pool_scale,
+                                  const void* y, void* dz, int dtype, const float* scale,
+                                  const float* shift, const float* mean, const float* rstd,
+                                  double* stats, int nrep, long rows, int ch, void* stream) {
+  PCAA_CHECK_ARG((da != nullptr) != (dpool != nullptr), "pcaa_bn_act_bwd_dz: exactly one of da / dpool");
+  PCAA_CHECK_ARG(y && dz && scale && shift && mean && rstd && stats, "pcaa_bn_act_bwd_dz: null pointer");
+  PCAA_CHECK_ARG(rows >= 1 && nrep >= 1 && ch_ok(ch), "pcaa_bn_act_bwd_dz: ch/4 must divide 256 (ch=%d)", ch);
+  PCAA_CHECK_ARG(!dpool || group_rows >= 1, "pcaa_bn_act_bwd_dz: bad group_rows");
+  const unsigned grid = (unsigned)cdiv(rows, ROWS_PER_BLOCK);
+  hipStream_t s = as_stream(stream);
+#define LAUNCH_DZ(T, POOL)                                                                       \
+  hipLaunchKernelGGL((bn_act_bwd_dz_kernel<T, POOL>), dim3(grid), dim3(256), 0, s, (const T*)da, \
+                     dpool, group_rows, pool_scale, (const T*)y, (T*)dz, scale, shift, mean,     \
+                     rstd, stats, nrep, rows, ch)
+  if (dtype == PCAA_F32) { if (dpool) LAUNCH_DZ(float, true); else LAUNCH_DZ(float, false); }
+  else if (dtype == PCAA_BF16) { if (dpool) LAUNCH_DZ(bf16_t, true); else LAUNCH_DZ(bf16_t, false); }
+  else { pcaa_set_error("pcaa_bn_act_bwd_dz: bad dtype"); return PCAA_ERR_INVALID_ARG; }
+#undef LAUNCH_DZ
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_act_bwd_dz");
+}
+
+extern "C" int pcaa_bn_bwd_finalize(const double* stats, int nrep, long count, const float* gamma,
+                                    const float* mean, const float* rstd, float* coef, float* dgamma,
+                                    float* dbeta, int ch, void* stream) {
+  PCAA_CHECK_ARG(stats && gamma && mean && rstd && coef, "pcaa_bn_bwd_finalize: null pointer");
+  PCAA_CHECK_ARG(nrep >= 1 && count >= 1 && ch >= 1, "pcaa_bn_bwd_finalize: bad sizes");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(ch, 256)), dim3(256), 0, as_stream(stream),
+                     stats, nrep, 1.0 / (double)count, gamma, mean, rstd, coef, dgamma, dbeta, ch);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_bwd_finalize");
+}
+
+extern "C" int pcaa_bn_bwd_dy(const void* dz, const void* y, void* dy, int dtype, const float* coef,
+                              long rows, int ch, void* stream) {
+  PCAA_CHECK_ARG(dz && y && dy && coef, "pcaa_bn_bwd_dy: null pointer");
+  PCAA_CHECK_ARG(rows >= 1 && ch >= 4 && (ch & 3) == 0, "pcaa_bn_bwd_dy: ch must be a multiple of 4");
+  const long nq = rows * (ch >> 2);
+  const int grid = grid_for(nq);
+  if (dtype == PCAA_F32)
+    hipLaunchKernelGGL(bn_bwd_dy_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream),
+                       (const float*)dz, (const float*)y, (float*)dy, coef, nq, ch >> 2, ch);
+  else if (dtype == PCAA_BF16)
+    hipLaunchKernelGGL(bn_bwd_dy_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream),
+                       (const bf16_t*)dz, (const bf16_t*)y, (bf16_t*)dy, coef, nq, ch >> 2, ch);
+  else { pcaa_set_error("pcaa_bn_bwd_dy: bad dtype"); return PCAA_ERR_INVALID_ARG; }
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_bwd_dy");
+}
+
+extern "C" int pcaa_bias_act(float* y, const float* bias, int act, long rows, int cols, void* stream) {
+  PCAA_CHECK_ARG(y && rows >= 1 && cols >= 1, "pcaa_bias_act: bad args");
+  PCAA_CHECK_ARG(act == PCAA_ACT_NONE || act == PCAA_ACT_ELU, "pcaa_bias_act: bad activation");
+  const long n = rows * cols;
+  hipLaunchKernelGGL(bias_act_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), y, bias, act, n, cols);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_bias_act");
+}
+
+extern "C" int pcaa_elu_bwd_from_out(const float* da, const float* a, float* dz, long n, void* stream) {
+  PCAA_CHECK_ARG(da && a && dz && n >= 1, "pcaa_elu_bwd_from_out: bad args");
+  hipLaunchKernelGGL(elu_bwd_from_out_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), da, a, dz, n);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_elu_bwd_from_out");
+}
+
+extern "C" int pcaa_colsum(const float* x, float* out, long rows, int cols, void* stream) {
+  PCAA_CHECK_ARG(x && out && rows >= 1 && cols >= 1, "pcaa_colsum: bad args");
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv(cols, 64)), dim3(256), 0, as_stream(stream), x, out, rows, cols);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_colsum");
+}
+
+extern "C" int pcaa_sum(const float* x, long n, float scale, float* out, void* stream) {
+  PCAA_CHECK_ARG(x && out && n >= 1, "pcaa_sum: bad args");
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, as_stream(stream), x, n, scale, out);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_sum");
+}
+
+extern "C" int pcaa_rowsum(const float* x, float* out, long rows, int cols, float scale, void* stream) {
+  PCAA_CHECK_ARG(x && out && rows >= 1 && cols >= 1, "pcaa_rowsum: bad args");
+  hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)rows), dim3(64), 0, as_stream(stream), x, out, cols, scale);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_rowsum");
+}
+
+extern "C" int pcaa_scale_by_device_scalar(const float* x, const float* s, float* out, long n, void* stream) {
+  PCAA_CHECK_ARG(x && s && out && n >= 1, "pcaa_scale_by_device_scalar: bad args");
+  hipLaunchKernelGGL(scale_dev_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, s, out, n);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_scale_by_device_scalar");
+}
+
+extern "C" int pcaa_scale_rows(const float* x, const float* s, float* out, long rows, int cols, void* stream) {
+  PCAA_CHECK_ARG(x && s && out && rows >= 1 && cols >= 1, "pcaa_scale_rows: bad args");
+  const long n = rows * cols;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, s, out, n, cols);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_scale_rows");
+}
+
+extern "C" int pcaa_prior_sample(const float* z0, const float* means, const long long* gt, int B, int K, int D,
+                                 float* z, float* onehot, void* stream) {
+  PCAA_CHECK_ARG(z0 && means && gt && z && onehot && B >= 1 && K >= 1 && D >= 1, "pcaa_prior_sample: bad args");
+  const int n = B * (D > K ? D : K);
+  hipLaunchKernelGGL(prior_sample_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), z0, means, gt, B, K, D, z, onehot);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_prior_sample");
+}
+
+extern "C" int pcaa_pack_points(const float* src, long sb, long sc, long st, long sn, float* dst,
+                                int B, int C, int T, int N, void* stream) {
+  PCAA_CHECK_ARG(src && dst && B >= 1 && C >= 1 && T >= 1 && N >= 1, "pcaa_pack_points: bad args");
+  const long n = (long)B * C * T * N;
+  hipLaunchKernelGGL(pack_points_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), src, sb, sc, st, sn, dst, B, C, T, N);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_pack_points");
+}
+
+extern "C" int pcaa_dtc_im2col(const float* a, float* col, int B, int T, int Cin, int dilation, void* stream) {
+  PCAA_CHECK_ARG(a && col && B >= 1 && T >= 1 && Cin >= 1 && dilation >= 1, "pcaa_dtc_im2col: bad args");
+  const long n = (long)B * T * Cin * 3;
+  hipLaunchKernelGGL(dtc_im2col_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), a, col, B, T, Cin, dilation);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_dtc_im2col");
+}
+
+extern "C" int pcaa_dtc_col2im(const float* dcol, float* da, int B, int T, int Cin, int dilation, void* stream) {
+  PCAA_CHECK_ARG(dcol && da && B >= 1 && T >= 1 && Cin >= 1 && dilation >= 1, "pcaa_dtc_col2im: bad args");
+  const long n = (long)B * T * Cin;
+  hipLaunchKernelGGL(dtc_col2im_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), dcol, da, B, T, Cin, dilation);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_dtc_col2im");
+}
+
+extern "C" int pcaa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                              float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                              void* stream) {
+  PCAA_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n >= 1 && step >= 1, "pcaa_adam_step: bad args");
+  PCAA_CHECK_ARG(((uintptr_t)param % 16) == 0 && ((uintptr_t)grad % 16) == 0 && ((uintptr_t)exp_avg % 16) == 0 &&
+                 ((uintptr_t)exp_avg_sq % 16) == 0, "pcaa_adam_step: buffers must be 16-B aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n >> 2, 256, 256 * 16)), dim3(256), 0, as_stream(stream),
+                     param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size, inv_bc2_sqrt, grad_scale);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_adam_step");
+}

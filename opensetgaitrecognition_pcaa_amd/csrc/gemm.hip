@@ -1,0 +1,457 @@
+// MFMA GEMM for the PCAA path (gfx950).
+//
+//   C[M,N] (=|+=) A(M,K) . B(K,N) (+bias) , optional BatchNorm column statistics.
+//
+// One 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each wave a
+// 64x64 sub-tile = 2x2 MFMA 32x32 accumulators).  Operand tiles are staged
+// global -> registers -> LDS with the next tile's global loads in flight while
+// the current tile is multiplied.  Two math flavours:
+//
+//   F32 : v_mfma_f32_32x32x2_f32 -- exact fp32 (bit-for-bit an fmaf chain).
+//         LDS holds [k][row] fp32 tiles; either operand may be stored
+//         contraction-contiguous (KC) or row-contiguous (RC) in HBM, fp32 or
+//         bf16.  Used for the fp32 parity mode and every small GEMM.
+//   BF16: v_mfma_f32_32x32x16_bf16, fp32 accumulate.  LDS holds [row][k] bf16
+//         tiles (144-B pitch: conflict-free ds_read_b128); KC operands only.
+//
+// Workgroup -> tile mapping is XCD-aware: the 8 XCDs each walk a contiguous
+// range of tiles with the N-tiles of one M-panel adjacent, so the A panel is
+// re-read from that XCD's L2 and not from HBM.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int KC = PCAA_LAYOUT_KC, RC = PCAA_LAYOUT_RC;
+
+struct GemmParams {
+  const void* A; const void* B; void* C;
+  long lda, ldb, ldc;
+  int M, N, K;
+  const float* bias;
+  double* colstats;
+  int nrep;
+  int k_per_split;
+  int atomic;
+};
+
+__device__ __forceinline__ void tile_coords(int M, int N, int& tm, int& tn) {
+  const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
+  const int nb = nbm * nbn;
+  const int bid = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  tm = v / nbn;
+  tn = v - tm * nbn;
+}
+
+// ---------------------------------------------------------------------------
+// F32 flavour
+// ---------------------------------------------------------------------------
+constexpr int F_BK = 32;
+template <int LAY> struct FPitch { static constexpr int v = (LAY == KC) ? 129 : 132; };
+
+// stage one 128 x 32 operand tile: 1024 chunks of 4 elements, 4 per thread
+template <typename T, int LAY, bool VEC>
+__device__ __forceinline__ void f_load_tile(const T* __restrict__ base, long ld, int row0, int R,
+                                            int k0, int kend, f32x4 (&reg)[4], int tid) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int q = tid + c * 256;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (LAY == KC) {
+      const int r = q >> 3, kc = (q & 7) << 2;
+      const int gr = row0 + r, gk = k0 + kc;
+      if (gr < R) {
+        const T* p = base + (long)gr * ld + gk;
+        if (VEC) {
+          if (gk < kend) v = load4(p);
+        } else {
+          if (gk + 0 < kend) v.x = load1(p + 0);
+          if (gk + 1 < kend) v.y = load1(p + 1);
+          if (gk + 2 < kend) v.z = load1(p + 2);
+          if (gk + 3 < kend) v.w = load1(p + 3);
+        }
+      }
+    } else {
+      const int k = q >> 5, rc = (q & 31) << 2;
+      const int gk = k0 + k, gr = row0 + rc;
+      if (gk < kend) {
+        const T* p = base + (long)gk * ld + gr;
+        if (VEC) {
+          if (gr < R) v = load4(p);
+        } else {
+          if (gr + 0 < R) v.x = load1(p + 0);
+          if (gr + 1 < R) v.y = load1(p + 1);
+          if (gr + 2 < R) v.z = load1(p + 2);
+          if (gr + 3 < R) v.w = load1(p + 3);
+        }
+      }
+    }
+    reg[c] = v;
+  }
+}
+
+template <int LAY>
+__device__ __forceinline__ void f_store_tile(float* __restrict__ s, const f32x4 (&reg)[4], int tid) {
+  constexpr int P = FPitch<LAY>::v;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int q = tid + c * 256;
+    if (LAY == KC) {
+      const int r = q >> 3, kc = (q & 7) << 2;
+      s[(kc + 0) * P + r] = reg[c].x;
+      s[(kc + 1) * P + r] = reg[c].y;
+      s[(kc + 2) * P + r] = reg[c].z;
+      s[(kc + 3) * P + r] = reg[c].w;
+    } else {
+      const int k = q >> 5, rc = (q & 31) << 2;
+      *reinterpret_cast<f32x4*>(&s[k * P + rc]) = reg[c];
+    }
+  }
+}
+
+// shared epilogue: bias, store / atomic, BatchNorm column statistics
+template <typename TC>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[2][2], float* smem,
+                                         int tm, int tn, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
+  TC* C = reinterpret_cast<TC*>(p.C);
+  const bool add_bias = p.bias != nullptr && (!p.atomic || blockIdx.z == 0);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int gn = tn * BN + wn * 64 + j * 32 + l31;
+    const float bv = (add_bias && gn < p.N) ? p.bias[gn] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = tm * BM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (gm < p.M && gn < p.N) {
+          const float v = acc[i][j][r] + bv;
+          if (p.atomic) {
+            atomicAdd(reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn, v);
+          } else {
+            store1(C + (long)gm * p.ldc + gn, v);
+          }
+        }
+      }
+    }
+  }
+  if (p.colstats != nullptr) {
+    // rows >= M were staged as zeros, so they add nothing to the bias-free sums
+    __syncthreads();  // everyone is done reading the operand tiles in smem
+    float* red = smem;  // [2 stats][2 wm][128 cols]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[i][j][r];
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (half == 0) {
+        const int col = wn * 64 + j * 32 + l31;
+        red[(0 * 2 + wm) * 128 + col] = s1;
+        red[(1 * 2 + wm) * 128 + col] = s2;
+      }
+    }
+    __syncthreads();
+    const int stat = tid >> 7, col = tid & 127;
+    const int gn = tn * BN + col;
+    if (gn < p.N) {
+      const double v = (double)red[(stat * 2 + 0) * 128 + col] + (double)red[(stat * 2 + 1) * 128 + col];
+      const int rep = tm % p.nrep;
+      unsafeAtomicAdd(&p.colstats[((long)rep * 2 + stat) * p.N + gn], v);
+    }
+  }
+}
+
+template <typename TA, typename TB, typename TC, int ALAY, int BLAY, bool VEC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+  constexpr int PA = FPitch<ALAY>::v, PB = FPitch<BLAY>::v;
+  __shared__ __attribute__((aligned(16))) float smem[F_BK * PA + F_BK * PB];
+  float* sA = smem;
+  float* sB = smem + F_BK * PA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
+  int tm, tn;
+  tile_coords(p.M, p.N, tm, tn);
+
+  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nt = (kend - kbeg + F_BK - 1) / F_BK;
+
+  const TA* A = reinterpret_cast<const TA*>(p.A);
+  const TB* B = reinterpret_cast<const TB*>(p.B);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[4], rb[4];
+  if (nt > 0) {
+    f_load_tile<TA, ALAY, VEC>(A, p.lda, tm * BM, p.M, kbeg, kend, ra, tid);
+    f_load_tile<TB, BLAY, VEC>(B, p.ldb, tn * BN, p.N, kbeg, kend, rb, tid);
+    f_store_tile<ALAY>(sA, ra, tid);
+    f_store_tile<BLAY>(sB, rb, tid);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const bool more = (t + 1 < nt);
+    if (more) {
+      const int k0 = kbeg + (t + 1) * F_BK;
+      f_load_tile<TA, ALAY, VEC>(A, p.lda, tm * BM, p.M, k0, kend, ra, tid);
+      f_load_tile<TB, BLAY, VEC>(B, p.ldb, tn * BN, p.N, k0, kend, rb, tid);
+    }
+    const float* pa = sA + half * PA + wm * 64 + l31;
+    const float* pb = sB + half * PB + wn * 64 + l31;
+#pragma unroll
+    for (int kk = 0; kk < F_BK; kk += 2) {
+      const float a0 = pa[kk * PA], a1 = pa[kk * PA + 32];
+      const float b0 = pb[kk * PB], b1 = pb[kk * PB + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) {
+      f_store_tile<ALAY>(sA, ra, tid);
+      f_store_tile<BLAY>(sB, rb, tid);
+      __syncthreads();
+    }
+  }
+  epilogue<TC>(p, acc, smem, tm, tn, tid);
+}
+
+// ---------------------------------------------------------------------------
+// BF16 flavour (KC operands).  Tile 128 x 64 per operand per step.
+// ---------------------------------------------------------------------------
+constexpr int H_BK = 64;
+constexpr int H_PITCH = H_BK + 8;  // bf16 elements; 144 B rows
+
+struct Raw8 { uint4 v; };  // 8 packed bf16
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 b;
+  b.x = (bf16_t)lo;
+  b.y = (bf16_t)hi;
+  return *reinterpret_cast<uint32_t*>(&b);
+}
+
+__device__ __forceinline__ uint4 load8_as_bf16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ uint4 load8_as_bf16(const float* p) {
+  const f32x4 lo = *reinterpret_cast<const f32x4*>(p);
+  const f32x4 hi = *reinterpret_cast<const f32x4*>(p + 4);
+  uint4 r;
+  r.x = pack_bf16x2(lo.x, lo.y);
+  r.y = pack_bf16x2(lo.z, lo.w);
+  r.z = pack_bf16x2(hi.x, hi.y);
+  r.w = pack_bf16x2(hi.z, hi.w);
+  return r;
+}
+
+// 128 rows x 64 k = 1024 chunks of 8 elements, 4 per thread
+template <typename T>
+__device__ __forceinline__ void h_load_tile(const T* __restrict__ base, long ld, int row0, int R,
+                                            int k0, int kend, uint4 (&reg)[4], int tid) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int q = tid + c * 256;
+    const int r = q >> 3, kc = (q & 7) << 3;
+    const int gr = row0 + r, gk = k0 + kc;
+    uint4 v = {0u, 0u, 0u, 0u};
+    if (gr < R && gk < kend) v = load8_as_bf16(base + (long)gr * ld + gk);
+    reg[c] = v;
+  }
+}
+
+__device__ __forceinline__ void h_store_tile(bf16_t* __restrict__ s, const uint4 (&reg)[4], int tid) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int q = tid + c * 256;
+    const int r = q >> 3, kc = (q & 7) << 3;
+    *reinterpret_cast<uint4*>(&s[r * H_PITCH + kc]) = reg[c];
+  }
+}
+
+template <typename TA, typename TB, typename TC>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float smem_f[(2 * BM * H_PITCH * 2) / 4];
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_f);
+  bf16_t* sB = sA + BM * H_PITCH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
+  int tm, tn;
+  tile_coords(p.M, p.N, tm, tn);
+
+  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nt = (kend - kbeg + H_BK - 1) / H_BK;
+
+  const TA* A = reinterpret_cast<const TA*>(p.A);
+  const TB* B = reinterpret_cast<const TB*>(p.B);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 ra[4], rb[4];
+  if (nt > 0) {
+    h_load_tile<TA>(A, p.lda, tm * BM, p.M, kbeg, kend, ra, tid);
+    h_load_tile<TB>(B, p.ldb, tn * BN, p.N, kbeg, kend, rb, tid);
+    h_store_tile(sA, ra, tid);
+    h_store_tile(sB, rb, tid);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const bool more = (t + 1 < nt);
+    if (more) {
+      const int k0 = kbeg + (t + 1) * H_BK;
+      h_load_tile<TA>(A, p.lda, tm * BM, p.M, k0, kend, ra, tid);
+      h_load_tile<TB>(B, p.ldb, tn * BN, p.N, k0, kend, rb, tid);
+    }
+    const bf16_t* pa = sA + (wm * 64 + l31) * H_PITCH + half * 8;
+    const bf16_t* pb = sB + (wn * 64 + l31) * H_PITCH + half * 8;
+#pragma unroll
+    for (int kk = 0; kk < H_BK; kk += 16) {
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(pa + kk);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(pa + 32 * H_PITCH + kk);
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(pb + kk);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(pb + 32 * H_PITCH + kk);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) {
+      h_store_tile(sA, ra, tid);
+      h_store_tile(sB, rb, tid);
+      __syncthreads();
+    }
+  }
+  epilogue<TC>(p, acc, smem_f, tm, tn, tid);
+}
+
+// ---------------------------------------------------------------------------
+// dispatch
+// ---------------------------------------------------------------------------
+template <typename TA, typename TB, typename TC, int ALAY, int BLAY>
+void launch_f32(const GemmParams& p, bool vec, dim3 grid, hipStream_t s) {
+  if (vec)
+    hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, TC, ALAY, BLAY, true>), grid, dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, TC, ALAY, BLAY, false>), grid, dim3(256), 0, s, p);
+}
+
+template <typename TA, typename TB, typename TC>
+void launch_f32_lay(const GemmParams& p, int al, int bl, bool vec, dim3 grid, hipStream_t s) {
+  if (al == KC && bl == KC) launch_f32<TA, TB, TC, KC, KC>(p, vec, grid, s);
+  else if (al == KC && bl == RC) launch_f32<TA, TB, TC, KC, RC>(p, vec, grid, s);
+  else if (al == RC && bl == KC) launch_f32<TA, TB, TC, RC, KC>(p, vec, grid, s);
+  else launch_f32<TA, TB, TC, RC, RC>(p, vec, grid, s);
+}
+
+inline size_t esize(int dt) { return dt == PCAA_BF16 ? 2 : 4; }
+
+}  // namespace
+
+extern "C" int pcaa_gemm(int math,
+                         const void* A, int a_dtype, int a_layout, long lda,
+                         const void* B, int b_dtype, int b_layout, long ldb,
+                         void* C, int c_dtype, long ldc,
+                         int M, int N, int K,
+                         const float* bias, double* colstats, int nrep,
+                         int split_k, int accumulate, void* stream) {
+  PCAA_CHECK_ARG(A && B && C, "pcaa_gemm: null operand");
+  PCAA_CHECK_ARG(M > 0 && N > 0 && K > 0, "pcaa_gemm: bad shape M=%d N=%d K=%d", M, N, K);
+  PCAA_CHECK_ARG(math == PCAA_F32 || math == PCAA_BF16, "pcaa_gemm: bad math %d", math);
+  PCAA_CHECK_ARG((a_dtype | 1) == 1 && (b_dtype | 1) == 1 && (c_dtype | 1) == 1, "pcaa_gemm: bad dtype");
+  PCAA_CHECK_ARG((a_layout | 1) == 1 && (b_layout | 1) == 1, "pcaa_gemm: bad layout");
+  PCAA_CHECK_ARG(split_k >= 1, "pcaa_gemm: split_k must be >= 1");
+  PCAA_CHECK_ARG(lda >= (a_layout == KC ? K : M) && ldb >= (b_layout == KC ? K : N) && ldc >= N,
+                 "pcaa_gemm: leading dimension too small");
+  const int atomic = (split_k > 1 || accumulate) ? 1 : 0;
+  PCAA_CHECK_ARG(!atomic || c_dtype == PCAA_F32, "pcaa_gemm: atomic accumulation needs fp32 C");
+  PCAA_CHECK_ARG(!(atomic && colstats), "pcaa_gemm: column statistics need a single K pass");
+  PCAA_CHECK_ARG(!colstats || nrep >= 1, "pcaa_gemm: nrep must be >= 1 with colstats");
+
+  GemmParams p;
+  p.A = A; p.B = B; p.C = C;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K;
+  p.bias = bias; p.colstats = colstats; p.nrep = nrep > 0 ? nrep : 1;
+  p.atomic = atomic;
+  const int bk = (math == PCAA_BF16) ? H_BK : F_BK;
+  int kps = (int)cdiv(cdiv(K, split_k), bk) * bk;
+  if (kps < bk) kps = bk;
+  const int nsplit = (int)cdiv(K, kps);
+  p.k_per_split = kps;
+  const long ntiles = cdiv(M, BM) * cdiv(N, BN);
+  PCAA_CHECK_ARG(ntiles < (1L << 31), "pcaa_gemm: too many tiles");
+  dim3 grid((unsigned)ntiles, 1, (unsigned)nsplit);
+  hipStream_t s = as_stream(stream);
+
+  if (math == PCAA_BF16) {
+    PCAA_CHECK_ARG(a_layout == KC && b_layout == KC, "pcaa_gemm: bf16 math needs KC operands");
+    PCAA_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "pcaa_gemm: bf16 math needs K, lda, ldb %% 8 == 0");
+    PCAA_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "pcaa_gemm: bf16 math needs 16-B aligned operands");
+    PCAA_CHECK_ARG(a_dtype == PCAA_BF16, "pcaa_gemm: bf16 math needs a bf16 A operand");
+    if (b_dtype == PCAA_BF16 && c_dtype == PCAA_BF16)
+      hipLaunchKernelGGL((gemm_bf16_kernel<bf16_t, bf16_t, bf16_t>), grid, dim3(256), 0, s, p);
+    else if (b_dtype == PCAA_BF16 && c_dtype == PCAA_F32)
+      hipLaunchKernelGGL((gemm_bf16_kernel<bf16_t, bf16_t, float>), grid, dim3(256), 0, s, p);
+    else if (b_dtype == PCAA_F32 && c_dtype == PCAA_BF16)
+      hipLaunchKernelGGL((gemm_bf16_kernel<bf16_t, float, bf16_t>), grid, dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL((gemm_bf16_kernel<bf16_t, float, float>), grid, dim3(256), 0, s, p);
+    PCAA_RETURN_LAUNCH_STATUS("pcaa_gemm(bf16)");
+  }
+
+  // vector (4-element) staging is legal when every 4-chunk is aligned and
+  // entirely inside or outside the operand
+  auto vec_ok = [&](const void* ptr, int dt, int lay, long ld, int rows) {
+    const size_t align = 4 * esize(dt);
+    if (((uintptr_t)ptr % align) != 0 || (ld % 4) != 0) return false;
+    if (lay == KC) return (K % 4) == 0;
+    return (rows % 4) == 0;
+  };
+  const bool vec = vec_ok(A, a_dtype, a_layout, lda, M) && vec_ok(B, b_dtype, b_layout, ldb, N);
+
+  if (a_dtype == PCAA_F32 && b_dtype == PCAA_F32 && c_dtype == PCAA_F32)
+    launch_f32_lay<float, float, float>(p, a_layout, b_layout, vec, grid, s);
+  else if (a_dtype == PCAA_BF16 && b_dtype == PCAA_BF16 && c_dtype == PCAA_F32)
+    launch_f32_lay<bf16_t, bf16_t, float>(p, a_layout, b_layout, vec, grid, s);
+  else if (a_dtype == PCAA_BF16 && b_dtype == PCAA_F32 && c_dtype == PCAA_F32)
+    launch_f32_lay<bf16_t, float, float>(p, a_layout, b_layout, vec, grid, s);
+  else if (a_dtype == PCAA_F32 && b_dtype == PCAA_F32 && c_dtype == PCAA_BF16)
+    launch_f32_lay<float, float, bf16_t>(p, a_layout, b_layout, vec, grid, s);
+  else {
+    pcaa_set_error("pcaa_gemm: unsupported dtype combination a=%d b=%d c=%d for fp32 math", a_dtype, b_dtype, c_dtype);
+    return PCAA_ERR_INVALID_ARG;
+  }
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_gemm(f32)");
+}

@@ -1,1 +1,561 @@
-"""placeholder -- replaced below"""
+"""Forward/backward engines of the PCAA modules on the HIP path, and the
+``torch.autograd.Function`` wrappers that make the drop-in modules of
+:mod:`.models` behave like the reference's (``models.py`` of the reference;
+see each function for file:line).
+
+Layout: activations are point-major ``[rows, channels]`` (rows = B*T*N points
+or B*T time steps).  The module-facing tensors keep the reference's logical
+shapes (``[B,C,T,N]``, ``[B,C,T]``) as zero-copy permuted views.
+
+Numerics modes (``set_precision``):
+  * ``"fp32"``  -- fp32 storage, exact-fp32 MFMA: the parity mode (1e-4 gate).
+  * ``"bf16"``  -- PointNet activations stored in bf16, PointNet GEMMs on the
+    bf16 MFMA pipe with fp32 accumulation; everything else fp32.
+"""
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import ops
+from ._lib import ACT_ELU, ACT_NONE, KC, PCAA_BF16, PCAA_F32, RC
+
+_PRECISION = {"mode": "fp32"}
+_SYNC_BN = {"group": None}
+
+
+def set_precision(mode: str):
+    if mode not in ("fp32", "bf16"):
+        raise ValueError("precision must be 'fp32' or 'bf16'")
+    _PRECISION["mode"] = mode
+
+
+def get_precision() -> str:
+    return _PRECISION["mode"]
+
+
+def set_sync_bn_group(group):
+    """``None`` (per-rank BatchNorm statistics, stock DDP semantics) or a
+    torch.distributed process group over which the fp64 batch statistics are
+    all-reduced (SyncBN: the 8-GPU step equals the single-process global-batch
+    step of the reference)."""
+    _SYNC_BN["group"] = group
+
+
+def _sync_stats(stats, count):
+    g = _SYNC_BN["group"]
+    if g is None:
+        return count
+    import torch.distributed as dist
+    dist.all_reduce(stats, group=g)
+    return count * dist.get_world_size(g)
+
+
+def _require_gpu(x, what):
+    if not isinstance(x, torch.Tensor) or not x.is_cuda:
+        raise RuntimeError(f"{what}: input must live on the HIP device; this package has no CPU path "
+                           "(the CPU restatement lives in oracle/ and is test infrastructure only)")
+
+
+def _point_major(x):
+    """logical [B,C,T,N] -> contiguous [B,T,N,C] storage (no copy if x already
+    is a permuted view of point-major storage)."""
+    xp = x.permute(0, 2, 3, 1)
+    if xp.is_contiguous() and x.dtype == torch.float32:
+        return xp
+    return ops.pack_points(x.float() if x.dtype != torch.float32 else x)
+
+
+# ======================================================================
+# Linear + BatchNorm + ELU stacks (PointNetBlock models.py:82-105 and
+# TemporalConvolutionBlock models.py:108-160)
+# ======================================================================
+class _LayerSave:
+    __slots__ = ("a_in", "col", "y", "scale", "shift", "mean", "rstd", "rows", "cin", "cout", "dil")
+
+
+def _linear_bn(a_in, W2d, lin_bias, bn, training, mode, first_layer):
+    """y = a_in @ W2d^T + b with BatchNorm statistics; returns y and BN coefficients."""
+    rows, cin = a_in.shape
+    cout = W2d.shape[0]
+    stats = ops.new_stats(cout, a_in.device) if training else None
+    use_bf16 = (mode == "bf16") and a_in.dtype == torch.bfloat16 and cin % 8 == 0
+    out_dtype = torch.bfloat16 if (mode == "bf16" and first_layer is not None) else torch.float32
+    y = ops.gemm(a_in, KC, W2d, KC, rows, cout, cin, bias=lin_bias, colstats=stats, out_dtype=out_dtype,
+                 math=PCAA_BF16 if use_bf16 else PCAA_F32)
+    if training:
+        count = _sync_stats(stats, rows)
+        scale, shift, mean, rstd = ops.bn_finalize(stats, count, lin_bias, bn, cout)
+    else:
+        scale, shift = ops.bn_eval_coeffs(bn, cout)
+        mean = rstd = None
+        count = rows
+    return y, scale, shift, mean, rstd, count
+
+
+def pointnet_forward(xp2d, layers, training, mode, pool_rows=0):
+    """xp2d: [P, C] fp32.  Returns (output, saves).  If pool_rows>0 the last
+    layer's ELU output is mean-pooled over groups of pool_rows rows (fp32
+    [P/pool_rows, ch]); else the last activation [P, ch] is returned."""
+    saves = []
+    a = xp2d
+    nl = len(layers)
+    for li, layer in enumerate(layers):
+        conv, bn = layer.module[0], layer.module[1]
+        cout, cin = conv.weight.shape[0], conv.weight.shape[1]
+        W2d = conv.weight.view(cout, cin)
+        y, scale, shift, mean, rstd, count = _linear_bn(a, W2d, conv.bias, bn, training, mode, True)
+        s = _LayerSave()
+        s.a_in, s.col, s.y, s.scale, s.shift, s.mean, s.rstd = a, None, y, scale, shift, mean, rstd
+        s.rows, s.cin, s.cout, s.dil = count, cin, cout, 0
+        saves.append(s)
+        if li == nl - 1 and pool_rows:
+            out = ops.bn_act_meanpool_fwd(y, scale, shift, y.shape[0] // pool_rows, pool_rows)
+            return out, saves
+        a = ops.bn_act_fwd(y, scale, shift)
+    return a, saves
+
+
+def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool_scale=1.0,
+                       need_dinput=True, lhs=None):
+    """Backward of one (linear, BN, ELU) layer.  ``lhs`` is the GEMM's left
+    operand ([rows, K]: the input activation or the im2col matrix).
+    Returns (dW2d, dgamma, dbeta, d_lhs or None)."""
+    y = s.y
+    rows_local, cout = y.shape
+    dz, stats = ops.bn_act_bwd_dz(y, s.scale, s.shift, s.mean, s.rstd, da=da, dpool=dpool,
+                                  group_rows=group_rows, pool_scale=pool_scale,
+                                  out=da if (da is not None and da.dtype == y.dtype) else None)
+    _sync_stats(stats, 0)
+    coef, dgamma, dbeta = ops.bn_bwd_finalize(stats, s.rows, bn, s.mean, s.rstd, cout)
+    dy = ops.bn_bwd_dy(dz, y, coef, out=dz)
+    K = lhs.shape[1]
+    # dW[cout, K] = dy^T . lhs   (contraction over the rows: both operands row-contiguous)
+    sk = ops.pick_split_k(cout, K, rows_local)
+    dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, split_k=sk, accumulate=sk > 1)
+    d_lhs = None
+    if need_dinput:
+        if mode == "bf16" and dy.dtype == torch.bfloat16 and cout % 8 == 0:
+            Wt = W2d.t().contiguous()          # [K, cout]: KC operand for the bf16 pipe
+            d_lhs = ops.gemm(dy, KC, Wt, KC, rows_local, K, cout, out_dtype=torch.bfloat16, math=PCAA_BF16)
+        else:
+            d_lhs = ops.gemm(dy, KC, W2d, RC, rows_local, K, cout,
+                             out_dtype=torch.float32)
+    return dW, dgamma, dbeta, d_lhs
+
+
+def pointnet_backward(saves, layers, mode, d_last=None, dpool=None, pool_rows=0, need_dx=False):
+    """Returns ({param_name_suffix: grad} per layer list, dx2d or None)."""
+    grads = []
+    da = d_last
+    for li in range(len(layers) - 1, -1, -1):
+        layer, s = layers[li], saves[li]
+        conv, bn = layer.module[0], layer.module[1]
+        W2d = conv.weight.view(s.cout, s.cin)
+        need_in = li > 0 or need_dx
+        if li == len(layers) - 1 and dpool is not None:
+            dW, dg, db, dprev = _bn_layer_backward(s, bn, W2d, mode, dpool=dpool, group_rows=pool_rows,
+                                                   pool_scale=1.0 / pool_rows, need_dinput=need_in, lhs=s.a_in)
+        else:
+            dW, dg, db, dprev = _bn_layer_backward(s, bn, W2d, mode, da=da, need_dinput=need_in, lhs=s.a_in)
+        grads.append({"module.0.weight": dW.view_as(conv.weight),
+                      "module.0.bias": torch.zeros_like(conv.bias),   # analytically zero (BN removes the mean)
+                      "module.1.weight": dg, "module.1.bias": db})
+        da = dprev
+    grads.reverse()
+    return grads, da
+
+
+def dtc_forward(a2d, B, T, layers, training, pool_time):
+    """a2d: [B*T, Cin] fp32 rows (b,t).  Causal dilated conv = im2col + GEMM."""
+    saves = []
+    a = a2d
+    nl = len(layers)
+    for li, layer in enumerate(layers):
+        conv, bn = layer.conv1d, layer.batch_norm
+        cout, cin = conv.weight.shape[0], conv.weight.shape[1]
+        col = ops.dtc_im2col(a, B, T, cin, layer.dilation)
+        W2d = conv.weight.view(cout, cin * 3)
+        y, scale, shift, mean, rstd, count = _linear_bn(col, W2d, conv.bias, bn, training, "fp32", None)
+        s = _LayerSave()
+        s.a_in, s.col, s.y, s.scale, s.shift, s.mean, s.rstd = a, col, y, scale, shift, mean, rstd
+        s.rows, s.cin, s.cout, s.dil = count, cin, cout, layer.dilation
+        saves.append(s)
+        if li == nl - 1 and pool_time:
+            return ops.bn_act_meanpool_fwd(y, scale, shift, B, T), saves
+        a = ops.bn_act_fwd(y, scale, shift)
+    return a, saves
+
+
+def dtc_backward(saves, layers, B, T, d_last=None, dpool=None, need_dx=True):
+    grads = []
+    da = d_last
+    for li in range(len(layers) - 1, -1, -1):
+        layer, s = layers[li], saves[li]
+        conv, bn = layer.conv1d, layer.batch_norm
+        W2d = conv.weight.view(s.cout, s.cin * 3)
+        need_in = li > 0 or need_dx
+        if li == len(layers) - 1 and dpool is not None:
+            dW, dg, db, dcol = _bn_layer_backward(s, bn, W2d, "fp32", dpool=dpool, group_rows=T,
+                                                  pool_scale=1.0 / T, need_dinput=need_in, lhs=s.col)
+        else:
+            dW, dg, db, dcol = _bn_layer_backward(s, bn, W2d, "fp32", da=da, need_dinput=need_in, lhs=s.col)
+        grads.append({"conv1d.weight": dW.view_as(conv.weight), "conv1d.bias": torch.zeros_like(conv.bias),
+                      "batch_norm.weight": dg, "batch_norm.bias": db})
+        da = ops.dtc_col2im(dcol, B, T, s.cin, s.dil) if need_in else None
+    grads.reverse()
+    return grads, da
+
+
+# ======================================================================
+# small dense layers (Linear + ELU): MLP heads, projection heads, decoder
+# ======================================================================
+def linear_act_forward(x, lin, act):
+    """act(x @ W^T + b) with fp32 MFMA; x [M,K] fp32 -> [M,N]."""
+    M, K = x.shape
+    N = lin.weight.shape[0]
+    sk = ops.pick_split_k(M, N, K)
+    if sk > 1:
+        y = ops.gemm(x, KC, lin.weight, KC, M, N, K, split_k=sk, accumulate=True)
+        return ops.bias_act_(y, lin.bias, act)
+    y = ops.gemm(x, KC, lin.weight, KC, M, N, K, bias=lin.bias if act == ACT_NONE else None)
+    if act != ACT_NONE:
+        ops.bias_act_(y, lin.bias, act)
+    return y
+
+
+def linear_act_backward(x, a_out, lin, act, d_out, need_dx=True, dW_out=None, db_out=None, dx_init=None):
+    """d_out is the gradient w.r.t. the layer output.  Returns (dW, db, dx)."""
+    M, K = x.shape
+    N = lin.weight.shape[0]
+    dz = ops.elu_bwd_from_out(d_out, a_out) if act == ACT_ELU else d_out
+    dz2 = dz.view(M, N)
+    db = ops.colsum(dz2, out=db_out)
+    dW = ops.gemm(dz2, RC, x, RC, N, K, M, out=dW_out)
+    dx = None
+    if need_dx:
+        sk = ops.pick_split_k(M, K, N)
+        if dx_init is not None:
+            dx = ops.gemm(dz2, KC, lin.weight, RC, M, K, N, out=dx_init, split_k=sk, accumulate=True)
+        else:
+            dx = ops.gemm(dz2, KC, lin.weight, RC, M, K, N, split_k=sk, accumulate=sk > 1)
+    return dW, db, dx
+
+
+# ======================================================================
+# CGEncoder (models.py:232-292)
+# ======================================================================
+class EncoderState:
+    pass
+
+
+def encoder_forward(enc, x, training, mode=None):
+    mode = get_precision() if mode is None else mode
+    _require_gpu(x, "CGEncoder")
+    if x.dim() != 4:
+        raise ValueError(f"CGEncoder expects [B,C,T,N], got {tuple(x.shape)}")
+    B, C, T, N = x.shape
+    l1 = enc.pc_block.pointnet1.module[0]
+    if C != l1.weight.shape[1]:
+        raise RuntimeError(f"CGEncoder: input has {C} features, first layer expects {l1.weight.shape[1]}")
+    if N != enc.nmax_points:
+        raise RuntimeError(f"CGEncoder: N={N} points but nmax_points={enc.nmax_points} "
+                           "(the reference's AvgPool2d((1,nmax_points)) would emit >1 column)")
+    st = EncoderState()
+    st.B, st.C, st.T, st.N, st.mode, st.training = B, C, T, N, mode, training
+    xp = _point_major(x).view(B * T * N, C)
+    st.xp = xp
+    x2, st.pn = pointnet_forward(xp, enc.pc_block.layers(), training, mode, pool_rows=N)   # [B*T, 1024]
+    st.x2 = x2
+    x4, st.dtc = dtc_forward(x2, B, T, enc.tc_block.layers(), training, pool_time=True)     # [B, 512]
+    st.x4 = x4
+    st.sup_fv = linear_act_forward(x4, enc.MLP_sup1[0], ACT_ELU)
+    h = st.sup_fv
+    if enc.use_projection_head:
+        st.h = linear_act_forward(st.sup_fv, enc.MLP_head[0], ACT_ELU)
+        h = st.h
+    st.logits = linear_act_forward(h, enc.MLP_sup2[0], ACT_ELU)
+    return st.logits, st.sup_fv, st
+
+
+def encoder_backward(enc, st, d_logits, d_supfv, need_dx=False):
+    """Returns ({state_dict-style name: grad}, dx [B,C,T,N] view or None)."""
+    if not st.training:
+        raise RuntimeError("CGEncoder backward in eval mode is not implemented on the HIP path "
+                           "(the reference only differentiates the train-mode encoder)")
+    g = {}
+    dev = st.sup_fv.device
+    B, T, N = st.B, st.T, st.N
+    dsup = d_supfv.contiguous().clone() if d_supfv is not None else torch.zeros_like(st.sup_fv)
+    if d_logits is not None:
+        h = st.h if enc.use_projection_head else st.sup_fv
+        if enc.use_projection_head:
+            dW, db, dh = linear_act_backward(h, st.logits, enc.MLP_sup2[0], ACT_ELU, d_logits.contiguous())
+            g["MLP_sup2.0.weight"], g["MLP_sup2.0.bias"] = dW, db
+            dW, db, dsup = linear_act_backward(st.sup_fv, st.h, enc.MLP_head[0], ACT_ELU, dh, dx_init=dsup)
+            g["MLP_head.0.weight"], g["MLP_head.0.bias"] = dW, db
+        else:
+            dW, db, dsup = linear_act_backward(h, st.logits, enc.MLP_sup2[0], ACT_ELU, d_logits.contiguous(),
+                                               dx_init=dsup)
+            g["MLP_sup2.0.weight"], g["MLP_sup2.0.bias"] = dW, db
+    else:
+        for nm in ("MLP_sup2.0", "MLP_head.0"):
+            mod = getattr(enc, nm.split(".")[0], None)
+            if mod is not None:
+                g[nm + ".weight"] = torch.zeros_like(mod[0].weight)
+                g[nm + ".bias"] = torch.zeros_like(mod[0].bias)
+    dW, db, dx4 = linear_act_backward(st.x4, st.sup_fv, enc.MLP_sup1[0], ACT_ELU, dsup)
+    g["MLP_sup1.0.weight"], g["MLP_sup1.0.bias"] = dW, db
+    dtc_layers = enc.tc_block.layers()
+    dg, dx2 = dtc_backward(st.dtc, dtc_layers, B, T, dpool=dx4, need_dx=True)
+    for i, d in enumerate(dg, start=1):
+        for k, v in d.items():
+            g[f"tc_block.dtc{i}.{k}"] = v
+    pn_layers = enc.pc_block.layers()
+    pg, dxp = pointnet_backward(st.pn, pn_layers, st.mode, dpool=dx2, pool_rows=N, need_dx=need_dx)
+    for i, d in enumerate(pg, start=1):
+        for k, v in d.items():
+            g[f"pc_block.pointnet{i}.{k}"] = v
+    dx = None
+    if need_dx:
+        dx = dxp.float().view(B, T, N, st.C).permute(0, 3, 1, 2)
+    return g, dx
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, x, *params):
+        logits, sup_fv, st = encoder_forward(enc, x, enc.training)
+        ctx.enc, ctx.st = enc, st
+        ctx.need_dx = x.requires_grad
+        ctx.names = [n for n, _ in enc.named_parameters()]
+        return logits, sup_fv
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_logits, d_supfv):
+        g, dx = encoder_backward(ctx.enc, ctx.st, d_logits, d_supfv, need_dx=ctx.need_dx)
+        return (None, dx) + tuple(g.get(n) for n in ctx.names)
+
+
+def cg_encoder(enc, x):
+    _require_gpu(x, "CGEncoder")
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in enc.parameters())):
+        return _EncoderFn.apply(enc, x, *enc.parameters())
+    logits, sup_fv, _ = encoder_forward(enc, x, enc.training)
+    return logits, sup_fv
+
+
+# ---------------------------------------------------------------- standalone blocks
+class _PointNetStackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, layers, training, x, *params):
+        B, C, T, N = x.shape
+        xp = _point_major(x).view(B * T * N, C)
+        a, saves = pointnet_forward(xp, layers, training, "fp32")
+        ctx.layers, ctx.saves, ctx.shape = layers, saves, (B, C, T, N)
+        ctx.need_dx = x.requires_grad
+        ctx.training = training
+        return a.view(B, T, N, -1).permute(0, 3, 1, 2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        if not ctx.training:
+            raise RuntimeError("PointNet backward in eval mode is not implemented on the HIP path")
+        B, C, T, N = ctx.shape
+        d = gout.permute(0, 2, 3, 1).contiguous().view(B * T * N, -1)
+        grads, dxp = pointnet_backward(ctx.saves, ctx.layers, "fp32", d_last=d, need_dx=ctx.need_dx)
+        flat = []
+        for gd in grads:
+            flat += [gd["module.0.weight"], gd["module.0.bias"], gd["module.1.weight"], gd["module.1.bias"]]
+        dx = dxp.view(B, T, N, C).permute(0, 3, 1, 2) if ctx.need_dx else None
+        return (None, None, dx) + tuple(flat)
+
+
+def pointnet_stack(x, layers, training):
+    _require_gpu(x, "PointNet")
+    params = []
+    for l in layers:
+        params += [l.module[0].weight, l.module[0].bias, l.module[1].weight, l.module[1].bias]
+    return _PointNetStackFn.apply(layers, training, x, *params)
+
+
+class _DtcStackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, layers, training, x, *params):
+        B, C, T = x.shape
+        a2d = x.permute(0, 2, 1).contiguous().view(B * T, C)
+        a, saves = dtc_forward(a2d, B, T, layers, training, pool_time=False)
+        ctx.layers, ctx.saves, ctx.shape, ctx.training = layers, saves, (B, C, T), training
+        return a.view(B, T, -1).permute(0, 2, 1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        if not ctx.training:
+            raise RuntimeError("DilTempConv1d backward in eval mode is not implemented on the HIP path")
+        B, C, T = ctx.shape
+        d = gout.permute(0, 2, 1).contiguous().view(B * T, -1)
+        grads, dx2d = dtc_backward(ctx.saves, ctx.layers, B, T, d_last=d, need_dx=True)
+        flat = []
+        for gd in grads:
+            flat += [gd["conv1d.weight"], gd["conv1d.bias"], gd["batch_norm.weight"], gd["batch_norm.bias"]]
+        return (None, None, dx2d.view(B, T, C).permute(0, 2, 1)) + tuple(flat)
+
+
+def dtc_stack(x, layers, training):
+    _require_gpu(x, "DilTempConv1d")
+    params = []
+    for l in layers:
+        params += [l.conv1d.weight, l.conv1d.bias, l.batch_norm.weight, l.batch_norm.bias]
+    return _DtcStackFn.apply(layers, training, x.float(), *params)
+
+
+# ======================================================================
+# CGDecoder (models.py:340-385)
+# ======================================================================
+def decoder_forward(dec, z):
+    _require_gpu(z, "CGDecoder")
+    if z.dim() != 2 or z.shape[1] != dec.dense1.weight.shape[1]:
+        raise RuntimeError(f"CGDecoder: expected [B,{dec.dense1.weight.shape[1]}], got {tuple(z.shape)}")
+    acts = [z.contiguous().float()]
+    layers = dec.dense_layers()
+    for i, lin in enumerate(layers):
+        acts.append(linear_act_forward(acts[-1], lin, ACT_ELU if i < 4 else ACT_NONE))
+    return acts[-1], acts
+
+
+def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=None):
+    layers = dec.dense_layers()
+    g = {}
+    d = d_out.contiguous().view(acts[-1].shape)
+    for i in range(4, -1, -1):
+        lin = layers[i]
+        nm = f"dense{i + 1}"
+        dW_out = grads_out[nm + ".weight"] if grads_out else None
+        db_out = grads_out[nm + ".bias"] if grads_out else None
+        dW, db, d = linear_act_backward(acts[i], acts[i + 1], lin, ACT_ELU if i < 4 else ACT_NONE, d,
+                                        need_dx=(i > 0 or need_dz), dW_out=dW_out, db_out=db_out,
+                                        dx_init=dz_init if i == 0 else None)
+        g[nm + ".weight"], g[nm + ".bias"] = dW.view_as(lin.weight), db
+    return g, d
+
+
+class _DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dec, z, *params):
+        out, acts = decoder_forward(dec, z)
+        ctx.dec, ctx.acts, ctx.need_dz = dec, acts, z.requires_grad
+        ctx.names = [n for n, _ in dec.named_parameters()]
+        return out.view(-1, dec.n_features, dec.n_steps, dec.nmax_points)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        g, dz = decoder_backward(ctx.dec, ctx.acts, gout.contiguous(), need_dz=ctx.need_dz)
+        return (None, dz) + tuple(g.get(n) for n in ctx.names)   # bn1..4: None (unused, like the reference)
+
+
+def cg_decoder(dec, z):
+    _require_gpu(z, "CGDecoder")
+    return _DecoderFn.apply(dec, z, *dec.parameters())
+
+
+# ======================================================================
+# CGDiscriminator (models.py:405-421) -- first-order autograd only; the
+# WGAN-GP double backward lives in ops.disc_wgan_gp (closed form).
+# ======================================================================
+class _DiscFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disc, x, label, *params):
+        x = x.contiguous().float()
+        label = label.contiguous().float()
+        ctx.disc, ctx.x, ctx.label = disc, x, label
+        ctx.need = (ctx.needs_input_grad[1], ctx.needs_input_grad[2], any(ctx.needs_input_grad[3:]))
+        return ops.disc_forward(x, label, list(params))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        params = ops._disc_params(ctx.disc)
+        dx, dl, grads = ops.disc_backward(ctx.x, ctx.label, params, gout.contiguous().view(-1),
+                                          want_dx=ctx.need[0], want_dlabel=ctx.need[1], want_params=ctx.need[2])
+        return (None, dx, dl) + (tuple(grads) if grads is not None else (None,) * 6)
+
+
+def cg_discriminator(disc, x, label):
+    _require_gpu(x, "CGDiscriminator")
+    return _DiscFn.apply(disc, x, label, *ops._disc_params(disc))
+
+
+# ======================================================================
+# GaussianMeanLearner (models.py:424-443): Linear+BN1d+ELU x3, Linear
+# ======================================================================
+class _GmlFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gml, x, *params):
+        m = gml.model
+        x = x.contiguous().float()
+        saves = []
+        a = x
+        for lin_i, bn_i in ((0, 1), (3, 4), (6, 7)):
+            lin, bn = m[lin_i], m[bn_i]
+            y, scale, shift, mean, rstd, count = _linear_bn(a, lin.weight, lin.bias, bn, gml.training, "fp32", None)
+            s = _LayerSave()
+            s.a_in, s.col, s.y, s.scale, s.shift, s.mean, s.rstd = a, None, y, scale, shift, mean, rstd
+            s.rows, s.cin, s.cout, s.dil = count, lin.weight.shape[1], lin.weight.shape[0], 0
+            saves.append(s)
+            a = ops.bn_act_fwd(y, scale, shift)
+        out = linear_act_forward(a, m[9], ACT_NONE)
+        ctx.gml, ctx.saves, ctx.a_last, ctx.training = gml, saves, a, gml.training
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        if not ctx.training:
+            raise RuntimeError("GaussianMeanLearner backward in eval mode is not implemented on the HIP path")
+        m = ctx.gml.model
+        dW9, db9, da = linear_act_backward(ctx.a_last, None, m[9], ACT_NONE, gout.contiguous())
+        out = []
+        for (lin_i, bn_i), s in reversed(list(zip(((0, 1), (3, 4), (6, 7)), ctx.saves))):
+            lin, bn = m[lin_i], m[bn_i]
+            dW, dg, db, da = _bn_layer_backward(s, bn, lin.weight, "fp32", da=da, need_dinput=True, lhs=s.a_in)
+            out = [dW, torch.zeros_like(lin.bias), dg, db] + out
+        return (None, da) + tuple(out) + (dW9, db9)
+
+
+def gaussian_mean_learner(gml, x):
+    _require_gpu(x, "GaussianMeanLearner")
+    return _GmlFn.apply(gml, x, *gml.parameters())
+
+
+# ======================================================================
+# SeqChamferLoss (utils.py:88-132)
+# ======================================================================
+class _ChamferFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, preds, gts, avg_out):
+        B, C, T, N = preds.shape
+        want = preds.requires_grad
+        scale = 1.0 / (B * T) if avg_out else 1.0 / T
+        fl, dp = ops.chamfer(preds.float(), gts.float(), want_grad=want, grad_scale=scale)
+        ctx.dp, ctx.avg_out, ctx.B = dp, avg_out, B
+        if avg_out:
+            return ops.total(fl, scale)
+        return ops.rowsum(fl, scale)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        if ctx.dp is None:
+            return None, None, None
+        gout = gout.contiguous().float()
+        if ctx.avg_out:
+            return ops.scale_by_device_scalar(ctx.dp, gout), None, None
+        return ops.scale_rows(ctx.dp, gout), None, None
+
+
+def seq_chamfer_loss(preds, gts, avg_out=True):
+    _require_gpu(preds, "SeqChamferLoss")
+    _require_gpu(gts, "SeqChamferLoss")
+    return _ChamferFn.apply(preds, gts, bool(avg_out))

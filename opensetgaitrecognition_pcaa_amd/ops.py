@@ -1,0 +1,370 @@
+"""Thin tensor-level wrappers over the C ABI (include/pcaa_hip.h).
+
+Every function takes torch CUDA(=HIP) tensors, validates what the kernels
+assume (device, dtype, contiguity, shapes) on the host BEFORE launching, and
+launches on torch's current stream.  torch is used for allocation only.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_ELU, ACT_NONE, KC, PCAA_BF16, PCAA_F32, RC, check
+
+NREP = 64          # replicas of a BatchNorm statistics row (spreads fp64 atomics)
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _s():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return PCAA_F32
+    if t.dtype == torch.bfloat16:
+        return PCAA_BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _chk(t, name, dtype=None, dim=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on the HIP device, got "
+                           f"{'cpu tensor' if isinstance(t, torch.Tensor) else type(t)} "
+                           "(this package has no CPU path)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if dim is not None and t.dim() != dim:
+        raise ValueError(f"{name}: expected {dim}-D, got shape {tuple(t.shape)}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous (shape {tuple(t.shape)}, strides {t.stride()})")
+    return t
+
+
+def new_stats(ch, device):
+    return torch.zeros((NREP, 2, ch), dtype=torch.float64, device=device)
+
+
+# ------------------------------------------------------------------ GEMM
+def gemm(A, a_layout, B, b_layout, M, N, K, *, lda=None, ldb=None, out=None, out_dtype=torch.float32,
+         bias=None, colstats=None, split_k=1, accumulate=False, math=PCAA_F32):
+    """out[M,N] (=|+=) A(M,K) . B(K,N) (+bias).  A/B are 2-D contiguous tensors
+    whose storage order is given by the layout flag (see pcaa_hip.h)."""
+    _chk(A, "gemm.A", dim=2)
+    _chk(B, "gemm.B", dim=2)
+    ea = (M, K) if a_layout == KC else (K, M)
+    eb = (N, K) if b_layout == KC else (K, N)
+    if tuple(A.shape) != ea or tuple(B.shape) != eb:
+        raise ValueError(f"gemm: operand shapes {tuple(A.shape)} {tuple(B.shape)} do not match "
+                         f"M={M} N={N} K={K} layouts {a_layout},{b_layout}")
+    lda = A.stride(0) if lda is None else lda
+    ldb = B.stride(0) if ldb is None else ldb
+    atomic = split_k > 1 or accumulate
+    if out is None:
+        if atomic:
+            out = torch.zeros((M, N), dtype=torch.float32, device=A.device)
+        else:
+            out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    else:
+        _chk(out, "gemm.out")
+        if out.numel() != M * N:
+            raise ValueError(f"gemm: out has {out.numel()} elements, need {M * N}")
+    if bias is not None:
+        _chk(bias, "gemm.bias", torch.float32)
+        if bias.numel() != N:
+            raise ValueError("gemm: bias length")
+    if colstats is not None:
+        _chk(colstats, "gemm.colstats", torch.float64)
+        if tuple(colstats.shape) != (NREP, 2, N):
+            raise ValueError("gemm: colstats shape")
+    lib = _lib.load()
+    check(lib.pcaa_gemm(math, _p(A), _dt(A), a_layout, lda, _p(B), _dt(B), b_layout, ldb,
+                        _p(out), _dt(out), N, M, N, K, _p(bias), _p(colstats), NREP,
+                        int(split_k), int(bool(accumulate)), _s()), "pcaa_gemm")
+    return out
+
+
+def pick_split_k(M, N, K, target_blocks=1024, bk=32):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= target_blocks:
+        return 1
+    s = max(1, target_blocks // tiles)
+    return max(1, min(s, K // (4 * bk) if K >= 4 * bk else 1))
+
+
+# ------------------------------------------------------------------ BatchNorm pieces
+def bn_finalize(stats, count, lin_bias, bn, ch, update_running=True):
+    dev = stats.device
+    scale = torch.empty(ch, dtype=torch.float32, device=dev)
+    shift = torch.empty_like(scale)
+    mean = torch.empty_like(scale)
+    rstd = torch.empty_like(scale)
+    lib = _lib.load()
+    rm = bn.running_mean if update_running else None
+    rv = bn.running_var if update_running else None
+    nbt = bn.num_batches_tracked if update_running else None
+    check(lib.pcaa_bn_finalize(_p(stats), NREP, int(count), _p(lin_bias), _p(bn.weight), _p(bn.bias),
+                               _p(rm), _p(rv), _p(nbt), BN_MOMENTUM if bn.momentum is None else bn.momentum,
+                               bn.eps, _p(scale), _p(shift), _p(mean), _p(rstd), ch, _s()), "pcaa_bn_finalize")
+    return scale, shift, mean, rstd
+
+
+def bn_eval_coeffs(bn, ch):
+    dev = bn.weight.device
+    scale = torch.empty(ch, dtype=torch.float32, device=dev)
+    shift = torch.empty_like(scale)
+    check(_lib.load().pcaa_bn_eval_coeffs(_p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
+                                          bn.eps, _p(scale), _p(shift), ch, _s()), "pcaa_bn_eval_coeffs")
+    return scale, shift
+
+
+def bn_act_fwd(y, scale, shift):
+    _chk(y, "bn_act_fwd.y", dim=2)
+    a = torch.empty_like(y)
+    check(_lib.load().pcaa_bn_act_fwd(_p(y), _p(a), _dt(y), _p(scale), _p(shift), y.shape[0], y.shape[1], _s()),
+          "pcaa_bn_act_fwd")
+    return a
+
+
+def bn_act_meanpool_fwd(y, scale, shift, groups, group_rows):
+    _chk(y, "bn_act_meanpool_fwd.y", dim=2)
+    if y.shape[0] != groups * group_rows:
+        raise ValueError("bn_act_meanpool_fwd: rows != groups*group_rows")
+    out = torch.empty((groups, y.shape[1]), dtype=torch.float32, device=y.device)
+    check(_lib.load().pcaa_bn_act_meanpool_fwd(_p(y), _dt(y), _p(scale), _p(shift), _p(out), groups, group_rows,
+                                               y.shape[1], _s()), "pcaa_bn_act_meanpool_fwd")
+    return out
+
+
+def bn_act_bwd_dz(y, scale, shift, mean, rstd, *, da=None, dpool=None, group_rows=0, pool_scale=1.0, out=None):
+    _chk(y, "bn_act_bwd_dz.y", dim=2)
+    rows, ch = y.shape
+    if da is not None:
+        _chk(da, "bn_act_bwd_dz.da", y.dtype, 2)
+        if da.shape != y.shape:
+            raise ValueError("bn_act_bwd_dz: da shape")
+    else:
+        _chk(dpool, "bn_act_bwd_dz.dpool", torch.float32, 2)
+        if dpool.shape[0] * group_rows != rows or dpool.shape[1] != ch:
+            raise ValueError("bn_act_bwd_dz: dpool shape")
+    dz = out if out is not None else torch.empty_like(y)
+    stats = new_stats(ch, y.device)
+    check(_lib.load().pcaa_bn_act_bwd_dz(_p(da), _p(dpool), int(group_rows), float(pool_scale), _p(y), _p(dz),
+                                         _dt(y), _p(scale), _p(shift), _p(mean), _p(rstd), _p(stats), NREP,
+                                         rows, ch, _s()), "pcaa_bn_act_bwd_dz")
+    return dz, stats
+
+
+def bn_bwd_finalize(stats, count, bn, mean, rstd, ch, dgamma=None, dbeta=None):
+    dev = stats.device
+    coef = torch.empty((3, ch), dtype=torch.float32, device=dev)
+    dgamma = torch.empty(ch, dtype=torch.float32, device=dev) if dgamma is None else dgamma
+    dbeta = torch.empty(ch, dtype=torch.float32, device=dev) if dbeta is None else dbeta
+    check(_lib.load().pcaa_bn_bwd_finalize(_p(stats), NREP, int(count), _p(bn.weight), _p(mean), _p(rstd),
+                                           _p(coef), _p(dgamma), _p(dbeta), ch, _s()), "pcaa_bn_bwd_finalize")
+    return coef, dgamma, dbeta
+
+
+def bn_bwd_dy(dz, y, coef, out=None):
+    dy = out if out is not None else torch.empty_like(dz)
+    check(_lib.load().pcaa_bn_bwd_dy(_p(dz), _p(y), _p(dy), _dt(y), _p(coef), y.shape[0], y.shape[1], _s()),
+          "pcaa_bn_bwd_dy")
+    return dy
+
+
+# ------------------------------------------------------------------ small helpers
+def bias_act_(y, bias, act):
+    _chk(y, "bias_act.y", torch.float32, 2)
+    check(_lib.load().pcaa_bias_act(_p(y), _p(bias), act, y.shape[0], y.shape[1], _s()), "pcaa_bias_act")
+    return y
+
+
+def elu_bwd_from_out(da, a, out=None):
+    _chk(da, "elu_bwd.da", torch.float32)
+    _chk(a, "elu_bwd.a", torch.float32)
+    dz = out if out is not None else torch.empty_like(da)
+    check(_lib.load().pcaa_elu_bwd_from_out(_p(da), _p(a), _p(dz), da.numel(), _s()), "pcaa_elu_bwd_from_out")
+    return dz
+
+
+def colsum(x, out=None):
+    _chk(x, "colsum.x", torch.float32, 2)
+    out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device) if out is None else out
+    check(_lib.load().pcaa_colsum(_p(x), _p(out), x.shape[0], x.shape[1], _s()), "pcaa_colsum")
+    return out
+
+
+def total(x, scale=1.0):
+    _chk(x, "sum.x", torch.float32)
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    check(_lib.load().pcaa_sum(_p(x), x.numel(), float(scale), _p(out), _s()), "pcaa_sum")
+    return out
+
+
+def rowsum(x, scale=1.0):
+    _chk(x, "rowsum.x", torch.float32, 2)
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    check(_lib.load().pcaa_rowsum(_p(x), _p(out), x.shape[0], x.shape[1], float(scale), _s()), "pcaa_rowsum")
+    return out
+
+
+def scale_by_device_scalar(x, s):
+    _chk(x, "scale.x", torch.float32)
+    _chk(s, "scale.s", torch.float32)
+    out = torch.empty_like(x)
+    check(_lib.load().pcaa_scale_by_device_scalar(_p(x), _p(s), _p(out), x.numel(), _s()), "pcaa_scale_by_device_scalar")
+    return out
+
+
+def scale_rows(x, s):
+    _chk(x, "scale_rows.x", torch.float32)
+    _chk(s, "scale_rows.s", torch.float32)
+    rows = s.numel()
+    out = torch.empty_like(x)
+    check(_lib.load().pcaa_scale_rows(_p(x), _p(s), _p(out), rows, x.numel() // rows, _s()), "pcaa_scale_rows")
+    return out
+
+
+def prior_sample(z0, means, gt, K):
+    _chk(z0, "prior.z0", torch.float32, 2)
+    _chk(means, "prior.means", torch.float32, 2)
+    _chk(gt, "prior.gt", torch.int64, 1)
+    B, D = z0.shape
+    z = torch.empty_like(z0)
+    oh = torch.empty((B, K), dtype=torch.float32, device=z0.device)
+    check(_lib.load().pcaa_prior_sample(_p(z0), _p(means), _p(gt), B, K, D, _p(z), _p(oh), _s()), "pcaa_prior_sample")
+    return z, oh
+
+
+def pack_points(x):
+    """logical [B,C,T,N] (any strides) -> contiguous point-major [B,T,N,C]."""
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+        raise RuntimeError("pack_points: expected a 4-D float32 tensor on the HIP device")
+    B, C, T, N = x.shape
+    out = torch.empty((B, T, N, C), dtype=torch.float32, device=x.device)
+    sb, sc, st, sn = x.stride()
+    check(_lib.load().pcaa_pack_points(_p(x), sb, sc, st, sn, _p(out), B, C, T, N, _s()), "pcaa_pack_points")
+    return out
+
+
+def dtc_im2col(a, B, T, Cin, d):
+    _chk(a, "im2col.a", torch.float32, 2)
+    col = torch.empty((B * T, 3 * Cin), dtype=torch.float32, device=a.device)
+    check(_lib.load().pcaa_dtc_im2col(_p(a), _p(col), B, T, Cin, d, _s()), "pcaa_dtc_im2col")
+    return col
+
+
+def dtc_col2im(dcol, B, T, Cin, d):
+    _chk(dcol, "col2im.dcol", torch.float32, 2)
+    da = torch.empty((B * T, Cin), dtype=torch.float32, device=dcol.device)
+    check(_lib.load().pcaa_dtc_col2im(_p(dcol), _p(da), B, T, Cin, d, _s()), "pcaa_dtc_col2im")
+    return da
+
+
+# ------------------------------------------------------------------ losses
+def chamfer(preds, gts, want_grad, grad_scale=1.0, grad_per_b=None):
+    """preds/gts logical [B,C,T,N] fp32 with arbitrary strides.  Returns
+    (frame_loss [B,T], dpreds contiguous [B,C,T,N] or None)."""
+    for t, nm in ((preds, "preds"), (gts, "gts")):
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4:
+            raise RuntimeError(f"chamfer: {nm} must be a 4-D float32 tensor on the HIP device")
+    if preds.shape != gts.shape:
+        raise ValueError("chamfer: shape mismatch")
+    B, C, T, N = preds.shape
+    fl = torch.empty((B, T), dtype=torch.float32, device=preds.device)
+    dp = torch.empty((B, C, T, N), dtype=torch.float32, device=preds.device) if want_grad else None
+    ds = dp.stride() if want_grad else (0, 0, 0, 0)
+    ps, gs = preds.stride(), gts.stride()
+    check(_lib.load().pcaa_chamfer_fwd_bwd(_p(preds), ps[0], ps[1], ps[2], ps[3], _p(gts), gs[0], gs[1], gs[2], gs[3],
+                                           B, T, N, C, _p(fl), _p(dp), ds[0], ds[1], ds[2], ds[3],
+                                           float(grad_scale), _p(grad_per_b), _s()), "pcaa_chamfer_fwd_bwd")
+    return fl, dp
+
+
+def cross_entropy(logits, target=None, want_loss=True, want_grad=False, grad_scale=1.0, want_preds=False):
+    _chk(logits, "ce.logits", torch.float32, 2)
+    B, K = logits.shape
+    if target is not None:
+        _chk(target, "ce.target", torch.int64, 1)
+    dev = logits.device
+    loss = torch.empty((), dtype=torch.float32, device=dev) if (want_loss and target is not None) else None
+    dl = torch.empty_like(logits) if want_grad else None
+    pr = torch.empty(B, dtype=torch.int64, device=dev) if want_preds else None
+    check(_lib.load().pcaa_cross_entropy(_p(logits), _p(target), B, K, _p(loss), _p(dl), float(grad_scale), _p(pr), _s()),
+          "pcaa_cross_entropy")
+    return loss, dl, pr
+
+
+# ------------------------------------------------------------------ discriminator
+def _disc_params(m):
+    lin = (m.model[0], m.model[2], m.model[4])
+    return [lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, lin[2].weight, lin[2].bias]
+
+
+def disc_workspace(B, K, device):
+    n = _lib.load().pcaa_disc_workspace_bytes(B, K)
+    return torch.empty(n // 4, dtype=torch.float32, device=device)
+
+
+def disc_forward(x, label, params):
+    _chk(x, "disc.x", torch.float32, 2)
+    _chk(label, "disc.label", torch.float32, 2)
+    B, K = label.shape
+    if x.shape != (B, 32) or params[0].shape != (64, 32 + K):
+        raise ValueError("disc_forward: shapes")
+    out = torch.empty((B, 1), dtype=torch.float32, device=x.device)
+    check(_lib.load().pcaa_disc_forward(_p(x), _p(label), B, K, *[_p(p) for p in params], _p(out), _s()),
+          "pcaa_disc_forward")
+    return out
+
+
+def disc_backward(x, label, params, gout, want_dx=True, want_dlabel=False, want_params=True, grads_out=None):
+    B, K = label.shape
+    _chk(gout, "disc.gout", torch.float32)
+    if gout.numel() != B:
+        raise ValueError("disc_backward: gout size")
+    dev = x.device
+    dx = torch.empty_like(x) if want_dx else None
+    dl = torch.empty_like(label) if want_dlabel else None
+    if want_params:
+        grads = grads_out if grads_out is not None else [torch.empty_like(p) for p in params]
+        ws = disc_workspace(B, K, dev)
+    else:
+        grads = [None] * 6
+        ws = None
+    check(_lib.load().pcaa_disc_backward(_p(x), _p(label), B, K, *[_p(p) for p in params], _p(gout), _p(dx), _p(dl),
+                                         *[_p(g) for g in grads], _p(ws), 0 if ws is None else ws.numel() * 4, _s()),
+          "pcaa_disc_backward")
+    return dx, dl, (grads if want_params else None)
+
+
+def disc_wgan_gp(z, fv, label, alphas, params, gp_weight, grads_out=None):
+    for t, nm in ((z, "z"), (fv, "fv"), (label, "label"), (alphas, "alphas")):
+        _chk(t, f"wgan.{nm}", torch.float32)
+    B, K = label.shape
+    if z.shape != (B, 32) or fv.shape != (B, 32) or alphas.numel() != B:
+        raise ValueError("disc_wgan_gp: shapes")
+    dev = z.device
+    losses = torch.empty(2, dtype=torch.float32, device=dev)
+    grads = grads_out if grads_out is not None else [torch.empty_like(p) for p in params]
+    ws = disc_workspace(B, K, dev)
+    check(_lib.load().pcaa_disc_wgan_gp(_p(z), _p(fv), _p(label), _p(alphas), B, K, *[_p(p) for p in params],
+                                        float(gp_weight), _p(losses), *[_p(g) for g in grads], _p(ws),
+                                        ws.numel() * 4, _s()), "pcaa_disc_wgan_gp")
+    return losses, grads
+
+
+# ------------------------------------------------------------------ optimizer
+def adam_step_(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0):
+    for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, f"adam.{nm}", torch.float32)
+    n = p.numel()
+    if not (g.numel() == n and m.numel() == n and v.numel() == n):
+        raise ValueError("adam_step_: size mismatch")
+    check(_lib.load().pcaa_adam_step(_p(p), _p(g), _p(m), _p(v), n, float(lr), float(b1), float(b2), float(eps),
+                                     int(step), float(grad_scale), _s()), "pcaa_adam_step")

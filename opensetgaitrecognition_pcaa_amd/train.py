@@ -1,0 +1,349 @@
+"""PCAA training loops on the HIP path, with the reference's call surface:
+
+* ``train_variant4(config, wandb_mode="online", proj_head_on_discriminator=False)``
+  -- the paper's PCAA (reference ``PCAA_ablation.py:746-1122``)
+* ``train_CGAAE(config)`` / ``train_variant2`` -- base loop without projection
+  heads (``train_AAE.py:25-364``, ``PCAA_ablation.py:381-389``)
+
+Both drive :class:`PCAATrainer`, which owns the five modules, flat fp32
+parameter / gradient / Adam buffers (one fused Adam launch per optimiser, one
+RCCL all-reduce per optimiser under data parallelism) and runs one step as a
+fixed sequence of HIP launches on the current stream with NO host
+synchronisation: losses stay on the device until the caller reads them.
+"""
+import itertools
+import math
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from . import constants
+from . import functional as F_hip
+from . import ops
+from ._lib import ACT_ELU
+from .models import CGDecoder, CGDiscriminator, CGEncoder
+from .utils import sample_distant_points, save_model
+
+_ALIGN = 64  # floats; keeps every parameter view 256-B aligned inside the flat buffers
+
+
+class FlatBuffer:
+    """Parameters re-pointed into one contiguous fp32 buffer (+ matching
+    gradient and Adam moment buffers)."""
+
+    def __init__(self, named_params, device):
+        self.names, self.offsets, self.sizes, self.params = [], [], [], []
+        total = 0
+        for name, p in named_params:
+            self.names.append(name)
+            self.offsets.append(total)
+            self.sizes.append(p.numel())
+            self.params.append(p)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.total = total
+        self.p = torch.zeros(total, dtype=torch.float32, device=device)
+        self.g = torch.zeros(total, dtype=torch.float32, device=device)
+        self.m = torch.zeros(total, dtype=torch.float32, device=device)
+        self.v = torch.zeros(total, dtype=torch.float32, device=device)
+        self.grad_views = {}
+        with torch.no_grad():
+            for name, p, o, n in zip(self.names, self.params, self.offsets, self.sizes):
+                self.p[o:o + n].copy_(p.detach().reshape(-1))
+                p.data = self.p[o:o + n].view(p.shape)
+                self.grad_views[name] = self.g[o:o + n].view(p.shape)
+        self.step = 0
+
+    def adam(self, lr, b1, b2, eps=1e-8, grad_scale=1.0):
+        self.step += 1
+        ops.adam_step_(self.p, self.g, self.m, self.v, lr, b1, b2, eps, self.step, grad_scale)
+
+
+class PCAATrainer:
+    """One process = one GPU.  ``variant`` "v4" (projection heads, the paper's
+    PCAA) or "base" (train_CGAAE / variant 2)."""
+
+    def __init__(self, config, n_classes=None, device="cuda", variant="v4", precision=None,
+                 process_group=None, sync_bn=False):
+        self.cfg = dict(config)
+        self.K = n_classes if n_classes is not None else len(config["TRAIN_CLASSES"])
+        self.N = config["NMAX"]
+        self.C = constants.NFEATURES
+        self.T = constants.NSTEPS
+        self.L = config["SUP_LATENT_DIM"]
+        self.variant = variant
+        self.device = torch.device(device)
+        self.precision = precision
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
+            if sync_bn:
+                F_hip.set_sync_bn_group(process_group)
+        head = variant == "v4"
+        # construction order = the reference's (PCAA_ablation.py:764-786): same draws from torch's RNG
+        self.encoder = CGEncoder(n_out_labels=self.K, use_projection_head=head, nmax_points=self.N).to(self.device).float()
+        self.decoder = CGDecoder(input_dim=self.L * 2 if head else self.L, nmax_points=self.N).to(self.device).float()
+        self.discriminator = CGDiscriminator(self.K).to(self.device).float()
+        if head:
+            self.decoder_projection_head = torch.nn.Sequential(
+                torch.nn.Linear(self.L, self.L * 2), torch.nn.ELU()).to(self.device).float()
+            self.discriminator_projection_head = torch.nn.Sequential(
+                torch.nn.Linear(self.L * 2, self.L), torch.nn.ELU()).to(self.device).float()
+        else:
+            self.decoder_projection_head = None
+            self.discriminator_projection_head = None
+        self.discriminator_means = None
+        self._flat_ready = False
+
+    # ------------------------------------------------------------------ setup
+    def set_prior_means(self, means):
+        self.discriminator_means = means.float().to(self.device).contiguous()
+
+    def sample_prior_means(self):
+        self.set_prior_means(sample_distant_points(dimension=self.L, n=self.K, min_dist=10, sphere_radius=10))
+        return self.discriminator_means
+
+    def modules(self):
+        d = {"E": self.encoder, "G": self.decoder, "D": self.discriminator}
+        if self.decoder_projection_head is not None:
+            d["GPH"] = self.decoder_projection_head
+            d["DPH"] = self.discriminator_projection_head
+        return d
+
+    def finalize(self):
+        """Build the flat buffers (call after loading/filling weights)."""
+        g_named = [("E." + n, p) for n, p in self.encoder.named_parameters()]
+        if self.decoder_projection_head is not None:
+            g_named += [("GPH." + n, p) for n, p in self.decoder_projection_head.named_parameters()]
+        # bn1..bn4 of the decoder never receive a gradient: torch.optim.Adam skips them
+        g_named += [("G." + n, p) for n, p in self.decoder.named_parameters() if n.startswith("dense")]
+        self.flat_g = FlatBuffer(g_named, self.device)
+        # the inert discriminator projection head is in optimizer_D but never gets a gradient
+        self.flat_d = FlatBuffer([("D." + n, p) for n, p in self.discriminator.named_parameters()], self.device)
+        self._d_params = ops._disc_params(self.discriminator)
+        self._d_grads = [self.flat_d.grad_views["D." + n] for n, _ in self.discriminator.named_parameters()]
+        self._dec_grads = {n: self.flat_g.grad_views["G." + n] for n, _ in self.decoder.named_parameters()
+                           if n.startswith("dense")}
+        self._flat_ready = True
+
+    def train(self):
+        for m in self.modules().values():
+            m.train()
+
+    def eval(self):
+        for m in self.modules().values():
+            m.eval()
+
+    # ------------------------------------------------------------------ one step
+    def _allreduce(self, t):
+        if self.pg is not None and self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, group=self.pg)
+
+    def step(self, pcs, gt, z0, alphas, supervise=True):
+        """One iteration of the reference's inner loop (PCAA_ablation.py:882-1021).
+        pcs [B,C,T,N] fp32 (ideally a permuted view of point-major storage),
+        gt [B] int64, z0 [B,L] fp32, alphas [B,1] fp32 -- all on the device.
+        Returns a dict of DEVICE tensors (no host sync)."""
+        if not self._flat_ready:
+            self.finalize()
+        if self.discriminator_means is None:
+            raise RuntimeError("prior means not set: call sample_prior_means() / set_prior_means()")
+        cfg = self.cfg
+        B = pcs.shape[0]
+        mode = self.precision or F_hip.get_precision()
+        enc, dec = self.encoder, self.decoder
+        gs = 1.0 / self.world
+
+        # (1) encoder forward (train-mode BatchNorm)
+        logits, sup_fv, st = F_hip.encoder_forward(enc, pcs, True, mode)
+        # (2) cross-entropy, its gradient and the predicted labels in one launch
+        sup_loss, dlogits, preds = ops.cross_entropy(logits, gt, want_loss=True, want_grad=supervise,
+                                                     grad_scale=1.0, want_preds=True)
+        # (3) D-step: prior sample, WGAN-GP loss + closed-form gradients, Adam
+        z, oh = ops.prior_sample(z0, self.discriminator_means, gt, self.K)
+        d_losses, _ = ops.disc_wgan_gp(z, sup_fv, oh, alphas.reshape(-1).contiguous(), self._d_params,
+                                       cfg["GP_WEIGHT"], grads_out=self._d_grads)
+        self._allreduce(self.flat_d.g)
+        self.flat_d.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs)
+
+        # (4) G-step forward: decoder + Chamfer (+ fused gradient), adversarial term with the UPDATED critic
+        if self.decoder_projection_head is not None:
+            hproj = F_hip.linear_act_forward(sup_fv, self.decoder_projection_head[0], ACT_ELU)
+        else:
+            hproj = sup_fv
+        rec, acts = F_hip.decoder_forward(dec, hproj)
+        rec4 = rec.view(B, self.C, self.T, self.N)
+        inv_bt = 1.0 / (B * self.T)
+        frame_loss, drec = ops.chamfer(rec4, pcs, want_grad=True, grad_scale=inv_bt)
+        rec_loss = ops.total(frame_loss, inv_bt)
+        adv = float(cfg["ADV_WEIGHT"])
+        synth = ops.disc_forward(sup_fv, oh, self._d_params)
+        loss_g = ops.total(synth, -adv / B)
+        gout = torch.full((B,), -adv / B, dtype=torch.float32, device=self.device)
+        dsup, _, _ = ops.disc_backward(sup_fv, oh, self._d_params, gout, want_dx=True, want_params=False)
+
+        # (5) G-step backward (the adversarial gradient w.r.t. sup_fvs seeds the accumulation)
+        if self.decoder_projection_head is not None:
+            _, dh = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads)
+            gv = self.flat_g.grad_views
+            _, _, dsup = F_hip.linear_act_backward(sup_fv, hproj, self.decoder_projection_head[0], ACT_ELU, dh,
+                                                   dx_init=dsup, dW_out=gv["GPH.0.weight"], db_out=gv["GPH.0.bias"])
+        else:
+            _, dsup = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads, dz_init=dsup)
+        eg, _ = F_hip.encoder_backward(enc, st, dlogits if supervise else None, dsup)
+        gv = self.flat_g.grad_views
+        for n, t in eg.items():
+            gv["E." + n].copy_(t.view_as(gv["E." + n]))
+        self._allreduce(self.flat_g.g)
+        self.flat_g.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs)
+
+        tot = rec_loss + loss_g + (sup_loss if supervise else 0.0)
+        return {"d_loss": d_losses[0], "gp": d_losses[1], "rec_loss": rec_loss, "loss_g": loss_g,
+                "sup_loss": sup_loss, "tot_loss": tot, "preds": preds, "out_labels": logits, "sup_fvs": sup_fv}
+
+    @torch.no_grad()
+    def evaluate_batch(self, pcs, gt):
+        """Validation forward (PCAA_ablation.py:1046-1064): eval-mode encoder ->
+        projection head -> decoder -> Chamfer, CE, argmax."""
+        mode = self.precision or F_hip.get_precision()
+        logits, sup_fv, _ = F_hip.encoder_forward(self.encoder, pcs, False, mode)
+        hproj = sup_fv
+        if self.decoder_projection_head is not None:
+            hproj = F_hip.linear_act_forward(sup_fv, self.decoder_projection_head[0], ACT_ELU)
+        rec, _ = F_hip.decoder_forward(self.decoder, hproj)
+        B = pcs.shape[0]
+        fl, _ = ops.chamfer(rec.view(B, self.C, self.T, self.N), pcs, want_grad=False)
+        rec_loss = ops.total(fl, 1.0 / (B * self.T))
+        ce, _, preds = ops.cross_entropy(logits, gt, want_loss=True, want_preds=True)
+        return rec_loss, ce, preds, sup_fv
+
+    # ------------------------------------------------------------------ checkpoints (format of the reference)
+    def save_checkpoints(self, folder, model_name):
+        suffix = {"E": "_E", "G": "_G", "D": "_D", "GPH": "_GPH", "DPH": "_DPH"}
+        for key, mod in self.modules().items():
+            save_model(mod, os.path.join(folder, f"{model_name}{suffix[key]}.pt"))
+
+
+# ----------------------------------------------------------------------
+# loops with the reference's call surface
+# ----------------------------------------------------------------------
+class _NullRun:
+    def finish(self):
+        pass
+
+
+def _wandb():
+    try:
+        import wandb  # noqa: F401
+        return wandb
+    except Exception:
+        return None
+
+
+def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=None):
+    from .datasets import MSRadarDataset
+    from .constants import SPLIT
+
+    nmax_points = config["NMAX"]
+    os.makedirs(f"models/{config['MODEL_NAME']}", exist_ok=True)
+    with open(os.path.join("models", config["MODEL_NAME"], "config.pkl"), "wb") as f:
+        pickle.dump(config, f)
+
+    trainer = PCAATrainer(config, variant=variant, process_group=process_group)
+    dev = trainer.device
+    make = dataset_factory or (lambda split: MSRadarDataset(split, subsample_factor=config["SUBSAMPLE_FACTOR"]))
+    train_set, valid_set = make(SPLIT.TRAIN), make(SPLIT.VALID)
+    loader_train = torch.utils.data.DataLoader(train_set, batch_size=config["BATCH_SIZE"], drop_last=True,
+                                               shuffle=True, num_workers=0)
+    loader_valid = torch.utils.data.DataLoader(valid_set, batch_size=config["BATCH_SIZE"], drop_last=True,
+                                               shuffle=False, num_workers=0)
+    _ = make(SPLIT.UNSEEN) if dataset_factory is None else None
+
+    wb = _wandb()
+    run = _NullRun()
+    if wb is not None and hasattr(wb, "init"):
+        wb.login()
+        run = wb.init(project=constants.WANDB_PROJECT, config=config, name=config["MODEL_NAME"],
+                      notes=config["NOTES"], reinit=True, mode=constants.WANDB_MODE)
+
+    means = trainer.sample_prior_means()
+    torch.save(means, os.path.join("models", config["MODEL_NAME"], "discriminator_means.pt"))
+    trainer.finalize()
+
+    best_valid_accuracy = 0
+    history = []
+    L = config["SUP_LATENT_DIM"]
+    for epoch in range(config["EPOCHS"]):
+        trainer.train()
+        steps = []
+        ys = []
+        for i, (pcs, gt_labels) in enumerate(loader_train):
+            pcs = pcs.to(dev, non_blocking=True)
+            gt_labels = gt_labels.to(dev, non_blocking=True)
+            # the reference's two host RNG draws, same generators, same order (:915-925, :944-948)
+            z0 = torch.from_numpy(np.random.normal(0.0, 1.0, (pcs.shape[0], L))).to(dev).float()
+            alphas = torch.rand(size=(pcs.shape[0], 1)).to(dev)
+            out = trainer.step(pcs, gt_labels, z0, alphas,
+                               supervise=(i % config["SUPERVISION_FREQUENCY"] == 0))
+            steps.append(out)
+            ys.append(gt_labels)
+        # one device->host transfer per epoch instead of four blocking .item() per step
+        rec_losses = torch.stack([o["rec_loss"] for o in steps]).cpu().numpy()
+        d_losses = torch.stack([o["d_loss"] for o in steps]).cpu().numpy()
+        sup_losses = torch.stack([o["sup_loss"] for o in steps]).cpu().numpy()
+        tot_losses = torch.stack([o["tot_loss"] for o in steps]).cpu().numpy()
+        y_hats = torch.cat([o["preds"] for o in steps]).cpu().numpy()
+        ys = torch.cat(ys).cpu().numpy()
+
+        trainer.eval()
+        v_rec, v_ce, v_hat, v_y = [], [], [], []
+        for valid_pc, valid_gt in loader_valid:
+            valid_pc = valid_pc.to(dev, non_blocking=True)
+            valid_gt = valid_gt.to(dev, non_blocking=True)
+            r, c, p, _ = trainer.evaluate_batch(valid_pc, valid_gt)
+            v_rec.append(r); v_ce.append(c); v_hat.append(p); v_y.append(valid_gt)
+        record = {
+            "Reconstruction Loss Train": float(np.mean(rec_losses)),
+            "Reconstruction Loss Valid": float(torch.stack(v_rec).mean().item()) if v_rec else float("nan"),
+            "Cross Entropy Loss Train": float(np.mean(sup_losses)),
+            "Cross Entropy Loss Valid": float(torch.stack(v_ce).mean().item()) if v_ce else float("nan"),
+            "Discriminator Loss": float(np.mean(d_losses)),
+            "Total Loss Train": float(np.mean(tot_losses)),
+            "Train Accuracy": float(np.mean(ys == y_hats)),
+            "Valid Accuracy": float((torch.cat(v_y) == torch.cat(v_hat)).float().mean().item()) if v_y else 0.0,
+        }
+        history.append(record)
+        if log_fn is not None:
+            log_fn(record)
+        elif wb is not None and hasattr(wb, "log"):
+            wb.log(record)
+        print(f"[Epoch {epoch}/{config['EPOCHS']}] " + " ".join(f"[{k}: {v:.4f}]" for k, v in record.items()))
+
+        if epoch % config["CHECKPOINT_FREQUENCY"] == 0 and record["Valid Accuracy"] > best_valid_accuracy:
+            best_valid_accuracy = record["Valid Accuracy"]
+            trainer.save_checkpoints(os.path.join("models", config["MODEL_NAME"]), config["MODEL_NAME"])
+    run.finish()
+    return trainer, history
+
+
+def train_variant4(config, wandb_mode="online", proj_head_on_discriminator=False, **kw):
+    """Variant 4 = the PCAA model of the paper (PCAA_ablation.py:746)."""
+    if proj_head_on_discriminator:
+        raise NotImplementedError(
+            "proj_head_on_discriminator=True is never used by the reference's drivers and would fail "
+            "there too (Linear(64,32) applied to the 32-wide sup_fvs, PCAA_ablation.py:783-786, :934)")
+    return _run_loop(config, "v4", **kw)
+
+
+def train_CGAAE(config=None, **kw):
+    """Base conditional-Gaussian AAE loop (train_AAE.py:25)."""
+    return _run_loop(constants.CONFIG if config is None else config, "base", **kw)
+
+
+def train_variant2(config, wandb_mode="online", **kw):
+    """Variant 2 == train_CGAAE (PCAA_ablation.py:381-389)."""
+    return train_CGAAE(config, **kw)

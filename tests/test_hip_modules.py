@@ -1,0 +1,294 @@
+"""Module- and step-level parity of the HIP path (drop-in modules, fused
+trainer) against the golden fixtures captured from the reference and against
+the CPU oracle on the same seeded inputs.  GPU only; tolerance for fp32 mode is
+the north-star's 1e-4 relative, argmax labels bit-exact."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import (T, check_against_record, is_pre_bn_bias, load_golden, make_decoder, make_disc,
+                     make_encoder, make_head, sd_clone)
+from opensetgaitrecognition_pcaa_amd import constants, functional as F_hip, models, ops, synthetic as syn
+from opensetgaitrecognition_pcaa_amd.train import PCAATrainer
+from opensetgaitrecognition_pcaa_amd.utils import SeqChamferLoss
+from oracle import pcaa_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-4
+
+
+def _close(a, ref, tol=TOL, floor=1e-6, what=""):
+    a = a.detach().float().cpu().double()
+    ref = torch.as_tensor(ref).double()
+    err = (a - ref).abs().max().item()
+    den = max(ref.abs().max().item(), floor)
+    assert err <= tol * den, f"{what}: abs err {err:.3e}, scale {den:.3e}, rel {err / den:.3e}"
+
+
+@pytest.mark.parametrize("tag", ["enc_cfg1_B4_N128_C5_K8", "enc_B2_N32_C4_K4", "enc_B3_N150_C4_K6_nohead"])
+def test_encoder_vs_golden(tag):
+    F_hip.set_precision("fp32")
+    g, m = load_golden(tag)
+    B, N, C, K, head = m["B"], m["N"], m["C"], m["K"], bool(m["head"])
+    enc = make_encoder(K, N, C, head, seed=m["fill_seed"]).to(DEV)
+    xpm = syn.synthetic_pcs(B, T, N, C, seed=m["pcs_seed"]).to(DEV)          # point-major storage
+    x = xpm.permute(0, 3, 1, 2)                                              # zero-copy [B,C,T,N] view
+    enc.eval()
+    with torch.no_grad():
+        oc, fv = enc(x)
+    _close(oc, g["eval_out_classes"], what="eval out_classes")
+    _close(fv, g["eval_sup_fv"], what="eval sup_fv")
+    # standard channel-major contiguous input (what the reference's DataLoader yields) gives the same
+    with torch.no_grad():
+        oc2, fv2 = enc(x.contiguous())
+    assert torch.equal(oc2, oc) and torch.equal(fv2, fv)
+
+    enc.train()
+    rng = np.random.default_rng(77)
+    r1 = torch.from_numpy(rng.standard_normal((B, K)).astype(np.float32)).to(DEV)
+    r2 = torch.from_numpy(rng.standard_normal((B, 32)).astype(np.float32)).to(DEV)
+    xg = x.detach().clone().requires_grad_(True)
+    oc, fv = enc(xg)
+    loss = (oc * r1).sum() + (fv * r2).sum()
+    loss.backward()
+    _close(oc, g["train_out_classes"], what="train out_classes")
+    _close(fv, g["train_sup_fv"], what="train sup_fv")
+    assert abs(loss.item() - float(g["train_loss"])) <= TOL * abs(float(g["train_loss"])) + 1e-5
+    assert abs(xg.grad.double().norm().item() - float(g["train_dx_l2"])) <= 2e-4 * float(g["train_dx_l2"])
+    wscale = max(float(np.abs(g[k]).max()) for k in g.files if k.startswith("grad.") and k.endswith("weight::full"))
+    for name, p in enc.named_parameters():
+        if is_pre_bn_bias(name):
+            assert p.grad is not None and float(p.grad.abs().max()) <= 1e-4 * wscale + 1e-4, name
+            continue
+        check_against_record(g, "grad.", name, p.grad, 3e-4)
+    sd = enc.state_dict()
+    for name, v in sd.items():
+        if "running" in name or "num_batches" in name:
+            check_against_record(g, "bn1.", name, v, 2e-5)
+    with torch.no_grad():
+        _, fv2 = enc(x)
+    _close(fv2, g["train2_sup_fv"], what="second train-mode forward")
+    for name, v in enc.state_dict().items():
+        if "running" in name or "num_batches" in name:
+            check_against_record(g, "bn2.", name, v, 2e-5)
+
+
+@pytest.mark.parametrize("tag", ["dec_B2_N32_C4", "dec_B3_N50_C5_in32"])
+def test_decoder_vs_golden(tag):
+    g, m = load_golden(tag)
+    B, N, C, in_dim = m["B"], m["N"], m["C"], m["in_dim"]
+    dec = make_decoder(in_dim, N, C, seed=m["fill_seed"]).to(DEV)
+    rng = np.random.default_rng(m["z_seed"])
+    z = torch.from_numpy(rng.standard_normal((B, in_dim)).astype(np.float32)).to(DEV).requires_grad_(True)
+    r = torch.from_numpy(rng.standard_normal((B, C, T, N)).astype(np.float32)).to(DEV)
+    y = dec(z)
+    assert tuple(y.shape) == (B, C, T, N)
+    (y * r).sum().backward()
+    assert abs(y.double().norm().item() - float(g["out_l2"])) <= TOL * float(g["out_l2"])
+    assert np.allclose(syn.checksum(y, 64)["samples"], g["out_samples"], rtol=1e-4, atol=1e-5)
+    _close(z.grad, g["dz"], what="dz")
+    for name, p in dec.named_parameters():
+        check_against_record(g, "grad.", name, p.grad, 2e-4)
+
+
+@pytest.mark.parametrize("tag", ["chamfer_B2_N32_C4", "chamfer_B2_N150_C5"])
+def test_chamfer_vs_golden(tag):
+    g, m = load_golden(tag)
+    B, N, C = m["B"], m["N"], m["C"]
+    gts = syn.synthetic_pcs(B, T, N, C, seed=m["gts_seed"]).to(DEV).permute(0, 3, 1, 2)      # strided view
+    preds = (syn.synthetic_pcs(B, T, N, C, seed=m["preds_seed"]) * 0.7 + 0.1).permute(0, 3, 1, 2)
+    preds = preds.contiguous().to(DEV).requires_grad_(True)
+    loss_fn = SeqChamferLoss()
+    l = loss_fn(preds, gts)
+    l.backward()
+    assert abs(l.item() - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    _close(loss_fn(preds.detach(), gts, avg_out=False), g["loss_per_seq"], 2e-5, what="per-seq loss")
+    _close(preds.grad, g["dpreds"], 1e-4, what="dpreds")
+    # avg_out=False backward with a non-trivial upstream gradient
+    p2 = preds.detach().clone().requires_grad_(True)
+    w = torch.tensor([0.5, -2.0], device=DEV)[:B]
+    (loss_fn(p2, gts, avg_out=False) * w).sum().backward()
+    pc = preds.detach().cpu().clone().requires_grad_(True)
+    (O.seq_chamfer_loss(pc, gts.cpu(), avg_out=False) * w.cpu()).sum().backward()
+    _close(p2.grad, pc.grad, 1e-4, what="dpreds (per-seq weights)")
+    # identity property
+    assert abs(loss_fn(gts, gts).item()) < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["disc_B6_K4", "disc_B16_K8"])
+def test_discriminator_and_wgan_gp_vs_golden(tag):
+    g, m = load_golden(tag)
+    K = m["K"]
+    disc = make_disc(K, seed=m["fill_seed"]).to(DEV)
+    fv, z, alphas = (torch.from_numpy(g[k]).to(DEV) for k in ("fv", "z", "alphas"))
+    gt = torch.from_numpy(g["gt"]).to(DEV)
+    oh = torch.nn.functional.one_hot(gt, K).float()
+    _close(disc(z, oh), g["real"], what="D(real)")
+    _close(disc(fv, oh), g["fake"], what="D(fake)")
+    params = ops._disc_params(disc)
+    losses, grads = ops.disc_wgan_gp(z, fv, oh, alphas.reshape(-1).contiguous(), params, 15.0)
+    assert abs(losses[1].item() - float(g["gp"])) <= TOL * abs(float(g["gp"]))
+    assert abs(losses[0].item() - float(g["d_loss"])) <= TOL * abs(float(g["d_loss"]))
+    for (name, _), gr in zip(disc.named_parameters(), grads):
+        check_against_record(g, "grad.", name, gr, 2e-4, scale_floor=1e-3)
+    # first-order autograd through the drop-in module vs the oracle
+    sd = sd_clone(disc.cpu())
+    disc.to(DEV)
+    for v in sd.values():
+        v.requires_grad_(True)
+    xc = fv.cpu().clone().requires_grad_(True)
+    w = torch.linspace(-1, 1, fv.shape[0]).view(-1, 1)
+    (O.cg_discriminator_forward(xc, oh.cpu(), sd) * w).sum().backward()
+    xg = fv.clone().requires_grad_(True)
+    disc.zero_grad()
+    (disc(xg, oh) * w.to(DEV)).sum().backward()
+    _close(xg.grad, xc.grad, what="dD/dx")
+    for name, p in disc.named_parameters():
+        _close(p.grad, sd[name].grad, 2e-4, what=name)
+
+
+def _trainer_from_golden(m, precision="fp32"):
+    B, N, C, K = m["B"], m["N"], m["C"], m["K"]
+    constants.NFEATURES = C
+    cfg = dict(constants.CONFIG)
+    cfg.update(NMAX=N, TRAIN_CLASSES=list(range(K)), BATCH_SIZE=B, LR=1e-4, B1=0.9, B2=0.99,
+               GP_WEIGHT=15, ADV_WEIGHT=1, SUP_LATENT_DIM=32)
+    tr = PCAATrainer(cfg, precision=precision)
+    s = m["fill_seeds"]
+    for mod, seed in zip((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head,
+                          tr.discriminator_projection_head), s):
+        syn.deterministic_fill_(mod, seed)
+    tr.finalize()
+    tr.train()
+    return tr
+
+
+def test_v4_train_steps_vs_golden():
+    g, m = load_golden("v4_B6_N32_C4_K4")
+    B, N, C, K, steps = m["B"], m["N"], m["C"], m["K"], m["steps"]
+    tr = _trainer_from_golden(m)
+    tr.set_prior_means(torch.from_numpy(g["means"]))
+    for s in range(steps):
+        pcs = syn.synthetic_pcs(B, T, N, C, seed=m["pcs_seed0"] + s).to(DEV).permute(0, 3, 1, 2)
+        gt = syn.synthetic_labels(B, K, seed=m["gt_seed0"] + s).to(DEV)
+        z0 = syn.synthetic_z0(B, 32, seed=m["z0_seed0"] + s).to(DEV)
+        al = syn.synthetic_alphas(B, seed=m["alpha_seed0"] + s).to(DEV)
+        out = tr.step(pcs, gt, z0, al)
+        got = np.array([out[k].item() for k in ("d_loss", "gp", "rec_loss", "loss_g", "sup_loss", "tot_loss")])
+        ref = g[f"s{s}.losses"]
+        assert np.allclose(got, ref, rtol=TOL, atol=1e-5), (s, got, ref)
+        assert np.array_equal(out["preds"].cpu().numpy(), g[f"s{s}.preds"]), "argmax labels must be bit-exact"
+        _close(out["sup_fvs"], g[f"s{s}.sup_fvs"], what=f"sup_fvs step {s}")
+        _close(out["out_labels"], g[f"s{s}.out_labels"], what=f"out_labels step {s}")
+        if s == 0:
+            for name, _ in tr.discriminator.named_parameters():
+                check_against_record(g, "s0.dgrad.", name, tr.flat_d.grad_views["D." + name], 2e-4, scale_floor=1e-3)
+            wscale = max(float(np.abs(g[k]).max()) for k in g.files
+                         if k.startswith("s0.ggrad.E.") and k.endswith("weight::full"))
+            for name, gv in tr.flat_g.grad_views.items():
+                if is_pre_bn_bias(name):
+                    assert float(gv.abs().max()) <= 1e-4 * wscale + 1e-4
+                    continue
+                check_against_record(g, "s0.ggrad.", name, gv, 5e-4)
+        if s in (0, steps - 1):
+            for nm, mod in tr.modules().items():
+                for name, v in mod.state_dict().items():
+                    if is_pre_bn_bias(name):
+                        continue
+                    if name.endswith("running_mean"):
+                        check_against_record(g, f"s{s}.param.{nm}.", name, v, 2e-5, scale_floor=5.0)
+                        continue
+                    check_against_record(g, f"s{s}.param.{nm}.", name, v, 5e-5)
+
+
+def test_v4_step_bf16_mode_close_to_fp32():
+    """bf16-MFMA throughput mode: fp32 accumulation, bf16 PointNet activations.
+    Stated tolerance: losses within 2e-2 relative, embeddings within 5e-2 of
+    their scale; argmax agreement reported, not required (bf16 cannot be
+    bit-exact through four BatchNorm layers)."""
+    g, m = load_golden("v4_B6_N32_C4_K4")
+    B, N, C, K = m["B"], m["N"], m["C"], m["K"]
+    tr = _trainer_from_golden(m, precision="bf16")
+    tr.set_prior_means(torch.from_numpy(g["means"]))
+    pcs = syn.synthetic_pcs(B, T, N, C, seed=m["pcs_seed0"]).to(DEV).permute(0, 3, 1, 2)
+    gt = syn.synthetic_labels(B, K, seed=m["gt_seed0"]).to(DEV)
+    out = tr.step(pcs, gt, syn.synthetic_z0(B, 32, seed=m["z0_seed0"]).to(DEV),
+                  syn.synthetic_alphas(B, seed=m["alpha_seed0"]).to(DEV))
+    got = np.array([out[k].item() for k in ("d_loss", "gp", "rec_loss", "loss_g", "sup_loss", "tot_loss")])
+    ref = g["s0.losses"]
+    assert np.allclose(got, ref, rtol=2e-2, atol=2e-2), (got, ref)
+    _close(out["sup_fvs"], g["s0.sup_fvs"], 5e-2, what="bf16 sup_fvs")
+
+
+def test_v4_step_vs_oracle_config_like_shapes():
+    """Seeded comparison with the CPU oracle at a mid-size shape the oracle
+    finishes in seconds (B=8, N=64, C=5, K=8) -- covers C=5 and a wider decoder."""
+    B, N, C, K = 8, 64, 5, 8
+    m = dict(B=B, N=N, C=C, K=K, fill_seeds=[20, 21, 22, 23, 24])
+    tr = _trainer_from_golden(m)
+    means = O.sample_distant_points(32, K, 10, 10).float()
+    tr.set_prior_means(means)
+    def sd_cpu(mod):
+        return {k: v.detach().cpu().clone() for k, v in mod.state_dict().items()}
+
+    st = O.V4State(*(sd_cpu(mod) for mod in (tr.encoder, tr.decoder, tr.discriminator,
+                                             tr.decoder_projection_head,
+                                             tr.discriminator_projection_head)), means, C, T, N, K)
+    cfg = dict(LR=1e-4, B1=0.9, B2=0.99, GP_WEIGHT=15, ADV_WEIGHT=1)
+    for s in range(2):
+        pcs = syn.synthetic_pcs(B, T, N, C, seed=500 + s)
+        gt = syn.synthetic_labels(B, K, seed=600 + s)
+        z0 = syn.synthetic_z0(B, 32, seed=700 + s)
+        al = syn.synthetic_alphas(B, seed=800 + s)
+        ref = O.v4_train_step(st, pcs.permute(0, 3, 1, 2), gt, z0, al, cfg)
+        out = tr.step(pcs.to(DEV).permute(0, 3, 1, 2), gt.to(DEV), z0.to(DEV), al.to(DEV))
+        for k in ("d_loss", "gp", "rec_loss", "loss_g", "sup_loss", "tot_loss"):
+            assert abs(out[k].item() - ref[k].item()) <= TOL * abs(ref[k].item()) + 1e-5, (s, k, out[k].item(), ref[k].item())
+        assert torch.equal(out["preds"].cpu(), ref["preds"])
+        _close(out["sup_fvs"], ref["sup_fvs"], what="sup_fvs")
+
+
+def test_state_dict_roundtrip_and_manifest():
+    g, _ = load_golden("misc")
+    man = json.loads(str(g["manifest_N32_C4_K8"]))
+    constants.NFEATURES = 4
+    enc = models.CGEncoder(8, nmax_points=32, use_projection_head=True).to(DEV)
+    assert list(enc.state_dict().keys()) == list(man["E"].keys())
+    sd = {k: torch.randn_like(v) if v.dtype.is_floating_point else v for k, v in enc.state_dict().items()}
+    enc.load_state_dict(sd)
+    for k, v in enc.state_dict().items():
+        assert torch.equal(v, sd[k])
+
+
+def test_cpu_input_is_refused():
+    constants.NFEATURES = 4
+    enc = models.CGEncoder(4, nmax_points=32).float()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        enc(torch.zeros(2, 4, 30, 32))
+
+
+def test_full_size_properties_config2():
+    """Size-independent checks at BASELINE config 2 (B=64, T=30, N=128, C=4):
+    BatchNorm'd features are finite, the pooled PointNet output equals the mean of
+    per-sequence evaluation (eval mode => no cross-sample coupling), Chamfer of a
+    cloud with itself is 0 and is permutation invariant."""
+    F_hip.set_precision("fp32")
+    B, N, C, K = 64, 128, 4, 8
+    enc = make_encoder(K, N, C, True, seed=0).to(DEV).eval()
+    x = syn.synthetic_pcs(B, T, N, C, seed=1234).to(DEV).permute(0, 3, 1, 2)
+    with torch.no_grad():
+        oc, fv = enc(x)
+        oc1, fv1 = enc(x[5:6])
+    assert torch.isfinite(oc).all() and torch.isfinite(fv).all()
+    _close(fv[5:6], fv1, 1e-5, what="eval-mode per-sequence independence")
+    perm = torch.randperm(N, device=DEV)
+    with torch.no_grad():
+        _, fvp = enc(x[:4][:, :, :, perm])
+    _close(fvp, fv[:4], 1e-4, what="point-permutation invariance of the set encoder")
+    loss_fn = SeqChamferLoss()
+    assert abs(loss_fn(x, x).item()) < 1e-3
+    a = loss_fn(x[:, :, :, perm], x).item()
+    assert abs(a) < 1e-3

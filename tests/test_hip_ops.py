@@ -1,0 +1,231 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against fp64 CPU
+arithmetic / the oracle.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from opensetgaitrecognition_pcaa_amd import ops
+from opensetgaitrecognition_pcaa_amd._lib import ACT_ELU, ACT_NONE, KC, PCAA_BF16, PCAA_F32, RC
+from oracle import pcaa_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(shape, seed, scale=1.0):
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float32))
+
+
+def _mk(layout, rows, K, seed, dtype):
+    """operand with logical shape (rows, K) stored per layout; returns (device tensor, logical fp64)."""
+    logical = _rand((rows, K), seed)
+    if dtype == torch.bfloat16:
+        logical = logical.bfloat16().float()
+    stored = logical if layout == KC else logical.t().contiguous()
+    return stored.to(DEV).to(dtype).contiguous(), logical.double()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 70, 45), (64, 15360 // 8, 960), (1000, 512, 512),
+                                   (37, 5, 1125), (256, 4, 512), (300, 130, 33)])
+@pytest.mark.parametrize("al,bl", [(KC, KC), (KC, RC), (RC, KC), (RC, RC)])
+def test_gemm_f32_layouts(M, N, K, al, bl):
+    A, Ad = _mk(al, M, K, 1, torch.float32)
+    B, Bd = _mk(bl, N, K, 2, torch.float32)
+    bias = _rand((N,), 3).to(DEV)
+    C = ops.gemm(A, al, B, bl, M, N, K, bias=bias)
+    ref = Ad @ Bd.t() + bias.cpu().double()
+    err = (C.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-6 * K ** 0.5 * ref.abs().max().item() + 1e-6, err
+
+
+@pytest.mark.parametrize("M,N,K,sk", [(64, 960, 7680, 8), (512, 512, 24576, 16), (130, 70, 4000, 5)])
+def test_gemm_split_k_atomic(M, N, K, sk):
+    A, Ad = _mk(RC, M, K, 4, torch.float32)
+    B, Bd = _mk(RC, N, K, 5, torch.float32)
+    C = ops.gemm(A, RC, B, RC, M, N, K, split_k=sk, accumulate=True)
+    ref = Ad @ Bd.t()
+    assert (C.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() * 4
+    # accumulate on top of an existing tensor, with bias
+    C0 = _rand((M, N), 6).to(DEV)
+    bias = _rand((N,), 7).to(DEV)
+    C1 = ops.gemm(A, RC, B, RC, M, N, K, out=C0.clone(), bias=bias, split_k=sk, accumulate=True)
+    ref1 = ref + C0.cpu().double() + bias.cpu().double()
+    assert (C1.cpu().double() - ref1).abs().max().item() <= 1e-5 * ref1.abs().max().item() * 4
+
+
+@pytest.mark.parametrize("M,N,K", [(3840, 512, 512), (1000, 1024, 64), (300, 96, 40)])
+def test_gemm_colstats(M, N, K):
+    A, Ad = _mk(KC, M, K, 8, torch.float32)
+    B, Bd = _mk(KC, N, K, 9, torch.float32)
+    bias = _rand((N,), 10).to(DEV)
+    stats = ops.new_stats(N, DEV)
+    C = ops.gemm(A, KC, B, KC, M, N, K, bias=bias, colstats=stats)
+    acc = Ad @ Bd.t()
+    s = stats.sum(0).cpu()
+    assert torch.allclose(s[0], acc.sum(0), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[1], (acc * acc).sum(0), rtol=1e-5, atol=1e-3)
+    assert (C.cpu().double() - (acc + bias.cpu().double())).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1000, 512, 512), (3840, 1024, 1024), (130, 72, 520)])
+@pytest.mark.parametrize("bdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_gemm_bf16(M, N, K, bdt, cdt):
+    A, Ad = _mk(KC, M, K, 11, torch.bfloat16)
+    B, Bd = _mk(KC, N, K, 12, bdt)
+    Bd = Bd.float().bfloat16().double()     # fp32 B operands are rounded to bf16 when staged
+    bias = _rand((N,), 13).to(DEV)
+    stats = ops.new_stats(N, DEV)
+    C = ops.gemm(A, KC, B, KC, M, N, K, bias=bias, colstats=stats, out_dtype=cdt, math=PCAA_BF16)
+    acc = Ad @ Bd.t()
+    ref = acc + bias.cpu().double()
+    tol = 1e-5 if cdt == torch.float32 else 1e-2
+    assert (C.cpu().double() - ref).abs().max().item() <= tol * ref.abs().max().item()
+    s = stats.sum(0).cpu()
+    assert torch.allclose(s[0], acc.sum(0), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(s[1], (acc * acc).sum(0), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("al,bl", [(KC, KC), (RC, RC), (KC, RC)])
+def test_gemm_f32_math_bf16_storage(al, bl):
+    M, N, K = 520, 260, 1000
+    A, Ad = _mk(al, M, K, 14, torch.bfloat16)
+    B, Bd = _mk(bl, N, K, 15, torch.bfloat16)
+    C = ops.gemm(A, al, B, bl, M, N, K)
+    ref = Ad @ Bd.t()
+    assert (C.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    B2, B2d = _mk(bl, N, K, 16, torch.float32)
+    C2 = ops.gemm(A, al, B2, bl, M, N, K)
+    ref2 = Ad @ B2d.t()
+    assert (C2.cpu().double() - ref2).abs().max().item() <= 1e-5 * ref2.abs().max().item()
+
+
+class _BN:
+    def __init__(self, ch, seed):
+        self.weight = (1 + 0.1 * _rand((ch,), seed)).to(DEV)
+        self.bias = (0.1 * _rand((ch,), seed + 1)).to(DEV)
+        self.running_mean = (0.1 * _rand((ch,), seed + 2)).to(DEV)
+        self.running_var = (1 + 0.1 * _rand((ch,), seed + 3).abs()).to(DEV)
+        self.num_batches_tracked = torch.zeros((), dtype=torch.int64, device=DEV)
+        self.momentum, self.eps = 0.1, 1e-5
+
+
+@pytest.mark.parametrize("rows,ch,dtype", [(3840, 1024, torch.float32), (1000, 512, torch.float32),
+                                           (180, 16, torch.float32), (3840, 512, torch.bfloat16)])
+def test_bn_forward_backward_chain(rows, ch, dtype):
+    """gemm(+stats) -> finalize -> bn_act_fwd ; bwd_dz -> finalize -> dy  vs fp64 autograd."""
+    K = 64
+    A, Ad = _mk(KC, rows, K, 20, torch.float32)
+    W, Wd = _mk(KC, ch, K, 21, torch.float32)
+    lin_b = (0.3 * _rand((ch,), 22)).to(DEV)
+    bn = _BN(ch, 23)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    stats = ops.new_stats(ch, DEV)
+    y = ops.gemm(A, KC, W, KC, rows, ch, K, bias=lin_b, colstats=stats, out_dtype=dtype)
+    scale, shift, mean, rstd = ops.bn_finalize(stats, rows, lin_b, bn, ch)
+    a = ops.bn_act_fwd(y, scale, shift)
+    # fp64 reference with autograd
+    yd = (Ad @ Wd.t() + lin_b.cpu().double()).requires_grad_(True)
+    mu = yd.mean(0)
+    var = ((yd - mu) ** 2).mean(0)
+    zd = (yd - mu) / torch.sqrt(var + 1e-5) * bn.weight.cpu().double() + bn.bias.cpu().double()
+    ad = torch.where(zd > 0, zd, torch.expm1(zd))
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    assert torch.allclose(mean.cpu().double(), mu.detach(), rtol=1e-5, atol=1e-5)
+    assert (a.float().cpu().double() - ad.detach()).abs().max().item() <= tol * max(1.0, ad.abs().max().item())
+    assert torch.allclose(bn.running_mean.cpu().double(), 0.9 * rm0.cpu().double() + 0.1 * mu.detach(), atol=1e-5)
+    assert torch.allclose(bn.running_var.cpu().double(),
+                          0.9 * rv0.cpu().double() + 0.1 * var.detach() * rows / (rows - 1), rtol=1e-4, atol=1e-5)
+    assert int(bn.num_batches_tracked.item()) == 1
+    # backward
+    g = _rand((rows, ch), 24)
+    (ad * g.double()).sum().backward()
+    da = g.to(DEV).to(dtype)
+    dz, st2 = ops.bn_act_bwd_dz(y, scale, shift, mean, rstd, da=da)
+    coef, dgamma, dbeta = ops.bn_bwd_finalize(st2, rows, bn, mean, rstd, ch)
+    dy = ops.bn_bwd_dy(dz, y, coef)
+    ref = yd.grad
+    gtol = 1e-4 if dtype == torch.float32 else 5e-2
+    assert (dy.float().cpu().double() - ref).abs().max().item() <= gtol * ref.abs().max().item()
+    # pooled variants
+    G = rows // 30
+    pooled = ops.bn_act_meanpool_fwd(y[: G * 30].contiguous(), scale, shift, G, 30)
+    refp = ad.detach()[: G * 30].view(G, 30, ch).mean(1)
+    assert (pooled.cpu().double() - refp).abs().max().item() <= tol * max(1.0, refp.abs().max().item())
+
+
+def test_bias_act_elu_colsum_sum():
+    x = _rand((70, 333), 30).to(DEV)
+    b = _rand((333,), 31).to(DEV)
+    y = ops.bias_act_(x.clone(), b, ACT_ELU)
+    ref = O.elu(x.cpu() + b.cpu())
+    assert torch.allclose(y.cpu(), ref, atol=1e-6)
+    da = _rand((70, 333), 32).to(DEV)
+    dz = ops.elu_bwd_from_out(da, y)
+    z = x.cpu() + b.cpu()
+    refd = da.cpu() * torch.where(z > 0, torch.ones_like(z), torch.exp(z))
+    assert torch.allclose(dz.cpu(), refd, atol=1e-5)
+    assert torch.allclose(ops.colsum(x).cpu(), x.cpu().sum(0), atol=1e-4)
+    assert abs(ops.total(x, 0.5).item() - 0.5 * x.cpu().double().sum().item()) < 1e-3
+    assert torch.allclose(ops.rowsum(x, 2.0).cpu(), 2 * x.cpu().sum(1), atol=1e-4)
+
+
+@pytest.mark.parametrize("d", [1, 2, 4])
+def test_dtc_im2col_col2im_adjoint(d):
+    B, T, Cin = 3, 30, 16
+    a = _rand((B * T, Cin), 40).to(DEV)
+    col = ops.dtc_im2col(a, B, T, Cin, d)
+    a3 = a.cpu().view(B, T, Cin)
+    ref = torch.zeros(B, T, Cin, 3)
+    for tap in range(3):
+        sh = (2 - tap) * d
+        if sh < T:
+            ref[:, sh:, :, tap] = a3[:, : T - sh]
+    assert torch.equal(col.cpu(), ref.view(B * T, Cin * 3))
+    # adjoint: <im2col(a), g> == <a, col2im(g)>
+    g = _rand((B * T, Cin * 3), 41).to(DEV)
+    back = ops.dtc_col2im(g, B, T, Cin, d)
+    lhs = (col.cpu().double() * g.cpu().double()).sum()
+    rhs = (a.cpu().double() * back.cpu().double()).sum()
+    assert abs(lhs - rhs) < 1e-6 * abs(lhs) + 1e-6
+
+
+def test_pack_points_and_prior():
+    x = _rand((3, 5, 30, 17), 50).to(DEV)
+    assert torch.equal(ops.pack_points(x).cpu(), x.cpu().permute(0, 2, 3, 1).contiguous())
+    z0 = _rand((6, 32), 51).to(DEV)
+    means = _rand((4, 32), 52).to(DEV)
+    gt = torch.tensor([0, 3, 1, 1, 2, 0], device=DEV)
+    z, oh = ops.prior_sample(z0, means, gt, 4)
+    assert torch.allclose(z.cpu(), z0.cpu() + means.cpu()[gt.cpu()])
+    assert torch.equal(oh.cpu(), torch.nn.functional.one_hot(gt.cpu(), 4).float())
+
+
+def test_adam_matches_reference_formula():
+    n = 1003
+    p = _rand((n + 1,), 60)[:n].clone()
+    params = {"p": p.clone()}
+    state = {}
+    pd, m, v = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    # 16-B aligned storage
+    for s in range(1, 4):
+        g = _rand((n,), 60 + s)
+        O.adam_step(params, {"p": g}, state, 1e-4, 0.9, 0.99)
+        ops.adam_step_(pd, g.to(DEV), m, v, 1e-4, 0.9, 0.99, 1e-8, s)
+        assert torch.allclose(pd.cpu(), params["p"], rtol=1e-6, atol=1e-7), s
+
+
+def test_cross_entropy_and_preds():
+    B, K = 37, 6
+    x = _rand((B, K), 70, 3.0)
+    x[3] = -20.0            # saturated ELU logits: exact ties -> first index
+    x[5, 2] = x[5, 4] = 5.0
+    t = torch.from_numpy(np.random.default_rng(71).integers(0, K, B))
+    xg = x.clone().requires_grad_(True)
+    ref = O.cross_entropy(xg, t)
+    ref.backward()
+    loss, dl, preds = ops.cross_entropy(x.to(DEV), t.to(DEV), want_loss=True, want_grad=True, want_preds=True)
+    assert abs(loss.item() - ref.item()) < 1e-5
+    assert torch.allclose(dl.cpu(), xg.grad, atol=1e-6)
+    assert torch.equal(preds.cpu(), O.predicted_labels(x))
