@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""PCAA train-step throughput on MI355X (BASELINE.json metric: gait sequences/s
+of a full V4 train step -- encoder + decoder + discriminator forward/backward,
+WGAN-GP D-step, Chamfer, both Adams -- on synthetic mmGait10-shaped batches).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload at every N: BASELINE config[1], B=64 sequences per GPU, T=30, N=128
+points, C=4 features, K=8 classes, inputs resident in HBM before the timed
+region; data parallel over N GPUs (weak scaling: global batch 64*N, RCCL
+all-reduce of the flat gradient buffers).  One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3       # f32-input MFMA
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--points", type=int, default=128)
+    ap.add_argument("--features", type=int, default=4)
+    ap.add_argument("--classes", type=int, default=8)
+    ap.add_argument("--sync-bn", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(B, N, C, K, T):
+    """The oracle (plain-PyTorch restatement of the reference, kind="port")
+    timed on this host's cores for ONE full train step of the same workload."""
+    from opensetgaitrecognition_pcaa_amd import constants, models, synthetic as syn
+    from oracle import pcaa_oracle as O
+    ncpu = os.cpu_count() or 1
+    constants.NFEATURES = C
+    enc = models.CGEncoder(K, nmax_points=N, use_projection_head=True).float()
+    dec = models.CGDecoder(input_dim=64, nmax_points=N).float()
+    disc = models.CGDiscriminator(K).float()
+    gph = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.ELU()).float()
+    dph = torch.nn.Sequential(torch.nn.Linear(64, 32), torch.nn.ELU()).float()
+    sds = []
+    for i, m in enumerate((enc, dec, disc, gph, dph)):
+        syn.deterministic_fill_(m, i)
+        sds.append({k: v.detach().clone() for k, v in m.state_dict().items()})
+    means = O.sample_distant_points(32, K, 10, 10).float()
+    st = O.V4State(*sds, means, C, T, N, K)
+    cfg = dict(LR=1e-4, B1=0.9, B2=0.99, GP_WEIGHT=15, ADV_WEIGHT=1)
+    pcs = syn.synthetic_pcs(B, T, N, C, seed=1234).permute(0, 3, 1, 2)
+    gt = syn.synthetic_labels(B, K, seed=1235)
+    z0 = syn.synthetic_z0(B, 32, seed=1236)
+    al = syn.synthetic_alphas(B, seed=1237)
+
+    def run(b, threads):
+        torch.set_num_threads(threads)
+        t0 = time.perf_counter()
+        O.v4_train_step(st, pcs[:b], gt[:b], z0[:b], al[:b], cfg)
+        return time.perf_counter() - t0
+
+    # torch's CPU kernels do not scale to every core of a big host (256 threads
+    # ran this step 10x slower than 32): pick the best thread count on a small
+    # sub-batch first, then time the bounded sample with it.
+    cal_b = min(8, B)
+    trials = {t: run(cal_b, t) for t in sorted({min(ncpu, t) for t in (16, 32, 64)})}
+    threads = min(trials, key=trials.get)
+    sample_b = B if trials[threads] * (B / cal_b) < 45.0 else max(cal_b, B // 4)
+    dt = run(sample_b, threads)
+    return {"value": sample_b / dt, "unit": "sequences/s", "cores": threads, "kind": "port",
+            "sample": f"1 full V4 train step (oracle, plain PyTorch fp32) at B={sample_b} of the workload's {B}, "
+                      f"N={N}, C={C}: {dt:.1f} s; {threads} threads (best of {sorted(trials)} on a B={cal_b} "
+                      f"calibration step) on a {ncpu}-CPU host, torch {torch.__version__}"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    from opensetgaitrecognition_pcaa_amd import constants, functional as F_hip, ops, synthetic as syn
+    from opensetgaitrecognition_pcaa_amd.train import PCAATrainer
+    from opensetgaitrecognition_pcaa_amd.utils import sample_distant_points
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        pg = dist.group.WORLD
+
+    B, N, C, K, T = a.batch, a.points, a.features, a.classes, constants.NSTEPS
+    constants.NFEATURES = C
+    cfg = dict(constants.CONFIG)
+    cfg.update(NMAX=N, TRAIN_CLASSES=list(range(K)), BATCH_SIZE=B)
+    F_hip.set_precision(a.precision)
+    tr = PCAATrainer(cfg, device=dev, precision=a.precision, process_group=pg, sync_bn=a.sync_bn)
+    for i, m in enumerate((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head,
+                           tr.discriminator_projection_head)):
+        syn.deterministic_fill_(m, i)
+    tr.set_prior_means(sample_distant_points(32, K, 10, 10))
+    tr.finalize()
+    tr.train()
+    # inputs resident in HBM (point-major storage, [B,C,T,N] view), different data per rank
+    pcs = syn.synthetic_pcs(B, T, N, C, seed=1234 + rank).to(dev).permute(0, 3, 1, 2)
+    gt = syn.synthetic_labels(B, K, seed=1235 + rank).to(dev)
+    z0 = syn.synthetic_z0(B, 32, seed=1236 + rank).to(dev)
+    al = syn.synthetic_alphas(B, seed=1237 + rank).to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out = tr.step(pcs, gt, z0, al)
+    barrier()
+    timer = None
+    if not a.no_kernel_timing:
+        timer = ops.LaunchTimer()
+        ops.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = tr.step(pcs, gt, z0, al)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.set_timer(None)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_ok = bool(torch.isfinite(out["tot_loss"]).item())
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        value = world * B * a.steps / dt
+        line = {
+            "metric": "gait sequences/sec (train step)", "value": value, "unit": "sequences/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if a.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"PCAA V4 train step (enc+dec+disc fwd/bwd, WGAN-GP, Chamfer, 2x Adam), "
+                                   f"B={B}/GPU T={T} N={N} C={C} K={K}, BASELINE config[1]",
+                       "global_batch": B * world, "precision": a.precision,
+                       "parallelism": f"dp{world}", "sync_bn": bool(a.sync_bn), "finite_loss": loss_ok},
+        }
+        if timer is not None:
+            agg = timer.summary()
+            dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+            name, r = dom
+            peak = PEAK_BF16_TFLOPS if name == "gemm_bf16_kernel" else PEAK_F32_TFLOPS
+            achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+            line["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak,
+                                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                                "launches_per_step": r["launches"] / a.steps,
+                                "avg_launch_ms": r["ms"] / r["launches"],
+                                "kernel_ms_per_step": r["ms"] / a.steps,
+                                "all_gemm_ms_per_step": sum(v["ms"] for v in agg.values()) / a.steps}
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(B, N, C, K, T)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,6 +46,34 @@ def _chk(t, name, dtype=None, dim=None):
     return t
 
 
+class LaunchTimer:
+    """Optional per-launch HIP-event timing of pcaa_gemm calls (bench.py uses it
+    to measure the dominant kernel's average duration inside the timed region;
+    events are recorded on the stream the kernels are launched on)."""
+
+    def __init__(self):
+        self.records = []      # (key, flops, bytes, start_event, end_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, flops, nbytes, e0, e1 in self.records:
+            a = agg.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            a["launches"] += 1
+            a["ms"] += e0.elapsed_time(e1)
+            a["flops"] += flops
+            a["bytes"] += nbytes
+        return agg
+
+
+TIMER = None
+
+
+def set_timer(timer):
+    global TIMER
+    TIMER = timer
+
+
 def new_stats(ch, device):
     return torch.zeros((NREP, 2, ch), dtype=torch.float64, device=device)
 
@@ -83,9 +111,19 @@ def gemm(A, a_layout, B, b_layout, M, N, K, *, lda=None, ldb=None, out=None, out
         if tuple(colstats.shape) != (NREP, 2, N):
             raise ValueError("gemm: colstats shape")
     lib = _lib.load()
+    timer = TIMER
+    if timer is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib.pcaa_gemm(math, _p(A), _dt(A), a_layout, lda, _p(B), _dt(B), b_layout, ldb,
                         _p(out), _dt(out), N, M, N, K, _p(bias), _p(colstats), NREP,
                         int(split_k), int(bool(accumulate)), _s()), "pcaa_gemm")
+    if timer is not None:
+        e1.record()
+        key = ("gemm_bf16_kernel" if math == PCAA_BF16 else "gemm_f32_kernel")
+        nbytes = A.numel() * A.element_size() + B.numel() * B.element_size() + out.numel() * out.element_size()
+        timer.records.append((key, 2.0 * M * N * K, float(nbytes), e0, e1))
     return out
 
 

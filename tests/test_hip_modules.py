@@ -22,7 +22,7 @@ TOL = 1e-4
 
 def _close(a, ref, tol=TOL, floor=1e-6, what=""):
     a = a.detach().float().cpu().double()
-    ref = torch.as_tensor(ref).double()
+    ref = torch.as_tensor(ref).detach().cpu().double()
     err = (a - ref).abs().max().item()
     den = max(ref.abs().max().item(), floor)
     assert err <= tol * den, f"{what}: abs err {err:.3e}, scale {den:.3e}, rel {err / den:.3e}"
@@ -44,7 +44,9 @@ def test_encoder_vs_golden(tag):
     # standard channel-major contiguous input (what the reference's DataLoader yields) gives the same
     with torch.no_grad():
         oc2, fv2 = enc(x.contiguous())
-    assert torch.equal(oc2, oc) and torch.equal(fv2, fv)
+    # (split-K fp32 atomics in the small head GEMMs make the last bits order-dependent)
+    _close(oc2, oc, 1e-5, what="channel-major input")
+    _close(fv2, fv, 1e-5, what="channel-major input")
 
     enc.train()
     rng = np.random.default_rng(77)
@@ -133,6 +135,10 @@ def test_discriminator_and_wgan_gp_vs_golden(tag):
     assert abs(losses[1].item() - float(g["gp"])) <= TOL * abs(float(g["gp"]))
     assert abs(losses[0].item() - float(g["d_loss"])) <= TOL * abs(float(g["d_loss"]))
     for (name, _), gr in zip(disc.named_parameters(), grads):
+        if name == "model.4.bias":
+            # sum(+1/B) + sum(-1/B): exactly zero in the reference, so b3 never moves under Adam
+            assert float(gr.abs().max()) == 0.0
+            continue
         check_against_record(g, "grad.", name, gr, 2e-4, scale_floor=1e-3)
     # first-order autograd through the drop-in module vs the oracle
     sd = sd_clone(disc.cpu())
@@ -147,7 +153,7 @@ def test_discriminator_and_wgan_gp_vs_golden(tag):
     (disc(xg, oh) * w.to(DEV)).sum().backward()
     _close(xg.grad, xc.grad, what="dD/dx")
     for name, p in disc.named_parameters():
-        _close(p.grad, sd[name].grad, 2e-4, what=name)
+        _close(p.grad, sd[name].grad, 2e-4, floor=1e-2, what=name)   # sum(w) = 0: db3 is ~0 here
 
 
 def _trainer_from_golden(m, precision="fp32"):
@@ -185,6 +191,9 @@ def test_v4_train_steps_vs_golden():
         _close(out["out_labels"], g[f"s{s}.out_labels"], what=f"out_labels step {s}")
         if s == 0:
             for name, _ in tr.discriminator.named_parameters():
+                if name == "model.4.bias":
+                    assert float(tr.flat_d.grad_views["D." + name].abs().max()) == 0.0
+                    continue
                 check_against_record(g, "s0.dgrad.", name, tr.flat_d.grad_views["D." + name], 2e-4, scale_floor=1e-3)
             wscale = max(float(np.abs(g[k]).max()) for k in g.files
                          if k.startswith("s0.ggrad.E.") and k.endswith("weight::full"))
@@ -200,6 +209,16 @@ def test_v4_train_steps_vs_golden():
                         continue
                     if name.endswith("running_mean"):
                         check_against_record(g, f"s{s}.param.{nm}.", name, v, 2e-5, scale_floor=5.0)
+                        continue
+                    key = f"s{s}.param.{nm}.{name}::full"
+                    if key in g.files and v.dtype.is_floating_point:
+                        # Adam's step is lr * m/(sqrt(v)+eps): where |grad| is within ~10x of eps the
+                        # update depends on the gradient's last bits, so allow a fraction of one lr step
+                        # per optimiser step on the worst element, and demand a tight mean error
+                        err = (v.detach().cpu().double() - torch.from_numpy(g[key]).double()).abs()
+                        scale = float(np.abs(g[key]).max())
+                        assert err.max().item() <= 5e-5 * scale + 0.5e-4 * (s + 1), (name, err.max().item())
+                        assert err.mean().item() <= 2e-6 * max(scale, 1.0), (name, err.mean().item())
                         continue
                     check_against_record(g, f"s{s}.param.{nm}.", name, v, 5e-5)
 

@@ -63,9 +63,11 @@ def test_gemm_colstats(M, N, K):
     C = ops.gemm(A, KC, B, KC, M, N, K, bias=bias, colstats=stats)
     acc = Ad @ Bd.t()
     s = stats.sum(0).cpu()
-    assert torch.allclose(s[0], acc.sum(0), rtol=1e-5, atol=1e-3)
-    assert torch.allclose(s[1], (acc * acc).sum(0), rtol=1e-5, atol=1e-3)
-    assert (C.cpu().double() - (acc + bias.cpu().double())).abs().max().item() < 1e-4
+    # fp32 accumulators carry ~1e-7 * sqrt(K) relative rounding each; sums over M rows random-walk
+    scale = acc.abs().max().item()
+    assert (s[0] - acc.sum(0)).abs().max().item() <= 2e-6 * scale * M ** 0.5 + 1e-4
+    assert torch.allclose(s[1], (acc * acc).sum(0), rtol=2e-6, atol=1e-3)
+    assert (C.cpu().double() - (acc + bias.cpu().double())).abs().max().item() < 1e-5 * scale
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1000, 512, 512), (3840, 1024, 1024), (130, 72, 520)])
