@@ -17,33 +17,15 @@
 // Workgroup -> tile mapping is XCD-aware: the 8 XCDs each walk a contiguous
 // range of tiles with the N-tiles of one M-panel adjacent, so the A panel is
 // re-read from that XCD's L2 and not from HBM.
-#include "common.h"
+#include "gemm_common.h"
 
 namespace {
 
 constexpr int BM = 128, BN = 128;
 constexpr int KC = PCAA_LAYOUT_KC, RC = PCAA_LAYOUT_RC;
 
-struct GemmParams {
-  const void* A; const void* B; void* C;
-  long lda, ldb, ldc;
-  int M, N, K;
-  const float* bias;
-  double* colstats;
-  int nrep;
-  int k_per_split;
-  int atomic;
-};
-
 __device__ __forceinline__ void tile_coords(int M, int N, int& tm, int& tn) {
-  const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
-  const int nb = nbm * nbn;
-  const int bid = blockIdx.x;
-  const int q = nb >> 3, r = nb & 7;
-  const int xcd = bid & 7, idx = bid >> 3;
-  const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  tm = v / nbn;
-  tn = v - tm * nbn;
+  xcd_tile_coords((M + BM - 1) / BM, (N + BN - 1) / BN, tm, tn);
 }
 
 // ---------------------------------------------------------------------------
@@ -416,10 +398,13 @@ extern "C" int pcaa_gemm(int math,
   hipStream_t s = as_stream(stream);
 
   if (math == PCAA_BF16) {
-    PCAA_CHECK_ARG(a_layout == KC && b_layout == KC, "pcaa_gemm: bf16 math needs KC operands");
+    PCAA_CHECK_ARG(a_dtype == PCAA_BF16, "pcaa_gemm: bf16 math needs a bf16 A operand");
+    // big shapes: 256x256-tile kernel (KC x KC forward/dgrad, RC x RC wgrad)
+    if (pcaa_launch_gemm_bf16_big(p, a_dtype, a_layout, b_dtype, b_layout, c_dtype, nsplit, s))
+      PCAA_RETURN_LAUNCH_STATUS("pcaa_gemm(bf16, 256x256)");
+    PCAA_CHECK_ARG(a_layout == KC && b_layout == KC, "pcaa_gemm: bf16 math on this shape needs KC operands");
     PCAA_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "pcaa_gemm: bf16 math needs K, lda, ldb %% 8 == 0");
     PCAA_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "pcaa_gemm: bf16 math needs 16-B aligned operands");
-    PCAA_CHECK_ARG(a_dtype == PCAA_BF16, "pcaa_gemm: bf16 math needs a bf16 A operand");
     if (b_dtype == PCAA_BF16 && c_dtype == PCAA_BF16)
       hipLaunchKernelGGL((gemm_bf16_kernel<bf16_t, bf16_t, bf16_t>), grid, dim3(256), 0, s, p);
     else if (b_dtype == PCAA_BF16 && c_dtype == PCAA_F32)

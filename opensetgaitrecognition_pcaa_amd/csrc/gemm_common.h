@@ -1,0 +1,33 @@
+// Shared between gemm.hip (fp32-MFMA and small-tile bf16 kernels, C-ABI entry)
+// and gemm_bf16.hip (256x256-tile bf16 kernel).
+#pragma once
+#include "common.h"
+
+struct GemmParams {
+  const void* A; const void* B; void* C;
+  long lda, ldb, ldc;
+  int M, N, K;
+  const float* bias;
+  double* colstats;
+  int nrep;
+  int k_per_split;
+  int atomic;
+};
+
+// XCD-aware, bijective block -> (tile_m, tile_n) map: the 8 XCDs (blocks b, b+8,
+// ... share one) each walk a contiguous range of tiles with the N-tiles of one
+// M-panel adjacent, so an A panel is re-read from that XCD's L2.
+__device__ __forceinline__ void xcd_tile_coords(int nbm, int nbn, int& tm, int& tn) {
+  const int nb = nbm * nbn;
+  const int bid = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  tm = v / nbn;
+  tn = v - tm * nbn;
+}
+
+// 256x256-tile bf16 kernel (gemm_bf16.hip).  Returns false if the shape/dtype
+// combination is not served by it (caller falls back to the small-tile kernel).
+bool pcaa_launch_gemm_bf16_big(const GemmParams& p, int a_dtype, int a_layout, int b_dtype, int b_layout,
+                               int c_dtype, int nsplit, hipStream_t stream);

@@ -129,8 +129,14 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
     dy = ops.bn_bwd_dy(dz, y, coef, out=dz)
     K = lhs.shape[1]
     # dW[cout, K] = dy^T . lhs   (contraction over the rows: both operands row-contiguous)
-    sk = ops.pick_split_k(cout, K, rows_local)
-    dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, split_k=sk, accumulate=sk > 1)
+    wgrad_bf16 = (mode == "bf16" and dy.dtype == torch.bfloat16 and lhs.dtype == torch.bfloat16
+                  and cout >= 256 and K >= 128 and cout % 8 == 0 and K % 8 == 0)
+    if wgrad_bf16:
+        sk = ops.pick_split_k(cout, K, rows_local, target_blocks=256, bk=64, tile=256)
+        dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, split_k=sk, accumulate=sk > 1, math=PCAA_BF16)
+    else:
+        sk = ops.pick_split_k(cout, K, rows_local)
+        dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, split_k=sk, accumulate=sk > 1)
     d_lhs = None
     if need_dinput:
         if mode == "bf16" and dy.dtype == torch.bfloat16 and cout % 8 == 0:

@@ -127,8 +127,8 @@ def gemm(A, a_layout, B, b_layout, M, N, K, *, lda=None, ldb=None, out=None, out
     return out
 
 
-def pick_split_k(M, N, K, target_blocks=1024, bk=32):
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+def pick_split_k(M, N, K, target_blocks=1024, bk=32, tile=128):
+    tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
     if tiles >= target_blocks:
         return 1
     s = max(1, target_blocks // tiles)

@@ -89,6 +89,37 @@ def test_gemm_bf16(M, N, K, bdt, cdt):
     assert torch.allclose(s[1], (acc * acc).sum(0), rtol=1e-4, atol=1e-2)
 
 
+@pytest.mark.parametrize("M,N,K,sk", [(512, 1024, 4000, 4), (1024, 1024, 30 * 128 * 3, 16), (256, 128, 520, 1),
+                                      (520, 264, 1000, 3)])
+def test_gemm_bf16_wgrad_rc_rc(M, N, K, sk):
+    """dW = dy^T . a : both operands row-contiguous bf16 (transpose-read LDS image), split-K atomics.
+    Exact-integer operands make a swapped fragment map impossible to miss."""
+    rng = np.random.default_rng(33)
+    Ai = torch.from_numpy(rng.integers(-3, 4, (M, K)).astype(np.float32))
+    Bi = torch.from_numpy(rng.integers(-3, 4, (N, K)).astype(np.float32))
+    A = Ai.t().contiguous().to(DEV).bfloat16()
+    B = Bi.t().contiguous().to(DEV).bfloat16()
+    C = ops.gemm(A, RC, B, RC, M, N, K, split_k=sk, accumulate=sk > 1, math=PCAA_BF16)
+    ref = Ai.double() @ Bi.double().t()
+    assert torch.equal(C.cpu().double(), ref)
+    # random bf16 data
+    A2, A2d = _mk(RC, M, K, 34, torch.bfloat16)
+    B2, B2d = _mk(RC, N, K, 35, torch.bfloat16)
+    C2 = ops.gemm(A2, RC, B2, RC, M, N, K, split_k=sk, accumulate=sk > 1, math=PCAA_BF16)
+    ref2 = A2d @ B2d.t()
+    assert (C2.cpu().double() - ref2).abs().max().item() <= 2e-5 * ref2.abs().max().item()
+
+
+def test_gemm_bf16_big_tile_exact_integers():
+    """asymmetric exact-integer check of the 256x256-tile KC x KC kernel (catches row/col swaps)."""
+    M, N, K = 700, 384, 200
+    rng = np.random.default_rng(36)
+    Ai = torch.from_numpy(rng.integers(-4, 5, (M, K)).astype(np.float32))
+    Bi = torch.from_numpy(rng.integers(-4, 5, (N, K)).astype(np.float32))
+    C = ops.gemm(Ai.to(DEV).bfloat16(), KC, Bi.to(DEV), KC, M, N, K, math=PCAA_BF16)
+    assert torch.equal(C.cpu().double(), Ai.double() @ Bi.double().t())
+
+
 @pytest.mark.parametrize("al,bl", [(KC, KC), (RC, RC), (KC, RC)])
 def test_gemm_f32_math_bf16_storage(al, bl):
     M, N, K = 520, 260, 1000
