@@ -67,6 +67,15 @@ int pcaa_gemm(int math,
               const float* bias, double* colstats, int nrep,
               int split_k, int accumulate, void* stream);
 
+/* First PointNet layer, Conv2d(C -> cout, 1x1) on the raw points x[P,C] (models.py:87-89):
+ * y[P,cout] = x . W[cout,C]^T + bias, with the same BatchNorm statistics as pcaa_gemm;
+ * and its weight gradient dW[cout,C] += dy[P,cout]^T . x (dW must be pre-initialised).
+ * C <= 8; the contraction is too narrow for MFMA, these stream y / dy at HBM rate. */
+int pcaa_pointnet_in_fwd(const float* x, int C, const float* W, const float* bias, void* y, int y_dtype,
+                         long P, int cout, double* stats, int nrep, void* stream);
+int pcaa_pointnet_in_wgrad(const void* dy, int dy_dtype, const float* x, int C, float* dW, long P,
+                           int cout, void* stream);
+
 /* ------------------------------------------------------------------ BatchNorm (+ELU) pieces
  * Training-mode BatchNorm2d/1d + ELU of PointNetModule (models.py:28-29) and
  * DilTempConv1d (models.py:71,77-78), split around the grid-wide statistics

@@ -398,10 +398,10 @@ extern "C" int pcaa_gemm(int math,
   hipStream_t s = as_stream(stream);
 
   if (math == PCAA_BF16) {
-    PCAA_CHECK_ARG(a_dtype == PCAA_BF16, "pcaa_gemm: bf16 math needs a bf16 A operand");
     // big shapes: 256x256-tile kernel (KC x KC forward/dgrad, RC x RC wgrad)
     if (pcaa_launch_gemm_bf16_big(p, a_dtype, a_layout, b_dtype, b_layout, c_dtype, nsplit, s))
       PCAA_RETURN_LAUNCH_STATUS("pcaa_gemm(bf16, 256x256)");
+    PCAA_CHECK_ARG(a_dtype == PCAA_BF16, "pcaa_gemm: bf16 math on this shape needs a bf16 A operand");
     PCAA_CHECK_ARG(a_layout == KC && b_layout == KC, "pcaa_gemm: bf16 math on this shape needs KC operands");
     PCAA_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "pcaa_gemm: bf16 math needs K, lda, ldb %% 8 == 0");
     PCAA_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "pcaa_gemm: bf16 math needs 16-B aligned operands");

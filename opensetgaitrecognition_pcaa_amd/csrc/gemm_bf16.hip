@@ -246,22 +246,34 @@ bool launch(const GemmParams& p, dim3 grid, hipStream_t s) {
 
 bool pcaa_launch_gemm_bf16_big(const GemmParams& p, int a_dtype, int a_layout, int b_dtype, int b_layout,
                                int c_dtype, int nsplit, hipStream_t stream) {
-  if (a_dtype != PCAA_BF16) return false;
-  if (p.M < 256 || p.N < 128) return false;
+  if (p.N < 128) return false;
   if ((p.lda % 8) || (p.ldb % 8) || ((uintptr_t)p.A % 16) || ((uintptr_t)p.B % 16)) return false;
+  // a KC operand needs whole 8-chunks along K, an RC operand whole 8-chunks along its rows
+  if ((a_layout == KC || b_layout == KC) && (p.K % 8)) return false;
+  if (a_layout == RC && (p.M % 8)) return false;
+  if (b_layout == RC && (p.N % 8)) return false;
   const long ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
   if (ntiles >= (1L << 31)) return false;
   dim3 grid((unsigned)ntiles, 1, (unsigned)nsplit);
+  const bool af = a_dtype == PCAA_F32, bf = b_dtype == PCAA_F32, cf = c_dtype == PCAA_F32;
   if (a_layout == KC && b_layout == KC) {
-    if (p.K % 8) return false;
-    if (b_dtype == PCAA_F32 && c_dtype == PCAA_BF16) return launch<bf16_t, float, bf16_t, KC, KC>(p, grid, stream);
-    if (b_dtype == PCAA_F32 && c_dtype == PCAA_F32) return launch<bf16_t, float, float, KC, KC>(p, grid, stream);
-    if (b_dtype == PCAA_BF16 && c_dtype == PCAA_BF16) return launch<bf16_t, bf16_t, bf16_t, KC, KC>(p, grid, stream);
-    return launch<bf16_t, bf16_t, float, KC, KC>(p, grid, stream);
+    // bf16 activations x fp32/bf16 weights (PointNet forward / dgrad), fp32 x fp32 (decoder forward)
+    if (!af && bf && !cf) return launch<bf16_t, float, bf16_t, KC, KC>(p, grid, stream);
+    if (!af && bf && cf) return launch<bf16_t, float, float, KC, KC>(p, grid, stream);
+    if (!af && !bf && !cf) return launch<bf16_t, bf16_t, bf16_t, KC, KC>(p, grid, stream);
+    if (!af && !bf && cf) return launch<bf16_t, bf16_t, float, KC, KC>(p, grid, stream);
+    if (af && bf && cf) return launch<float, float, float, KC, KC>(p, grid, stream);
+    return false;
   }
   if (a_layout == RC && b_layout == RC) {
-    if ((p.M % 8) || (p.N % 8)) return false;
-    if (b_dtype == PCAA_BF16 && c_dtype == PCAA_F32) return launch<bf16_t, bf16_t, float, RC, RC>(p, grid, stream);
+    // wgrad: contraction over rows
+    if (!af && !bf && cf) return launch<bf16_t, bf16_t, float, RC, RC>(p, grid, stream);
+    if (af && bf && cf) return launch<float, float, float, RC, RC>(p, grid, stream);
+    return false;
+  }
+  if (a_layout == KC && b_layout == RC) {
+    // decoder dgrad: dX = dY . W with W stored [out, in]
+    if (af && bf && cf) return launch<float, float, float, KC, RC>(p, grid, stream);
     return false;
   }
   return false;

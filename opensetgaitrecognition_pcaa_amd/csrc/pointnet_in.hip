@@ -1,0 +1,140 @@
+// First PointNet layer (reference models.py:87-89: Conv2d(C -> 512, 1x1) on the raw
+// points) and its weight gradient.  The contraction is only C = 4/5 wide, so
+// this is HBM-bound streaming of the [P, 512] output (forward) or of dy
+// (wgrad), not MFMA work: FMAs from registers, the point tile of each
+// workgroup staged once in LDS, BatchNorm statistics as in the GEMM epilogue.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 8;
+constexpr int FWD_ROWS = 128;    // points per workgroup (forward)
+constexpr int WG_ROWS = 512;     // points per workgroup (wgrad)
+
+template <typename T>
+__global__ __launch_bounds__(256) void pointnet_in_fwd_kernel(const float* __restrict__ x, int C,
+                                                              const float* __restrict__ W,   // [cout, C]
+                                                              const float* __restrict__ bias,
+                                                              T* __restrict__ y, long P, int cout,
+                                                              double* __restrict__ stats, int nrep) {
+  __shared__ float xs[FWD_ROWS * MAXC];
+  __shared__ f32x4 red[2][256];
+  const int qpr = cout >> 2, rl = 256 / qpr;
+  const int cq = threadIdx.x % qpr, rlane = threadIdx.x / qpr;
+  const long r0 = (long)blockIdx.x * FWD_ROWS;
+  const int nrows = (int)min((long)FWD_ROWS, P - r0);
+  for (int e = threadIdx.x; e < FWD_ROWS * MAXC; e += 256) {
+    const int r = e / MAXC, c = e - r * MAXC;
+    xs[e] = (r < nrows && c < C) ? x[(r0 + r) * C + c] : 0.f;
+  }
+  float w[4][MAXC];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) w[j][c] = (c < C) ? W[(cq * 4 + j) * C + c] : 0.f;
+  const f32x4 b = bias ? load4(bias + cq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  for (int r = rlane; r < nrows; r += rl) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const float xv = xs[r * MAXC + c];
+      acc.x = fmaf(w[0][c], xv, acc.x);
+      acc.y = fmaf(w[1][c], xv, acc.y);
+      acc.z = fmaf(w[2][c], xv, acc.z);
+      acc.w = fmaf(w[3][c], xv, acc.w);
+    }
+    s1 += acc;
+    s2 += acc * acc;
+    store4(y + (r0 + r) * cout + cq * 4, acc + b);
+  }
+  if (stats) {
+    red[0][threadIdx.x] = s1;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = threadIdx.x; o < 2 * cout; o += 256) {
+      const int stat = o / cout, cc = o - stat * cout;
+      double v = 0.0;
+      for (int l = 0; l < rl; ++l) v += (double)red[stat][l * qpr + (cc >> 2)][cc & 3];
+      unsafeAtomicAdd(&stats[((long)(blockIdx.x % nrep) * 2 + stat) * cout + cc], v);
+    }
+  }
+}
+
+// dW[o][c] += sum_p dy[p][o] * x[p][c]
+template <typename T>
+__global__ __launch_bounds__(256) void pointnet_in_wgrad_kernel(const T* __restrict__ dy,
+                                                                const float* __restrict__ x, int C,
+                                                                float* __restrict__ dW, long P, int cout) {
+  __shared__ float xs[WG_ROWS * MAXC];
+  const int qpr = cout >> 2, rl = 256 / qpr;
+  const int cq = threadIdx.x % qpr, rlane = threadIdx.x / qpr;
+  const long r0 = (long)blockIdx.x * WG_ROWS;
+  const int nrows = (int)min((long)WG_ROWS, P - r0);
+  for (int e = threadIdx.x; e < WG_ROWS * MAXC; e += 256) {
+    const int r = e / MAXC, c = e - r * MAXC;
+    xs[e] = (r < nrows && c < C) ? x[(r0 + r) * C + c] : 0.f;
+  }
+  __syncthreads();
+  float acc[4][MAXC];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) acc[j][c] = 0.f;
+  for (int r = rlane; r < nrows; r += rl) {
+    const f32x4 d = load4(dy + (r0 + r) * cout + cq * 4);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const float xv = xs[r * MAXC + c];
+      acc[0][c] = fmaf(d.x, xv, acc[0][c]);
+      acc[1][c] = fmaf(d.y, xv, acc[1][c]);
+      acc[2][c] = fmaf(d.z, xv, acc[2][c]);
+      acc[3][c] = fmaf(d.w, xv, acc[3][c]);
+    }
+  }
+  // every (row lane, channel) pair adds its partial: cout*C*rl atomics per workgroup
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) atomicAdd(&dW[(cq * 4 + j) * C + c], acc[j][c]);
+}
+
+inline bool shape_ok(int C, int cout) {
+  if (C < 1 || C > MAXC || cout < 4 || cout > 1024 || (cout & 3)) return false;
+  return (256 % (cout >> 2)) == 0;
+}
+
+}  // namespace
+
+extern "C" int pcaa_pointnet_in_fwd(const float* x, int C, const float* W, const float* bias, void* y,
+                                    int y_dtype, long P, int cout, double* stats, int nrep, void* stream) {
+  PCAA_CHECK_ARG(x && W && y && P >= 1, "pcaa_pointnet_in_fwd: bad args");
+  PCAA_CHECK_ARG(shape_ok(C, cout), "pcaa_pointnet_in_fwd: need C<=%d and cout/4 dividing 256 (C=%d cout=%d)", MAXC, C, cout);
+  PCAA_CHECK_ARG(!stats || nrep >= 1, "pcaa_pointnet_in_fwd: bad nrep");
+  const unsigned grid = (unsigned)cdiv(P, FWD_ROWS);
+  if (y_dtype == PCAA_F32)
+    hipLaunchKernelGGL(pointnet_in_fwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), x, C, W, bias,
+                       (float*)y, P, cout, stats, nrep);
+  else if (y_dtype == PCAA_BF16)
+    hipLaunchKernelGGL(pointnet_in_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), x, C, W, bias,
+                       (bf16_t*)y, P, cout, stats, nrep);
+  else { pcaa_set_error("pcaa_pointnet_in_fwd: bad dtype"); return PCAA_ERR_INVALID_ARG; }
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_fwd");
+}
+
+extern "C" int pcaa_pointnet_in_wgrad(const void* dy, int dy_dtype, const float* x, int C, float* dW, long P,
+                                      int cout, void* stream) {
+  PCAA_CHECK_ARG(dy && x && dW && P >= 1, "pcaa_pointnet_in_wgrad: bad args");
+  PCAA_CHECK_ARG(shape_ok(C, cout), "pcaa_pointnet_in_wgrad: need C<=%d and cout/4 dividing 256 (C=%d cout=%d)", MAXC, C, cout);
+  const unsigned grid = (unsigned)cdiv(P, WG_ROWS);
+  if (dy_dtype == PCAA_F32)
+    hipLaunchKernelGGL(pointnet_in_wgrad_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream),
+                       (const float*)dy, x, C, dW, P, cout);
+  else if (dy_dtype == PCAA_BF16)
+    hipLaunchKernelGGL(pointnet_in_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream),
+                       (const bf16_t*)dy, x, C, dW, P, cout);
+  else { pcaa_set_error("pcaa_pointnet_in_wgrad: bad dtype"); return PCAA_ERR_INVALID_ARG; }
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_wgrad");
+}

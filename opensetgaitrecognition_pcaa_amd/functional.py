@@ -79,8 +79,12 @@ def _linear_bn(a_in, W2d, lin_bias, bn, training, mode, first_layer):
     stats = ops.new_stats(cout, a_in.device) if training else None
     use_bf16 = (mode == "bf16") and a_in.dtype == torch.bfloat16 and cin % 8 == 0
     out_dtype = torch.bfloat16 if (mode == "bf16" and first_layer is not None) else torch.float32
-    y = ops.gemm(a_in, KC, W2d, KC, rows, cout, cin, bias=lin_bias, colstats=stats, out_dtype=out_dtype,
-                 math=PCAA_BF16 if use_bf16 else PCAA_F32)
+    if first_layer is not None and a_in.dtype == torch.float32 and cin <= 8 and ops.pointnet_in_ok(cin, cout):
+        # raw points -> first PointNet layer: C-wide contraction, HBM-bound streaming kernel
+        y = ops.pointnet_in_fwd(a_in, W2d, lin_bias, out_dtype, stats)
+    else:
+        y = ops.gemm(a_in, KC, W2d, KC, rows, cout, cin, bias=lin_bias, colstats=stats, out_dtype=out_dtype,
+                     math=PCAA_BF16 if use_bf16 else PCAA_F32)
     if training:
         count = _sync_stats(stats, rows)
         scale, shift, mean, rstd = ops.bn_finalize(stats, count, lin_bias, bn, cout)
@@ -115,9 +119,11 @@ def pointnet_forward(xp2d, layers, training, mode, pool_rows=0):
 
 
 def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool_scale=1.0,
-                       need_dinput=True, lhs=None):
+                       need_dinput=True, lhs=None, outs=None):
     """Backward of one (linear, BN, ELU) layer.  ``lhs`` is the GEMM's left
-    operand ([rows, K]: the input activation or the im2col matrix).
+    operand ([rows, K]: the input activation or the im2col matrix).  ``outs`` =
+    (dW, dgamma, dbeta) destination views (dW PRE-ZEROED: the trainer's flat
+    gradient buffer) or None to allocate.
     Returns (dW2d, dgamma, dbeta, d_lhs or None)."""
     y = s.y
     rows_local, cout = y.shape
@@ -125,18 +131,24 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
                                   group_rows=group_rows, pool_scale=pool_scale,
                                   out=da if (da is not None and da.dtype == y.dtype) else None)
     _sync_stats(stats, 0)
-    coef, dgamma, dbeta = ops.bn_bwd_finalize(stats, s.rows, bn, s.mean, s.rstd, cout)
+    coef, dgamma, dbeta = ops.bn_bwd_finalize(stats, s.rows, bn, s.mean, s.rstd, cout,
+                                              dgamma=outs[1] if outs else None, dbeta=outs[2] if outs else None)
     dy = ops.bn_bwd_dy(dz, y, coef, out=dz)
     K = lhs.shape[1]
+    dW_out = outs[0].view(cout, K) if outs else None
     # dW[cout, K] = dy^T . lhs   (contraction over the rows: both operands row-contiguous)
     wgrad_bf16 = (mode == "bf16" and dy.dtype == torch.bfloat16 and lhs.dtype == torch.bfloat16
                   and cout >= 256 and K >= 128 and cout % 8 == 0 and K % 8 == 0)
-    if wgrad_bf16:
+    if lhs.dtype == torch.float32 and K <= 8 and s.col is None and ops.pointnet_in_ok(K, cout):
+        dW = ops.pointnet_in_wgrad(dy, lhs, out=dW_out, out_is_zero=True)
+    elif wgrad_bf16:
         sk = ops.pick_split_k(cout, K, rows_local, target_blocks=256, bk=64, tile=256)
-        dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, split_k=sk, accumulate=sk > 1, math=PCAA_BF16)
+        dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, split_k=sk,
+                      accumulate=sk > 1 or dW_out is not None, math=PCAA_BF16)
     else:
         sk = ops.pick_split_k(cout, K, rows_local)
-        dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, split_k=sk, accumulate=sk > 1)
+        dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, split_k=sk,
+                      accumulate=sk > 1 or dW_out is not None)
     d_lhs = None
     if need_dinput:
         if mode == "bf16" and dy.dtype == torch.bfloat16 and cout % 8 == 0:
@@ -148,8 +160,16 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
     return dW, dgamma, dbeta, d_lhs
 
 
-def pointnet_backward(saves, layers, mode, d_last=None, dpool=None, pool_rows=0, need_dx=False):
-    """Returns ({param_name_suffix: grad} per layer list, dx2d or None)."""
+def _layer_outs(gout, prefix, wname, gname, bname):
+    if gout is None:
+        return None
+    return gout[prefix + wname], gout[prefix + gname], gout[prefix + bname]
+
+
+def pointnet_backward(saves, layers, mode, d_last=None, dpool=None, pool_rows=0, need_dx=False, gout=None,
+                      prefix="pc_block.pointnet"):
+    """Returns ({param_name_suffix: grad} per layer list, dx2d or None).  ``gout``:
+    optional {state_dict name: pre-zeroed gradient view} to write into."""
     grads = []
     da = d_last
     for li in range(len(layers) - 1, -1, -1):
@@ -157,13 +177,17 @@ def pointnet_backward(saves, layers, mode, d_last=None, dpool=None, pool_rows=0,
         conv, bn = layer.module[0], layer.module[1]
         W2d = conv.weight.view(s.cout, s.cin)
         need_in = li > 0 or need_dx
+        outs = _layer_outs(gout, f"{prefix}{li + 1}.", "module.0.weight", "module.1.weight", "module.1.bias")
         if li == len(layers) - 1 and dpool is not None:
             dW, dg, db, dprev = _bn_layer_backward(s, bn, W2d, mode, dpool=dpool, group_rows=pool_rows,
-                                                   pool_scale=1.0 / pool_rows, need_dinput=need_in, lhs=s.a_in)
+                                                   pool_scale=1.0 / pool_rows, need_dinput=need_in, lhs=s.a_in,
+                                                   outs=outs)
         else:
-            dW, dg, db, dprev = _bn_layer_backward(s, bn, W2d, mode, da=da, need_dinput=need_in, lhs=s.a_in)
-        grads.append({"module.0.weight": dW.view_as(conv.weight),
-                      "module.0.bias": torch.zeros_like(conv.bias),   # analytically zero (BN removes the mean)
+            dW, dg, db, dprev = _bn_layer_backward(s, bn, W2d, mode, da=da, need_dinput=need_in, lhs=s.a_in,
+                                                   outs=outs)
+        # the conv bias gradient is analytically zero (BatchNorm removes the mean)
+        zb = gout[f"{prefix}{li + 1}.module.0.bias"] if gout is not None else torch.zeros_like(conv.bias)
+        grads.append({"module.0.weight": dW.view_as(conv.weight), "module.0.bias": zb,
                       "module.1.weight": dg, "module.1.bias": db})
         da = dprev
     grads.reverse()
@@ -191,7 +215,7 @@ def dtc_forward(a2d, B, T, layers, training, pool_time):
     return a, saves
 
 
-def dtc_backward(saves, layers, B, T, d_last=None, dpool=None, need_dx=True):
+def dtc_backward(saves, layers, B, T, d_last=None, dpool=None, need_dx=True, gout=None, prefix="tc_block.dtc"):
     grads = []
     da = d_last
     for li in range(len(layers) - 1, -1, -1):
@@ -199,12 +223,15 @@ def dtc_backward(saves, layers, B, T, d_last=None, dpool=None, need_dx=True):
         conv, bn = layer.conv1d, layer.batch_norm
         W2d = conv.weight.view(s.cout, s.cin * 3)
         need_in = li > 0 or need_dx
+        outs = _layer_outs(gout, f"{prefix}{li + 1}.", "conv1d.weight", "batch_norm.weight", "batch_norm.bias")
         if li == len(layers) - 1 and dpool is not None:
             dW, dg, db, dcol = _bn_layer_backward(s, bn, W2d, "fp32", dpool=dpool, group_rows=T,
-                                                  pool_scale=1.0 / T, need_dinput=need_in, lhs=s.col)
+                                                  pool_scale=1.0 / T, need_dinput=need_in, lhs=s.col, outs=outs)
         else:
-            dW, dg, db, dcol = _bn_layer_backward(s, bn, W2d, "fp32", da=da, need_dinput=need_in, lhs=s.col)
-        grads.append({"conv1d.weight": dW.view_as(conv.weight), "conv1d.bias": torch.zeros_like(conv.bias),
+            dW, dg, db, dcol = _bn_layer_backward(s, bn, W2d, "fp32", da=da, need_dinput=need_in, lhs=s.col,
+                                                  outs=outs)
+        zb = gout[f"{prefix}{li + 1}.conv1d.bias"] if gout is not None else torch.zeros_like(conv.bias)
+        grads.append({"conv1d.weight": dW.view_as(conv.weight), "conv1d.bias": zb,
                       "batch_norm.weight": dg, "batch_norm.bias": db})
         da = ops.dtc_col2im(dcol, B, T, s.cin, s.dil) if need_in else None
     grads.reverse()
@@ -214,10 +241,23 @@ def dtc_backward(saves, layers, B, T, d_last=None, dpool=None, need_dx=True):
 # ======================================================================
 # small dense layers (Linear + ELU): MLP heads, projection heads, decoder
 # ======================================================================
-def linear_act_forward(x, lin, act):
-    """act(x @ W^T + b) with fp32 MFMA; x [M,K] fp32 -> [M,N]."""
+def _wide_bf16(mode, M, N, K):
+    """Route a dense layer through the 256x256-tile bf16 MFMA kernel: only the
+    weight-streaming decoder layers qualify (bf16 throughput mode, wide, 8-aligned)."""
+    return mode == "bf16" and N >= 512 and K >= 512 and N % 8 == 0 and K % 8 == 0 and M % 8 == 0
+
+
+def linear_act_forward(x, lin, act, mode="fp32"):
+    """act(x @ W^T + b); x [M,K] fp32 -> [M,N] fp32.  fp32 MFMA, or (bf16 mode,
+    wide layers) bf16 MFMA with fp32 accumulation: the layer is bound by
+    streaming W from HBM either way, the bf16 pipe just keeps the MFMA time out
+    of the way of the stream."""
     M, K = x.shape
     N = lin.weight.shape[0]
+    if _wide_bf16(mode, M, N, K):
+        sk = ops.pick_split_k(M, N, K, target_blocks=256, bk=64, tile=256)
+        y = ops.gemm(x, KC, lin.weight, KC, M, N, K, split_k=sk, accumulate=True, math=PCAA_BF16)
+        return ops.bias_act_(y, lin.bias, act)
     sk = ops.pick_split_k(M, N, K)
     if sk > 1:
         y = ops.gemm(x, KC, lin.weight, KC, M, N, K, split_k=sk, accumulate=True)
@@ -228,21 +268,28 @@ def linear_act_forward(x, lin, act):
     return y
 
 
-def linear_act_backward(x, a_out, lin, act, d_out, need_dx=True, dW_out=None, db_out=None, dx_init=None):
+def linear_act_backward(x, a_out, lin, act, d_out, need_dx=True, dW_out=None, db_out=None, dx_init=None,
+                        mode="fp32"):
     """d_out is the gradient w.r.t. the layer output.  Returns (dW, db, dx)."""
     M, K = x.shape
     N = lin.weight.shape[0]
     dz = ops.elu_bwd_from_out(d_out, a_out) if act == ACT_ELU else d_out
     dz2 = dz.view(M, N)
     db = ops.colsum(dz2, out=db_out)
-    dW = ops.gemm(dz2, RC, x, RC, N, K, M, out=dW_out)
+    wide = _wide_bf16(mode, M, N, K)
+    dW = ops.gemm(dz2, RC, x, RC, N, K, M, out=dW_out, math=PCAA_BF16 if wide else PCAA_F32)
     dx = None
     if need_dx:
-        sk = ops.pick_split_k(M, K, N)
-        if dx_init is not None:
-            dx = ops.gemm(dz2, KC, lin.weight, RC, M, K, N, out=dx_init, split_k=sk, accumulate=True)
+        if wide:
+            sk = ops.pick_split_k(M, K, N, target_blocks=256, bk=64, tile=256)
+            math = PCAA_BF16
         else:
-            dx = ops.gemm(dz2, KC, lin.weight, RC, M, K, N, split_k=sk, accumulate=sk > 1)
+            sk = ops.pick_split_k(M, K, N)
+            math = PCAA_F32
+        if dx_init is not None:
+            dx = ops.gemm(dz2, KC, lin.weight, RC, M, K, N, out=dx_init, split_k=sk, accumulate=True, math=math)
+        else:
+            dx = ops.gemm(dz2, KC, lin.weight, RC, M, K, N, split_k=sk, accumulate=sk > 1 or wide, math=math)
     return dW, db, dx
 
 
@@ -282,41 +329,50 @@ def encoder_forward(enc, x, training, mode=None):
     return st.logits, st.sup_fv, st
 
 
-def encoder_backward(enc, st, d_logits, d_supfv, need_dx=False):
-    """Returns ({state_dict-style name: grad}, dx [B,C,T,N] view or None)."""
+def encoder_backward(enc, st, d_logits, d_supfv, need_dx=False, gout=None):
+    """Returns ({state_dict-style name: grad}, dx [B,C,T,N] view or None).
+    ``gout``: optional {name: gradient view}; split-K products accumulate into
+    them, so they must arrive ZEROED (the trainer zeroes its flat buffer once)."""
     if not st.training:
         raise RuntimeError("CGEncoder backward in eval mode is not implemented on the HIP path "
                            "(the reference only differentiates the train-mode encoder)")
     g = {}
-    dev = st.sup_fv.device
     B, T, N = st.B, st.T, st.N
+
+    def dst(name):
+        return (gout[name + ".weight"], gout[name + ".bias"]) if gout is not None else (None, None)
+
     dsup = d_supfv.contiguous().clone() if d_supfv is not None else torch.zeros_like(st.sup_fv)
     if d_logits is not None:
         h = st.h if enc.use_projection_head else st.sup_fv
+        w_o, b_o = dst("MLP_sup2.0")
         if enc.use_projection_head:
-            dW, db, dh = linear_act_backward(h, st.logits, enc.MLP_sup2[0], ACT_ELU, d_logits.contiguous())
+            dW, db, dh = linear_act_backward(h, st.logits, enc.MLP_sup2[0], ACT_ELU, d_logits.contiguous(),
+                                             dW_out=w_o, db_out=b_o)
             g["MLP_sup2.0.weight"], g["MLP_sup2.0.bias"] = dW, db
-            dW, db, dsup = linear_act_backward(st.sup_fv, st.h, enc.MLP_head[0], ACT_ELU, dh, dx_init=dsup)
+            w_o, b_o = dst("MLP_head.0")
+            dW, db, dsup = linear_act_backward(st.sup_fv, st.h, enc.MLP_head[0], ACT_ELU, dh, dx_init=dsup,
+                                               dW_out=w_o, db_out=b_o)
             g["MLP_head.0.weight"], g["MLP_head.0.bias"] = dW, db
         else:
             dW, db, dsup = linear_act_backward(h, st.logits, enc.MLP_sup2[0], ACT_ELU, d_logits.contiguous(),
-                                               dx_init=dsup)
+                                               dx_init=dsup, dW_out=w_o, db_out=b_o)
             g["MLP_sup2.0.weight"], g["MLP_sup2.0.bias"] = dW, db
     else:
         for nm in ("MLP_sup2.0", "MLP_head.0"):
             mod = getattr(enc, nm.split(".")[0], None)
             if mod is not None:
-                g[nm + ".weight"] = torch.zeros_like(mod[0].weight)
-                g[nm + ".bias"] = torch.zeros_like(mod[0].bias)
-    dW, db, dx4 = linear_act_backward(st.x4, st.sup_fv, enc.MLP_sup1[0], ACT_ELU, dsup)
+                g[nm + ".weight"] = gout[nm + ".weight"] if gout is not None else torch.zeros_like(mod[0].weight)
+                g[nm + ".bias"] = gout[nm + ".bias"] if gout is not None else torch.zeros_like(mod[0].bias)
+    w_o, b_o = dst("MLP_sup1.0")
+    dW, db, dx4 = linear_act_backward(st.x4, st.sup_fv, enc.MLP_sup1[0], ACT_ELU, dsup, dW_out=w_o, db_out=b_o)
     g["MLP_sup1.0.weight"], g["MLP_sup1.0.bias"] = dW, db
-    dtc_layers = enc.tc_block.layers()
-    dg, dx2 = dtc_backward(st.dtc, dtc_layers, B, T, dpool=dx4, need_dx=True)
+    dg, dx2 = dtc_backward(st.dtc, enc.tc_block.layers(), B, T, dpool=dx4, need_dx=True, gout=gout)
     for i, d in enumerate(dg, start=1):
         for k, v in d.items():
             g[f"tc_block.dtc{i}.{k}"] = v
-    pn_layers = enc.pc_block.layers()
-    pg, dxp = pointnet_backward(st.pn, pn_layers, st.mode, dpool=dx2, pool_rows=N, need_dx=need_dx)
+    pg, dxp = pointnet_backward(st.pn, enc.pc_block.layers(), st.mode, dpool=dx2, pool_rows=N, need_dx=need_dx,
+                                gout=gout)
     for i, d in enumerate(pg, start=1):
         for k, v in d.items():
             g[f"pc_block.pointnet{i}.{k}"] = v
@@ -419,18 +475,20 @@ def dtc_stack(x, layers, training):
 # ======================================================================
 # CGDecoder (models.py:340-385)
 # ======================================================================
-def decoder_forward(dec, z):
+def decoder_forward(dec, z, mode=None):
+    mode = get_precision() if mode is None else mode
     _require_gpu(z, "CGDecoder")
     if z.dim() != 2 or z.shape[1] != dec.dense1.weight.shape[1]:
         raise RuntimeError(f"CGDecoder: expected [B,{dec.dense1.weight.shape[1]}], got {tuple(z.shape)}")
     acts = [z.contiguous().float()]
     layers = dec.dense_layers()
     for i, lin in enumerate(layers):
-        acts.append(linear_act_forward(acts[-1], lin, ACT_ELU if i < 4 else ACT_NONE))
+        acts.append(linear_act_forward(acts[-1], lin, ACT_ELU if i < 4 else ACT_NONE, mode))
     return acts[-1], acts
 
 
-def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=None):
+def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=None, mode=None):
+    mode = get_precision() if mode is None else mode
     layers = dec.dense_layers()
     g = {}
     d = d_out.contiguous().view(acts[-1].shape)
@@ -441,7 +499,7 @@ def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=Non
         db_out = grads_out[nm + ".bias"] if grads_out else None
         dW, db, d = linear_act_backward(acts[i], acts[i + 1], lin, ACT_ELU if i < 4 else ACT_NONE, d,
                                         need_dx=(i > 0 or need_dz), dW_out=dW_out, db_out=db_out,
-                                        dx_init=dz_init if i == 0 else None)
+                                        dx_init=dz_init if i == 0 else None, mode=mode)
         g[nm + ".weight"], g[nm + ".bias"] = dW.view_as(lin.weight), db
     return g, d
 

@@ -74,7 +74,41 @@ def set_timer(timer):
     TIMER = timer
 
 
+class StatsPool:
+    """One fp64 buffer for all BatchNorm statistics of a step, cleared by ONE
+    fill at the start of the step instead of one per layer and direction."""
+
+    def __init__(self, device, capacity_doubles=4 << 20):
+        self.buf = torch.zeros(capacity_doubles, dtype=torch.float64, device=device)
+        self.off = 0
+
+    def begin(self):
+        if self.off:
+            self.buf[:self.off].zero_()
+        self.off = 0
+
+    def take(self, ch):
+        n = NREP * 2 * ch
+        if self.off + n > self.buf.numel():
+            return None
+        v = self.buf[self.off:self.off + n].view(NREP, 2, ch)
+        self.off += n
+        return v
+
+
+STATS_POOL = None
+
+
+def set_stats_pool(pool):
+    global STATS_POOL
+    STATS_POOL = pool
+
+
 def new_stats(ch, device):
+    if STATS_POOL is not None and STATS_POOL.buf.device == torch.device(device):
+        v = STATS_POOL.take(ch)
+        if v is not None:
+            return v
     return torch.zeros((NREP, 2, ch), dtype=torch.float64, device=device)
 
 
@@ -133,6 +167,40 @@ def pick_split_k(M, N, K, target_blocks=1024, bk=32, tile=128):
         return 1
     s = max(1, target_blocks // tiles)
     return max(1, min(s, K // (4 * bk) if K >= 4 * bk else 1))
+
+
+def pointnet_in_ok(C, cout):
+    return 1 <= C <= 8 and cout % 4 == 0 and cout <= 1024 and 256 % (cout // 4) == 0
+
+
+def pointnet_in_fwd(x2d, W2d, bias, out_dtype, stats=None):
+    """y[P,cout] = x2d[P,C] . W2d[cout,C]^T + bias (+ BatchNorm statistics)."""
+    _chk(x2d, "pointnet_in.x", torch.float32, 2)
+    _chk(W2d, "pointnet_in.W", torch.float32, 2)
+    P, C = x2d.shape
+    cout = W2d.shape[0]
+    if W2d.shape[1] != C or not pointnet_in_ok(C, cout):
+        raise ValueError(f"pointnet_in_fwd: unsupported shape C={C} cout={cout}")
+    y = torch.empty((P, cout), dtype=out_dtype, device=x2d.device)
+    check(_lib.load().pcaa_pointnet_in_fwd(_p(x2d), C, _p(W2d), _p(bias), _p(y), _dt(y), P, cout, _p(stats), NREP, _s()),
+          "pcaa_pointnet_in_fwd")
+    return y
+
+
+def pointnet_in_wgrad(dy, x2d, out=None, out_is_zero=False):
+    _chk(dy, "pointnet_in_wgrad.dy", dim=2)
+    _chk(x2d, "pointnet_in_wgrad.x", torch.float32, 2)
+    P, cout = dy.shape
+    C = x2d.shape[1]
+    if x2d.shape[0] != P or not pointnet_in_ok(C, cout):
+        raise ValueError("pointnet_in_wgrad: unsupported shape")
+    if out is None:
+        out = torch.zeros((cout, C), dtype=torch.float32, device=dy.device)
+    elif not out_is_zero:
+        out.zero_()
+    check(_lib.load().pcaa_pointnet_in_wgrad(_p(dy), _dt(dy), _p(x2d), C, _p(out), P, cout, _s()),
+          "pcaa_pointnet_in_wgrad")
+    return out
 
 
 # ------------------------------------------------------------------ BatchNorm pieces

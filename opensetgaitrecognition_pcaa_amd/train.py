@@ -127,6 +127,13 @@ class PCAATrainer:
         self._d_grads = [self.flat_d.grad_views["D." + n] for n, _ in self.discriminator.named_parameters()]
         self._dec_grads = {n: self.flat_g.grad_views["G." + n] for n, _ in self.decoder.named_parameters()
                            if n.startswith("dense")}
+        # encoder gradients are produced straight into the flat buffer; the split-K products
+        # accumulate, so that (leading) region is cleared by one fill per step
+        self._enc_grads = {n: self.flat_g.grad_views["E." + n] for n, _ in self.encoder.named_parameters()}
+        n_enc = sum(1 for nm in self.flat_g.names if nm.startswith("E."))
+        self._enc_region = self.flat_g.g[: self.flat_g.offsets[n_enc] if n_enc < len(self.flat_g.offsets)
+                                         else self.flat_g.total]
+        self._stats_pool = ops.StatsPool(self.device)
         self._flat_ready = True
 
     def train(self):
@@ -157,6 +164,9 @@ class PCAATrainer:
         mode = self.precision or F_hip.get_precision()
         enc, dec = self.encoder, self.decoder
         gs = 1.0 / self.world
+        ops.set_stats_pool(self._stats_pool)
+        self._stats_pool.begin()
+        self._enc_region.zero_()
 
         # (1) encoder forward (train-mode BatchNorm)
         logits, sup_fv, st = F_hip.encoder_forward(enc, pcs, True, mode)
@@ -175,7 +185,7 @@ class PCAATrainer:
             hproj = F_hip.linear_act_forward(sup_fv, self.decoder_projection_head[0], ACT_ELU)
         else:
             hproj = sup_fv
-        rec, acts = F_hip.decoder_forward(dec, hproj)
+        rec, acts = F_hip.decoder_forward(dec, hproj, mode)
         rec4 = rec.view(B, self.C, self.T, self.N)
         inv_bt = 1.0 / (B * self.T)
         frame_loss, drec = ops.chamfer(rec4, pcs, want_grad=True, grad_scale=inv_bt)
@@ -188,16 +198,13 @@ class PCAATrainer:
 
         # (5) G-step backward (the adversarial gradient w.r.t. sup_fvs seeds the accumulation)
         if self.decoder_projection_head is not None:
-            _, dh = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads)
+            _, dh = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads, mode=mode)
             gv = self.flat_g.grad_views
             _, _, dsup = F_hip.linear_act_backward(sup_fv, hproj, self.decoder_projection_head[0], ACT_ELU, dh,
                                                    dx_init=dsup, dW_out=gv["GPH.0.weight"], db_out=gv["GPH.0.bias"])
         else:
-            _, dsup = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads, dz_init=dsup)
-        eg, _ = F_hip.encoder_backward(enc, st, dlogits if supervise else None, dsup)
-        gv = self.flat_g.grad_views
-        for n, t in eg.items():
-            gv["E." + n].copy_(t.view_as(gv["E." + n]))
+            _, dsup = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads, dz_init=dsup, mode=mode)
+        F_hip.encoder_backward(enc, st, dlogits if supervise else None, dsup, gout=self._enc_grads)
         self._allreduce(self.flat_g.g)
         self.flat_g.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs)
 
@@ -214,7 +221,7 @@ class PCAATrainer:
         hproj = sup_fv
         if self.decoder_projection_head is not None:
             hproj = F_hip.linear_act_forward(sup_fv, self.decoder_projection_head[0], ACT_ELU)
-        rec, _ = F_hip.decoder_forward(self.decoder, hproj)
+        rec, _ = F_hip.decoder_forward(self.decoder, hproj, mode)
         B = pcs.shape[0]
         fl, _ = ops.chamfer(rec.view(B, self.C, self.T, self.N), pcs, want_grad=False)
         rec_loss = ops.total(fl, 1.0 / (B * self.T))

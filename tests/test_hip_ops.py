@@ -262,3 +262,24 @@ def test_cross_entropy_and_preds():
     assert abs(loss.item() - ref.item()) < 1e-5
     assert torch.allclose(dl.cpu(), xg.grad, atol=1e-6)
     assert torch.equal(preds.cpu(), O.predicted_labels(x))
+
+
+@pytest.mark.parametrize("P,C,cout,dtype", [(5000, 4, 512, torch.float32), (3333, 5, 512, torch.float32),
+                                            (4096, 4, 512, torch.bfloat16), (700, 3, 64, torch.float32)])
+def test_pointnet_input_layer_kernels(P, C, cout, dtype):
+    x = _rand((P, C), 80).to(DEV)
+    W = _rand((cout, C), 81).to(DEV)
+    b = _rand((cout,), 82).to(DEV)
+    stats = ops.new_stats(cout, DEV)
+    y = ops.pointnet_in_fwd(x, W, b, dtype, stats)
+    acc = x.cpu().double() @ W.cpu().double().t()
+    ref = acc + b.cpu().double()
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert (y.float().cpu().double() - ref).abs().max().item() <= tol * ref.abs().max().item()
+    s = stats.sum(0).cpu()
+    assert torch.allclose(s[0], acc.sum(0), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[1], (acc * acc).sum(0), rtol=1e-5, atol=1e-3)
+    dy = _rand((P, cout), 83).to(DEV).to(dtype)
+    dW = ops.pointnet_in_wgrad(dy, x)
+    refw = dy.float().cpu().double().t() @ x.cpu().double()
+    assert (dW.cpu().double() - refw).abs().max().item() <= 2e-6 * refw.abs().max().item() * P ** 0.5 / 10 + 1e-5

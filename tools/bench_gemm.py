@@ -84,6 +84,13 @@ def main():
         print(f"dec dX   [64,{nout}]x[{nout},{kin}]   sk={sk:<3d}          {ms:9.3f} {fl / ms / 1e9:9.1f}  {by / ms / 1e6:7.0f} GB/s")
         ms = timeit(lambda: ops.gemm(dyv, RC, x, RC, nout, kin, 64, out=dW), a.iters)
         print(f"dec dW   [{nout},{kin}] K=64                       {ms:9.3f} {fl / ms / 1e9:9.1f}  {by / ms / 1e6:7.0f} GB/s")
+        for sk in (4, 8, 16):
+            ms = timeit(lambda: ops.gemm(x, KC, W, KC, 64, nout, kin, split_k=sk, accumulate=True, math=PCAA_BF16), a.iters)
+            print(f"dec fwd  bf16-math sk={sk:<3d}                          {ms:9.3f} {fl / ms / 1e9:9.1f}  {by / ms / 1e6:7.0f} GB/s")
+            ms = timeit(lambda: ops.gemm(dyv, KC, W, RC, 64, kin, nout, split_k=sk, accumulate=True, math=PCAA_BF16), a.iters)
+            print(f"dec dX   bf16-math sk={sk:<3d}                          {ms:9.3f} {fl / ms / 1e9:9.1f}  {by / ms / 1e6:7.0f} GB/s")
+        ms = timeit(lambda: ops.gemm(dyv, RC, x, RC, nout, kin, 64, out=dW, math=PCAA_BF16), a.iters)
+        print(f"dec dW   bf16-math                                 {ms:9.3f} {fl / ms / 1e9:9.1f}  {by / ms / 1e6:7.0f} GB/s")
 
 
 if __name__ == "__main__":
