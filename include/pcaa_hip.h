@@ -76,6 +76,10 @@ int pcaa_pointnet_in_fwd(const float* x, int C, const float* W, const float* bia
 int pcaa_pointnet_in_wgrad(const void* dy, int dy_dtype, const float* x, int C, float* dW, long P,
                            int cout, void* stream);
 
+/* bf16 shadow of an fp32 weight matrix src[R,C]: dst[R,C] and/or its transpose dst_t[C,R]
+ * (either may be NULL).  Lets the bf16 GEMM stream both operands by LDS-DMA. */
+int pcaa_cast_bf16(const float* src, void* dst, void* dst_t, int R, int C, void* stream);
+
 /* ------------------------------------------------------------------ BatchNorm (+ELU) pieces
  * Training-mode BatchNorm2d/1d + ELU of PointNetModule (models.py:28-29) and
  * DilTempConv1d (models.py:71,77-78), split around the grid-wide statistics

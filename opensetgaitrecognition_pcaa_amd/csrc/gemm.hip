@@ -387,6 +387,8 @@ extern "C" int pcaa_gemm(int math,
   p.M = M; p.N = N; p.K = K;
   p.bias = bias; p.colstats = colstats; p.nrep = nrep > 0 ? nrep : 1;
   p.atomic = atomic;
+  p.nsplit = 1;
+  p.split_fast = 0;
   const int bk = (math == PCAA_BF16) ? H_BK : F_BK;
   int kps = (int)cdiv(cdiv(K, split_k), bk) * bk;
   if (kps < bk) kps = bk;

@@ -107,6 +107,69 @@ __device__ __forceinline__ bf16x8 load_frag(const bf16_t* s, int off, int kk) {
   return u.v;
 }
 
+// Epilogue store.  The MFMA accumulator layout (column on the lane, rows in the
+// registers) makes a direct bf16 store a 2-byte-per-lane, 64-B-per-row partial-line
+// write -- measured ~30 us per 256x256 tile, more than the K=512 main loop.  bf16
+// outputs are therefore transposed through the (now idle) LDS: each wave parks its
+// 128x64 sub-tile as [row][col] bf16 and streams it out as 16 B per lane, 8 lanes =
+// one whole 128-B line per row.  fp32 outputs / atomics already write 128 B per
+// half-wave and go out directly.
+template <typename TC, int PITCH>
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, f32x16 (&acc)[FM][FN], bf16_t* smem,
+                                               int tm, int tn, int tid, int split) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, half = lane >> 5;
+  const bool add_bias = p.bias != nullptr && (!p.atomic || split == 0);
+  constexpr bool kBf16 = sizeof(TC) == 2;
+  const bool wide = kBf16 && !p.atomic && (p.ldc % 8) == 0 && (p.N % 8) == 0 && ((uintptr_t)p.C % 16) == 0;
+  if (wide) {
+    bf16_t* w = smem + wave * 128 * PITCH;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int gn = tn * BN + wn * 64 + j * 32 + l31;
+      const float bv = (add_bias && gn < p.N) ? p.bias[gn] : 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          w[row * PITCH + j * 32 + l31] = (bf16_t)(acc[i][j][r] + bv);
+        }
+    }
+    __syncthreads();
+    bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+    const int cg = (lane & 7) * 8;
+    const int gn = tn * BN + wn * 64 + cg;
+#pragma unroll
+    for (int pass = 0; pass < 16; ++pass) {
+      const int row = pass * 8 + (lane >> 3);
+      const int gm = tm * BM + wm * 128 + row;
+      const uint4 v = *reinterpret_cast<const uint4*>(&w[row * PITCH + cg]);
+      if (gm < p.M && gn < p.N) *reinterpret_cast<uint4*>(&C[(long)gm * p.ldc + gn]) = v;
+    }
+    __syncthreads();   // the statistics reduction reuses this LDS
+    return;
+  }
+  TC* C = reinterpret_cast<TC*>(p.C);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int gn = tn * BN + wn * 64 + j * 32 + l31;
+    const float bv = (add_bias && gn < p.N) ? p.bias[gn] : 0.f;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = tm * BM + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (gm < p.M && gn < p.N) {
+          const float v = acc[i][j][r] + bv;
+          if (p.atomic) atomicAdd(reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn, v);
+          else store1(C + (long)gm * p.ldc + gn, v);
+        }
+      }
+    }
+  }
+}
+
 template <typename TA, typename TB, typename TC, int ALAY, int BLAY>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_big_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -115,9 +178,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_big_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, half = lane >> 5;
   int tm, tn;
-  xcd_tile_coords((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, tm, tn);
+  const int split = block_coords(p, (p.M + BM - 1) / BM, (p.N + BN - 1) / BN, tm, tn);
 
-  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kbeg = split * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int nt = (kend - kbeg + BK - 1) / BK;
   const TA* A = reinterpret_cast<const TA*>(p.A);
@@ -176,26 +239,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_big_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  // ---------------- epilogue: bias, store / atomic accumulate
-  TC* C = reinterpret_cast<TC*>(p.C);
-  const bool add_bias = p.bias != nullptr && (!p.atomic || blockIdx.z == 0);
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int gn = tn * BN + wn * 64 + j * 32 + l31;
-    const float bv = (add_bias && gn < p.N) ? p.bias[gn] : 0.f;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int gm = tm * BM + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (gm < p.M && gn < p.N) {
-          const float v = acc[i][j][r] + bv;
-          if (p.atomic) atomicAdd(reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn, v);
-          else store1(C + (long)gm * p.ldc + gn, v);
-        }
-      }
-    }
-  }
+  // ---------------- epilogue: bias, store / atomic accumulate (the loop ended on a barrier)
+  epilogue_store<TC, P_KC>(p, acc, smem, tm, tn, tid, split);
   // ---------------- BatchNorm column statistics of the bias-free accumulator
   if (p.colstats != nullptr) {
     float* red = reinterpret_cast<float*>(smem_raw);   // [2 stats][2 wm][256 cols]; loop ended on a barrier
@@ -228,6 +273,174 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_big_kernel(GemmParams p) {
   }
 }
 
+// ===========================================================================
+// LDS-DMA variant: both operands already bf16 in HBM, shapes whole tiles
+// (M % 256 == N % 256 == 0, K-range % 64 == 0).  Tiles go HBM -> LDS with
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write pass); the LDS images are
+// unpadded, so the bank-conflict fix is an XOR swizzle applied to the per-lane
+// SOURCE address (the DMA writes LDS linearly: base + lane*16) and again on the
+// fragment reads:
+//   KC image [256 rows][64 k] (128-B rows): 16-B granule g of row r holds global k-granule
+//     g ^ ((r>>1)&7)  -> ds_read_b128 of 16 consecutive rows hits 16 distinct 16-B slots.
+//   RC image [64 k][256 rows] (512-B rows): 16-B granule c of k-row k holds global row-granule
+//     c ^ 4*(k&3)     -> the 4 k-rows of a transpose read land on disjoint bank quarters.
+// One barrier per 64-deep step: the DMA of step t+1 is issued before the MFMAs of
+// step t and drained (vmcnt(0), emitted by __syncthreads) at the barrier.
+// ===========================================================================
+constexpr int D_TILE = 256 * 64;                       // elements per operand per stage (32 KB)
+constexpr int D_LDS_BYTES = 2 * 2 * D_TILE * 2;        // 131072
+
+template <int LAY>
+__device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ base, long ld, int row0, int R, int k0,
+                                         bf16_t* s_tile, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = wave * 4 + j;       // 1-KB piece index, 32 per tile
+    const bf16_t* src;
+    if (LAY == KC) {
+      const int r = 8 * p + (lane >> 3);
+      const int g = (lane & 7) ^ ((r >> 1) & 7);
+      src = base + (long)min(row0 + r, R - 1) * ld + k0 + 8 * g;
+    } else {
+      const int k = 2 * p + (lane >> 5);
+      const int c = (lane & 31) ^ (4 * (k & 3));
+      src = base + (long)(k0 + k) * ld + row0 + 8 * c;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(s_tile + p * 512), 16, 0, 0);
+  }
+}
+
+// per-lane element offset of fragment rows [row_base, row_base+32) at k-step 0 (row_base % 32 == 0)
+template <int LAY>
+__device__ __forceinline__ int dma_frag_offset(int row_base, int lane) {
+  if (LAY == KC) return (row_base + (lane & 31)) * 64;
+  const int j = lane & 15, mb = 16 * ((lane >> 4) & 1), h = lane >> 5;
+  const int q = j >> 2, ch = row_base + mb + 4 * (j & 3);
+  return (8 * h + q) * 256 + ((((ch >> 3) ^ (4 * q)) << 3) | (ch & 7));
+}
+
+template <int LAY>
+__device__ __forceinline__ bf16x8 dma_load_frag(const bf16_t* s, int off, int kstep, const int (&kofs)[4]) {
+  if (LAY == KC) return *reinterpret_cast<const bf16x8*>(s + off + kofs[kstep]);
+  const bf16_t* p = s + off + kstep * 16 * 256;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * 256));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo;
+  u.s.b = hi;
+  return u.v;
+}
+
+template <typename TC, int ALAY, int BLAY>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, half = lane >> 5;
+  int tm, tn;
+  const int split = block_coords(p, p.M / BM, p.N / BN, tm, tn);
+
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nt = (kend - kbeg) / BK;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int offA[FM], offB[FN], kofs[4];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) offA[i] = dma_frag_offset<ALAY>(wm * 128 + i * 32, lane);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) offB[j] = dma_frag_offset<BLAY>(wn * 64 + j * 32, lane);
+  {
+    const int swz = (l31 >> 1) & 7;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kofs[s] = ((2 * s + half) ^ swz) * 8;
+  }
+
+  if (nt > 0) {
+    dma_tile<ALAY>(A, p.lda, tm * BM, p.M, kbeg, smem, wave, lane);
+    dma_tile<BLAY>(B, p.ldb, tn * BN, p.N, kbeg, smem + D_TILE, wave, lane);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const bf16_t* sA = smem + (t & 1) * 2 * D_TILE;
+    const bf16_t* sB = sA + D_TILE;
+    if (t + 1 < nt) {
+      bf16_t* nA = smem + ((t + 1) & 1) * 2 * D_TILE;
+      const int k0 = kbeg + (t + 1) * BK;
+      dma_tile<ALAY>(A, p.lda, tm * BM, p.M, k0, nA, wave, lane);
+      dma_tile<BLAY>(B, p.ldb, tn * BN, p.N, k0, nA + D_TILE, wave, lane);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[FM], bfr[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = dma_load_frag<ALAY>(sA, offA[i], ks, kofs);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bfr[j] = dma_load_frag<BLAY>(sB, offB[j], ks, kofs);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  epilogue_store<TC, 64>(p, acc, smem, tm, tn, tid, split);
+  if (p.colstats != nullptr) {
+    float* red = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[i][j][r];
+          s1 += v;
+          s2 += v * v;
+        }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (half == 0) {
+        const int col = wn * 64 + j * 32 + l31;
+        red[(0 * 2 + wm) * 256 + col] = s1;
+        red[(1 * 2 + wm) * 256 + col] = s2;
+      }
+    }
+    __syncthreads();
+    const int stat = tid >> 8, col = tid & 255;
+    const double v = (double)red[(stat * 2 + 0) * 256 + col] + (double)red[(stat * 2 + 1) * 256 + col];
+    unsafeAtomicAdd(&p.colstats[((long)(tm % p.nrep) * 2 + stat) * p.N + tn * BN + col], v);
+  }
+}
+
+template <typename TC, int ALAY, int BLAY>
+bool launch_dma(const GemmParams& p, dim3 grid, hipStream_t s) {
+  static bool configured = false;
+  auto kern = gemm_bf16_dma_kernel<TC, ALAY, BLAY>;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            D_LDS_BYTES) != hipSuccess)
+      return false;
+    configured = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), D_LDS_BYTES, s, p);
+  return true;
+}
+
 template <typename TA, typename TB, typename TC, int ALAY, int BLAY>
 bool launch(const GemmParams& p, dim3 grid, hipStream_t s) {
   static bool configured = false;
@@ -244,8 +457,9 @@ bool launch(const GemmParams& p, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
-bool pcaa_launch_gemm_bf16_big(const GemmParams& p, int a_dtype, int a_layout, int b_dtype, int b_layout,
+bool pcaa_launch_gemm_bf16_big(const GemmParams& p_in, int a_dtype, int a_layout, int b_dtype, int b_layout,
                                int c_dtype, int nsplit, hipStream_t stream) {
+  GemmParams p = p_in;
   if (p.N < 128) return false;
   if ((p.lda % 8) || (p.ldb % 8) || ((uintptr_t)p.A % 16) || ((uintptr_t)p.B % 16)) return false;
   // a KC operand needs whole 8-chunks along K, an RC operand whole 8-chunks along its rows
@@ -253,9 +467,21 @@ bool pcaa_launch_gemm_bf16_big(const GemmParams& p, int a_dtype, int a_layout, i
   if (a_layout == RC && (p.M % 8)) return false;
   if (b_layout == RC && (p.N % 8)) return false;
   const long ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
-  if (ntiles >= (1L << 31)) return false;
+  if (ntiles * nsplit >= (1L << 31)) return false;
+  p.nsplit = nsplit;
+  // split_fast (all tiles of one K-range on one XCD) measured neutral-to-negative on MI355X
+  // (wgrad 1024x512 K=245760: 0.53 -> 1.36 ms at 128 blocks; 1024^2: 0.61 -> 0.59): the re-reads
+  // were already served by the Infinity Cache, and co-locating them adds same-line contention.
+  p.split_fast = 0;
   dim3 grid((unsigned)ntiles, 1, (unsigned)nsplit);
+  if (p.split_fast) grid = dim3((unsigned)(ntiles * nsplit), 1, 1);
   const bool af = a_dtype == PCAA_F32, bf = b_dtype == PCAA_F32, cf = c_dtype == PCAA_F32;
+  // LDS-DMA kernel: bf16 x bf16, whole tiles only
+  if (!af && !bf && (p.M % BM) == 0 && (p.N % BN) == 0 && (p.K % BK) == 0 && (p.k_per_split % BK) == 0 &&
+      a_layout == b_layout) {
+    if (a_layout == KC) return cf ? launch_dma<float, KC, KC>(p, grid, stream) : launch_dma<bf16_t, KC, KC>(p, grid, stream);
+    if (cf) return launch_dma<float, RC, RC>(p, grid, stream);
+  }
   if (a_layout == KC && b_layout == KC) {
     // bf16 activations x fp32/bf16 weights (PointNet forward / dgrad), fp32 x fp32 (decoder forward)
     if (!af && bf && !cf) return launch<bf16_t, float, bf16_t, KC, KC>(p, grid, stream);

@@ -12,6 +12,8 @@ struct GemmParams {
   int nrep;
   int k_per_split;
   int atomic;
+  int nsplit;       // number of K splits
+  int split_fast;   // 1: 1-D grid, block b -> split b % nsplit, tile b / nsplit (see block_coords)
 };
 
 // XCD-aware, bijective block -> (tile_m, tile_n) map: the 8 XCDs (blocks b, b+8,
@@ -25,6 +27,20 @@ __device__ __forceinline__ void xcd_tile_coords(int nbm, int nbn, int& tm, int& 
   const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   tm = v / nbn;
   tn = v - tm * nbn;
+}
+
+// Block -> (split, tile).  With split_fast (wgrad: long K, few tiles, nsplit % 8 == 0) all tiles
+// of one K-range land on one XCD (blocks b and b+8 share an XCD), so the operand rows of that
+// range are fetched from HBM once and re-read by the other tiles from that XCD's L2.
+__device__ __forceinline__ int block_coords(const GemmParams& p, int nbm, int nbn, int& tm, int& tn) {
+  if (p.split_fast) {
+    const int s = blockIdx.x % p.nsplit, t = blockIdx.x / p.nsplit;
+    tm = t / nbn;
+    tn = t - tm * nbn;
+    return s;
+  }
+  xcd_tile_coords(nbm, nbn, tm, tn);
+  return blockIdx.z;
 }
 
 // 256x256-tile bf16 kernel (gemm_bf16.hip).  Returns false if the shape/dtype

@@ -9,7 +9,7 @@ namespace {
 
 constexpr int MAXC = 8;
 constexpr int FWD_ROWS = 128;    // points per workgroup (forward)
-constexpr int WG_ROWS = 512;     // points per workgroup (wgrad)
+constexpr int WG_ROWS = 1024;    // points per workgroup (wgrad)
 
 template <typename T>
 __global__ __launch_bounds__(256) void pointnet_in_fwd_kernel(const float* __restrict__ x, int C,
@@ -93,12 +93,35 @@ __global__ __launch_bounds__(256) void pointnet_in_wgrad_kernel(const T* __restr
       acc[3][c] = fmaf(d.w, xv, acc[3][c]);
     }
   }
-  // every (row lane, channel) pair adds its partial: cout*C*rl atomics per workgroup
+  // combine the row lanes through LDS (xs is free now), then ONE atomic per (channel, feature)
+  // per workgroup: all workgroups add into the same cout*C words, so the count matters
+  __syncthreads();
+  float* red = xs;   // [rl][cout][MAXC]  (rl * cout * 8 floats <= 256 * 4 * 8 = 8192 <= WG_ROWS * MAXC)
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-      if (c < C) atomicAdd(&dW[(cq * 4 + j) * C + c], acc[j][c]);
+    for (int c = 0; c < MAXC; ++c) red[(rlane * cout + cq * 4 + j) * MAXC + c] = acc[j][c];
+  __syncthreads();
+  for (int o = threadIdx.x; o < cout * C; o += 256) {
+    const int ch = o / C, c = o - ch * C;
+    float v = 0.f;
+    for (int l = 0; l < rl; ++l) v += red[(l * cout + ch) * MAXC + c];
+    atomicAdd(&dW[o], v);
+  }
+}
+
+// dst[r][c] = bf16(src[r][c]); dst_t[c][r] = bf16(src[r][c])  (weights: a few MB at most)
+__global__ void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                 bf16_t* __restrict__ dst_t, int R, int C) {
+  const long n = (long)R * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const bf16_t v = (bf16_t)src[i];
+    if (dst) dst[i] = v;
+    if (dst_t) {
+      const int r = (int)(i / C), c = (int)(i - (long)r * C);
+      dst_t[(long)c * R + r] = v;
+    }
+  }
 }
 
 inline bool shape_ok(int C, int cout) {
@@ -137,4 +160,14 @@ extern "C" int pcaa_pointnet_in_wgrad(const void* dy, int dy_dtype, const float*
                        (const bf16_t*)dy, x, C, dW, P, cout);
   else { pcaa_set_error("pcaa_pointnet_in_wgrad: bad dtype"); return PCAA_ERR_INVALID_ARG; }
   PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_wgrad");
+}
+
+extern "C" int pcaa_cast_bf16(const float* src, void* dst, void* dst_t, int R, int C, void* stream) {
+  PCAA_CHECK_ARG(src && (dst || dst_t) && R >= 1 && C >= 1, "pcaa_cast_bf16: bad args");
+  const long n = (long)R * C;
+  long g = cdiv(n, 256);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), src, (bf16_t*)dst,
+                     (bf16_t*)dst_t, R, C);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_cast_bf16");
 }

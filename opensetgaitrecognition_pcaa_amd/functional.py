@@ -18,6 +18,7 @@ from torch.autograd.function import once_differentiable
 from . import ops
 from ._lib import ACT_ELU, ACT_NONE, KC, PCAA_BF16, PCAA_F32, RC
 
+_W16_CACHE = {}     # weight data_ptr -> transposed bf16 shadow made in the forward pass of this step
 _PRECISION = {"mode": "fp32"}
 _SYNC_BN = {"group": None}
 
@@ -82,9 +83,16 @@ def _linear_bn(a_in, W2d, lin_bias, bn, training, mode, first_layer):
     if first_layer is not None and a_in.dtype == torch.float32 and cin <= 8 and ops.pointnet_in_ok(cin, cout):
         # raw points -> first PointNet layer: C-wide contraction, HBM-bound streaming kernel
         y = ops.pointnet_in_fwd(a_in, W2d, lin_bias, out_dtype, stats)
+    elif use_bf16:
+        # bf16 shadow of the weights so both operands stream by LDS-DMA (the transposed copy
+        # serves the dgrad GEMM of the backward pass)
+        w16, wt16 = ops.cast_bf16(W2d, True, training)
+        _W16_CACHE[W2d.data_ptr()] = wt16
+        y = ops.gemm(a_in, KC, w16, KC, rows, cout, cin, bias=lin_bias, colstats=stats, out_dtype=out_dtype,
+                     math=PCAA_BF16)
     else:
         y = ops.gemm(a_in, KC, W2d, KC, rows, cout, cin, bias=lin_bias, colstats=stats, out_dtype=out_dtype,
-                     math=PCAA_BF16 if use_bf16 else PCAA_F32)
+                     math=PCAA_F32)
     if training:
         count = _sync_stats(stats, rows)
         scale, shift, mean, rstd = ops.bn_finalize(stats, count, lin_bias, bn, cout)
@@ -152,7 +160,9 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
     d_lhs = None
     if need_dinput:
         if mode == "bf16" and dy.dtype == torch.bfloat16 and cout % 8 == 0:
-            Wt = W2d.t().contiguous()          # [K, cout]: KC operand for the bf16 pipe
+            Wt = _W16_CACHE.pop(W2d.data_ptr(), None)      # bf16 [K, cout] made by the forward pass
+            if Wt is None or tuple(Wt.shape) != (K, cout):
+                _, Wt = ops.cast_bf16(W2d, False, True)
             d_lhs = ops.gemm(dy, KC, Wt, KC, rows_local, K, cout, out_dtype=torch.bfloat16, math=PCAA_BF16)
         else:
             d_lhs = ops.gemm(dy, KC, W2d, RC, rows_local, K, cout,

@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._lib import ACT_ELU, ACT_NONE, KC, PCAA_BF16, PCAA_F32, RC, check
 
-NREP = 64          # replicas of a BatchNorm statistics row (spreads fp64 atomics)
+NREP = 16          # replicas of a BatchNorm statistics row (spreads fp64 atomics)
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
@@ -167,6 +167,16 @@ def pick_split_k(M, N, K, target_blocks=1024, bk=32, tile=128):
         return 1
     s = max(1, target_blocks // tiles)
     return max(1, min(s, K // (4 * bk) if K >= 4 * bk else 1))
+
+
+def cast_bf16(W2d, want_plain=True, want_transposed=True):
+    """bf16 shadows of an fp32 weight matrix [R,C]: (W16 [R,C], W16t [C,R])."""
+    _chk(W2d, "cast_bf16.W", torch.float32, 2)
+    R, C = W2d.shape
+    w = torch.empty((R, C), dtype=torch.bfloat16, device=W2d.device) if want_plain else None
+    wt = torch.empty((C, R), dtype=torch.bfloat16, device=W2d.device) if want_transposed else None
+    check(_lib.load().pcaa_cast_bf16(_p(W2d), _p(w), _p(wt), R, C, _s()), "pcaa_cast_bf16")
+    return w, wt
 
 
 def pointnet_in_ok(C, cout):

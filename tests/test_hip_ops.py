@@ -120,6 +120,29 @@ def test_gemm_bf16_big_tile_exact_integers():
     assert torch.equal(C.cpu().double(), Ai.double() @ Bi.double().t())
 
 
+@pytest.mark.parametrize("lay,M,N,K,sk", [(KC, 512, 256, 128, 1), (KC, 768, 512, 1024, 1), (RC, 256, 512, 640, 2),
+                                          (RC, 1024, 512, 64 * 40, 5), (KC, 256, 256, 64, 1)])
+def test_gemm_bf16_lds_dma_exact_integers(lay, M, N, K, sk):
+    """whole-tile bf16 x bf16 shapes take the LDS-DMA kernel (swizzled source addresses, swizzled
+    fragment reads): exact small-integer operands must reproduce the integer product exactly."""
+    rng = np.random.default_rng(37)
+    Ai = torch.from_numpy(rng.integers(-3, 4, (M, K)).astype(np.float32))
+    Bi = torch.from_numpy(rng.integers(-3, 4, (N, K)).astype(np.float32))
+    A = (Ai if lay == KC else Ai.t().contiguous()).to(DEV).bfloat16()
+    B = (Bi if lay == KC else Bi.t().contiguous()).to(DEV).bfloat16()
+    bias = torch.from_numpy(rng.integers(-2, 3, (N,)).astype(np.float32)).to(DEV)
+    stats = ops.new_stats(N, DEV) if sk == 1 else None
+    C = ops.gemm(A, lay, B, lay, M, N, K, bias=bias, colstats=stats, split_k=sk, accumulate=sk > 1, math=PCAA_BF16)
+    acc = Ai.double() @ Bi.double().t()
+    assert torch.equal(C.cpu().double(), acc + bias.cpu().double())
+    if stats is not None:
+        s = stats.sum(0).cpu()
+        assert torch.equal(s[0], acc.sum(0))
+        assert torch.allclose(s[1], (acc * acc).sum(0), rtol=1e-6)     # squares exceed fp32's exact-integer range
+        Cb = ops.gemm(A, lay, B, lay, M, N, K, out_dtype=torch.bfloat16, math=PCAA_BF16)
+        assert torch.equal(Cb.float().cpu().double(), acc.float().bfloat16().double())
+
+
 @pytest.mark.parametrize("al,bl", [(KC, KC), (RC, RC), (KC, RC)])
 def test_gemm_f32_math_bf16_storage(al, bl):
     M, N, K = 520, 260, 1000

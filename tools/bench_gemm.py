@@ -43,6 +43,7 @@ def main():
         x = rnd(P, cin)
         W = rnd(cout, cin, dtype=torch.float32)
         Wt = W.t().contiguous()
+        W16, Wt16 = ops.cast_bf16(W)
         dy = rnd(P, cout)
         bias = rnd(cout, dtype=torch.float32)
         stats = ops.new_stats(cout, dev)
@@ -53,6 +54,10 @@ def main():
         print(f"fwd  bf16 [{P},{cin}]x[{cout},{cin}]^T +stats        {ms:9.3f} {fl / ms / 1e9:9.1f}")
         ms = timeit(lambda: ops.gemm(dy, KC, Wt, KC, P, cin, cout, out=da, math=PCAA_BF16), a.iters)
         print(f"dgrd bf16 [{P},{cout}]x[{cin},{cout}]^T               {ms:9.3f} {fl / ms / 1e9:9.1f}")
+        ms = timeit(lambda: ops.gemm(x, KC, W16, KC, P, cout, cin, bias=bias, colstats=stats, out=y, math=PCAA_BF16), a.iters)
+        print(f"fwd  bf16 LDS-DMA (bf16 weights) +stats              {ms:9.3f} {fl / ms / 1e9:9.1f}")
+        ms = timeit(lambda: ops.gemm(dy, KC, Wt16, KC, P, cin, cout, out=da, math=PCAA_BF16), a.iters)
+        print(f"dgrd bf16 LDS-DMA (bf16 weights)                     {ms:9.3f} {fl / ms / 1e9:9.1f}")
         for sk in (16, 64):
             dW = torch.zeros(cout, cin, device=dev)
             try:
