@@ -186,6 +186,16 @@ int pcaa_disc_wgan_gp(const float* z, const float* fv, const float* label, const
                       float* dW1, float* db1, float* dW2, float* db2, float* dW3, float* db3,
                       float* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------ open-set scoring
+ * joint_likelihood (inference_PCAA.py:129-136): lik[b] = (1/K) sum_k N(x_b; mu_k, I_D), float64,
+ * evaluated as exp(log-pdf) like scipy.stats.multivariate_normal.pdf.
+ * k-window vote (inference_PCAA.py:263-271): window w covers crops [w*k,(w+1)*k); known iff
+ * #(lik > threshold) > k/2 -> most frequent predicted label (lowest on ties), else n_labels. */
+int pcaa_joint_likelihood(const float* x, const float* means, int B, int K, int D, double* lik,
+                          void* stream);
+int pcaa_kvote(const double* lik, const long long* preds, double threshold, int k, int n_labels,
+               int n_windows, long long* out, void* stream);
+
 /* ------------------------------------------------------------------ optimizer
  * torch.optim.Adam (no weight decay, no amsgrad; PCAA_ablation.py:820-833) on a
  * flat fp32 buffer. `step` is the 1-based step count after this update. */
