@@ -101,9 +101,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or os.environ.get("PCAA_DP_FORCE", "0") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         pg = dist.group.WORLD
 
     B, N, C, K, T = a.batch, a.points, a.features, a.classes, constants.NSTEPS
@@ -165,7 +166,7 @@ def main():
             agg = timer.summary()
             dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
             name, r = dom
-            peak = PEAK_BF16_TFLOPS if name == "gemm_bf16_kernel" else PEAK_F32_TFLOPS
+            peak = PEAK_BF16_TFLOPS if name.startswith("gemm_bf16") else PEAK_F32_TFLOPS
             achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
             line["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak,
                                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
@@ -176,7 +177,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(B, N, C, K, T)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if pg is not None:
         dist.destroy_process_group()
 
 

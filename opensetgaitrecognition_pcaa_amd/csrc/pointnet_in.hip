@@ -9,7 +9,7 @@ namespace {
 
 constexpr int MAXC = 8;
 constexpr int FWD_ROWS = 128;    // points per workgroup (forward)
-constexpr int WG_ROWS = 1024;    // points per workgroup (wgrad)
+constexpr int WG_ROWS = 256;     // points per workgroup (wgrad): 960 workgroups at P = 245760
 
 template <typename T>
 __global__ __launch_bounds__(256) void pointnet_in_fwd_kernel(const float* __restrict__ x, int C,
@@ -67,7 +67,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void pointnet_in_wgrad_kernel(const T* __restrict__ dy,
                                                                 const float* __restrict__ x, int C,
                                                                 float* __restrict__ dW, long P, int cout) {
-  __shared__ float xs[WG_ROWS * MAXC];
+  // also reused for the [rl][cout][MAXC] row-lane combine below: rl*cout = 1024 -> 8192 floats
+  __shared__ float xs[(WG_ROWS * MAXC > 8192) ? WG_ROWS * MAXC : 8192];
   const int qpr = cout >> 2, rl = 256 / qpr;
   const int cq = threadIdx.x % qpr, rlane = threadIdx.x / qpr;
   const long r0 = (long)blockIdx.x * WG_ROWS;
@@ -82,7 +83,25 @@ __global__ __launch_bounds__(256) void pointnet_in_wgrad_kernel(const T* __restr
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) acc[j][c] = 0.f;
-  for (int r = rlane; r < nrows; r += rl) {
+  // 4 rows per trip: four independent 8/16-B loads in flight per lane (the loop is latency-bound)
+  int r = rlane;
+  for (; r + 3 * rl < nrows; r += 4 * rl) {
+    f32x4 d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) d[u] = load4(dy + (r0 + r + u * rl) * cout + cq * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        const float xv = xs[(r + u * rl) * MAXC + c];
+        acc[0][c] = fmaf(d[u].x, xv, acc[0][c]);
+        acc[1][c] = fmaf(d[u].y, xv, acc[1][c]);
+        acc[2][c] = fmaf(d[u].z, xv, acc[2][c]);
+        acc[3][c] = fmaf(d[u].w, xv, acc[3][c]);
+      }
+    }
+  }
+  for (; r < nrows; r += rl) {
     const f32x4 d = load4(dy + (r0 + r) * cout + cq * 4);
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {

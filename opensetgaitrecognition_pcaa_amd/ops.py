@@ -155,7 +155,13 @@ def gemm(A, a_layout, B, b_layout, M, N, K, *, lda=None, ldb=None, out=None, out
                         int(split_k), int(bool(accumulate)), _s()), "pcaa_gemm")
     if timer is not None:
         e1.record()
-        key = ("gemm_bf16_kernel" if math == PCAA_BF16 else "gemm_f32_kernel")
+        if math != PCAA_BF16:
+            key = "gemm_f32_kernel"
+        elif (A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and a_layout == b_layout
+              and M % 256 == 0 and N % 256 == 0 and K % 64 == 0):
+            key = "gemm_bf16_dma_kernel"          # same dispatch rule as pcaa_launch_gemm_bf16_big
+        else:
+            key = "gemm_bf16_big_kernel"
         nbytes = A.numel() * A.element_size() + B.numel() * B.element_size() + out.numel() * out.element_size()
         timer.records.append((key, 2.0 * M * N * K, float(nbytes), e0, e1))
     return out

@@ -131,8 +131,14 @@ class PCAATrainer:
         # accumulate, so that (leading) region is cleared by one fill per step
         self._enc_grads = {n: self.flat_g.grad_views["E." + n] for n, _ in self.encoder.named_parameters()}
         n_enc = sum(1 for nm in self.flat_g.names if nm.startswith("E."))
-        self._enc_region = self.flat_g.g[: self.flat_g.offsets[n_enc] if n_enc < len(self.flat_g.offsets)
-                                         else self.flat_g.total]
+        enc_end = self.flat_g.offsets[n_enc] if n_enc < len(self.flat_g.offsets) else self.flat_g.total
+        self._enc_region = self.flat_g.g[:enc_end]
+        # projection-head + decoder gradients (>98 % of the bytes) are complete before the encoder
+        # backward starts: their all-reduce is issued asynchronously and overlaps it
+        self._tail_region = self.flat_g.g[enc_end:]
+        self.overlap_allreduce = os.environ.get("PCAA_DP_OVERLAP", "1") != "0"
+        # PCAA_DP_FORCE=1 issues the collectives even on a 1-rank group (exercises the RCCL path on one GPU)
+        self._force_collectives = os.environ.get("PCAA_DP_FORCE", "0") == "1"
         self._stats_pool = ops.StatsPool(self.device)
         self._flat_ready = True
 
@@ -145,10 +151,11 @@ class PCAATrainer:
             m.eval()
 
     # ------------------------------------------------------------------ one step
-    def _allreduce(self, t):
-        if self.pg is not None and self.world > 1:
+    def _allreduce(self, t, async_op=False):
+        if self.pg is not None and (self.world > 1 or self._force_collectives) and t.numel():
             import torch.distributed as dist
-            dist.all_reduce(t, group=self.pg)
+            return dist.all_reduce(t, group=self.pg, async_op=async_op)
+        return None
 
     def step(self, pcs, gt, z0, alphas, supervise=True):
         """One iteration of the reference's inner loop (PCAA_ablation.py:882-1021).
@@ -204,8 +211,16 @@ class PCAATrainer:
                                                    dx_init=dsup, dW_out=gv["GPH.0.weight"], db_out=gv["GPH.0.bias"])
         else:
             _, dsup = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads, dz_init=dsup, mode=mode)
+        pending = None
+        if self.overlap_allreduce:
+            pending = self._allreduce(self._tail_region, async_op=True)
         F_hip.encoder_backward(enc, st, dlogits if supervise else None, dsup, gout=self._enc_grads)
-        self._allreduce(self.flat_g.g)
+        if self.overlap_allreduce:
+            self._allreduce(self._enc_region)
+            if pending is not None:
+                pending.wait()          # stream-side wait, no host block
+        else:
+            self._allreduce(self.flat_g.g)
         self.flat_g.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs)
 
         tot = rec_loss + loss_g + (sup_loss if supervise else 0.0)
