@@ -168,8 +168,22 @@ def main():
             name, r = dom
             peak = PEAK_BF16_TFLOPS if name.startswith("gemm_bf16") else PEAK_F32_TFLOPS
             achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+            # HBM bytes per launch of that kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled
+            # per the gfx950 correction, + WRITE_SIZE), committed as profiles/r01_pmc_summary.json;
+            # only valid for the workload it was collected on
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+                    pmc = json.load(f)
+                if pmc.get("workload") == f"B={B} T={T} N={N} C={C} K={K} {a.precision}" and name in pmc["kernels"]:
+                    traffic = pmc["kernels"][name]["hbm_bytes_per_launch"]
+            except (OSError, ValueError, KeyError):
+                pass
             line["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak,
-                                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                                "traffic_unit": "HBM bytes per launch (PMC)",
+                                "algorithmic_flop_per_launch": r["flops"] / r["launches"],
+                                "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
                                 "launches_per_step": r["launches"] / a.steps,
                                 "avg_launch_ms": r["ms"] / r["launches"],
                                 "kernel_ms_per_step": r["ms"] / a.steps,

@@ -67,6 +67,21 @@ int pcaa_gemm(int math,
               const float* bias, double* colstats, int nrep,
               int split_k, int accumulate, void* stream);
 
+/* Split-K without atomics (the long-K weight-gradient products): split s writes its partial
+ * M x N product to slabs + s * slab_stride (fp32), pcaa_splitk_reduce sums the slabs into
+ * out (=|+=).  pcaa_gemm_num_splits tells how many splits pcaa_gemm / pcaa_gemm_slabs will
+ * actually run for a requested split_k (K is cut into multiples of the kernel's K step). */
+int pcaa_gemm_num_splits(int math, int K, int split_k);
+int pcaa_gemm_slabs(int math,
+                    const void* A, int a_dtype, int a_layout, long lda,
+                    const void* B, int b_dtype, int b_layout, long ldb,
+                    float* slabs, long slab_stride, int M, int N, int K, int split_k, void* stream);
+int pcaa_splitk_reduce(const float* slabs, int nsplit, long slab_stride, long n, float* out,
+                       int accumulate, void* stream);
+/* same, for out[rows, ch], plus the BatchNorm column statistics of out (stats as in pcaa_gemm) */
+int pcaa_splitk_reduce_stats(const float* slabs, int nsplit, long slab_stride, float* out,
+                             double* stats, int nrep, long rows, int ch, void* stream);
+
 /* First PointNet layer, Conv2d(C -> cout, 1x1) on the raw points x[P,C] (models.py:87-89):
  * y[P,cout] = x . W[cout,C]^T + bias, with the same BatchNorm statistics as pcaa_gemm;
  * and its weight gradient dW[cout,C] += dy[P,cout]^T . x (dW must be pre-initialised).
@@ -91,10 +106,12 @@ int pcaa_bn_finalize(const double* stats, int nrep, long count, const float* lin
                      float* running_mean, float* running_var, long long* num_batches_tracked,
                      float momentum, float eps,
                      float* scale, float* shift, float* mean, float* rstd, int ch, void* stream);
-/* eval mode: scale/shift from the running statistics */
+/* eval mode: scale/shift from the running statistics.  NOTE: the pre-BN tensor y of these
+ * layers is stored WITHOUT the linear layer's bias (it cancels in train-mode BatchNorm; here
+ * it is folded into shift), hence lin_bias in both finalisers. */
 int pcaa_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
-                        const float* running_var, float eps, float* scale, float* shift,
-                        int ch, void* stream);
+                        const float* running_var, const float* lin_bias, float eps, float* scale,
+                        float* shift, int ch, void* stream);
 /* a = ELU(y*scale + shift) */
 int pcaa_bn_act_fwd(const void* y, void* a, int dtype, const float* scale, const float* shift,
                     long rows, int ch, void* stream);

@@ -47,12 +47,15 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int nrep, d
   const double m0 = s1 * inv_count;                 // mean of the bias-free linear output
   double var = s2 * inv_count - m0 * m0;            // biased variance
   if (var < 0.0) var = 0.0;
+  // The linear layer's bias is NOT in the stored pre-BN tensor y (= the bias-free accumulator):
+  // BatchNorm subtracts the batch mean, so in train mode the bias cancels exactly --
+  // BN(acc + b) = gamma*(acc - mean(acc))*rstd + beta.  It only enters the running mean.
   const double mean = m0 + (lin_bias ? (double)lin_bias[c] : 0.0);
   const double rstd = 1.0 / sqrt(var + (double)eps);
   const float sc = (float)((double)gamma[c] * rstd);
   scale[c] = sc;
-  shift[c] = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
-  mean_out[c] = (float)mean;
+  shift[c] = (float)((double)beta[c] - m0 * (double)gamma[c] * rstd);
+  mean_out[c] = (float)m0;
   rstd_out[c] = (float)rstd;
   if (running_mean) {
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
@@ -61,13 +64,15 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int nrep, d
 }
 
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm,
-                                      const float* rv, float eps, float* scale, float* shift, int ch) {
+                                      const float* rv, const float* lin_bias, float eps, float* scale,
+                                      float* shift, int ch) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ch) return;
   const float rstd = 1.f / sqrtf(rv[c] + eps);
   const float sc = gamma[c] * rstd;
   scale[c] = sc;
-  shift[c] = beta[c] - rm[c] * sc;
+  // y is stored bias-free: z = (acc + b - running_mean) * sc + beta
+  shift[c] = beta[c] + ((lin_bias ? lin_bias[c] : 0.f) - rm[c]) * sc;
 }
 
 // ---------------------------------------------------------------- a = ELU(y*scale+shift)
@@ -398,11 +403,11 @@ extern "C" int pcaa_bn_finalize(const double* stats, int nrep, long count, const
 }
 
 extern "C" int pcaa_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
-                                   const float* running_var, float eps, float* scale, float* shift,
-                                   int ch, void* stream) {
+                                   const float* running_var, const float* lin_bias, float eps, float* scale,
+                                   float* shift, int ch, void* stream) {
   PCAA_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && ch >= 1, "pcaa_bn_eval_coeffs: bad args");
   hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((unsigned)cdiv(ch, 256)), dim3(256), 0, as_stream(stream),
-                     gamma, beta, running_mean, running_var, eps, scale, shift, ch);
+                     gamma, beta, running_mean, running_var, lin_bias, eps, scale, shift, ch);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_eval_coeffs");
 }
 
@@ -556,6 +561,72 @@ extern "C" int pcaa_dtc_col2im(const float* dcol, float* da, int B, int T, int C
   const long n = (long)B * T * Cin;
   hipLaunchKernelGGL(dtc_col2im_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), dcol, da, B, T, Cin, dilation);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_dtc_col2im");
+}
+
+namespace {
+// out[i] (=|+=) sum_s slabs[s*stride + i]   -- second half of slab split-K (no atomics, deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int nsplit,
+                                                            long stride, long nquads, float* __restrict__ out,
+                                                            int accumulate) {
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (long)gridDim.x * 256) {
+    f32x4 acc = accumulate ? load4(out + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsplit; ++s) acc += load4(slabs + s * stride + q * 4);
+    store4(out + q * 4, acc);
+  }
+}
+}  // namespace
+
+namespace {
+// out[r][c] = sum_s slabs[s][r][c], plus the BatchNorm column statistics (sum, sum of squares
+// over the rows) of the result: lets a statistics-producing GEMM with a tiny tile grid (the
+// temporal block: 15-60 tiles on 256 CUs) still be split over K.
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* __restrict__ slabs, int nsplit,
+                                                                  long stride, float* __restrict__ out,
+                                                                  double* __restrict__ stats, int nrep,
+                                                                  long rows, int ch) {
+  __shared__ f32x4 red[2][256];
+  const int qpr = ch >> 2, rl = 256 / qpr;
+  const int cq = threadIdx.x % qpr, rlane = threadIdx.x / qpr;
+  const int c = cq * 4;
+  constexpr int RPB = 32;
+  const long r0 = (long)blockIdx.x * RPB, r1 = min(rows, r0 + RPB);
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  for (long r = r0 + rlane; r < r1; r += rl) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsplit; ++s) acc += load4(slabs + s * stride + r * ch + c);
+    store4(out + r * ch + c, acc);
+    s1 += acc;
+    s2 += acc * acc;
+  }
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * ch; o += 256) {
+    const int stat = o / ch, cc = o - stat * ch;
+    double v = 0.0;
+    for (int l = 0; l < rl; ++l) v += (double)red[stat][l * qpr + (cc >> 2)][cc & 3];
+    unsafeAtomicAdd(&stats[((long)(blockIdx.x % nrep) * 2 + stat) * ch + cc], v);
+  }
+}
+}  // namespace
+
+extern "C" int pcaa_splitk_reduce_stats(const float* slabs, int nsplit, long slab_stride, float* out,
+                                        double* stats, int nrep, long rows, int ch, void* stream) {
+  PCAA_CHECK_ARG(slabs && out && stats && nsplit >= 1 && nrep >= 1 && rows >= 1, "pcaa_splitk_reduce_stats: bad args");
+  PCAA_CHECK_ARG(ch_ok(ch) && (slab_stride % 4) == 0, "pcaa_splitk_reduce_stats: ch/4 must divide 256 (ch=%d)", ch);
+  hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((unsigned)cdiv(rows, 32)), dim3(256), 0, as_stream(stream),
+                     slabs, nsplit, slab_stride, out, stats, nrep, rows, ch);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_splitk_reduce_stats");
+}
+
+extern "C" int pcaa_splitk_reduce(const float* slabs, int nsplit, long slab_stride, long n, float* out,
+                                  int accumulate, void* stream) {
+  PCAA_CHECK_ARG(slabs && out && nsplit >= 1 && n >= 4 && (n % 4) == 0 && (slab_stride % 4) == 0,
+                 "pcaa_splitk_reduce: n and slab_stride must be multiples of 4");
+  PCAA_CHECK_ARG(((uintptr_t)slabs % 16) == 0 && ((uintptr_t)out % 16) == 0, "pcaa_splitk_reduce: 16-B alignment");
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, as_stream(stream), slabs, nsplit,
+                     slab_stride, n >> 2, out, accumulate);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_splitk_reduce");
 }
 
 extern "C" int pcaa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,

@@ -100,7 +100,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[2][2
                                          int tm, int tn, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
-  TC* C = reinterpret_cast<TC*>(p.C);
+  TC* C = reinterpret_cast<TC*>(p.C) + (long)blockIdx.z * p.c_split_stride;   // slab split-K (0 otherwise)
   const bool add_bias = p.bias != nullptr && (!p.atomic || blockIdx.z == 0);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -361,13 +361,26 @@ inline size_t esize(int dt) { return dt == PCAA_BF16 ? 2 : 4; }
 
 }  // namespace
 
-extern "C" int pcaa_gemm(int math,
-                         const void* A, int a_dtype, int a_layout, long lda,
-                         const void* B, int b_dtype, int b_layout, long ldb,
-                         void* C, int c_dtype, long ldc,
-                         int M, int N, int K,
-                         const float* bias, double* colstats, int nrep,
-                         int split_k, int accumulate, void* stream) {
+static int gemm_num_splits(int math, int K, int split_k, int* kps_out) {
+  const int bk = (math == PCAA_BF16) ? H_BK : F_BK;
+  int kps = (int)cdiv(cdiv(K, split_k), bk) * bk;
+  if (kps < bk) kps = bk;
+  if (kps_out) *kps_out = kps;
+  return (int)cdiv(K, kps);
+}
+
+extern "C" int pcaa_gemm_num_splits(int math, int K, int split_k) {
+  if (K < 1 || split_k < 1) return 0;
+  return gemm_num_splits(math, K, split_k, nullptr);
+}
+
+static int gemm_impl(int math,
+                     const void* A, int a_dtype, int a_layout, long lda,
+                     const void* B, int b_dtype, int b_layout, long ldb,
+                     void* C, int c_dtype, long ldc,
+                     int M, int N, int K,
+                     const float* bias, double* colstats, int nrep,
+                     int split_k, int accumulate, long c_split_stride, void* stream) {
   PCAA_CHECK_ARG(A && B && C, "pcaa_gemm: null operand");
   PCAA_CHECK_ARG(M > 0 && N > 0 && K > 0, "pcaa_gemm: bad shape M=%d N=%d K=%d", M, N, K);
   PCAA_CHECK_ARG(math == PCAA_F32 || math == PCAA_BF16, "pcaa_gemm: bad math %d", math);
@@ -376,7 +389,7 @@ extern "C" int pcaa_gemm(int math,
   PCAA_CHECK_ARG(split_k >= 1, "pcaa_gemm: split_k must be >= 1");
   PCAA_CHECK_ARG(lda >= (a_layout == KC ? K : M) && ldb >= (b_layout == KC ? K : N) && ldc >= N,
                  "pcaa_gemm: leading dimension too small");
-  const int atomic = (split_k > 1 || accumulate) ? 1 : 0;
+  const int atomic = (c_split_stride == 0 && (split_k > 1 || accumulate)) ? 1 : 0;
   PCAA_CHECK_ARG(!atomic || c_dtype == PCAA_F32, "pcaa_gemm: atomic accumulation needs fp32 C");
   PCAA_CHECK_ARG(!(atomic && colstats), "pcaa_gemm: column statistics need a single K pass");
   PCAA_CHECK_ARG(!colstats || nrep >= 1, "pcaa_gemm: nrep must be >= 1 with colstats");
@@ -389,10 +402,10 @@ extern "C" int pcaa_gemm(int math,
   p.atomic = atomic;
   p.nsplit = 1;
   p.split_fast = 0;
-  const int bk = (math == PCAA_BF16) ? H_BK : F_BK;
-  int kps = (int)cdiv(cdiv(K, split_k), bk) * bk;
-  if (kps < bk) kps = bk;
-  const int nsplit = (int)cdiv(K, kps);
+  p.diag = 0;
+  p.c_split_stride = c_split_stride;
+  int kps = 0;
+  const int nsplit = gemm_num_splits(math, K, split_k, &kps);
   p.k_per_split = kps;
   const long ntiles = cdiv(M, BM) * cdiv(N, BN);
   PCAA_CHECK_ARG(ntiles < (1L << 31), "pcaa_gemm: too many tiles");
@@ -441,4 +454,25 @@ extern "C" int pcaa_gemm(int math,
     return PCAA_ERR_INVALID_ARG;
   }
   PCAA_RETURN_LAUNCH_STATUS("pcaa_gemm(f32)");
+}
+
+extern "C" int pcaa_gemm(int math,
+                         const void* A, int a_dtype, int a_layout, long lda,
+                         const void* B, int b_dtype, int b_layout, long ldb,
+                         void* C, int c_dtype, long ldc,
+                         int M, int N, int K,
+                         const float* bias, double* colstats, int nrep,
+                         int split_k, int accumulate, void* stream) {
+  return gemm_impl(math, A, a_dtype, a_layout, lda, B, b_dtype, b_layout, ldb, C, c_dtype, ldc, M, N, K, bias,
+                   colstats, nrep, split_k, accumulate, 0, stream);
+}
+
+// split-K without atomics: split s writes its partial product to slabs + s * slab_stride
+extern "C" int pcaa_gemm_slabs(int math,
+                               const void* A, int a_dtype, int a_layout, long lda,
+                               const void* B, int b_dtype, int b_layout, long ldb,
+                               float* slabs, long slab_stride, int M, int N, int K, int split_k, void* stream) {
+  PCAA_CHECK_ARG(slabs && slab_stride >= (long)M * N, "pcaa_gemm_slabs: slab stride must cover an M x N tile");
+  return gemm_impl(math, A, a_dtype, a_layout, lda, B, b_dtype, b_layout, ldb, slabs, PCAA_F32, N, M, N, K, nullptr,
+                   nullptr, 0, split_k, 0, slab_stride, stream);
 }

@@ -150,7 +150,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, f32x16 (&acc
     __syncthreads();   // the statistics reduction reuses this LDS
     return;
   }
-  TC* C = reinterpret_cast<TC*>(p.C);
+  TC* C = reinterpret_cast<TC*>(p.C) + (long)split * p.c_split_stride;   // slab split-K (0 otherwise)
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     const int gn = tn * BN + wn * 64 + j * 32 + l31;
@@ -166,6 +166,73 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, f32x16 (&acc
           else store1(C + (long)gm * p.ldc + gn, v);
         }
       }
+    }
+  }
+}
+
+// Full-tile epilogue of the LDS-DMA kernels (M, N multiples of 256: no bounds checks, 32-bit
+// offsets).  PMC/diagnostic builds put 40 % of the forward GEMM's time in the generic epilogue
+// (4.4 K instructions, per-element exec-mask branches, 64-bit address math, 240 spill
+// instructions), so this one is specialised at compile time:
+//   bf16 out : neighbouring lanes exchange one value (DPP quad_perm [1,0,3,2]) so that every lane
+//              owns two adjacent columns of one row -> v_cvt_pk_bf16_f32 + ds_write_b32 (64 per
+//              lane instead of 128 ds_write_b16), then 16-B-per-lane row-contiguous stores.
+//   fp32 out : plain stores (slab split-K: C is offset by split * c_split_stride) or atomics.
+__device__ __forceinline__ float dpp_swap_neighbour(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+template <typename TC>
+__device__ __forceinline__ void epilogue_full_tile(const GemmParams& p, f32x16 (&acc)[FM][FN], bf16_t* smem,
+                                                   int tm, int tn, int tid, int split) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, half = lane >> 5;
+  const bool add_bias = p.bias != nullptr && (!p.atomic || split == 0);
+  if constexpr (sizeof(TC) == 2) {
+    constexpr int PITCH = 64;
+    uint32_t* w32 = reinterpret_cast<uint32_t*>(smem + wave * 128 * PITCH);
+    const bool odd = lane & 1;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const float bv = add_bias ? p.bias[tn * BN + wn * 64 + j * 32 + l31] : 0.f;
+      const int colw = (j * 32 + (l31 & ~1)) >> 1;            // 32-bit word index of the column pair
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float va = acc[i][j][r] + bv, vb = acc[i][j][r + 1] + bv;   // rows R and R+1, my column
+          const float got = dpp_swap_neighbour(odd ? va : vb);
+          // even lane: row R, (mine, right neighbour's) ; odd lane: row R+1, (left neighbour's, mine)
+          const uint32_t packed = odd ? pack2(got, vb) : pack2(va, got);
+          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + (odd ? 1 : 0);
+          w32[row * (PITCH / 2) + colw] = packed;
+        }
+    }
+    __syncthreads();
+    bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + (long)(tm * BM + wm * 128) * p.ldc + tn * BN + wn * 64;
+    const bf16_t* w = smem + wave * 128 * PITCH;
+    const int cg = (lane & 7) * 8, r0 = lane >> 3;
+#pragma unroll
+    for (int pass = 0; pass < 16; ++pass) {
+      const int row = pass * 8 + r0;
+      *reinterpret_cast<uint4*>(C + (long)row * p.ldc + cg) = *reinterpret_cast<const uint4*>(&w[row * PITCH + cg]);
+    }
+    __syncthreads();   // the statistics reduction reuses this LDS
+  } else {
+    float* C = reinterpret_cast<float*>(p.C) + (long)split * p.c_split_stride +
+               (long)(tm * BM + wm * 128 + 4 * half) * p.ldc + tn * BN + wn * 64 + l31;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const float bv = add_bias ? p.bias[tn * BN + wn * 64 + j * 32 + l31] : 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* dst = C + (long)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldc + j * 32;
+          const float v = acc[i][j][r] + bv;
+          if (p.atomic) atomicAdd(dst, v);
+          else *dst = v;
+        }
     }
   }
 }
@@ -332,7 +399,9 @@ __device__ __forceinline__ bf16x8 dma_load_frag(const bf16_t* s, int off, int ks
   return u.v;
 }
 
-template <typename TC, int ALAY, int BLAY>
+// DIAG != 0: timing-only builds (WRONG results) used to attribute the loop time:
+//   1 no DMA inside the loop, 2 no MFMA, 3 no epilogue.  Selected with PCAA_GEMM_DIAG.
+template <typename TC, int ALAY, int BLAY, int DIAG = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
@@ -376,29 +445,472 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   for (int t = 0; t < nt; ++t) {
     const bf16_t* sA = smem + (t & 1) * 2 * D_TILE;
     const bf16_t* sB = sA + D_TILE;
-    if (t + 1 < nt) {
+    if (t + 1 < nt && DIAG != 1) {
       bf16_t* nA = smem + ((t + 1) & 1) * 2 * D_TILE;
       const int k0 = kbeg + (t + 1) * BK;
       dma_tile<ALAY>(A, p.lda, tm * BM, p.M, k0, nA, wave, lane);
       dma_tile<BLAY>(B, p.ldb, tn * BN, p.N, k0, nA + D_TILE, wave, lane);
     }
+    // software-pipelined fragment reads: the 6 ds_reads of k-step ks+1 are issued before the 8
+    // MFMAs of k-step ks, so only the first read group of a stage exposes LDS latency (the
+    // compiler's own schedule was "read; s_waitcnt lgkmcnt(0); mfma" per group)
+    bf16x8 af[2][FM], bfr[2][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) af[0][i] = dma_load_frag<ALAY>(sA, offA[i], 0, kofs);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bfr[0][j] = dma_load_frag<BLAY>(sB, offB[j], 0, kofs);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 af[FM], bfr[FN];
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks < 3) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = dma_load_frag<ALAY>(sA, offA[i], ks, kofs);
+        for (int i = 0; i < FM; ++i) af[nxt][i] = dma_load_frag<ALAY>(sA, offA[i], ks + 1, kofs);
 #pragma unroll
-      for (int j = 0; j < FN; ++j) bfr[j] = dma_load_frag<BLAY>(sB, offB[j], ks, kofs);
+        for (int j = 0; j < FN; ++j) bfr[nxt][j] = dma_load_frag<BLAY>(sB, offB[j], ks + 1, kofs);
+      }
+      // pin: next step's reads stay ABOVE this step's MFMAs (the machine scheduler otherwise sinks
+      // them to just before their use and waits lgkmcnt(0))
+      __builtin_amdgcn_sched_barrier(0);
+      if (DIAG != 2) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(af[cur][i]));
+#pragma unroll
+        for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(bfr[cur][j]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
 
-  epilogue_store<TC, 64>(p, acc, smem, tm, tn, tid, split);
+  if (DIAG == 3) {
+    if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = 1.f;   // keep the accumulators live
+    return;
+  }
+  epilogue_full_tile<TC>(p, acc, smem, tm, tn, tid, split);
+  if (p.colstats != nullptr) {
+    float* red = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[i][j][r];
+          s1 += v;
+          s2 += v * v;
+        }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (half == 0) {
+        const int col = wn * 64 + j * 32 + l31;
+        red[(0 * 2 + wm) * 256 + col] = s1;
+        red[(1 * 2 + wm) * 256 + col] = s2;
+      }
+    }
+    __syncthreads();
+    const int stat = tid >> 8, col = tid & 255;
+    const double v = (double)red[(stat * 2 + 0) * 256 + col] + (double)red[(stat * 2 + 1) * 256 + col];
+    unsafeAtomicAdd(&p.colstats[((long)(tm % p.nrep) * 2 + stat) * p.N + tn * BN + col], v);
+  }
+}
+
+// ===========================================================================
+// Persistent LDS-DMA kernel (forward / dgrad: thousands of 256x256 tiles, K only 512-1024).
+// Timing-only builds of the kernel above put ~40 % of its time OUTSIDE the K loop: workgroup
+// launch, the exposed latency of the first DMA of every tile, and the drain of the C stores
+// before the workgroup can retire (one workgroup per CU, nothing to overlap with).  Here each
+// workgroup walks a list of tiles with ONE continuous DMA stream:
+//   * the first stage of tile i+1 is requested during the last K step of tile i, into the
+//     stage that step is not reading;
+//   * the epilogue of tile i runs out of the stage that step just consumed (64 KB, two
+//     half-tile passes), entirely wave-local in LDS (a wave reads back only what it wrote, and
+//     a wave's LDS operations execute in order), while that DMA and the C stores are in flight;
+//   * the wait before tile i+1's first MFMA is a COUNTED vmcnt: only the 16 C stores (+1
+//     statistics atomic) issued after the DMA may still be pending, so the stores keep draining
+//     under the next tile's MFMAs.
+// Tile order: every XCD (workgroups b, b+8, ...) walks its own contiguous range of the XCD-aware
+// tile list, so an A panel is still shared through that XCD's L2.
+// ===========================================================================
+__device__ __forceinline__ bool persistent_tile(int nb, int nbn, int it, int& tm, int& tn) {
+  const int q = nb >> 3, r = nb & 7;
+  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;       // gridDim.x is a multiple of 8
+  const int idx = (blockIdx.x >> 3) + it * per_xcd;
+  const int count = q + (xcd < r ? 1 : 0);
+  if (idx >= count) return false;
+  const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  tm = v / nbn;
+  tn = v - tm * nbn;
+  return true;
+}
+
+template <int ALAY, int BLAY>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_dmap_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, half = lane >> 5;
+  const int nbm = p.M / BM, nbn = p.N / BN, nb = nbm * nbn;
+  const int nt = p.K / BK;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+  bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+
+  int offA[FM], offB[FN], kofs[4];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) offA[i] = dma_frag_offset<ALAY>(wm * 128 + i * 32, lane);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) offB[j] = dma_frag_offset<BLAY>(wn * 64 + j * 32, lane);
+  {
+    const int swz = (l31 >> 1) & 7;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kofs[s] = ((2 * s + half) ^ swz) * 8;
+  }
+
+  int tm, tn, ntm = 0, ntn = 0;
+  bool have = persistent_tile(nb, nbn, 0, tm, tn);
+  if (!have) return;                       // (uniform: whole workgroup)
+  dma_tile<ALAY>(A, p.lda, tm * BM, p.M, 0, smem, wave, lane);
+  dma_tile<BLAY>(B, p.ldb, tn * BN, p.N, 0, smem + D_TILE, wave, lane);
+  __syncthreads();
+
+  int g = 0;                               // global K-step counter: stage = g & 1
+  for (int it = 0; have; ++it) {
+    const bool have_next = persistent_tile(nb, nbn, it + 1, ntm, ntn);
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int t = 0; t < nt; ++t, ++g) {
+      const bf16_t* sA = smem + (g & 1) * 2 * D_TILE;
+      const bf16_t* sB = sA + D_TILE;
+      bf16_t* nA = smem + ((g + 1) & 1) * 2 * D_TILE;
+      const bool last = (t + 1 == nt);
+      if (!last) {
+        dma_tile<ALAY>(A, p.lda, tm * BM, p.M, (t + 1) * BK, nA, wave, lane);
+        dma_tile<BLAY>(B, p.ldb, tn * BN, p.N, (t + 1) * BK, nA + D_TILE, wave, lane);
+      } else if (have_next) {
+        dma_tile<ALAY>(A, p.lda, ntm * BM, p.M, 0, nA, wave, lane);
+        dma_tile<BLAY>(B, p.ldb, ntn * BN, p.N, 0, nA + D_TILE, wave, lane);
+      }
+      bf16x8 af[2][FM], bfr[2][FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[0][i] = dma_load_frag<ALAY>(sA, offA[i], 0, kofs);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bfr[0][j] = dma_load_frag<BLAY>(sB, offB[j], 0, kofs);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks < 3) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) af[nxt][i] = dma_load_frag<ALAY>(sA, offA[i], ks + 1, kofs);
+#pragma unroll
+          for (int j = 0; j < FN; ++j) bfr[nxt][j] = dma_load_frag<BLAY>(sB, offB[j], ks + 1, kofs);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!last) {
+        __syncthreads();                   // vmcnt(0) + barrier: step t+1 has landed everywhere
+      } else {
+        // every wave is done READING this stage; the next tile's DMA stays in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+
+    // ---- epilogue out of the stage the last step consumed (g was already advanced past it)
+    bf16_t* scratch = smem + ((g - 1) & 1) * 2 * D_TILE;          // 64 KB
+    uint32_t* w32 = reinterpret_cast<uint32_t*>(scratch + wave * 64 * 64);
+    const bf16_t* wr = scratch + wave * 64 * 64;
+    const bool odd = lane & 1;
+    bf16_t* Ct = C + (long)(tm * BM + wm * 128) * p.ldc + tn * BN + wn * 64;
+    const int cg = (lane & 7) * 8, r0 = lane >> 3;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      asm volatile("" ::: "memory");       // keep the previous half's LDS reads above these writes
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int colw = (j * 32 + (l31 & ~1)) >> 1;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int i = 2 * h2 + ii;
+            // no bias here (an ordinary global load next to an in-flight LDS-DMA makes hipcc
+            // drain the DMA with vmcnt(0)); the launcher only takes this kernel with bias == NULL
+            const float va = acc[i][j][r], vb = acc[i][j][r + 1];
+            const float got = dpp_swap_neighbour(odd ? va : vb);
+            const uint32_t packed = odd ? pack2(got, vb) : pack2(va, got);
+            const int row = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + (odd ? 1 : 0);
+            w32[row * 32 + colw] = packed;
+          }
+      }
+      asm volatile("" ::: "memory");       // LDS is in-order per wave; this pins the compiler's order too
+#pragma unroll
+      for (int pass = 0; pass < 8; ++pass) {
+        const int row = pass * 8 + r0;
+        *reinterpret_cast<uint4*>(Ct + (long)(h2 * 64 + row) * p.ldc + cg) =
+            *reinterpret_cast<const uint4*>(&wr[row * 64 + cg]);
+      }
+    }
+    // ---- BatchNorm column statistics (bias-free accumulator)
+    if (p.colstats != nullptr) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();        // every wave has finished with its scratch area
+      float* red = reinterpret_cast<float*>(scratch);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[i][j][r];
+            s1 += v;
+            s2 += v * v;
+          }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (half == 0) {
+          const int col = wn * 64 + j * 32 + l31;
+          red[(0 * 2 + wm) * 256 + col] = s1;
+          red[(1 * 2 + wm) * 256 + col] = s2;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int stat = tid >> 8, col = tid & 255;
+      const double v = (double)red[(stat * 2 + 0) * 256 + col] + (double)red[(stat * 2 + 1) * 256 + col];
+      unsafeAtomicAdd(&p.colstats[((long)(tm % p.nrep) * 2 + stat) * p.N + tn * BN + col], v);
+    }
+    // ---- next tile: its first stage (8 DMA instructions per wave, issued before the 16 stores and
+    // the atomic above) must have landed; the stores may still be pending
+    if (have_next) {
+      asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    tm = ntm;
+    tn = ntn;
+    have = have_next;
+  }
+}
+
+template <int ALAY, int BLAY>
+bool launch_dmap(const GemmParams& p, hipStream_t s) {
+  static bool configured = false;
+  static int ncu = 0;
+  auto kern = gemm_bf16_dmap_kernel<ALAY, BLAY>;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            D_LDS_BYTES) != hipSuccess)
+      return false;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    ncu = prop.multiProcessorCount;
+    configured = true;
+  }
+  const long ntiles = (long)(p.M / BM) * (p.N / BN);
+  long grid = ncu - (ncu % 8);
+  if (grid < 8) grid = 8;
+  if (grid > ntiles) grid = ((ntiles + 7) / 8) * 8;      // surplus workgroups find no tile and exit
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), D_LDS_BYTES, s, p);
+  return true;
+}
+
+// ===========================================================================
+// 4-stage LDS-DMA variant (BK = 32 per stage, same 128 KB of LDS): the DMA of
+// step t+3 is issued at the top of step t, so up to three 32-KB stages (96 KB per
+// CU, vs 64 KB in the 2-stage kernel) are in flight behind the MFMAs.  PMC on the
+// 2-stage kernel showed 40 % (KC) / 59 % (RC) of wave time parked in s_waitcnt /
+// s_barrier with zero LDS bank conflicts: the fix is prefetch depth, and that needs
+// COUNTED waits -- __syncthreads() would drain every DMA (vmcnt(0)) each step.  Each
+// wave issues exactly 4 DMA instructions per step (2 pieces of A, 2 of B), so
+// "all but the youngest g groups have landed" is s_waitcnt vmcnt(4*g); the wait sits
+// immediately before the raw s_barrier that precedes the first read of that stage
+// (RAW), and a stage is refilled only after the barrier that follows its last read
+// (WAR).  No ordinary global load lives in the loop (it would force vmcnt(0)).
+//   KC image [256 rows][32 k] (64-B rows): granule g of row r holds k-granule g ^ ((r>>2)&3)
+//   RC image [32 k][256 rows]: as in the 2-stage kernel.
+// ===========================================================================
+constexpr int Q_BK = 32;
+constexpr int Q_STAGES = 4;
+constexpr int Q_TILE = 256 * Q_BK;                          // elements per operand per stage (16 KB)
+constexpr int Q_LDS_BYTES = Q_STAGES * 2 * Q_TILE * 2;      // 131072
+
+template <int LAY>
+__device__ __forceinline__ void q_dma_tile(const bf16_t* __restrict__ base, long ld, int row0, int R, int k0,
+                                           bf16_t* s_tile, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int p = wave * 2 + j;       // 1-KB piece index, 16 per tile
+    const bf16_t* src;
+    if (LAY == KC) {
+      const int r = 16 * p + (lane >> 2);
+      const int g = (lane & 3) ^ ((r >> 2) & 3);
+      src = base + (long)min(row0 + r, R - 1) * ld + k0 + 8 * g;
+    } else {
+      const int k = 2 * p + (lane >> 5);
+      const int c = (lane & 31) ^ (4 * (k & 3));
+      src = base + (long)(k0 + k) * ld + row0 + 8 * c;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(s_tile + p * 512), 16, 0, 0);
+  }
+}
+
+template <int LAY>
+__device__ __forceinline__ int q_frag_offset(int row_base, int lane) {
+  if (LAY == KC) return (row_base + (lane & 31)) * Q_BK;
+  const int j = lane & 15, mb = 16 * ((lane >> 4) & 1), h = lane >> 5;
+  const int q = j >> 2, ch = row_base + mb + 4 * (j & 3);
+  return (8 * h + q) * 256 + ((((ch >> 3) ^ (4 * q)) << 3) | (ch & 7));
+}
+
+template <int LAY>
+__device__ __forceinline__ bf16x8 q_load_frag(const bf16_t* s, int off, int kstep, const int (&kofs)[2]) {
+  if (LAY == KC) return *reinterpret_cast<const bf16x8*>(s + off + kofs[kstep]);
+  const bf16_t* p = s + off + kstep * 16 * 256;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * 256));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo;
+  u.s.b = hi;
+  return u.v;
+}
+
+template <typename TC, int ALAY, int BLAY>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma4_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, half = lane >> 5;
+  int tm, tn;
+  const int split = block_coords(p, p.M / BM, p.N / BN, tm, tn);
+
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nt = (kend - kbeg) / Q_BK;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int offA[FM], offB[FN], kofs[2];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) offA[i] = q_frag_offset<ALAY>(wm * 128 + i * 32, lane);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) offB[j] = q_frag_offset<BLAY>(wn * 64 + j * 32, lane);
+  {
+    const int swz = (l31 >> 2) & 3;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) kofs[s] = ((2 * s + half) ^ swz) * 8;
+  }
+
+  // prologue: stages 0..2 <- steps 0..2 (as many as exist); step 0 must have landed before the loop
+  const int pre = min(nt, Q_STAGES - 1);
+  for (int t = 0; t < pre; ++t) {
+    bf16_t* st = smem + t * 2 * Q_TILE;
+    q_dma_tile<ALAY>(A, p.lda, tm * BM, p.M, kbeg + t * Q_BK, st, wave, lane);
+    q_dma_tile<BLAY>(B, p.ldb, tn * BN, p.N, kbeg + t * Q_BK, st + Q_TILE, wave, lane);
+  }
+  if (pre >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (pre == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // Ping-pong: the DMA instructions are expensive to ISSUE (~100 cycles each while the wave can do
+  // nothing else), and with all 8 waves in lockstep both waves of a SIMD issued them at the same
+  // time while the MFMA pipe idled.  The two wave groups (waves 0-3 / 4-7: wave w and w+4 share a
+  // SIMD) now run half a step apart: in every phase one group issues its 4 DMA instructions for
+  // step t+3 while the other runs its 16 MFMAs alone on the pipe; a raw barrier ends each phase.
+  //   phase 2t  : group 1 computes step t      | group 0 issues DMA(t+3)
+  //   phase 2t+1: group 1 issues DMA(t+3), then both wait "step t+1 landed" | group 0 computes step t
+  // WAR: stage (t+3)&3 was last read in step t-1 (group 0: phase 2t-1, group 1: phase 2t-2).
+  // RAW: every wave's counted vmcnt + the barrier ending phase 2t+1 precede the first read of
+  // step t+1 (group 1, phase 2t+2).
+  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+  auto compute = [&](int t) {
+    const bf16_t* sA = smem + (t & (Q_STAGES - 1)) * 2 * Q_TILE;
+    const bf16_t* sB = sA + Q_TILE;
+    bf16x8 af[2][FM], bfr[2][FN];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[ks][i] = q_load_frag<ALAY>(sA, offA[i], ks, kofs);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bfr[ks][j] = q_load_frag<BLAY>(sB, offB[j], ks, kofs);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+  };
+  auto refill = [&](int t) {
+    if (t + 3 < nt) {
+      bf16_t* st = smem + ((t + 3) & (Q_STAGES - 1)) * 2 * Q_TILE;
+      const int k0 = kbeg + (t + 3) * Q_BK;
+      q_dma_tile<ALAY>(A, p.lda, tm * BM, p.M, k0, st, wave, lane);
+      q_dma_tile<BLAY>(B, p.ldb, tn * BN, p.N, k0, st + Q_TILE, wave, lane);
+    }
+  };
+  auto wait_next = [&](int t) {
+    // this wave's groups younger than step t+1's: steps t+2, t+3 where they exist
+    const int ahead = min(nt - 1, t + 3) - (t + 1);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  if (grp == 1) {
+    for (int t = 0; t < nt; ++t) {
+      compute(t);
+      __builtin_amdgcn_s_barrier();      // end of phase 2t
+      refill(t);
+      wait_next(t);
+      __builtin_amdgcn_s_barrier();      // end of phase 2t+1
+    }
+  } else {
+    for (int t = 0; t < nt; ++t) {
+      refill(t);
+      __builtin_amdgcn_s_barrier();      // end of phase 2t
+      compute(t);
+      wait_next(t);
+      __builtin_amdgcn_s_barrier();      // end of phase 2t+1
+    }
+  }
+  // the fragment reads of the last step were consumed by its MFMAs before the final barrier;
+  // make the epilogue's LDS reuse safe against any straggling LDS traffic
+  __syncthreads();
+
+  epilogue_full_tile<TC>(p, acc, smem, tm, tn, tid, split);
   if (p.colstats != nullptr) {
     float* red = reinterpret_cast<float*>(smem_raw);
 #pragma unroll
@@ -428,9 +940,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
 }
 
 template <typename TC, int ALAY, int BLAY>
+bool launch_dma4(const GemmParams& p, dim3 grid, hipStream_t s) {
+  static bool configured = false;
+  auto kern = gemm_bf16_dma4_kernel<TC, ALAY, BLAY>;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            Q_LDS_BYTES) != hipSuccess)
+      return false;
+    configured = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), Q_LDS_BYTES, s, p);
+  return true;
+}
+
+template <typename TC, int ALAY, int BLAY, int DIAG = 0>
 bool launch_dma(const GemmParams& p, dim3 grid, hipStream_t s) {
   static bool configured = false;
-  auto kern = gemm_bf16_dma_kernel<TC, ALAY, BLAY>;
+  auto kern = gemm_bf16_dma_kernel<TC, ALAY, BLAY, DIAG>;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             D_LDS_BYTES) != hipSuccess)
@@ -473,14 +999,45 @@ bool pcaa_launch_gemm_bf16_big(const GemmParams& p_in, int a_dtype, int a_layout
   // (wgrad 1024x512 K=245760: 0.53 -> 1.36 ms at 128 blocks; 1024^2: 0.61 -> 0.59): the re-reads
   // were already served by the Infinity Cache, and co-locating them adds same-line contention.
   p.split_fast = 0;
+  { const char* d = getenv("PCAA_GEMM_DIAG"); p.diag = d ? atoi(d) : 0; }
   dim3 grid((unsigned)ntiles, 1, (unsigned)nsplit);
   if (p.split_fast) grid = dim3((unsigned)(ntiles * nsplit), 1, 1);
   const bool af = a_dtype == PCAA_F32, bf = b_dtype == PCAA_F32, cf = c_dtype == PCAA_F32;
   // LDS-DMA kernel: bf16 x bf16, whole tiles only
   if (!af && !bf && (p.M % BM) == 0 && (p.N % BN) == 0 && (p.K % BK) == 0 && (p.k_per_split % BK) == 0 &&
       a_layout == b_layout) {
-    if (a_layout == KC) return cf ? launch_dma<float, KC, KC>(p, grid, stream) : launch_dma<bf16_t, KC, KC>(p, grid, stream);
-    if (cf) return launch_dma<float, RC, RC>(p, grid, stream);
+    // the 4-stage / BK=32 / counted-vmcnt kernel measured 5-17 % SLOWER than the 2-stage one
+    // (twice the barriers per K outweigh the deeper prefetch); kept behind PCAA_GEMM_DMA4 for A/B
+    static const bool two_stage = getenv("PCAA_GEMM_DMA2") != nullptr;
+    if (two_stage && p.diag) {
+      if (a_layout == KC && !cf) {
+        if (p.diag == 1) return launch_dma<bf16_t, KC, KC, 1>(p, grid, stream);
+        if (p.diag == 2) return launch_dma<bf16_t, KC, KC, 2>(p, grid, stream);
+        return launch_dma<bf16_t, KC, KC, 3>(p, grid, stream);
+      }
+      if (a_layout == RC && cf) {
+        if (p.diag == 1) return launch_dma<float, RC, RC, 1>(p, grid, stream);
+        if (p.diag == 2) return launch_dma<float, RC, RC, 2>(p, grid, stream);
+        return launch_dma<float, RC, RC, 3>(p, grid, stream);
+      }
+    }
+    // forward / dgrad (no split, bf16 out, no bias): persistent kernel
+    // measured equal to the one-tile-per-workgroup kernel (0.61 vs 0.59 ms on [245760,1024]x[1024,1024]):
+    // a no-MFMA timing build shows the loop is bound by L2->LDS delivery of the operand tiles
+    // (~36 GB/s per CU), which persistence cannot change.  Opt-in: PCAA_GEMM_PERSISTENT=1.
+    static const bool persistent = getenv("PCAA_GEMM_PERSISTENT") != nullptr;
+    if (persistent && nsplit == 1 && !cf && p.bias == nullptr && !p.atomic && (p.ldc % 8) == 0 &&
+        ((uintptr_t)p.C % 16) == 0) {
+      if (a_layout == KC) return launch_dmap<KC, KC>(p, stream);
+      return launch_dmap<RC, RC>(p, stream);
+    }
+    if (two_stage) {
+      if (a_layout == KC) return cf ? launch_dma<float, KC, KC>(p, grid, stream) : launch_dma<bf16_t, KC, KC>(p, grid, stream);
+      if (cf) return launch_dma<float, RC, RC>(p, grid, stream);
+    } else {
+      if (a_layout == KC) return cf ? launch_dma4<float, KC, KC>(p, grid, stream) : launch_dma4<bf16_t, KC, KC>(p, grid, stream);
+      if (cf) return launch_dma4<float, RC, RC>(p, grid, stream);
+    }
   }
   if (a_layout == KC && b_layout == KC) {
     // bf16 activations x fp32/bf16 weights (PointNet forward / dgrad), fp32 x fp32 (decoder forward)

@@ -14,6 +14,8 @@ struct GemmParams {
   int atomic;
   int nsplit;       // number of K splits
   int split_fast;   // 1: 1-D grid, block b -> split b % nsplit, tile b / nsplit (see block_coords)
+  long c_split_stride;   // slab split-K: split s stores its partial tile at C + s * c_split_stride (no atomics)
+  int diag;       // timing-only diagnostics of the 2-stage DMA kernel (WRONG results): 1 no DMA in the loop, 2 no MFMA, 3 no epilogue
 };
 
 // XCD-aware, bijective block -> (tile_m, tile_n) map: the 8 XCDs (blocks b, b+8,

@@ -74,7 +74,9 @@ class _LayerSave:
 
 
 def _linear_bn(a_in, W2d, lin_bias, bn, training, mode, first_layer):
-    """y = a_in @ W2d^T + b with BatchNorm statistics; returns y and BN coefficients."""
+    """y = a_in @ W2d^T (the linear bias is NOT added: it cancels in train-mode BatchNorm and
+    is folded into ``shift`` in eval mode; see bn_finalize_kernel) with BatchNorm statistics;
+    returns the bias-free y and the BN coefficients that apply to it."""
     rows, cin = a_in.shape
     cout = W2d.shape[0]
     stats = ops.new_stats(cout, a_in.device) if training else None
@@ -82,22 +84,28 @@ def _linear_bn(a_in, W2d, lin_bias, bn, training, mode, first_layer):
     out_dtype = torch.bfloat16 if (mode == "bf16" and first_layer is not None) else torch.float32
     if first_layer is not None and a_in.dtype == torch.float32 and cin <= 8 and ops.pointnet_in_ok(cin, cout):
         # raw points -> first PointNet layer: C-wide contraction, HBM-bound streaming kernel
-        y = ops.pointnet_in_fwd(a_in, W2d, lin_bias, out_dtype, stats)
+        y = ops.pointnet_in_fwd(a_in, W2d, None, out_dtype, stats)
     elif use_bf16:
         # bf16 shadow of the weights so both operands stream by LDS-DMA (the transposed copy
         # serves the dgrad GEMM of the backward pass)
         w16, wt16 = ops.cast_bf16(W2d, True, training)
         _W16_CACHE[W2d.data_ptr()] = wt16
-        y = ops.gemm(a_in, KC, w16, KC, rows, cout, cin, bias=lin_bias, colstats=stats, out_dtype=out_dtype,
-                     math=PCAA_BF16)
+        y = ops.gemm(a_in, KC, w16, KC, rows, cout, cin, colstats=stats, out_dtype=out_dtype, math=PCAA_BF16)
     else:
-        y = ops.gemm(a_in, KC, W2d, KC, rows, cout, cin, bias=lin_bias, colstats=stats, out_dtype=out_dtype,
-                     math=PCAA_F32)
+        tiles = ((rows + 127) // 128) * ((cout + 127) // 128)
+        sk = ops.pick_split_k(rows, cout, cin, target_blocks=512)
+        if (training and out_dtype == torch.float32 and tiles < 128 and sk > 1 and cout % 4 == 0
+                and 256 % (cout // 4) == 0 and cout <= 1024):
+            # few output tiles, long K (the temporal block): split K through slabs; the reduction
+            # pass also produces the BatchNorm statistics the GEMM epilogue would have
+            y = ops.gemm_slabs(a_in, KC, W2d, KC, rows, cout, cin, sk, math=PCAA_F32, colstats=stats)
+        else:
+            y = ops.gemm(a_in, KC, W2d, KC, rows, cout, cin, colstats=stats, out_dtype=out_dtype, math=PCAA_F32)
     if training:
         count = _sync_stats(stats, rows)
         scale, shift, mean, rstd = ops.bn_finalize(stats, count, lin_bias, bn, cout)
     else:
-        scale, shift = ops.bn_eval_coeffs(bn, cout)
+        scale, shift = ops.bn_eval_coeffs(bn, cout, lin_bias)
         mean = rstd = None
         count = rows
     return y, scale, shift, mean, rstd, count
@@ -151,8 +159,10 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
         dW = ops.pointnet_in_wgrad(dy, lhs, out=dW_out, out_is_zero=True)
     elif wgrad_bf16:
         sk = ops.pick_split_k(cout, K, rows_local, target_blocks=256, bk=64, tile=256)
-        dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, split_k=sk,
-                      accumulate=sk > 1 or dW_out is not None, math=PCAA_BF16)
+        if sk > 1:
+            dW = ops.gemm_slabs(dy, RC, lhs, RC, cout, K, rows_local, sk, out=dW_out, math=PCAA_BF16)
+        else:
+            dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, math=PCAA_BF16)
     else:
         sk = ops.pick_split_k(cout, K, rows_local)
         dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, split_k=sk,

@@ -167,6 +167,52 @@ def gemm(A, a_layout, B, b_layout, M, N, K, *, lda=None, ldb=None, out=None, out
     return out
 
 
+def gemm_slabs(A, a_layout, B, b_layout, M, N, K, split_k, out=None, accumulate=False, math=PCAA_BF16,
+               colstats=None):
+    """Split-K product without atomics: every split writes its partial [M,N] slab, a second
+    launch sums the slabs into ``out`` (=|+=).  Used for the long-K weight gradients, where the
+    atomic epilogue (256 KB of fp32 atomics per workgroup) cost as much as the MFMA loop."""
+    _chk(A, "gemm_slabs.A", dim=2)
+    _chk(B, "gemm_slabs.B", dim=2)
+    if (M * N) % 4:
+        raise ValueError("gemm_slabs: M*N must be a multiple of 4")
+    lib = _lib.load()
+    ns = lib.pcaa_gemm_num_splits(math, K, int(split_k))
+    stride = M * N
+    slabs = torch.empty(ns * stride, dtype=torch.float32, device=A.device)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    else:
+        _chk(out, "gemm_slabs.out", torch.float32)
+        if out.numel() != M * N:
+            raise ValueError("gemm_slabs: out size")
+    timer = TIMER
+    if timer is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.pcaa_gemm_slabs(math, _p(A), _dt(A), a_layout, A.stride(0), _p(B), _dt(B), b_layout, B.stride(0),
+                              _p(slabs), stride, M, N, K, int(split_k), _s()), "pcaa_gemm_slabs")
+    if timer is not None:
+        e1.record()
+        dma = (math == PCAA_BF16 and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and a_layout == b_layout
+               and M % 256 == 0 and N % 256 == 0 and K % 64 == 0)
+        key = "gemm_bf16_dma_kernel" if dma else ("gemm_bf16_big_kernel" if math == PCAA_BF16 else "gemm_f32_kernel")
+        nbytes = A.numel() * A.element_size() + B.numel() * B.element_size() + ns * stride * 4
+        timer.records.append((key, 2.0 * M * N * K, float(nbytes), e0, e1))
+    if colstats is not None:
+        # reduction fused with the BatchNorm column statistics of the result
+        if accumulate:
+            raise ValueError("gemm_slabs: colstats with accumulate is not supported")
+        _chk(colstats, "gemm_slabs.colstats", torch.float64)
+        check(lib.pcaa_splitk_reduce_stats(_p(slabs), ns, stride, _p(out), _p(colstats), NREP, M, N, _s()),
+              "pcaa_splitk_reduce_stats")
+        return out
+    check(lib.pcaa_splitk_reduce(_p(slabs), ns, stride, stride, _p(out), int(bool(accumulate)), _s()),
+          "pcaa_splitk_reduce")
+    return out
+
+
 def pick_split_k(M, N, K, target_blocks=1024, bk=32, tile=128):
     tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
     if tiles >= target_blocks:
@@ -236,12 +282,13 @@ def bn_finalize(stats, count, lin_bias, bn, ch, update_running=True):
     return scale, shift, mean, rstd
 
 
-def bn_eval_coeffs(bn, ch):
+def bn_eval_coeffs(bn, ch, lin_bias=None):
     dev = bn.weight.device
     scale = torch.empty(ch, dtype=torch.float32, device=dev)
     shift = torch.empty_like(scale)
     check(_lib.load().pcaa_bn_eval_coeffs(_p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
-                                          bn.eps, _p(scale), _p(shift), ch, _s()), "pcaa_bn_eval_coeffs")
+                                          _p(lin_bias), bn.eps, _p(scale), _p(shift), ch, _s()),
+          "pcaa_bn_eval_coeffs")
     return scale, shift
 
 

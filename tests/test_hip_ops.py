@@ -143,6 +143,25 @@ def test_gemm_bf16_lds_dma_exact_integers(lay, M, N, K, sk):
         assert torch.equal(Cb.float().cpu().double(), acc.float().bfloat16().double())
 
 
+@pytest.mark.parametrize("M,N,K,sk,math", [(1024, 512, 64 * 40, 5, PCAA_BF16), (256, 256, 64 * 6, 3, PCAA_BF16),
+                                           (520, 264, 1000, 3, PCAA_BF16), (130, 68, 900, 4, PCAA_F32)])
+def test_gemm_slab_split_k(M, N, K, sk, math):
+    """split-K through per-split slabs + reduce (no atomics): exact on integer data, for the
+    LDS-DMA kernel (whole tiles), the register-staged bf16 kernel (ragged) and the fp32 kernel."""
+    rng = np.random.default_rng(38)
+    Ai = torch.from_numpy(rng.integers(-3, 4, (M, K)).astype(np.float32))
+    Bi = torch.from_numpy(rng.integers(-3, 4, (N, K)).astype(np.float32))
+    dt = torch.bfloat16 if math == PCAA_BF16 else torch.float32
+    A = Ai.t().contiguous().to(DEV).to(dt)
+    B = Bi.t().contiguous().to(DEV).to(dt)
+    ref = Ai.double() @ Bi.double().t()
+    C = ops.gemm_slabs(A, RC, B, RC, M, N, K, sk, math=math)
+    assert torch.equal(C.cpu().double(), ref)
+    C0 = torch.from_numpy(rng.integers(-5, 6, (M, N)).astype(np.float32)).to(DEV)
+    C1 = ops.gemm_slabs(A, RC, B, RC, M, N, K, sk, out=C0.clone(), accumulate=True, math=math)
+    assert torch.equal(C1.cpu().double(), ref + C0.cpu().double())
+
+
 @pytest.mark.parametrize("al,bl", [(KC, KC), (RC, RC), (KC, RC)])
 def test_gemm_f32_math_bf16_storage(al, bl):
     M, N, K = 520, 260, 1000
@@ -178,7 +197,8 @@ def test_bn_forward_backward_chain(rows, ch, dtype):
     bn = _BN(ch, 23)
     rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
     stats = ops.new_stats(ch, DEV)
-    y = ops.gemm(A, KC, W, KC, rows, ch, K, bias=lin_b, colstats=stats, out_dtype=dtype)
+    # the stored pre-BN tensor is the bias-free accumulator (the bias cancels in BatchNorm)
+    y = ops.gemm(A, KC, W, KC, rows, ch, K, colstats=stats, out_dtype=dtype)
     scale, shift, mean, rstd = ops.bn_finalize(stats, rows, lin_b, bn, ch)
     a = ops.bn_act_fwd(y, scale, shift)
     # fp64 reference with autograd
@@ -188,7 +208,7 @@ def test_bn_forward_backward_chain(rows, ch, dtype):
     zd = (yd - mu) / torch.sqrt(var + 1e-5) * bn.weight.cpu().double() + bn.bias.cpu().double()
     ad = torch.where(zd > 0, zd, torch.expm1(zd))
     tol = 2e-5 if dtype == torch.float32 else 3e-2
-    assert torch.allclose(mean.cpu().double(), mu.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(mean.cpu().double() + lin_b.cpu().double(), mu.detach(), rtol=1e-5, atol=1e-5)
     assert (a.float().cpu().double() - ad.detach()).abs().max().item() <= tol * max(1.0, ad.abs().max().item())
     assert torch.allclose(bn.running_mean.cpu().double(), 0.9 * rm0.cpu().double() + 0.1 * mu.detach(), atol=1e-5)
     assert torch.allclose(bn.running_var.cpu().double(),

@@ -65,6 +65,8 @@ def main():
                 print(f"wgrd bf16 [{cout},{cin}] K={P} split{sk:3d}               {ms:9.3f} {fl / ms / 1e9:9.1f}")
             except Exception as e:  # noqa: BLE001
                 print("wgrd bf16 failed:", str(e)[:100])
+            ms = timeit(lambda: ops.gemm_slabs(dy, RC, x, RC, cout, cin, P, sk, out=dW, math=PCAA_BF16), a.iters)
+            print(f"wgrd bf16 slabs+reduce split{sk:3d}                        {ms:9.3f} {fl / ms / 1e9:9.1f}")
         if (cin, cout) == (1024, 1024):
             xf, dyf = x.float(), dy.float()
             yf = torch.empty(P, cout, device=dev)
