@@ -1008,7 +1008,7 @@ bool pcaa_launch_gemm_bf16_big(const GemmParams& p_in, int a_dtype, int a_layout
       a_layout == b_layout) {
     // the 4-stage / BK=32 / counted-vmcnt kernel measured 5-17 % SLOWER than the 2-stage one
     // (twice the barriers per K outweigh the deeper prefetch); kept behind PCAA_GEMM_DMA4 for A/B
-    static const bool two_stage = getenv("PCAA_GEMM_DMA2") != nullptr;
+    static const bool two_stage = getenv("PCAA_GEMM_DMA4") == nullptr;   // default: 2-stage kernel
     if (two_stage && p.diag) {
       if (a_layout == KC && !cf) {
         if (p.diag == 1) return launch_dma<bf16_t, KC, KC, 1>(p, grid, stream);
