@@ -132,6 +132,12 @@ int pcaa_bn_bwd_finalize(const double* stats, int nrep, long count, const float*
                          float* coef, float* dgamma, float* dbeta, int ch, void* stream);
 int pcaa_bn_bwd_dy(const void* dz, const void* y, void* dy, int dtype, const float* coef,
                    long rows, int ch, void* stream);
+/* Two-pass form that never materialises dz: first pcaa_bn_act_bwd_dz with dz == NULL
+ * (statistics only), then dy = coef0 * (da * ELU'(y*scale+shift)) + coef1 * y + coef2 here
+ * (da / dpool as in pcaa_bn_act_bwd_dz; dy may alias da). */
+int pcaa_bn_bwd_dy_fused(const void* da, const float* dpool, int group_rows, float pool_scale,
+                         const void* y, void* dy, int dtype, const float* scale, const float* shift,
+                         const float* coef, long rows, int ch, void* stream);
 
 /* ------------------------------------------------------------------ small fp32 helpers */
 /* y = act(y + bias[col])  (Linear bias + ELU of the decoder / MLP heads, models.py:373-382) */
@@ -212,6 +218,29 @@ int pcaa_joint_likelihood(const float* x, const float* means, int B, int K, int 
                           void* stream);
 int pcaa_kvote(const double* lik, const long long* preds, double threshold, int k, int n_labels,
                int n_windows, long long* out, void* stream);
+
+/* ------------------------------------------------------------------ batch-skinny Linear layers
+ * The CGDecoder's Linear stack (models.py CGDecoder: nn.Linear(32+K, S/16) ... nn.Linear(S/2, S),
+ * called from PCAA_ablation.py train_variant4) with M = batch <= 64 rows: each product is one
+ * pass over the fp32 weight matrix W[N][K] (N = out_features, K = in_features, ldw elements
+ * between rows), streamed from HBM straight into bf16 MFMA fragments (fp32 accumulate).
+ *   fwd  : y[M][N]  = act(x[M][K] . W^T + bias)
+ *   dgrad: dx[M][K] (=|+=) (dz[M][N] . W) * ELU'(a_prev)   (a_prev = ELU output of the layer
+ *          below, NULL: no factor) -- i.e. the gradient w.r.t. that layer's pre-activation
+ *   wgrad: dW[N][K] = dz^T . x
+ * fwd/dgrad split the contraction into `nsplit` slabs in `ws` (>= nsplit*M*N resp. nsplit*M*K
+ * floats) and reduce them deterministically; nsplit must come from pcaa_skinny_splits (kind 0
+ * fwd, 1 dgrad).  pcaa_skinny_supported: M <= 64, N and K multiples of 64 and >= 128. */
+int pcaa_skinny_supported(int M, int N, int K);
+int pcaa_skinny_splits(int kind, int M, int N, int K);
+int pcaa_skinny_linear_fwd(const float* x, long ldx, const float* W, long ldw, const float* bias, int act,
+                           float* y, float* ws, long ws_floats, int M, int N, int K, int nsplit,
+                           void* stream);
+int pcaa_skinny_linear_dgrad(const float* dz, long lddz, const float* W, long ldw, float* dx,
+                             const float* a_prev, int accumulate, float* ws, long ws_floats, int M, int N,
+                             int K, int nsplit, void* stream);
+int pcaa_skinny_linear_wgrad(const float* dz, long lddz, const float* x, long ldx, float* dW, long lddw,
+                             int M, int N, int K, void* stream);
 
 /* ------------------------------------------------------------------ optimizer
  * torch.optim.Adam (no weight decay, no amsgrad; PCAA_ablation.py:820-833) on a

@@ -41,6 +41,17 @@ static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 __device__ __forceinline__ float elu_f(float z) { return z > 0.f ? z : expm1f(z); }
 // derivative of ELU evaluated from the pre-activation
 __device__ __forceinline__ float elu_grad_from_pre(float z) { return z > 0.f ? 1.f : expf(z); }
+// bf16-storage variants: v_exp_f32-based (2 instructions instead of ~20).  The result is rounded
+// to 8 mantissa bits anyway; the fp32 parity path keeps expm1f / expf.  With libm exp the
+// bf16 elementwise passes were VALU-bound, not HBM-bound.
+template <typename T> __device__ __forceinline__ float elu_t(float z) {
+  if constexpr (sizeof(T) == 2) return z > 0.f ? z : __expf(z) - 1.f;
+  else return elu_f(z);
+}
+template <typename T> __device__ __forceinline__ float elu_grad_from_pre_t(float z) {
+  if constexpr (sizeof(T) == 2) return z > 0.f ? 1.f : __expf(z);
+  else return elu_grad_from_pre(z);
+}
 // derivative of ELU evaluated from the OUTPUT a = ELU(z):  z<=0 -> e^z = a + 1
 __device__ __forceinline__ float elu_grad_from_out(float a) { return a > 0.f ? 1.f : a + 1.f; }
 

@@ -86,10 +86,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
     const f32x4 v = load4(y + q * 4);
     const f32x4 sc = load4(scale + c), sh = load4(shift + c);
     f32x4 o;
-    o.x = elu_f(v.x * sc.x + sh.x);
-    o.y = elu_f(v.y * sc.y + sh.y);
-    o.z = elu_f(v.z * sc.z + sh.z);
-    o.w = elu_f(v.w * sc.w + sh.w);
+    o.x = elu_t<T>(v.x * sc.x + sh.x);
+    o.y = elu_t<T>(v.y * sc.y + sh.y);
+    o.z = elu_t<T>(v.z * sc.z + sh.z);
+    o.w = elu_t<T>(v.w * sc.w + sh.w);
     store4(a + q * 4, o);
   }
 }
@@ -112,10 +112,10 @@ __global__ __launch_bounds__(256) void bn_act_meanpool_kernel(const T* __restric
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int r = rlane; r < group_rows; r += rl) {
     const f32x4 v = load4(base + (long)r * ch);
-    acc.x += elu_f(v.x * sc.x + sh.x);
-    acc.y += elu_f(v.y * sc.y + sh.y);
-    acc.z += elu_f(v.z * sc.z + sh.z);
-    acc.w += elu_f(v.w * sc.w + sh.w);
+    acc.x += elu_t<T>(v.x * sc.x + sh.x);
+    acc.y += elu_t<T>(v.y * sc.y + sh.y);
+    acc.z += elu_t<T>(v.z * sc.z + sh.z);
+    acc.w += elu_t<T>(v.w * sc.w + sh.w);
   }
   red[threadIdx.x] = acc;
   __syncthreads();
@@ -161,11 +161,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(const T* __restrict_
       g = load4(da + r * ch + c);
     }
     f32x4 d;
-    d.x = g.x * elu_grad_from_pre(yv.x * sc.x + sh.x);
-    d.y = g.y * elu_grad_from_pre(yv.y * sc.y + sh.y);
-    d.z = g.z * elu_grad_from_pre(yv.z * sc.z + sh.z);
-    d.w = g.w * elu_grad_from_pre(yv.w * sc.w + sh.w);
-    store4(dz + r * ch + c, d);
+    d.x = g.x * elu_grad_from_pre_t<T>(yv.x * sc.x + sh.x);
+    d.y = g.y * elu_grad_from_pre_t<T>(yv.y * sc.y + sh.y);
+    d.z = g.z * elu_grad_from_pre_t<T>(yv.z * sc.z + sh.z);
+    d.w = g.w * elu_grad_from_pre_t<T>(yv.w * sc.w + sh.w);
+    if (dz) store4(dz + r * ch + c, d);       // dz == NULL: statistics-only pass
     s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
     s2.x += d.x * ((yv.x - mu.x) * rs.x);
     s2.y += d.y * ((yv.y - mu.y) * rs.y);
@@ -446,7 +446,7 @@ extern "C" int pcaa_bn_act_bwd_dz(const void* da, const float* dpool, int group_
                                   const float* shift, const float* mean, const float* rstd,
                                   double* stats, int nrep, long rows, int ch, void* stream) {
   PCAA_CHECK_ARG((da != nullptr) != (dpool != nullptr), "pcaa_bn_act_bwd_dz: exactly one of da / dpool");
-  PCAA_CHECK_ARG(y && dz && scale && shift && mean && rstd && stats, "pcaa_bn_act_bwd_dz: null pointer");
+  PCAA_CHECK_ARG(y && scale && shift && mean && rstd && stats, "pcaa_bn_act_bwd_dz: null pointer");
   PCAA_CHECK_ARG(rows >= 1 && nrep >= 1 && ch_ok(ch), "pcaa_bn_act_bwd_dz: ch/4 must divide 256 (ch=%d)", ch);
   PCAA_CHECK_ARG(!dpool || group_rows >= 1, "pcaa_bn_act_bwd_dz: bad group_rows");
   const unsigned grid = (unsigned)cdiv(rows, ROWS_PER_BLOCK);
@@ -460,6 +460,60 @@ extern "C" int pcaa_bn_act_bwd_dz(const void* da, const float* dpool, int group_
   else { pcaa_set_error("pcaa_bn_act_bwd_dz: bad dtype"); return PCAA_ERR_INVALID_ARG; }
 #undef LAUNCH_DZ
   PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_act_bwd_dz");
+}
+
+namespace {
+// dy = c0 * (da * ELU'(y*scale+shift)) + c1 * y + c2 in ONE pass: dz is never materialised
+// (the statistics pass before it reads da and y but writes nothing)
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_dy_fused_kernel(const T* __restrict__ da,
+                                                              const float* __restrict__ dpool, int group_rows,
+                                                              float pool_scale, const T* __restrict__ y,
+                                                              T* __restrict__ dy, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              const float* __restrict__ coef, long nquads,
+                                                              int qpr, int ch) {
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (long)gridDim.x * 256) {
+    const long r = q / qpr;
+    const int c = (int)(q - r * qpr) << 2;
+    const f32x4 yv = load4(y + q * 4);
+    f32x4 g;
+    if (POOL) {
+      g = load4(dpool + (r / group_rows) * ch + c);
+      g *= pool_scale;
+    } else {
+      g = load4(da + q * 4);
+    }
+    const f32x4 sc = load4(scale + c), sh = load4(shift + c);
+    const f32x4 k0 = load4(coef + c), k1 = load4(coef + ch + c), k2 = load4(coef + 2 * ch + c);
+    f32x4 o;
+    o.x = k0.x * (g.x * elu_grad_from_pre_t<T>(yv.x * sc.x + sh.x)) + k1.x * yv.x + k2.x;
+    o.y = k0.y * (g.y * elu_grad_from_pre_t<T>(yv.y * sc.y + sh.y)) + k1.y * yv.y + k2.y;
+    o.z = k0.z * (g.z * elu_grad_from_pre_t<T>(yv.z * sc.z + sh.z)) + k1.z * yv.z + k2.z;
+    o.w = k0.w * (g.w * elu_grad_from_pre_t<T>(yv.w * sc.w + sh.w)) + k1.w * yv.w + k2.w;
+    store4(dy + q * 4, o);
+  }
+}
+}  // namespace
+
+extern "C" int pcaa_bn_bwd_dy_fused(const void* da, const float* dpool, int group_rows, float pool_scale,
+                                    const void* y, void* dy, int dtype, const float* scale, const float* shift,
+                                    const float* coef, long rows, int ch, void* stream) {
+  PCAA_CHECK_ARG((da != nullptr) != (dpool != nullptr), "pcaa_bn_bwd_dy_fused: exactly one of da / dpool");
+  PCAA_CHECK_ARG(y && dy && scale && shift && coef, "pcaa_bn_bwd_dy_fused: null pointer");
+  PCAA_CHECK_ARG(rows >= 1 && ch >= 4 && (ch & 3) == 0, "pcaa_bn_bwd_dy_fused: ch must be a multiple of 4");
+  PCAA_CHECK_ARG(!dpool || group_rows >= 1, "pcaa_bn_bwd_dy_fused: bad group_rows");
+  const long nq = rows * (ch >> 2);
+  const int grid = grid_for(nq);
+  hipStream_t s = as_stream(stream);
+#define LAUNCH_DYF(T, POOL)                                                                             \
+  hipLaunchKernelGGL((bn_bwd_dy_fused_kernel<T, POOL>), dim3(grid), dim3(256), 0, s, (const T*)da, dpool, \
+                     group_rows, pool_scale, (const T*)y, (T*)dy, scale, shift, coef, nq, ch >> 2, ch)
+  if (dtype == PCAA_F32) { if (dpool) LAUNCH_DYF(float, true); else LAUNCH_DYF(float, false); }
+  else if (dtype == PCAA_BF16) { if (dpool) LAUNCH_DYF(bf16_t, true); else LAUNCH_DYF(bf16_t, false); }
+  else { pcaa_set_error("pcaa_bn_bwd_dy_fused: bad dtype"); return PCAA_ERR_INVALID_ARG; }
+#undef LAUNCH_DYF
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_bwd_dy_fused");
 }
 
 extern "C" int pcaa_bn_bwd_finalize(const double* stats, int nrep, long count, const float* gamma,

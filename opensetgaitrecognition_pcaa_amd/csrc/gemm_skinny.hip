@@ -1,0 +1,415 @@
+// Batch-skinny dense layers (M = batch <= 64 rows): the CGDecoder's Linear stack
+// (reference models.py CGDecoder.forward: 32+K -> S/16 -> S/8 -> S/4 -> S/2 -> S, S = T*C*N).
+//
+// With 64 rows every product is a pass over the fp32 weight matrix W[N_out][K_in] (157 M
+// parameters at T=30,C=4,N=128): forward and dgrad READ it once, wgrad WRITES a matrix of that
+// size once.  The 256x256-tile kernel spent 75 % of its tile on padding and reached 1.4-1.8 TB/s
+// on these; here the weights are streamed straight from HBM into MFMA fragments:
+//
+//   forward  y[m][n]  = sum_k x[m][k]  W[n][k]   contraction index contiguous in W: each wave
+//            reads its 32 rows as 256-B runs (dwordx4), converts to bf16 and redistributes them
+//            through a WAVE-PRIVATE LDS image (no workgroup barrier, LDS is in-order per wave).
+//   dgrad    dx[m][k] = sum_n dz[m][n] W[n][k]   contraction index is the ROW of W: lane l of a
+//            32-column fragment reads W[n0+8h+e][k0+l], e = 0..7 -- eight dword loads, each one
+//            two whole 128-B lines per wave; no LDS for W at all.
+//   wgrad    dW[n][k] = sum_m dz[m][n] x[m][k]   contraction over the <= 64 batch rows: both
+//            operands load like dgrad's W (rows = contraction), the kernel is a pure fp32 store
+//            stream (128 B per row per half-wave).
+//
+// The 64-row operand of forward/dgrad is shared by the 4 waves of a workgroup through a
+// double-buffered bf16 LDS image ([64][64+8]); the workgroup barrier is a raw s_barrier after
+// s_waitcnt lgkmcnt(0), NOT __syncthreads(): the latter drains vmcnt and with it the weight
+// prefetch that is the whole point.  Split-K partials go to slabs (no atomics); the reduction
+// kernel fuses bias + ELU (forward) or ELU'(previous activation) (dgrad).
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int SP = 72;            // LDS pitch in bf16 elements of a 64-deep chunk row (144 B)
+constexpr int CH = 64;            // contraction elements per chunk (4 MFMA steps)
+
+__device__ __forceinline__ uint32_t pk2(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 b;
+  b.x = (bf16_t)lo;
+  b.y = (bf16_t)hi;
+  return __builtin_bit_cast(uint32_t, b);
+}
+__device__ __forceinline__ bf16x8 pack8(const float (&t)[8]) {
+  uint4 u;
+  u.x = pk2(t[0], t[1]); u.y = pk2(t[2], t[3]); u.z = pk2(t[4], t[5]); u.w = pk2(t[6], t[7]);
+  return __builtin_bit_cast(bf16x8, u);
+}
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ---- shared 64-row operand: thread t stages row t>>2, floats [16*(t&3), +16) of the chunk
+struct SmallStage { f32x4 v[4]; };
+__device__ __forceinline__ void small_load(SmallStage& st, const float* __restrict__ S, long ld, int M, int k0,
+                                           int tid) {
+  const int m = tid >> 2, seg = (tid & 3) * 16;
+  if (m < M) {
+    const float* p = S + (long)m * ld + k0 + seg;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st.v[q] = load4(p + 4 * q);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st.v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+__device__ __forceinline__ void small_store(const SmallStage& st, bf16_t* buf, int tid) {
+  const int m = tid >> 2, seg = (tid & 3) * 16;
+  uint4 a, b;
+  a.x = pk2(st.v[0].x, st.v[0].y); a.y = pk2(st.v[0].z, st.v[0].w);
+  a.z = pk2(st.v[1].x, st.v[1].y); a.w = pk2(st.v[1].z, st.v[1].w);
+  b.x = pk2(st.v[2].x, st.v[2].y); b.y = pk2(st.v[2].z, st.v[2].w);
+  b.z = pk2(st.v[3].x, st.v[3].y); b.w = pk2(st.v[3].z, st.v[3].w);
+  *reinterpret_cast<uint4*>(&buf[m * SP + seg]) = a;
+  *reinterpret_cast<uint4*>(&buf[m * SP + seg + 8]) = b;
+}
+__device__ __forceinline__ bf16x8 small_frag(const bf16_t* buf, int mf, int s, int l31, int h) {
+  return *reinterpret_cast<const bf16x8*>(&buf[(mf * 32 + l31) * SP + s * 16 + h * 8]);
+}
+
+// slab store of a wave's 64(m) x 32(col) accumulators
+__device__ __forceinline__ void store_acc(const f32x16 (&acc)[2], float* __restrict__ out, long ld, int M, int col,
+                                          int ncols, int h) {
+  if (col >= ncols) return;
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m < M) out[(long)m * ld + col] = acc[mf][r];
+    }
+}
+
+// ------------------------------------------------------------------ dgrad: dx = dz . W
+// grid (ceil(K/128), nsplit); wave w owns columns [128 bx + 32 w, +32); split by owns cps chunks of n
+__global__ __launch_bounds__(256) void skinny_dgrad_kernel(const float* __restrict__ dz, long lddz,
+                                                           const float* __restrict__ W, long ldw,
+                                                           float* __restrict__ slabs, long slab_stride, int M,
+                                                           int N, int K, int cps) {
+  __shared__ __attribute__((aligned(16))) bf16_t sbuf[2][64 * SP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int col = blockIdx.x * 128 + wave * 32 + l31;
+  const int c0 = blockIdx.y * cps;
+  const int nch = min(cps, N / CH - c0);
+  if (nch <= 0) return;                                  // uniform; the host never launches such a split
+  const int lane_off = 8 * h * (int)ldw + min(col, K - 1);   // < 2^31: checked on the host
+  const float* Wc = W + (long)c0 * CH * ldw;             // uniform base of this split
+
+  float wr[4][8];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wr[s][e] = (Wc + (long)(s * 16 + e) * ldw)[lane_off];
+  SmallStage st;
+  small_load(st, dz, lddz, M, c0 * CH, tid);
+  small_store(st, sbuf[0], tid);
+  f32x16 acc[2];
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mf][r] = 0.f;
+  lds_barrier();
+
+  for (int c = 0; c < nch; ++c) {
+    const bool more = c + 1 < nch;
+    const bf16_t* cur = sbuf[c & 1];
+    if (more) small_load(st, dz, lddz, M, (c0 + c + 1) * CH, tid);
+    // the last iteration re-reads its own chunk (L2 hit) instead of branching around the prefetch:
+    // a conditional here made the compiler rotate the whole register ring with v_mov every step
+    const float* Wn = Wc + (long)min(c + 1, nch - 1) * CH * ldw;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 b = pack8(wr[s]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wr[s][e] = (Wn + (long)(s * 16 + e) * ldw)[lane_off];
+      const bf16x8 a0 = small_frag(cur, 0, s, l31, h), a1 = small_frag(cur, 1, s, l31, h);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[1], 0, 0, 0);
+    }
+    if (more) small_store(st, sbuf[(c + 1) & 1], tid);
+    lds_barrier();
+  }
+  store_acc(acc, slabs + (long)blockIdx.y * slab_stride, K, M, col, K, h);
+}
+
+// ------------------------------------------------------------------ forward: y = x . W^T
+// grid (ceil(N/128), nsplit); wave w owns output columns (rows of W) [128 bx + 32 w, +32)
+__global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, long ldx,
+                                                         const float* __restrict__ W, long ldw,
+                                                         float* __restrict__ slabs, long slab_stride, int M,
+                                                         int N, int K, int cps) {
+  __shared__ __attribute__((aligned(16))) bf16_t sbuf[2][64 * SP];
+  __shared__ __attribute__((aligned(16))) bf16_t wbuf[4][32 * SP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.x * 128 + wave * 32;
+  const int c0 = blockIdx.y * cps;
+  const int nch = min(cps, K / CH - c0);
+  if (nch <= 0) return;
+  // load map: instruction i reads rows 4i .. 4i+3 of the wave's 32, 16 lanes x 16 B = one 256-B run each
+  const int lr = lane >> 4, kseg = (lane & 15) * 4;
+  int roff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) roff[i] = min(n0 + 4 * i + lr, N - 1) * (int)ldw + kseg;   // < 2^31: host-checked
+  bf16_t* wl = wbuf[wave];
+
+  f32x4 wr[8];
+  const float* Wk = W + (long)c0 * CH;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) wr[i] = load4(Wk + roff[i]);
+  SmallStage st;
+  small_load(st, x, ldx, M, c0 * CH, tid);
+  small_store(st, sbuf[0], tid);
+  f32x16 acc[2];
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mf][r] = 0.f;
+  lds_barrier();
+
+  for (int c = 0; c < nch; ++c) {
+    const bool more = c + 1 < nch;
+    const bf16_t* cur = sbuf[c & 1];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      uint2 u;
+      u.x = pk2(wr[i].x, wr[i].y);
+      u.y = pk2(wr[i].z, wr[i].w);
+      *reinterpret_cast<uint2*>(&wl[(4 * i + lr) * SP + kseg]) = u;
+    }
+    {
+      const float* Wn = Wk + (long)min(c + 1, nch - 1) * CH;      // last iteration: harmless re-read
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wr[i] = load4(Wn + roff[i]);
+    }
+    if (more) small_load(st, x, ldx, M, (c0 + c + 1) * CH, tid);
+    // the wave reads back its own LDS image: LDS executes a wave's operations in order, the
+    // compiler barrier keeps the reads below the writes
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(&wl[l31 * SP + s * 16 + h * 8]);
+      const bf16x8 a0 = small_frag(cur, 0, s, l31, h), a1 = small_frag(cur, 1, s, l31, h);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[1], 0, 0, 0);
+    }
+    if (more) small_store(st, sbuf[(c + 1) & 1], tid);
+    lds_barrier();
+  }
+  store_acc(acc, slabs + (long)blockIdx.y * slab_stride, N, M, n0 + l31, N, h);
+}
+
+// ------------------------------------------------------------------ wgrad: dW = dz^T . x
+// grid (ceil(K / (4*32*JL)), ceil(N/128)); the workgroup owns dW rows [128 by, +128), wave w the
+// columns [(4 bx + w) * 32 JL, + 32 JL).  The dz panel of those 128 rows is packed ONCE per
+// workgroup into MFMA-fragment order in LDS (16 KB) and re-read per 32-column step -- holding it
+// in registers (64 VGPRs + 128 loads in flight per wave) cost the kernel its occupancy.
+// 32-bit element offsets from uniform base pointers (host-checked < 2^31) so loads and stores use
+// the SGPR-base + VGPR-offset form.  Rows m >= M: dz is zeroed after a clamped load, x is only
+// clamped (0 * finite = 0).
+template <int JL, bool FULLN>
+__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restrict__ dz, long lddz,
+                                                           const float* __restrict__ x, long ldx,
+                                                           float* __restrict__ dW, long lddw, int M, int N,
+                                                           int K) {
+  __shared__ __attribute__((aligned(16))) bf16x8 apan[4][4][64];      // [row fragment i][k-step s][lane]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.y * 128;
+  const int kb = (blockIdx.x * 4 + wave) * (32 * JL);
+  const int jn = kb < K ? min(JL, (K - kb) / 32) : 0;
+
+  {
+    const int s = wave;                                   // wave w packs k-step w of all 4 fragments
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned ncol = (unsigned)min(n0 + 32 * i + l31, N - 1);
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int m = 16 * s + 8 * h + e;
+        const float v = dz[(unsigned)min(m, M - 1) * (unsigned)lddz + ncol];
+        t[e] = m < M ? v : 0.f;
+      }
+      apan[i][s][lane] = pack8(t);
+    }
+  }
+  unsigned xoff[4][8];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      xoff[s][e] = (unsigned)min(16 * s + 8 * h + e, M - 1) * (unsigned)ldx + min(kb, K - 32) + l31;
+  float br[4][8];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) br[s][e] = x[xoff[s][e]];
+  __syncthreads();
+
+  const unsigned row0 = (unsigned)(n0 + 4 * h);
+  for (int j = 0; j < jn; ++j) {
+    bf16x8 bf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bf[s] = pack8(br[s]);
+    {
+      const float* xn = x + 32 * min(j + 1, jn - 1);      // last iteration: harmless re-read
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) br[s][e] = xn[xoff[s][e]];
+    }
+    asm volatile("" ::: "memory");
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apan[i][s][lane], bf[s], acc[i], 0, 0, 0);
+    float* dj = dW + kb + 32 * j;                          // uniform
+    unsigned o0 = row0 * (unsigned)lddw + l31;
+    // opaque to the optimiser: LICM otherwise hoists all 64 store offsets (and the 16 LDS
+    // fragment reads, hence the memory clobber) out of the j loop -- 360 VGPRs, one wave per SIMD
+    asm volatile("" : "+v"(o0) : : "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned rr = 32 * i + (r & 3) + 8 * (r >> 2);
+        if (FULLN || row0 + rr < (unsigned)N) dj[o0 + rr * (unsigned)lddw] = acc[i][r];
+      }
+  }
+}
+
+// ------------------------------------------------------------------ slab reduction (+ bias/ELU, or * ELU'(a_prev))
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* __restrict__ slabs, int ns, long stride,
+                                                            float* __restrict__ out, const float* __restrict__ bias,
+                                                            int act, const float* __restrict__ a_prev,
+                                                            int accumulate, long nquads, int qpr) {
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (long)gridDim.x * 256) {
+    f32x4 v = load4(slabs + q * 4);
+    for (int s = 1; s < ns; ++s) v += load4(slabs + s * stride + q * 4);
+    if (bias) v += load4(bias + (int)((unsigned)q % (unsigned)qpr) * 4);
+    if (act == PCAA_ACT_ELU) { v.x = elu_f(v.x); v.y = elu_f(v.y); v.z = elu_f(v.z); v.w = elu_f(v.w); }
+    if (a_prev) {
+      const f32x4 a = load4(a_prev + q * 4);
+      v.x *= elu_grad_from_out(a.x); v.y *= elu_grad_from_out(a.y);
+      v.z *= elu_grad_from_out(a.z); v.w *= elu_grad_from_out(a.w);
+    }
+    if (accumulate) v += load4(out + q * 4);
+    store4(out + q * 4, v);
+  }
+}
+
+int target_blocks() {
+  static int t = -1;
+  if (t < 0) {
+    const char* e = getenv("PCAA_SKINNY_TARGET");
+    t = e ? atoi(e) : 768;
+    if (t < 1) t = 1;
+  }
+  return t;
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p % 16) == 0; }
+
+int reduce_launch(const float* ws, int ns, long stride, float* out, const float* bias, int act, const float* a_prev,
+                  int accumulate, int M, int ncols, hipStream_t s) {
+  const long nq = (long)M * ncols / 4;
+  const int grid = (int)std::min<long>(cdiv(nq, 256), 4096);
+  hipLaunchKernelGGL(skinny_reduce_kernel, dim3(grid), dim3(256), 0, s, ws, ns, stride, out, bias, act, a_prev,
+                     accumulate, nq, ncols / 4);
+  return 0;
+}
+
+}  // namespace
+
+// kind 0: forward (groups over N, contraction K); kind 1: dgrad (groups over K, contraction N)
+extern "C" int pcaa_skinny_splits(int kind, int M, int N, int K) {
+  (void)M;
+  const int groups = (int)cdiv(kind == 0 ? N : K, 128);
+  const int chunks = (kind == 0 ? K : N) / CH;
+  if (chunks < 1) return 1;
+  int ns = std::max(1, std::min(chunks, (target_blocks() + groups - 1) / groups));
+  const int cps = (int)cdiv(chunks, ns);
+  return (int)cdiv(chunks, cps);
+}
+
+extern "C" int pcaa_skinny_supported(int M, int N, int K) {
+  return M >= 1 && M <= 64 && N >= 128 && K >= 128 && N % 64 == 0 && K % 64 == 0 && (long)N * K < (1L << 31) - (1L << 20);
+}
+
+extern "C" int pcaa_skinny_linear_fwd(const float* x, long ldx, const float* W, long ldw, const float* bias, int act,
+                                      float* y, float* ws, long ws_floats, int M, int N, int K, int nsplit,
+                                      void* stream) {
+  PCAA_CHECK_ARG(x && W && y && ws, "pcaa_skinny_linear_fwd: null pointer");
+  PCAA_CHECK_ARG(pcaa_skinny_supported(M, N, K), "pcaa_skinny_linear_fwd: unsupported shape M=%d N=%d K=%d", M, N, K);
+  PCAA_CHECK_ARG(ldx >= K && ldx % 4 == 0 && ldw >= K && ldw % 4 == 0 && ldw * (long)N < (1L << 31),
+                 "pcaa_skinny_linear_fwd: bad leading dimensions");
+  PCAA_CHECK_ARG(aligned16(x) && aligned16(W) && aligned16(y) && aligned16(ws) && (!bias || aligned16(bias)),
+                 "pcaa_skinny_linear_fwd: buffers must be 16-B aligned");
+  PCAA_CHECK_ARG(act == PCAA_ACT_NONE || act == PCAA_ACT_ELU, "pcaa_skinny_linear_fwd: bad act");
+  const int chunks = K / CH;
+  PCAA_CHECK_ARG(nsplit >= 1 && nsplit <= chunks, "pcaa_skinny_linear_fwd: bad nsplit");
+  const int cps = (int)cdiv(chunks, nsplit);
+  PCAA_CHECK_ARG(cdiv(chunks, cps) == nsplit, "pcaa_skinny_linear_fwd: nsplit leaves empty splits (use pcaa_skinny_splits)");
+  const long stride = (long)M * N;
+  PCAA_CHECK_ARG(ws_floats >= stride * nsplit, "pcaa_skinny_linear_fwd: workspace too small");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(skinny_fwd_kernel, dim3((unsigned)cdiv(N, 128), nsplit), dim3(256), 0, s, x, ldx, W, ldw, ws,
+                     stride, M, N, K, cps);
+  reduce_launch(ws, nsplit, stride, y, bias, act, nullptr, 0, M, N, s);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_fwd");
+}
+
+extern "C" int pcaa_skinny_linear_dgrad(const float* dz, long lddz, const float* W, long ldw, float* dx,
+                                        const float* a_prev, int accumulate, float* ws, long ws_floats, int M, int N,
+                                        int K, int nsplit, void* stream) {
+  PCAA_CHECK_ARG(dz && W && dx && ws, "pcaa_skinny_linear_dgrad: null pointer");
+  PCAA_CHECK_ARG(pcaa_skinny_supported(M, N, K), "pcaa_skinny_linear_dgrad: unsupported shape M=%d N=%d K=%d", M, N, K);
+  PCAA_CHECK_ARG(lddz >= N && lddz % 4 == 0 && ldw >= K && ldw * (long)N < (1L << 31),
+                 "pcaa_skinny_linear_dgrad: bad leading dimensions");
+  PCAA_CHECK_ARG(aligned16(dz) && aligned16(dx) && aligned16(ws) && (!a_prev || aligned16(a_prev)),
+                 "pcaa_skinny_linear_dgrad: buffers must be 16-B aligned");
+  const int chunks = N / CH;
+  PCAA_CHECK_ARG(nsplit >= 1 && nsplit <= chunks, "pcaa_skinny_linear_dgrad: bad nsplit");
+  const int cps = (int)cdiv(chunks, nsplit);
+  PCAA_CHECK_ARG(cdiv(chunks, cps) == nsplit, "pcaa_skinny_linear_dgrad: nsplit leaves empty splits (use pcaa_skinny_splits)");
+  const long stride = (long)M * K;
+  PCAA_CHECK_ARG(ws_floats >= stride * nsplit, "pcaa_skinny_linear_dgrad: workspace too small");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(skinny_dgrad_kernel, dim3((unsigned)cdiv(K, 128), nsplit), dim3(256), 0, s, dz, lddz, W, ldw, ws,
+                     stride, M, N, K, cps);
+  reduce_launch(ws, nsplit, stride, dx, nullptr, PCAA_ACT_NONE, a_prev, accumulate, M, K, s);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_dgrad");
+}
+
+extern "C" int pcaa_skinny_linear_wgrad(const float* dz, long lddz, const float* x, long ldx, float* dW, long lddw,
+                                        int M, int N, int K, void* stream) {
+  PCAA_CHECK_ARG(dz && x && dW, "pcaa_skinny_linear_wgrad: null pointer");
+  PCAA_CHECK_ARG(M >= 1 && M <= 64 && N >= 1 && K >= 32 && K % 32 == 0,
+                 "pcaa_skinny_linear_wgrad: unsupported shape M=%d N=%d K=%d", M, N, K);
+  PCAA_CHECK_ARG(lddz >= N && ldx >= K && lddw >= K, "pcaa_skinny_linear_wgrad: bad leading dimensions");
+  PCAA_CHECK_ARG((long)M * lddz < (1L << 31) && (long)M * ldx < (1L << 31) && (long)N * lddw < (1L << 31),
+                 "pcaa_skinny_linear_wgrad: operands beyond 32-bit element offsets");
+  constexpr int JL = 4;
+  const dim3 grid((unsigned)cdiv(K, 4 * 32 * JL), (unsigned)cdiv(N, 128));
+  if (N % 128 == 0)
+    hipLaunchKernelGGL((skinny_wgrad_kernel<JL, true>), grid, dim3(256), 0, as_stream(stream), dz, lddz, x, ldx, dW,
+                       lddw, M, N, K);
+  else
+    hipLaunchKernelGGL((skinny_wgrad_kernel<JL, false>), grid, dim3(256), 0, as_stream(stream), dz, lddz, x, ldx, dW,
+                       lddw, M, N, K);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_wgrad");
+}

@@ -143,13 +143,17 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
     Returns (dW2d, dgamma, dbeta, d_lhs or None)."""
     y = s.y
     rows_local, cout = y.shape
-    dz, stats = ops.bn_act_bwd_dz(y, s.scale, s.shift, s.mean, s.rstd, da=da, dpool=dpool,
-                                  group_rows=group_rows, pool_scale=pool_scale,
-                                  out=da if (da is not None and da.dtype == y.dtype) else None)
+    # pass 1: statistics only (reads da/dpool and y, writes nothing); pass 2: dy directly, with
+    # dz = da*ELU'(z) recomputed in registers -- dz is never materialised
+    if da is not None and da.dtype != y.dtype:
+        da = da.to(y.dtype)
+    stats = ops.bn_act_bwd_stats(y, s.scale, s.shift, s.mean, s.rstd, da=da, dpool=dpool,
+                                 group_rows=group_rows, pool_scale=pool_scale)
     _sync_stats(stats, 0)
     coef, dgamma, dbeta = ops.bn_bwd_finalize(stats, s.rows, bn, s.mean, s.rstd, cout,
                                               dgamma=outs[1] if outs else None, dbeta=outs[2] if outs else None)
-    dy = ops.bn_bwd_dy(dz, y, coef, out=dz)
+    dy = ops.bn_bwd_dy_fused(y, s.scale, s.shift, coef, da=da, dpool=dpool, group_rows=group_rows,
+                             pool_scale=pool_scale, out=da)
     K = lhs.shape[1]
     dW_out = outs[0].view(cout, K) if outs else None
     # dW[cout, K] = dy^T . lhs   (contraction over the rows: both operands row-contiguous)
@@ -267,6 +271,11 @@ def _wide_bf16(mode, M, N, K):
     return mode == "bf16" and N >= 512 and K >= 512 and N % 8 == 0 and K % 8 == 0 and M % 8 == 0
 
 
+def _skinny(mode, M, N, K):
+    """Batch-skinny streaming kernels (gemm_skinny.hip): bf16 throughput mode, M <= 64 rows."""
+    return mode == "bf16" and ops.skinny_supported(M, N, K)
+
+
 def linear_act_forward(x, lin, act, mode="fp32"):
     """act(x @ W^T + b); x [M,K] fp32 -> [M,N] fp32.  fp32 MFMA, or (bf16 mode,
     wide layers) bf16 MFMA with fp32 accumulation: the layer is bound by
@@ -274,6 +283,8 @@ def linear_act_forward(x, lin, act, mode="fp32"):
     of the way of the stream."""
     M, K = x.shape
     N = lin.weight.shape[0]
+    if _skinny(mode, M, N, K):
+        return ops.skinny_linear_fwd(x, lin.weight, lin.bias, act)
     if _wide_bf16(mode, M, N, K):
         sk = ops.pick_split_k(M, N, K, target_blocks=256, bk=64, tile=256)
         y = ops.gemm(x, KC, lin.weight, KC, M, N, K, split_k=sk, accumulate=True, math=PCAA_BF16)
@@ -289,13 +300,25 @@ def linear_act_forward(x, lin, act, mode="fp32"):
 
 
 def linear_act_backward(x, a_out, lin, act, d_out, need_dx=True, dW_out=None, db_out=None, dx_init=None,
-                        mode="fp32"):
-    """d_out is the gradient w.r.t. the layer output.  Returns (dW, db, dx)."""
+                        mode="fp32", d_is_pre=False, fuse_elu_in=False):
+    """d_out is the gradient w.r.t. the layer output (d_is_pre: already w.r.t. its
+    pre-activation).  Returns (dW, db, dx).  fuse_elu_in (skinny path only, x = ELU output of
+    the layer below): dx is multiplied by ELU'(x), i.e. it is the gradient w.r.t. that layer's
+    pre-activation -- the caller passes it on with d_is_pre=True."""
     M, K = x.shape
     N = lin.weight.shape[0]
-    dz = ops.elu_bwd_from_out(d_out, a_out) if act == ACT_ELU else d_out
+    dz = ops.elu_bwd_from_out(d_out, a_out) if (act == ACT_ELU and not d_is_pre) else d_out
     dz2 = dz.view(M, N)
     db = ops.colsum(dz2, out=db_out)
+    if _skinny(mode, M, N, K):
+        dW = ops.skinny_linear_wgrad(dz2, x, out=dW_out)
+        dx = None
+        if need_dx:
+            dx = ops.skinny_linear_dgrad(dz2, lin.weight, a_prev=x if fuse_elu_in else None, out=dx_init,
+                                         accumulate=dx_init is not None)
+        return dW, db, dx
+    if fuse_elu_in:
+        raise RuntimeError("linear_act_backward: fuse_elu_in is only served by the skinny path")
     wide = _wide_bf16(mode, M, N, K)
     dW = ops.gemm(dz2, RC, x, RC, N, K, M, out=dW_out, math=PCAA_BF16 if wide else PCAA_F32)
     dx = None
@@ -512,14 +535,19 @@ def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=Non
     layers = dec.dense_layers()
     g = {}
     d = d_out.contiguous().view(acts[-1].shape)
+    pre = False           # d is w.r.t. the layer's pre-activation (ELU' already applied by the dgrad above)
     for i in range(4, -1, -1):
         lin = layers[i]
         nm = f"dense{i + 1}"
         dW_out = grads_out[nm + ".weight"] if grads_out else None
         db_out = grads_out[nm + ".bias"] if grads_out else None
+        M, K = acts[i].shape
+        fuse = i > 0 and _skinny(mode, M, lin.weight.shape[0], K)      # acts[i] is an ELU output for i >= 1
         dW, db, d = linear_act_backward(acts[i], acts[i + 1], lin, ACT_ELU if i < 4 else ACT_NONE, d,
                                         need_dx=(i > 0 or need_dz), dW_out=dW_out, db_out=db_out,
-                                        dx_init=dz_init if i == 0 else None, mode=mode)
+                                        dx_init=dz_init if i == 0 else None, mode=mode, d_is_pre=pre,
+                                        fuse_elu_in=fuse)
+        pre = fuse
         g[nm + ".weight"], g[nm + ".bias"] = dW.view_as(lin.weight), db
     return g, d
 

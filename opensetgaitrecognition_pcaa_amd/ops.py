@@ -329,6 +329,28 @@ def bn_act_bwd_dz(y, scale, shift, mean, rstd, *, da=None, dpool=None, group_row
     return dz, stats
 
 
+def bn_act_bwd_stats(y, scale, shift, mean, rstd, *, da=None, dpool=None, group_rows=0, pool_scale=1.0):
+    """Statistics-only pass of the BatchNorm backward (sum dz, sum dz*yhat): reads, writes nothing."""
+    _chk(y, "bn_act_bwd_stats.y", dim=2)
+    rows, ch = y.shape
+    stats = new_stats(ch, y.device)
+    check(_lib.load().pcaa_bn_act_bwd_dz(_p(da), _p(dpool), int(group_rows), float(pool_scale), _p(y), None,
+                                         _dt(y), _p(scale), _p(shift), _p(mean), _p(rstd), _p(stats), NREP,
+                                         rows, ch, _s()), "pcaa_bn_act_bwd_dz(stats)")
+    return stats
+
+
+def bn_bwd_dy_fused(y, scale, shift, coef, *, da=None, dpool=None, group_rows=0, pool_scale=1.0, out=None):
+    """dy = coef0*(da*ELU'(BN(y))) + coef1*y + coef2 in one pass (dz never stored)."""
+    _chk(y, "bn_bwd_dy_fused.y", dim=2)
+    rows, ch = y.shape
+    dy = out if out is not None else torch.empty_like(y)
+    check(_lib.load().pcaa_bn_bwd_dy_fused(_p(da), _p(dpool), int(group_rows), float(pool_scale), _p(y), _p(dy),
+                                           _dt(y), _p(scale), _p(shift), _p(coef), rows, ch, _s()),
+          "pcaa_bn_bwd_dy_fused")
+    return dy
+
+
 def bn_bwd_finalize(stats, count, bn, mean, rstd, ch, dgamma=None, dbeta=None):
     dev = stats.device
     coef = torch.empty((3, ch), dtype=torch.float32, device=dev)
@@ -365,6 +387,92 @@ def colsum(x, out=None):
     _chk(x, "colsum.x", torch.float32, 2)
     out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device) if out is None else out
     check(_lib.load().pcaa_colsum(_p(x), _p(out), x.shape[0], x.shape[1], _s()), "pcaa_colsum")
+    return out
+
+
+# ------------------------------------------------------------------ batch-skinny Linear layers (decoder)
+def skinny_supported(M, N, K):
+    return bool(_lib.load().pcaa_skinny_supported(int(M), int(N), int(K)))
+
+
+def _skinny_timed(fn, flops, nbytes):
+    timer = TIMER
+    if timer is None:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    timer.records.append(("gemm_skinny_kernel", flops, float(nbytes), e0, e1))
+
+
+def skinny_linear_fwd(x, W, bias, act):
+    """act(x[M,K] @ W[N,K]^T + bias) with M <= 64: one streaming pass over W."""
+    _chk(x, "skinny_fwd.x", torch.float32, 2)
+    _chk(W, "skinny_fwd.W", torch.float32, 2)
+    M, K = x.shape
+    N = W.shape[0]
+    if W.shape[1] != K:
+        raise ValueError("skinny_linear_fwd: shape mismatch")
+    lib = _lib.load()
+    ns = lib.pcaa_skinny_splits(0, M, N, K)
+    ws = torch.empty(ns * M * N, dtype=torch.float32, device=x.device)
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _skinny_timed(lambda: check(lib.pcaa_skinny_linear_fwd(_p(x), x.stride(0), _p(W), W.stride(0), _p(bias), act,
+                                                           _p(y), _p(ws), ws.numel(), M, N, K, ns, _s()),
+                                "pcaa_skinny_linear_fwd"), 2.0 * M * N * K, 4 * (N * K + M * K + M * N))
+    return y
+
+
+def skinny_linear_dgrad(dz, W, a_prev=None, out=None, accumulate=False):
+    """dx[M,K] (=|+=) (dz[M,N] @ W[N,K]) * ELU'(a_prev) (a_prev: ELU OUTPUT of the layer below or None)."""
+    _chk(dz, "skinny_dgrad.dz", torch.float32, 2)
+    _chk(W, "skinny_dgrad.W", torch.float32, 2)
+    M, N = dz.shape
+    K = W.shape[1]
+    if W.shape[0] != N:
+        raise ValueError("skinny_linear_dgrad: shape mismatch")
+    if a_prev is not None:
+        _chk(a_prev, "skinny_dgrad.a_prev", torch.float32)
+        if a_prev.numel() != M * K:
+            raise ValueError("skinny_linear_dgrad: a_prev size")
+    if out is None:
+        if accumulate:
+            raise ValueError("skinny_linear_dgrad: accumulate needs out")
+        out = torch.empty((M, K), dtype=torch.float32, device=dz.device)
+    else:
+        _chk(out, "skinny_dgrad.out", torch.float32)
+        if out.numel() != M * K:
+            raise ValueError("skinny_linear_dgrad: out size")
+    lib = _lib.load()
+    ns = lib.pcaa_skinny_splits(1, M, N, K)
+    ws = torch.empty(ns * M * K, dtype=torch.float32, device=dz.device)
+    _skinny_timed(lambda: check(lib.pcaa_skinny_linear_dgrad(_p(dz), dz.stride(0), _p(W), W.stride(0), _p(out),
+                                                             _p(a_prev), int(bool(accumulate)), _p(ws), ws.numel(),
+                                                             M, N, K, ns, _s()),
+                                "pcaa_skinny_linear_dgrad"), 2.0 * M * N * K, 4 * (N * K + M * K + M * N))
+    return out
+
+
+def skinny_linear_wgrad(dz, x, out=None):
+    """dW[N,K] = dz[M,N]^T @ x[M,K] with M <= 64: one streaming store pass over dW."""
+    _chk(dz, "skinny_wgrad.dz", torch.float32, 2)
+    _chk(x, "skinny_wgrad.x", torch.float32, 2)
+    M, N = dz.shape
+    K = x.shape[1]
+    if x.shape[0] != M:
+        raise ValueError("skinny_linear_wgrad: shape mismatch")
+    if out is None:
+        out = torch.empty((N, K), dtype=torch.float32, device=dz.device)
+    else:
+        _chk(out, "skinny_wgrad.out", torch.float32)
+        if out.numel() != N * K:
+            raise ValueError("skinny_linear_wgrad: out size")
+    lib = _lib.load()
+    _skinny_timed(lambda: check(lib.pcaa_skinny_linear_wgrad(_p(dz), dz.stride(0), _p(x), x.stride(0), _p(out), K,
+                                                             M, N, K, _s()),
+                                "pcaa_skinny_linear_wgrad"), 2.0 * M * N * K, 4 * (N * K + M * K + M * N))
     return out
 
 

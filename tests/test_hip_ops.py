@@ -143,6 +143,68 @@ def test_gemm_bf16_lds_dma_exact_integers(lay, M, N, K, sk):
         assert torch.equal(Cb.float().cpu().double(), acc.float().bfloat16().double())
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 1920, 960), (64, 960, 1920), (37, 320, 704), (8, 128, 128), (1, 192, 256),
+                                   (64, 15360 // 2, 7680 // 2)])
+def test_skinny_linear_layers_exact_integers(M, N, K):
+    """batch-skinny (M <= 64) decoder kernels: weights streamed HBM -> MFMA fragments.  Small
+    integers are exact in bf16, so forward / dgrad / wgrad must equal the integer products
+    (asymmetric shapes, ragged M, N not a multiple of the 128-row workgroup tile)."""
+    assert ops.skinny_supported(M, N, K)
+    rng = np.random.default_rng(39)
+    x = torch.from_numpy(rng.integers(-3, 4, (M, K)).astype(np.float32))
+    W = torch.from_numpy(rng.integers(-3, 4, (N, K)).astype(np.float32))
+    b = torch.from_numpy(rng.integers(-2, 3, (N,)).astype(np.float32))
+    dz = torch.from_numpy(rng.integers(-3, 4, (M, N)).astype(np.float32))
+    xd, Wd, bd, dzd = x.to(DEV), W.to(DEV), b.to(DEV), dz.to(DEV)
+    ref = x.double() @ W.double().t() + b.double()
+    y = ops.skinny_linear_fwd(xd, Wd, bd, ACT_NONE)
+    assert torch.equal(y.cpu().double(), ref)
+    ye = ops.skinny_linear_fwd(xd, Wd, bd, ACT_ELU)
+    assert torch.allclose(ye.cpu().double(), torch.nn.functional.elu(ref), rtol=1e-6, atol=1e-7)
+    # dgrad: plain, accumulate, and with the ELU'(a_prev) factor of the layer below
+    dref = dz.double() @ W.double()
+    dx = ops.skinny_linear_dgrad(dzd, Wd)
+    assert torch.equal(dx.cpu().double(), dref)
+    init = torch.from_numpy(rng.integers(-5, 6, (M, K)).astype(np.float32))
+    dx2 = ops.skinny_linear_dgrad(dzd, Wd, out=init.to(DEV), accumulate=True)
+    assert torch.equal(dx2.cpu().double(), dref + init.double())
+    a_prev = torch.from_numpy(rng.uniform(-0.9, 2.0, (M, K)).astype(np.float32))
+    dx3 = ops.skinny_linear_dgrad(dzd, Wd, a_prev=a_prev.to(DEV))
+    fac = torch.where(a_prev > 0, torch.ones_like(a_prev), a_prev + 1).double()
+    assert torch.allclose(dx3.cpu().double(), dref * fac, rtol=1e-6, atol=1e-6)
+    # wgrad
+    dW = ops.skinny_linear_wgrad(dzd, xd)
+    assert torch.equal(dW.cpu().double(), dz.double().t() @ x.double())
+
+
+def test_skinny_linear_layers_random_bf16_rounding():
+    """random fp32 operands: result equals the fp64 product of the bf16-ROUNDED operands to fp32
+    accumulation accuracy (the only approximation is the operand rounding)."""
+    M, N, K = 64, 3840, 1920
+    rng = np.random.default_rng(40)
+    x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32))
+    W = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    dz = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32))
+    r = lambda t: t.bfloat16().double()
+    y = ops.skinny_linear_fwd(x.to(DEV), W.to(DEV), None, ACT_NONE).cpu().double()
+    ref = r(x) @ r(W).t()
+    assert (y - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    dx = ops.skinny_linear_dgrad(dz.to(DEV), W.to(DEV)).cpu().double()
+    ref = r(dz) @ r(W)
+    assert (dx - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    dW = ops.skinny_linear_wgrad(dz.to(DEV), x.to(DEV)).cpu().double()
+    ref = r(dz).t() @ r(x)
+    assert (dW - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+def test_skinny_rejects_unsupported_shapes():
+    assert not ops.skinny_supported(65, 1920, 960)
+    assert not ops.skinny_supported(64, 1200, 960)
+    assert not ops.skinny_supported(64, 960, 32)
+    with pytest.raises(RuntimeError):
+        ops.skinny_linear_fwd(torch.zeros(65, 128, device=DEV), torch.zeros(128, 128, device=DEV), None, ACT_NONE)
+
+
 @pytest.mark.parametrize("M,N,K,sk,math", [(1024, 512, 64 * 40, 5, PCAA_BF16), (256, 256, 64 * 6, 3, PCAA_BF16),
                                            (520, 264, 1000, 3, PCAA_BF16), (130, 68, 900, 4, PCAA_F32)])
 def test_gemm_slab_split_k(M, N, K, sk, math):
