@@ -76,21 +76,26 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 }
 
 // ---------------------------------------------------------------- a = ELU(y*scale+shift)
+// Flat quad index, grid-stride loop.  The host rounds the grid so that the stride (gridDim*256
+// quads) is a multiple of the quads per row: a thread then stays on ONE channel quad for its whole
+// life -- its coefficients live in registers and there is no per-element index division (the
+// 64-bit q % qpr, q / qpr of the first version cost more VALU time than the HBM stream).
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, T* __restrict__ a,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
-                                                         long nquads, int qpr) {
-  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (long)gridDim.x * 256) {
-    const int c = (int)(q % qpr) << 2;
-    const f32x4 v = load4(y + q * 4);
-    const f32x4 sc = load4(scale + c), sh = load4(shift + c);
+                                                         unsigned nquads, unsigned qpr) {
+  const unsigned q0 = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+  const unsigned c = (q0 % qpr) << 2;
+  const f32x4 sc = load4(scale + c), sh = load4(shift + c);
+  for (unsigned q = q0; q < nquads; q += stride) {
+    const f32x4 v = load4(y + (size_t)q * 4);
     f32x4 o;
     o.x = elu_t<T>(v.x * sc.x + sh.x);
     o.y = elu_t<T>(v.y * sc.y + sh.y);
     o.z = elu_t<T>(v.z * sc.z + sh.z);
     o.w = elu_t<T>(v.w * sc.w + sh.w);
-    store4(a + q * 4, o);
+    store4(a + (size_t)q * 4, o);
   }
 }
 
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(const T* __restrict_
     const f32x4 yv = load4(y + r * ch + c);
     f32x4 g;
     if (POOL) {
-      g = load4(dpool + (r / group_rows) * ch + c);
+      g = load4(dpool + (size_t)((unsigned)r / (unsigned)group_rows) * ch + c);   // rows < 2^31 (host-checked)
       g.x *= pool_scale; g.y *= pool_scale; g.z *= pool_scale; g.w *= pool_scale;
     } else {
       g = load4(da + r * ch + c);
@@ -384,6 +389,17 @@ inline int grid_for(long work_items, int per_block = 256, int cap = 256 * 8) {
   return (int)g;
 }
 
+// grid whose stride (grid*256 quads) is a multiple of the quads per row: every thread keeps one channel quad
+inline int col_invariant_grid(long nquads, int qpr) {
+  int a = qpr, b = 256;
+  while (b) { const int t = a % b; a = b; b = t; }
+  const int unit = qpr / a;                           // grid must be a multiple of qpr / gcd(qpr, 256)
+  long g = cdiv(nquads, 256);
+  if (g > 2048) g = 2048;
+  g = cdiv(g, unit) * unit;
+  return (int)g;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- C ABI
@@ -416,13 +432,14 @@ extern "C" int pcaa_bn_act_fwd(const void* y, void* a, int dtype, const float* s
   PCAA_CHECK_ARG(y && a && scale && shift, "pcaa_bn_act_fwd: null pointer");
   PCAA_CHECK_ARG(rows >= 1 && ch >= 4 && (ch & 3) == 0, "pcaa_bn_act_fwd: ch must be a multiple of 4");
   const long nq = rows * (ch >> 2);
-  const int grid = grid_for(nq);
+  PCAA_CHECK_ARG(nq < (1L << 31), "pcaa_bn_act_fwd: tensor too large for 32-bit quad indices");
+  const int grid = col_invariant_grid(nq, ch >> 2);
   if (dtype == PCAA_F32)
     hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream),
-                       (const float*)y, (float*)a, scale, shift, nq, ch >> 2);
+                       (const float*)y, (float*)a, scale, shift, (unsigned)nq, (unsigned)(ch >> 2));
   else if (dtype == PCAA_BF16)
     hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream),
-                       (const bf16_t*)y, (bf16_t*)a, scale, shift, nq, ch >> 2);
+                       (const bf16_t*)y, (bf16_t*)a, scale, shift, (unsigned)nq, (unsigned)(ch >> 2));
   else { pcaa_set_error("pcaa_bn_act_fwd: bad dtype"); return PCAA_ERR_INVALID_ARG; }
   PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_act_fwd");
 }
@@ -447,7 +464,8 @@ extern "C" int pcaa_bn_act_bwd_dz(const void* da, const float* dpool, int group_
                                   double* stats, int nrep, long rows, int ch, void* stream) {
   PCAA_CHECK_ARG((da != nullptr) != (dpool != nullptr), "pcaa_bn_act_bwd_dz: exactly one of da / dpool");
   PCAA_CHECK_ARG(y && scale && shift && mean && rstd && stats, "pcaa_bn_act_bwd_dz: null pointer");
-  PCAA_CHECK_ARG(rows >= 1 && nrep >= 1 && ch_ok(ch), "pcaa_bn_act_bwd_dz: ch/4 must divide 256 (ch=%d)", ch);
+  PCAA_CHECK_ARG(rows >= 1 && rows < (1L << 31) && nrep >= 1 && ch_ok(ch),
+                 "pcaa_bn_act_bwd_dz: ch/4 must divide 256 (ch=%d), rows < 2^31", ch);
   PCAA_CHECK_ARG(!dpool || group_rows >= 1, "pcaa_bn_act_bwd_dz: bad group_rows");
   const unsigned grid = (unsigned)cdiv(rows, ROWS_PER_BLOCK);
   hipStream_t s = as_stream(stream);
@@ -467,31 +485,35 @@ namespace {
 // (the statistics pass before it reads da and y but writes nothing)
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_dy_fused_kernel(const T* __restrict__ da,
-                                                              const float* __restrict__ dpool, int group_rows,
+                                                              const float* __restrict__ dpool, unsigned group_rows,
                                                               float pool_scale, const T* __restrict__ y,
                                                               T* __restrict__ dy, const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
-                                                              const float* __restrict__ coef, long nquads,
-                                                              int qpr, int ch) {
-  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (long)gridDim.x * 256) {
-    const long r = q / qpr;
-    const int c = (int)(q - r * qpr) << 2;
-    const f32x4 yv = load4(y + q * 4);
+                                                              const float* __restrict__ coef, unsigned nquads,
+                                                              unsigned qpr, unsigned ch) {
+  // column-invariant grid (see bn_act_fwd_kernel): coefficients in registers, rows advance by a
+  // constant; the pooled variant's group index is one 32-bit division per quad
+  const unsigned q0 = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+  const unsigned c = (q0 % qpr) << 2;
+  const unsigned rstep = stride / qpr;
+  unsigned r = q0 / qpr;
+  const f32x4 sc = load4(scale + c), sh = load4(shift + c);
+  const f32x4 k0 = load4(coef + c), k1 = load4(coef + ch + c), k2 = load4(coef + 2 * ch + c);
+  for (unsigned q = q0; q < nquads; q += stride, r += rstep) {
+    const f32x4 yv = load4(y + (size_t)q * 4);
     f32x4 g;
     if (POOL) {
-      g = load4(dpool + (r / group_rows) * ch + c);
+      g = load4(dpool + (size_t)(r / group_rows) * ch + c);
       g *= pool_scale;
     } else {
-      g = load4(da + q * 4);
+      g = load4(da + (size_t)q * 4);
     }
-    const f32x4 sc = load4(scale + c), sh = load4(shift + c);
-    const f32x4 k0 = load4(coef + c), k1 = load4(coef + ch + c), k2 = load4(coef + 2 * ch + c);
     f32x4 o;
     o.x = k0.x * (g.x * elu_grad_from_pre_t<T>(yv.x * sc.x + sh.x)) + k1.x * yv.x + k2.x;
     o.y = k0.y * (g.y * elu_grad_from_pre_t<T>(yv.y * sc.y + sh.y)) + k1.y * yv.y + k2.y;
     o.z = k0.z * (g.z * elu_grad_from_pre_t<T>(yv.z * sc.z + sh.z)) + k1.z * yv.z + k2.z;
     o.w = k0.w * (g.w * elu_grad_from_pre_t<T>(yv.w * sc.w + sh.w)) + k1.w * yv.w + k2.w;
-    store4(dy + q * 4, o);
+    store4(dy + (size_t)q * 4, o);
   }
 }
 }  // namespace
@@ -504,11 +526,13 @@ extern "C" int pcaa_bn_bwd_dy_fused(const void* da, const float* dpool, int grou
   PCAA_CHECK_ARG(rows >= 1 && ch >= 4 && (ch & 3) == 0, "pcaa_bn_bwd_dy_fused: ch must be a multiple of 4");
   PCAA_CHECK_ARG(!dpool || group_rows >= 1, "pcaa_bn_bwd_dy_fused: bad group_rows");
   const long nq = rows * (ch >> 2);
-  const int grid = grid_for(nq);
+  PCAA_CHECK_ARG(nq < (1L << 31), "pcaa_bn_bwd_dy_fused: tensor too large for 32-bit quad indices");
+  const int grid = col_invariant_grid(nq, ch >> 2);
   hipStream_t s = as_stream(stream);
 #define LAUNCH_DYF(T, POOL)                                                                             \
   hipLaunchKernelGGL((bn_bwd_dy_fused_kernel<T, POOL>), dim3(grid), dim3(256), 0, s, (const T*)da, dpool, \
-                     group_rows, pool_scale, (const T*)y, (T*)dy, scale, shift, coef, nq, ch >> 2, ch)
+                     (unsigned)group_rows, pool_scale, (const T*)y, (T*)dy, scale, shift, coef, (unsigned)nq, \
+                     (unsigned)(ch >> 2), (unsigned)ch)
   if (dtype == PCAA_F32) { if (dpool) LAUNCH_DYF(float, true); else LAUNCH_DYF(float, false); }
   else if (dtype == PCAA_BF16) { if (dpool) LAUNCH_DYF(bf16_t, true); else LAUNCH_DYF(bf16_t, false); }
   else { pcaa_set_error("pcaa_bn_bwd_dy_fused: bad dtype"); return PCAA_ERR_INVALID_ARG; }
