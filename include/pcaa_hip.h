@@ -244,10 +244,12 @@ int pcaa_skinny_linear_wgrad(const float* dz, long lddz, const float* x, long ld
 
 /* ------------------------------------------------------------------ optimizer
  * torch.optim.Adam (no weight decay, no amsgrad; PCAA_ablation.py:820-833) on a
- * flat fp32 buffer. `step` is the 1-based step count after this update. */
+ * flat fp32 buffer. `step` is the 1-based step count after this update.  max_blocks (0 =
+ * default, fill the device) caps the grid: <= 1024 selects the 4-quads-per-thread kernel that
+ * saturates HBM from 1-2 workgroups per CU, for updates that run beside other kernels. */
 int pcaa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
                    float lr, float beta1, float beta2, float eps, int step, float grad_scale,
-                   void* stream);
+                   int max_blocks, void* stream);
 
 #ifdef __cplusplus
 }

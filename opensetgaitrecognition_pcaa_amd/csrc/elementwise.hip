@@ -16,7 +16,7 @@ void pcaa_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* pcaa_last_error(void) { return g_err; }
-extern "C" int pcaa_abi_version(void) { return 1; }
+extern "C" int pcaa_abi_version(void) { return 2; }
 
 namespace {
 
@@ -351,24 +351,40 @@ __global__ void dtc_col2im_kernel(const float* __restrict__ dcol, float* __restr
 }
 
 // ---------------------------------------------------------------- Adam
+// HBM-bound: 4 reads + 3 writes of 16 B per quad.  U quads per thread per trip keep U x 64 B per
+// lane in flight, so a SMALL grid (1-2 workgroups per CU) still saturates HBM -- which is what
+// lets the decoder's update run on a side stream beside the latency-bound temporal-conv / head
+// kernels without taking their wave slots (a 4096-block grid made those 2-7x slower).
+template <int U>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n,
                                                    float b1, float b2, float eps, float step_size,
                                                    float inv_bc2_sqrt, float grad_scale) {
   const long nq = n >> 2;
-  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
-    f32x4 pv = load4(p + q * 4), gv = load4(g + q * 4), mv = load4(m + q * 4), vv = load4(v + q * 4);
+  const long stride = (long)gridDim.x * 256;
+  for (long q0 = (long)blockIdx.x * 256 + threadIdx.x; q0 < nq; q0 += stride * U) {
+    f32x4 pv[U], gv[U], mv[U], vv[U];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float gg = gv[e] * grad_scale;
-      mv[e] = b1 * mv[e] + (1.f - b1) * gg;
-      vv[e] = b2 * vv[e] + (1.f - b2) * gg * gg;
-      const float denom = sqrtf(vv[e]) * inv_bc2_sqrt + eps;
-      pv[e] -= step_size * (mv[e] / denom);
+    for (int u = 0; u < U; ++u) {
+      const long q = q0 + u * stride;
+      if (q < nq) { pv[u] = load4(p + q * 4); gv[u] = load4(g + q * 4); mv[u] = load4(m + q * 4); vv[u] = load4(v + q * 4); }
     }
-    store4(p + q * 4, pv);
-    store4(m + q * 4, mv);
-    store4(v + q * 4, vv);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long q = q0 + u * stride;
+      if (q >= nq) break;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gg = gv[u][e] * grad_scale;
+        mv[u][e] = b1 * mv[u][e] + (1.f - b1) * gg;
+        vv[u][e] = b2 * vv[u][e] + (1.f - b2) * gg * gg;
+        const float denom = sqrtf(vv[u][e]) * inv_bc2_sqrt + eps;
+        pv[u][e] -= step_size * (mv[u][e] / denom);
+      }
+      store4(p + q * 4, pv[u]);
+      store4(m + q * 4, mv[u]);
+      store4(v + q * 4, vv[u]);
+    }
   }
   // tail (n % 4)
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -709,15 +725,22 @@ extern "C" int pcaa_splitk_reduce(const float* slabs, int nsplit, long slab_stri
 
 extern "C" int pcaa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
                               float lr, float beta1, float beta2, float eps, int step, float grad_scale,
-                              void* stream) {
-  PCAA_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n >= 1 && step >= 1, "pcaa_adam_step: bad args");
+                              int max_blocks, void* stream) {
+  PCAA_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n >= 1 && step >= 1 && max_blocks >= 0,
+                 "pcaa_adam_step: bad args");
   PCAA_CHECK_ARG(((uintptr_t)param % 16) == 0 && ((uintptr_t)grad % 16) == 0 && ((uintptr_t)exp_avg % 16) == 0 &&
                  ((uintptr_t)exp_avg_sq % 16) == 0, "pcaa_adam_step: buffers must be 16-B aligned");
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const float step_size = (float)((double)lr / bc1);
   const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n >> 2, 256, 256 * 16)), dim3(256), 0, as_stream(stream),
-                     param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size, inv_bc2_sqrt, grad_scale);
+  static const int env_cap = getenv("PCAA_ADAM_BLOCKS") ? atoi(getenv("PCAA_ADAM_BLOCKS")) : 0;
+  const int cap = env_cap > 0 ? env_cap : (max_blocks > 0 ? max_blocks : 256 * 16);
+  if (cap <= 1024)
+    hipLaunchKernelGGL(adam_kernel<4>, dim3(grid_for(n >> 4, 256, cap)), dim3(256), 0, as_stream(stream), param, grad,
+                       exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size, inv_bc2_sqrt, grad_scale);
+  else
+    hipLaunchKernelGGL(adam_kernel<1>, dim3(grid_for(n >> 2, 256, cap)), dim3(256), 0, as_stream(stream), param, grad,
+                       exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size, inv_bc2_sqrt, grad_scale);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_adam_step");
 }

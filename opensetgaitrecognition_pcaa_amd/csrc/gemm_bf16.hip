@@ -995,10 +995,14 @@ bool pcaa_launch_gemm_bf16_big(const GemmParams& p_in, int a_dtype, int a_layout
   const long ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
   if (ntiles * nsplit >= (1L << 31)) return false;
   p.nsplit = nsplit;
-  // split_fast (all tiles of one K-range on one XCD) measured neutral-to-negative on MI355X
-  // (wgrad 1024x512 K=245760: 0.53 -> 1.36 ms at 128 blocks; 1024^2: 0.61 -> 0.59): the re-reads
-  // were already served by the Infinity Cache, and co-locating them adds same-line contention.
-  p.split_fast = 0;
+  // split_fast: all tiles of one K-range on one XCD, so the operand rows of that range cross the
+  // fabric once instead of once per XCD that holds a tile.  Slab split-K (the wgrad products), >= 256
+  // workgroups: fabric fetch per launch 3022 -> 1009 MB (= the algorithmic 1006 MB) on
+  // dW[1024,1024], time -5..-8 % on the three wgrad shapes (tools/wgrad_exp.sh).  With the atomic
+  // epilogue at 128 workgroups it had measured slower (0.53 -> 1.36 ms), so it stays off there.
+  static const bool split_fast_off = getenv("PCAA_GEMM_SPLIT_FAST") && atoi(getenv("PCAA_GEMM_SPLIT_FAST")) == 0;
+  p.split_fast = (!split_fast_off && p.c_split_stride != 0 && nsplit >= 8 && nsplit % 8 == 0 &&
+                  ntiles * nsplit >= 256) ? 1 : 0;
   { const char* d = getenv("PCAA_GEMM_DIAG"); p.diag = d ? atoi(d) : 0; }
   dim3 grid((unsigned)ntiles, 1, (unsigned)nsplit);
   if (p.split_fast) grid = dim3((unsigned)(ntiles * nsplit), 1, 1);

@@ -372,7 +372,7 @@ def encoder_forward(enc, x, training, mode=None):
     return st.logits, st.sup_fv, st
 
 
-def encoder_backward(enc, st, d_logits, d_supfv, need_dx=False, gout=None):
+def encoder_backward(enc, st, d_logits, d_supfv, need_dx=False, gout=None, before_pointnet=None):
     """Returns ({state_dict-style name: grad}, dx [B,C,T,N] view or None).
     ``gout``: optional {name: gradient view}; split-K products accumulate into
     them, so they must arrive ZEROED (the trainer zeroes its flat buffer once)."""
@@ -414,6 +414,8 @@ def encoder_backward(enc, st, d_logits, d_supfv, need_dx=False, gout=None):
     for i, d in enumerate(dg, start=1):
         for k, v in d.items():
             g[f"tc_block.dtc{i}.{k}"] = v
+    if before_pointnet is not None:
+        before_pointnet()        # trainer hook: everything enqueued so far is the latency-bound part of the backward
     pg, dxp = pointnet_backward(st.pn, enc.pc_block.layers(), st.mode, dpool=dx2, pool_rows=N, need_dx=need_dx,
                                 gout=gout)
     for i, d in enumerate(pg, start=1):

@@ -51,8 +51,14 @@ class LaunchTimer:
     to measure the dominant kernel's average duration inside the timed region;
     events are recorded on the stream the kernels are launched on)."""
 
-    def __init__(self):
+    def __init__(self, only_prefix=None):
         self.records = []      # (key, flops, bytes, start_event, end_event)
+        # every timed launch costs two event packets on the stream (~0.3 ms per step when all ~45
+        # GEMM launches are timed); bench.py restricts the timing to the kernel it reports
+        self.only_prefix = only_prefix
+
+    def wants(self, key):
+        return self.only_prefix is None or key.startswith(self.only_prefix)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -113,6 +119,13 @@ def new_stats(ch, device):
 
 
 # ------------------------------------------------------------------ GEMM
+def _dma_key(out_dtype, layout):
+    """LaunchTimer / PMC key of one gemm_bf16_dma_kernel instantiation (rocprofv3 lists them as
+    separate kernels: <__bf16, 0, 0, 0> = PointNet forward/dgrad, <float, 1, 1, 0> = wgrad)."""
+    lay = "KC" if layout == KC else "RC"
+    return f"gemm_bf16_dma_kernel<{'bf16' if out_dtype == torch.bfloat16 else 'f32'},{lay},{lay}>"
+
+
 def gemm(A, a_layout, B, b_layout, M, N, K, *, lda=None, ldb=None, out=None, out_dtype=torch.float32,
          bias=None, colstats=None, split_k=1, accumulate=False, math=PCAA_F32):
     """out[M,N] (=|+=) A(M,K) . B(K,N) (+bias).  A/B are 2-D contiguous tensors
@@ -147,6 +160,15 @@ def gemm(A, a_layout, B, b_layout, M, N, K, *, lda=None, ldb=None, out=None, out
     lib = _lib.load()
     timer = TIMER
     if timer is not None:
+        if math != PCAA_BF16:
+            key = "gemm_f32_kernel"
+        elif (A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and a_layout == b_layout
+              and M % 256 == 0 and N % 256 == 0 and K % 64 == 0):
+            key = _dma_key(out.dtype, a_layout)   # same dispatch rule as pcaa_launch_gemm_bf16_big
+        else:
+            key = "gemm_bf16_big_kernel"
+        timer = timer if timer.wants(key) else None
+    if timer is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -155,13 +177,6 @@ def gemm(A, a_layout, B, b_layout, M, N, K, *, lda=None, ldb=None, out=None, out
                         int(split_k), int(bool(accumulate)), _s()), "pcaa_gemm")
     if timer is not None:
         e1.record()
-        if math != PCAA_BF16:
-            key = "gemm_f32_kernel"
-        elif (A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and a_layout == b_layout
-              and M % 256 == 0 and N % 256 == 0 and K % 64 == 0):
-            key = "gemm_bf16_dma_kernel"          # same dispatch rule as pcaa_launch_gemm_bf16_big
-        else:
-            key = "gemm_bf16_big_kernel"
         nbytes = A.numel() * A.element_size() + B.numel() * B.element_size() + out.numel() * out.element_size()
         timer.records.append((key, 2.0 * M * N * K, float(nbytes), e0, e1))
     return out
@@ -188,6 +203,11 @@ def gemm_slabs(A, a_layout, B, b_layout, M, N, K, split_k, out=None, accumulate=
             raise ValueError("gemm_slabs: out size")
     timer = TIMER
     if timer is not None:
+        dma = (math == PCAA_BF16 and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and a_layout == b_layout
+               and M % 256 == 0 and N % 256 == 0 and K % 64 == 0)
+        key = _dma_key(torch.float32, a_layout) if dma else ("gemm_bf16_big_kernel" if math == PCAA_BF16 else "gemm_f32_kernel")
+        timer = timer if timer.wants(key) else None
+    if timer is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -195,9 +215,6 @@ def gemm_slabs(A, a_layout, B, b_layout, M, N, K, split_k, out=None, accumulate=
                               _p(slabs), stride, M, N, K, int(split_k), _s()), "pcaa_gemm_slabs")
     if timer is not None:
         e1.record()
-        dma = (math == PCAA_BF16 and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and a_layout == b_layout
-               and M % 256 == 0 and N % 256 == 0 and K % 64 == 0)
-        key = "gemm_bf16_dma_kernel" if dma else ("gemm_bf16_big_kernel" if math == PCAA_BF16 else "gemm_f32_kernel")
         nbytes = A.numel() * A.element_size() + B.numel() * B.element_size() + ns * stride * 4
         timer.records.append((key, 2.0 * M * N * K, float(nbytes), e0, e1))
     if colstats is not None:
@@ -397,7 +414,7 @@ def skinny_supported(M, N, K):
 
 def _skinny_timed(fn, flops, nbytes):
     timer = TIMER
-    if timer is None:
+    if timer is None or not timer.wants("gemm_skinny_kernel"):
         return fn()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
@@ -637,11 +654,11 @@ def disc_wgan_gp(z, fv, label, alphas, params, gp_weight, grads_out=None):
 
 
 # ------------------------------------------------------------------ optimizer
-def adam_step_(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0):
+def adam_step_(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0, max_blocks=0):
     for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t, f"adam.{nm}", torch.float32)
     n = p.numel()
     if not (g.numel() == n and m.numel() == n and v.numel() == n):
         raise ValueError("adam_step_: size mismatch")
     check(_lib.load().pcaa_adam_step(_p(p), _p(g), _p(m), _p(v), n, float(lr), float(b1), float(b2), float(eps),
-                                     int(step), float(grad_scale), _s()), "pcaa_adam_step")
+                                     int(step), float(grad_scale), int(max_blocks), _s()), "pcaa_adam_step")

@@ -55,9 +55,15 @@ class FlatBuffer:
                 self.grad_views[name] = self.g[o:o + n].view(p.shape)
         self.step = 0
 
-    def adam(self, lr, b1, b2, eps=1e-8, grad_scale=1.0):
-        self.step += 1
-        ops.adam_step_(self.p, self.g, self.m, self.v, lr, b1, b2, eps, self.step, grad_scale)
+    def adam(self, lr, b1, b2, eps=1e-8, grad_scale=1.0, lo=0, hi=None, advance=True, max_blocks=0):
+        """One Adam update of the elements [lo, hi) (default: everything).  ``advance=False``:
+        a further range of the SAME optimizer step (the step count is shared)."""
+        if advance:
+            self.step += 1
+        hi = self.total if hi is None else hi
+        if hi > lo:
+            ops.adam_step_(self.p[lo:hi], self.g[lo:hi], self.m[lo:hi], self.v[lo:hi], lr, b1, b2, eps, self.step,
+                           grad_scale, max_blocks)
 
 
 class PCAATrainer:
@@ -136,6 +142,19 @@ class PCAATrainer:
         # projection-head + decoder gradients (>98 % of the bytes) are complete before the encoder
         # backward starts: their all-reduce is issued asynchronously and overlaps it
         self._tail_region = self.flat_g.g[enc_end:]
+        # The decoder's parameters (98 % of optimizer_G's bytes: a 0.8 ms HBM-bound Adam pass) are
+        # final once its backward -- and, data-parallel, the all-reduce of that region -- is done,
+        # long before the encoder backward ends.  Their Adam update runs on a side stream beside the
+        # latency-bound temporal-conv / MLP-head backward kernels instead of after everything.
+        dec_names = [i for i, nm in enumerate(self.flat_g.names) if nm.startswith("G.")]
+        self._dec_start = self.flat_g.offsets[dec_names[0]] if dec_names else self.flat_g.total
+        self.early_decoder_adam = os.environ.get("PCAA_EARLY_ADAM", "1") != "0"
+        self._side_adam_blocks = int(os.environ.get("PCAA_SIDE_ADAM_BLOCKS", "256"))
+        # measured (same box, ms/step): no side stream 8.08-8.26 | beside the temporal-conv/head backward
+        # 7.90 (256 blocks), 7.99 (128) | beside the PointNet backward GEMMs 8.29 (256) .. 9.03 (32):
+        # the GEMMs lose more to the extra HBM stream than the update costs on its own
+        self._side_adam_at = os.environ.get("PCAA_SIDE_ADAM_AT", "dtc")
+        self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self.overlap_allreduce = os.environ.get("PCAA_DP_OVERLAP", "1") != "0"
         # PCAA_DP_FORCE=1 issues the collectives even on a 1-rank group (exercises the RCCL path on one GPU)
         self._force_collectives = os.environ.get("PCAA_DP_FORCE", "0") == "1"
@@ -214,14 +233,42 @@ class PCAATrainer:
         pending = None
         if self.overlap_allreduce:
             pending = self._allreduce(self._tail_region, async_op=True)
-        F_hip.encoder_backward(enc, st, dlogits if supervise else None, dsup, gout=self._enc_grads)
+        early = self.early_decoder_adam and self.overlap_allreduce and self._side is not None
+        hook = None
+        if early:
+            self.flat_g.step += 1
+            done = []
+
+            def launch_side_adam():
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream())
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(ready)        # everything enqueued on the main stream so far
+                    if pending is not None:
+                        pending.wait()                  # side stream waits for the decoder-region all-reduce
+                    self.flat_g.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs, lo=self._dec_start,
+                                     advance=False, max_blocks=self._side_adam_blocks)
+                    ev = torch.cuda.Event()
+                    ev.record(self._side)
+                    done.append(ev)
+
+            if self._side_adam_at == "pointnet":
+                hook = launch_side_adam                 # beside the MFMA-bound PointNet backward
+            else:
+                launch_side_adam()                      # beside the temporal-conv / head backward
+        F_hip.encoder_backward(enc, st, dlogits if supervise else None, dsup, gout=self._enc_grads,
+                               before_pointnet=hook)
         if self.overlap_allreduce:
             self._allreduce(self._enc_region)
             if pending is not None:
                 pending.wait()          # stream-side wait, no host block
         else:
             self._allreduce(self.flat_g.g)
-        self.flat_g.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs)
+        if early:
+            self.flat_g.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs, hi=self._dec_start, advance=False)
+            torch.cuda.current_stream().wait_event(done[0])      # next forward reads the updated decoder
+        else:
+            self.flat_g.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs)
 
         tot = rec_loss + loss_g + (sup_loss if supervise else 0.0)
         return {"d_loss": d_losses[0], "gp": d_losses[1], "rec_loss": rec_loss, "loss_g": loss_g,

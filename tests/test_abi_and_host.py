@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in protos:
         assert hasattr(lib, name), f"{name} declared in include/pcaa_hip.h but not exported"
-    assert lib.pcaa_abi_version() == 1
+    assert lib.pcaa_abi_version() == 2
     assert lib.pcaa_disc_workspace_bytes(64, 8) > 0
 
 
@@ -28,7 +28,7 @@ def test_argument_validation_reports_errors_without_a_gpu():
     rc = lib.pcaa_gemm(0, None, 0, 0, 0, None, 0, 0, 0, None, 0, 0, 4, 4, 4, None, None, 0, 1, 0, None)
     assert rc == 1
     assert b"null operand" in lib.pcaa_last_error()
-    rc = lib.pcaa_adam_step(None, None, None, None, 0, 0.0, 0.0, 0.0, 0.0, 0, 1.0, None)
+    rc = lib.pcaa_adam_step(None, None, None, None, 0, 0.0, 0.0, 0.0, 0.0, 0, 1.0, 0, None)
     assert rc == 1
 
 

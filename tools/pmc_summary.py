@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Aggregate the rocprofv3 PMC passes of tools/pmc_step.sh into profiles/<tag>_pmc_summary.json:
+fabric-side bytes per launch of every kernel (FETCH_SIZE doubled per the gfx950 correction of
+MI355X_MICROARCH.md, + WRITE_SIZE; both counters are in KiB and are L2->fabric requests, so
+Infinity-Cache hits are included).  python tools/pmc_summary.py <gpurun_out dir> <tag> <out.json>"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def key_of(name):
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
+    if m:                                   # rocprofv3 leaves some template instantiations mangled
+        ln = int(m.group(1))
+        base, rest = name[m.end():m.end() + ln], name[m.end() + ln:]
+        if base == "gemm_bf16_dma_kernel":
+            t = re.match(r"I(DF16b|f)Li(\d)ELi(\d)E", rest)
+            lay = "KC" if t.group(2) == "0" else "RC"
+            return f"gemm_bf16_dma_kernel<{'bf16' if t.group(1) == 'DF16b' else 'f32'},{lay},{lay}>"
+        return base + ("<bf16>" if rest.startswith("IDF16b") else "")
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    m = re.match(r"gemm_bf16_dma_kernel<(__bf16|float), (\d), (\d)", n)
+    if m:
+        lay = "KC" if m.group(2) == "0" else "RC"
+        return f"gemm_bf16_dma_kernel<{'bf16' if m.group(1) == '__bf16' else 'f32'},{lay},{lay}>"
+    n = re.sub(r"\(.*", "", n)
+    n = re.sub(r"<.*", "", n)
+    return n
+
+
+def collect(d, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                a = agg[key_of(r["Kernel_Name"])]
+                a[0] += 1
+                a[1] += float(r["Counter_Value"])
+    return agg
+
+
+def main():
+    root, tag, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    fetch = collect(f"{root}/pmc_{tag}_fetch", "FETCH_SIZE")
+    write = collect(f"{root}/pmc_{tag}_write", "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fetch) | set(write)):
+        nf, vf = fetch.get(k, (0, 0.0))
+        nw, vw = write.get(k, (0, 0.0))
+        fb = 2.0 * 1024.0 * vf / max(nf, 1)
+        wb = 1024.0 * vw / max(nw, 1)
+        if fb + wb < 8e6:
+            continue                       # keep the file small: only kernels that move >= 8 MB per launch
+        kernels[k] = {"launches_profiled": max(nf, nw), "fetch_bytes_per_launch_corrected": fb,
+                      "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
+    doc = {
+        "source": "tools/pmc_step.sh: rocprofv3 --kernel-trace --pmc <C> -- python bench.py --steps 2 --warmup 1 "
+                  "--no-cpu-baseline --no-kernel-timing (separate passes for FETCH_SIZE and WRITE_SIZE)",
+        "workload": "B=64 T=30 N=128 C=4 K=8 bf16",
+        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> doubled; "
+                      "WRITE_SIZE exact; both in KiB; both are L2->fabric requests, Infinity-Cache hits included "
+                      "(MI355X_MICROARCH.md HBM section)",
+        "kernels": kernels,
+    }
+    with open(out, "w") as f:
+        json.dump(doc, f, indent=1)
+    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+        print(f"{k:48s} n={v['launches_profiled']:3d} fetch {v['fetch_bytes_per_launch_corrected'] / 1e6:9.1f} MB "
+              f"write {v['write_bytes_per_launch'] / 1e6:9.1f} MB")
+
+
+if __name__ == "__main__":
+    main()
