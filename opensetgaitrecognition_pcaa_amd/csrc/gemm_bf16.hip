@@ -357,7 +357,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_big_kernel(GemmParams p) {
 constexpr int D_TILE = 256 * 64;                       // elements per operand per stage (32 KB)
 constexpr int D_LDS_BYTES = 2 * 2 * D_TILE * 2;        // 131072
 
-template <int LAY>
+// MODE 1 / 2: timing-only address patterns (WRONG data): 1 = no source swizzle, 2 = each piece one
+// contiguous 1-KB run
+template <int LAY, int MODE = 0>
 __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ base, long ld, int row0, int R, int k0,
                                          bf16_t* s_tile, int wave, int lane) {
 #pragma unroll
@@ -366,8 +368,9 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ base, long l
     const bf16_t* src;
     if (LAY == KC) {
       const int r = 8 * p + (lane >> 3);
-      const int g = (lane & 7) ^ ((r >> 1) & 7);
-      src = base + (long)min(row0 + r, R - 1) * ld + k0 + 8 * g;
+      const int g = MODE == 1 ? (lane & 7) : ((lane & 7) ^ ((r >> 1) & 7));
+      if (MODE == 2) src = base + (long)min(row0 + p, R - 2) * ld + (k0 & 511) + 8 * lane;
+      else src = base + (long)min(row0 + r, R - 1) * ld + k0 + 8 * g;
     } else {
       const int k = 2 * p + (lane >> 5);
       const int c = (lane & 31) ^ (4 * (k & 3));
@@ -442,6 +445,45 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   }
   __syncthreads();
 
+  if (DIAG >= 11 && DIAG <= 13) {
+    // timing only: the DMA stream alone (no MFMA, no LDS reads), three source-address patterns
+    constexpr int MODE = DIAG - 11;
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt) {
+        bf16_t* nA = smem + ((t + 1) & 1) * 2 * D_TILE;
+        const int k0 = kbeg + (t + 1) * BK;
+        dma_tile<ALAY, MODE>(A, p.lda, tm * BM, p.M, k0, nA, wave, lane);
+        dma_tile<BLAY, MODE>(B, p.ldb, tn * BN, p.N, k0, nA + D_TILE, wave, lane);
+      }
+      __syncthreads();
+    }
+  } else if (DIAG == 9 || DIAG == 10) {
+    // timing only: the MFMAs run on fragments read ONCE (no LDS reads in the loop); 9 keeps the DMA
+    bf16x8 af0[FM], bf0[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) af0[i] = dma_load_frag<ALAY>(smem, offA[i], 0, kofs);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bf0[j] = dma_load_frag<BLAY>(smem + D_TILE, offB[j], 0, kofs);
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt && DIAG == 9) {
+        bf16_t* nA = smem + ((t + 1) & 1) * 2 * D_TILE;
+        const int k0 = kbeg + (t + 1) * BK;
+        dma_tile<ALAY>(A, p.lda, tm * BM, p.M, k0, nA, wave, lane);
+        dma_tile<BLAY>(B, p.ldb, tn * BN, p.N, k0, nA + D_TILE, wave, lane);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af0[i], bf0[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+  } else
   for (int t = 0; t < nt; ++t) {
     const bf16_t* sA = smem + (t & 1) * 2 * D_TILE;
     const bf16_t* sB = sA + D_TILE;
@@ -1017,6 +1059,11 @@ bool pcaa_launch_gemm_bf16_big(const GemmParams& p_in, int a_dtype, int a_layout
       if (a_layout == KC && !cf) {
         if (p.diag == 1) return launch_dma<bf16_t, KC, KC, 1>(p, grid, stream);
         if (p.diag == 2) return launch_dma<bf16_t, KC, KC, 2>(p, grid, stream);
+        if (p.diag == 9) return launch_dma<bf16_t, KC, KC, 9>(p, grid, stream);
+        if (p.diag == 10) return launch_dma<bf16_t, KC, KC, 10>(p, grid, stream);
+        if (p.diag == 11) return launch_dma<bf16_t, KC, KC, 11>(p, grid, stream);
+        if (p.diag == 12) return launch_dma<bf16_t, KC, KC, 12>(p, grid, stream);
+        if (p.diag == 13) return launch_dma<bf16_t, KC, KC, 13>(p, grid, stream);
         return launch_dma<bf16_t, KC, KC, 3>(p, grid, stream);
       }
       if (a_layout == RC && cf) {
