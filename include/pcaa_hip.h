@@ -116,9 +116,17 @@ int pcaa_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
 int pcaa_bn_act_fwd(const void* y, void* a, int dtype, const float* scale, const float* shift,
                     long rows, int ch, void* stream);
 /* pooled[g][c] = mean_{r in group g} ELU(y[g*group_rows + r][c]*scale[c] + shift[c])
- * (AvgPool2d over the N points, models.py:242-243,282; AvgPool1d over T, :249,284) */
+ * (AvgPool2d over the N points, models.py:242-243,282; AvgPool1d over T, :249,284).
+ * Training (e1, e2, mean, rstd non-NULL; all NULL in eval): also
+ *   e1[g][c] = sum_r ELU'(z),  e2[g][c] = sum_r ELU'(z) * (y - mean[c]) * rstd[c]
+ * from which pcaa_bn_pool_bwd_stats forms this layer's BatchNorm-backward statistics
+ *   stats += { sum_g dpool*pool_scale*e1, sum_g dpool*pool_scale*e2 }
+ * without re-reading y (the incoming gradient is constant over a group). */
 int pcaa_bn_act_meanpool_fwd(const void* y, int dtype, const float* scale, const float* shift,
-                             float* pooled, long groups, int group_rows, int ch, void* stream);
+                             const float* mean, const float* rstd, float* pooled, float* e1, float* e2,
+                             long groups, int group_rows, int ch, void* stream);
+int pcaa_bn_pool_bwd_stats(const float* dpool, const float* e1, const float* e2, float pool_scale,
+                           double* stats, int nrep, long groups, int ch, void* stream);
 /* backward through ELU (+ the mean-pool broadcast when dpool != NULL):
  *   da = (dpool ? dpool[row / group_rows][c] * pool_scale : da[row][c])
  *   dz = da * ELU'(y*scale + shift);   stats += { sum dz, sum dz * yhat }  (fp64) */

@@ -101,37 +101,77 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
 
 // ---------------------------------------------------------------- mean-pool of ELU(BN(y)) over group_rows
 // one workgroup per (group, 1024-channel slab): thread = channel quad x row lane
-template <typename T>
+// TRAIN: also emits, per (group, channel), E1 = sum_r ELU'(z) and E2 = sum_r ELU'(z) * yhat.  The
+// gradient that comes back is one value per (group, channel), so the BatchNorm-backward statistics
+// of this layer are sum_g dpool * E1 and sum_g dpool * E2 (pcaa_bn_pool_bwd_stats): a pass over
+// [groups, ch] instead of a second read of the whole pre-activation tensor.
+template <typename T, bool TRAIN>
 __global__ __launch_bounds__(256) void bn_act_meanpool_kernel(const T* __restrict__ y,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
-                                                              float* __restrict__ pooled,
-                                                              int group_rows, int ch) {
-  __shared__ f32x4 red[256];
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd,
+                                                              float* __restrict__ pooled, float* __restrict__ e1,
+                                                              float* __restrict__ e2, int group_rows, int ch) {
+  __shared__ f32x4 red[TRAIN ? 3 : 1][256];
   const int qpr = ch >> 2;              // quads per row
   const int rl = 256 / qpr;             // row lanes
   const int cq = threadIdx.x % qpr, rlane = threadIdx.x / qpr;
   const long g = blockIdx.x;
   const T* base = y + g * (long)group_rows * ch + cq * 4;
   const f32x4 sc = load4(scale + cq * 4), sh = load4(shift + cq * 4);
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = mu;
+  if (TRAIN) { mu = load4(mean + cq * 4); rs = load4(rstd + cq * 4); }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, a1 = acc, a2 = acc;
   for (int r = rlane; r < group_rows; r += rl) {
     const f32x4 v = load4(base + (long)r * ch);
-    acc.x += elu_t<T>(v.x * sc.x + sh.x);
-    acc.y += elu_t<T>(v.y * sc.y + sh.y);
-    acc.z += elu_t<T>(v.z * sc.z + sh.z);
-    acc.w += elu_t<T>(v.w * sc.w + sh.w);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = v[e] * sc[e] + sh[e];
+      const float a = elu_t<T>(z);
+      acc[e] += a;
+      if (TRAIN) {
+        const float d = z > 0.f ? 1.f : a + 1.f;      // ELU'(z) = e^z = ELU(z) + 1 for z <= 0
+        a1[e] += d;
+        a2[e] += d * ((v[e] - mu[e]) * rs[e]);
+      }
+    }
   }
-  red[threadIdx.x] = acc;
+  red[0][threadIdx.x] = acc;
+  if (TRAIN) { red[1][threadIdx.x] = a1; red[2][threadIdx.x] = a2; }
   __syncthreads();
   if (rlane == 0) {
     for (int l = 1; l < rl; ++l) {
-      const f32x4 o = red[l * qpr + cq];
-      acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+      acc += red[0][l * qpr + cq];
+      if (TRAIN) { a1 += red[1][l * qpr + cq]; a2 += red[2][l * qpr + cq]; }
     }
     const float inv = 1.f / (float)group_rows;
-    acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+    acc *= inv;
     store4(pooled + g * (long)ch + cq * 4, acc);
+    if (TRAIN) {
+      store4(e1 + g * (long)ch + cq * 4, a1);
+      store4(e2 + g * (long)ch + cq * 4, a2);
+    }
+  }
+}
+
+// stats[0][c] += sum_g dpool[g][c]*pool_scale*E1[g][c];  stats[1][c] += sum_g dpool[g][c]*pool_scale*E2[g][c]
+// grid: one block per 32 groups, thread = channel (strided over ch)
+__global__ __launch_bounds__(256) void bn_pool_bwd_stats_kernel(const float* __restrict__ dpool,
+                                                                const float* __restrict__ e1,
+                                                                const float* __restrict__ e2, float pool_scale,
+                                                                double* __restrict__ stats, int nrep, long groups,
+                                                                int ch) {
+  const long g0 = (long)blockIdx.x * 32, g1 = min(groups, g0 + 32);
+  for (int c = threadIdx.x; c < ch; c += 256) {
+    double s1 = 0.0, s2 = 0.0;
+    for (long g = g0; g < g1; ++g) {
+      const float d = dpool[g * ch + c] * pool_scale;
+      s1 += (double)(d * e1[g * ch + c]);
+      s2 += (double)(d * e2[g * ch + c]);
+    }
+    unsafeAtomicAdd(&stats[((long)(blockIdx.x % nrep) * 2 + 0) * ch + c], s1);
+    unsafeAtomicAdd(&stats[((long)(blockIdx.x % nrep) * 2 + 1) * ch + c], s2);
   }
 }
 
@@ -461,17 +501,31 @@ extern "C" int pcaa_bn_act_fwd(const void* y, void* a, int dtype, const float* s
 }
 
 extern "C" int pcaa_bn_act_meanpool_fwd(const void* y, int dtype, const float* scale, const float* shift,
-                                        float* pooled, long groups, int group_rows, int ch, void* stream) {
+                                        const float* mean, const float* rstd, float* pooled, float* e1, float* e2,
+                                        long groups, int group_rows, int ch, void* stream) {
   PCAA_CHECK_ARG(y && scale && shift && pooled, "pcaa_bn_act_meanpool_fwd: null pointer");
   PCAA_CHECK_ARG(groups >= 1 && group_rows >= 1 && ch_ok(ch), "pcaa_bn_act_meanpool_fwd: ch/4 must divide 256 (ch=%d)", ch);
-  if (dtype == PCAA_F32)
-    hipLaunchKernelGGL(bn_act_meanpool_kernel<float>, dim3((unsigned)groups), dim3(256), 0, as_stream(stream),
-                       (const float*)y, scale, shift, pooled, group_rows, ch);
-  else if (dtype == PCAA_BF16)
-    hipLaunchKernelGGL(bn_act_meanpool_kernel<bf16_t>, dim3((unsigned)groups), dim3(256), 0, as_stream(stream),
-                       (const bf16_t*)y, scale, shift, pooled, group_rows, ch);
+  const bool train = e1 != nullptr;
+  PCAA_CHECK_ARG((e2 != nullptr) == train && (!train || (mean && rstd)),
+                 "pcaa_bn_act_meanpool_fwd: e1, e2, mean, rstd come together");
+  hipStream_t s = as_stream(stream);
+#define LAUNCH_MP(T, TRAIN)                                                                                   \
+  hipLaunchKernelGGL((bn_act_meanpool_kernel<T, TRAIN>), dim3((unsigned)groups), dim3(256), 0, s, (const T*)y, \
+                     scale, shift, mean, rstd, pooled, e1, e2, group_rows, ch)
+  if (dtype == PCAA_F32) { if (train) LAUNCH_MP(float, true); else LAUNCH_MP(float, false); }
+  else if (dtype == PCAA_BF16) { if (train) LAUNCH_MP(bf16_t, true); else LAUNCH_MP(bf16_t, false); }
   else { pcaa_set_error("pcaa_bn_act_meanpool_fwd: bad dtype"); return PCAA_ERR_INVALID_ARG; }
+#undef LAUNCH_MP
   PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_act_meanpool_fwd");
+}
+
+extern "C" int pcaa_bn_pool_bwd_stats(const float* dpool, const float* e1, const float* e2, float pool_scale,
+                                      double* stats, int nrep, long groups, int ch, void* stream) {
+  PCAA_CHECK_ARG(dpool && e1 && e2 && stats, "pcaa_bn_pool_bwd_stats: null pointer");
+  PCAA_CHECK_ARG(groups >= 1 && ch >= 1 && nrep >= 1, "pcaa_bn_pool_bwd_stats: bad sizes");
+  hipLaunchKernelGGL(bn_pool_bwd_stats_kernel, dim3((unsigned)cdiv(groups, 32)), dim3(256), 0, as_stream(stream),
+                     dpool, e1, e2, pool_scale, stats, nrep, groups, ch);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_pool_bwd_stats");
 }
 
 extern "C" int pcaa_bn_act_bwd_dz(const void* da, const float* dpool, int group_rows, float pool_scale,

@@ -70,7 +70,10 @@ def _point_major(x):
 # TemporalConvolutionBlock models.py:108-160)
 # ======================================================================
 class _LayerSave:
-    __slots__ = ("a_in", "col", "y", "scale", "shift", "mean", "rstd", "rows", "cin", "cout", "dil")
+    __slots__ = ("a_in", "col", "y", "scale", "shift", "mean", "rstd", "rows", "cin", "cout", "dil", "pool_e")
+
+    def __init__(self):
+        self.pool_e = None
 
 
 def _linear_bn(a_in, W2d, lin_bias, bn, training, mode, first_layer):
@@ -128,7 +131,10 @@ def pointnet_forward(xp2d, layers, training, mode, pool_rows=0):
         s.rows, s.cin, s.cout, s.dil = count, cin, cout, 0
         saves.append(s)
         if li == nl - 1 and pool_rows:
-            out = ops.bn_act_meanpool_fwd(y, scale, shift, y.shape[0] // pool_rows, pool_rows)
+            if training:
+                out, s.pool_e = ops.bn_act_meanpool_fwd(y, scale, shift, y.shape[0] // pool_rows, pool_rows, mean, rstd)
+            else:
+                out = ops.bn_act_meanpool_fwd(y, scale, shift, y.shape[0] // pool_rows, pool_rows)
             return out, saves
         a = ops.bn_act_fwd(y, scale, shift)
     return a, saves
@@ -147,8 +153,13 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
     # dz = da*ELU'(z) recomputed in registers -- dz is never materialised
     if da is not None and da.dtype != y.dtype:
         da = da.to(y.dtype)
-    stats = ops.bn_act_bwd_stats(y, s.scale, s.shift, s.mean, s.rstd, da=da, dpool=dpool,
-                                 group_rows=group_rows, pool_scale=pool_scale)
+    pool_e = getattr(s, "pool_e", None)
+    if dpool is not None and pool_e is not None:
+        # mean-pooled layer: the statistics follow from the forward's per-group sums, y is not re-read
+        stats = ops.bn_pool_bwd_stats(dpool, pool_e, pool_scale)
+    else:
+        stats = ops.bn_act_bwd_stats(y, s.scale, s.shift, s.mean, s.rstd, da=da, dpool=dpool,
+                                     group_rows=group_rows, pool_scale=pool_scale)
     _sync_stats(stats, 0)
     coef, dgamma, dbeta = ops.bn_bwd_finalize(stats, s.rows, bn, s.mean, s.rstd, cout,
                                               dgamma=outs[1] if outs else None, dbeta=outs[2] if outs else None)
@@ -234,6 +245,9 @@ def dtc_forward(a2d, B, T, layers, training, pool_time):
         s.rows, s.cin, s.cout, s.dil = count, cin, cout, layer.dilation
         saves.append(s)
         if li == nl - 1 and pool_time:
+            if training:
+                out, s.pool_e = ops.bn_act_meanpool_fwd(y, scale, shift, B, T, mean, rstd)
+                return out, saves
             return ops.bn_act_meanpool_fwd(y, scale, shift, B, T), saves
         a = ops.bn_act_fwd(y, scale, shift)
     return a, saves

@@ -317,14 +317,34 @@ def bn_act_fwd(y, scale, shift):
     return a
 
 
-def bn_act_meanpool_fwd(y, scale, shift, groups, group_rows):
+def bn_act_meanpool_fwd(y, scale, shift, groups, group_rows, mean=None, rstd=None):
+    """Mean over each group of rows of ELU(BN(y)).  With mean/rstd (training) also returns the
+    per-(group, channel) sums (e1, e2) that bn_pool_bwd_stats turns into the backward statistics."""
     _chk(y, "bn_act_meanpool_fwd.y", dim=2)
     if y.shape[0] != groups * group_rows:
         raise ValueError("bn_act_meanpool_fwd: rows != groups*group_rows")
     out = torch.empty((groups, y.shape[1]), dtype=torch.float32, device=y.device)
-    check(_lib.load().pcaa_bn_act_meanpool_fwd(_p(y), _dt(y), _p(scale), _p(shift), _p(out), groups, group_rows,
-                                               y.shape[1], _s()), "pcaa_bn_act_meanpool_fwd")
-    return out
+    e = None
+    if mean is not None:
+        e = torch.empty((2, groups, y.shape[1]), dtype=torch.float32, device=y.device)
+    check(_lib.load().pcaa_bn_act_meanpool_fwd(_p(y), _dt(y), _p(scale), _p(shift), _p(mean), _p(rstd), _p(out),
+                                               _p(e[0]) if e is not None else None,
+                                               _p(e[1]) if e is not None else None,
+                                               groups, group_rows, y.shape[1], _s()), "pcaa_bn_act_meanpool_fwd")
+    return out if e is None else (out, e)
+
+
+def bn_pool_bwd_stats(dpool, e, pool_scale):
+    """BatchNorm-backward statistics of a mean-pooled layer from the forward's (e1, e2) sums."""
+    _chk(dpool, "bn_pool_bwd_stats.dpool", torch.float32, 2)
+    _chk(e, "bn_pool_bwd_stats.e", torch.float32, 3)
+    groups, ch = dpool.shape
+    if tuple(e.shape) != (2, groups, ch):
+        raise ValueError("bn_pool_bwd_stats: e shape")
+    stats = new_stats(ch, dpool.device)
+    check(_lib.load().pcaa_bn_pool_bwd_stats(_p(dpool), _p(e[0]), _p(e[1]), float(pool_scale), _p(stats), NREP,
+                                             groups, ch, _s()), "pcaa_bn_pool_bwd_stats")
+    return stats
 
 
 def bn_act_bwd_dz(y, scale, shift, mean, rstd, *, da=None, dpool=None, group_rows=0, pool_scale=1.0, out=None):

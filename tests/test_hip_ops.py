@@ -291,6 +291,17 @@ def test_bn_forward_backward_chain(rows, ch, dtype):
     pooled = ops.bn_act_meanpool_fwd(y[: G * 30].contiguous(), scale, shift, G, 30)
     refp = ad.detach()[: G * 30].view(G, 30, ch).mean(1)
     assert (pooled.cpu().double() - refp).abs().max().item() <= tol * max(1.0, refp.abs().max().item())
+    # training variant: same pooled values + the per-group sums from which the backward statistics of
+    # a pooled layer follow without re-reading y: must equal the statistics pass over (dpool, y)
+    yp = y[: G * 30].contiguous()
+    pooled2, e = ops.bn_act_meanpool_fwd(yp, scale, shift, G, 30, mean, rstd)
+    assert torch.equal(pooled2, pooled)
+    dpool = _rand((G, ch), 25).to(DEV)
+    st_a = ops.bn_act_bwd_stats(yp, scale, shift, mean, rstd, dpool=dpool, group_rows=30, pool_scale=1.0 / 30)
+    st_b = ops.bn_pool_bwd_stats(dpool, e, 1.0 / 30)
+    sa, sb = st_a.sum(0).cpu(), st_b.sum(0).cpu()
+    stol = 2e-6 if dtype == torch.float32 else 2e-3
+    assert (sa - sb).abs().max().item() <= stol * max(1.0, sa.abs().max().item())
 
 
 def test_bias_act_elu_colsum_sum():
