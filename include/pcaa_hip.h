@@ -90,6 +90,19 @@ int pcaa_pointnet_in_fwd(const float* x, int C, const float* W, const float* bia
                          long P, int cout, double* stats, int nrep, void* stream);
 int pcaa_pointnet_in_wgrad(const void* dy, int dy_dtype, const float* x, int C, float* dW, long P,
                            int cout, void* stream);
+/* Recompute path of the same layer (+ its BatchNorm2d + ELU, models.py:20-29): y costs C FMAs per
+ * element, so it is never stored.  Forward: pcaa_pointnet_in_fwd with y == NULL (statistics only),
+ * pcaa_bn_finalize, then  a = ELU((x.W^T)*scale + shift).  Backward, two passes over the incoming
+ * gradient da only: statistics {sum dz, sum dz*yhat} with dz = da*ELU'(z) (then
+ * pcaa_bn_bwd_finalize), and  dW += dy^T.x  with dy = coef0*dz + coef1*y + coef2 formed in registers. */
+int pcaa_pointnet_in_apply(const float* x, int C, const float* W, const float* scale, const float* shift,
+                           void* a, int a_dtype, long P, int cout, void* stream);
+int pcaa_pointnet_in_bwd_stats(const void* da, int dtype, const float* x, int C, const float* W,
+                               const float* scale, const float* shift, const float* mean, const float* rstd,
+                               double* stats, int nrep, long P, int cout, void* stream);
+int pcaa_pointnet_in_bwd_wgrad(const void* da, int dtype, const float* x, int C, const float* W,
+                               const float* scale, const float* shift, const float* coef, float* dW,
+                               long P, int cout, void* stream);
 
 /* bf16 shadow of an fp32 weight matrix src[R,C]: dst[R,C] and/or its transpose dst_t[C,R]
  * (either may be NULL).  Lets the bf16 GEMM stream both operands by LDS-DMA. */

@@ -10,6 +10,7 @@ namespace {
 constexpr int MAXC = 8;
 constexpr int FWD_ROWS = 128;    // points per workgroup (forward)
 constexpr int WG_ROWS = 256;     // points per workgroup (wgrad): 960 workgroups at P = 245760
+constexpr int BWD_ROWS = 128;   // points per workgroup of the recompute backward passes (1920 workgroups)
 
 template <typename T>
 __global__ __launch_bounds__(256) void pointnet_in_fwd_kernel(const float* __restrict__ x, int C,
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void pointnet_in_fwd_kernel(const float* __res
     }
     s1 += acc;
     s2 += acc * acc;
-    store4(y + (r0 + r) * cout + cq * 4, acc + b);
+    if (y) store4(y + (r0 + r) * cout + cq * 4, acc + b);     // y == NULL: statistics only (recompute path)
   }
   if (stats) {
     red[0][threadIdx.x] = s1;
@@ -58,6 +59,155 @@ __global__ __launch_bounds__(256) void pointnet_in_fwd_kernel(const float* __res
       double v = 0.0;
       for (int l = 0; l < rl; ++l) v += (double)red[stat][l * qpr + (cc >> 2)][cc & 3];
       unsafeAtomicAdd(&stats[((long)(blockIdx.x % nrep) * 2 + stat) * cout + cc], v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Recompute path: the layer's pre-activation y = x . W^T costs C (4-5) FMAs per element, less than
+// reading it back, so it is never stored.  Forward = statistics pass (kernel above, y == NULL) +
+// apply pass (a = ELU(BN(y)) straight from x); backward = two passes over the incoming gradient
+// da only: statistics (dz = da * ELU'(z) and y-hat recomputed), then dy = c0*dz + c1*y + c2 formed
+// in registers and contracted with x into dW -- neither dz nor dy nor y touch HBM.
+// ---------------------------------------------------------------------------------------------
+template <int CP>
+__device__ __forceinline__ void stage_points(float* xs, const float* __restrict__ x, int C, long r0, int nrows,
+                                             int rows_cap) {
+  for (int e = threadIdx.x; e < rows_cap * CP; e += 256) {
+    const int r = e / CP, c = e - r * CP;
+    xs[e] = (r < nrows && c < C) ? x[(r0 + r) * C + c] : 0.f;
+  }
+}
+template <int CP>
+__device__ __forceinline__ void load_weights(float (&w)[4][CP], const float* __restrict__ W, int C, int cq) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < CP; ++c) w[j][c] = (c < C) ? W[(cq * 4 + j) * C + c] : 0.f;
+}
+template <int CP>
+__device__ __forceinline__ f32x4 point_dot(const float (&w)[4][CP], const float* xr) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < CP; ++c) {
+    const float xv = xr[c];
+    acc.x = fmaf(w[0][c], xv, acc.x);
+    acc.y = fmaf(w[1][c], xv, acc.y);
+    acc.z = fmaf(w[2][c], xv, acc.z);
+    acc.w = fmaf(w[3][c], xv, acc.w);
+  }
+  return acc;
+}
+
+template <typename T, int CP>
+__global__ __launch_bounds__(256) void pointnet_in_apply_kernel(const float* __restrict__ x, int C,
+                                                                const float* __restrict__ W,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, T* __restrict__ a,
+                                                                long P, int cout) {
+  __shared__ float xs[FWD_ROWS * CP];
+  const int qpr = cout >> 2, rl = 256 / qpr;
+  const int cq = threadIdx.x % qpr, rlane = threadIdx.x / qpr;
+  const long r0 = (long)blockIdx.x * FWD_ROWS;
+  const int nrows = (int)min((long)FWD_ROWS, P - r0);
+  stage_points<CP>(xs, x, C, r0, nrows, FWD_ROWS);
+  float w[4][CP];
+  load_weights<CP>(w, W, C, cq);
+  const f32x4 sc = load4(scale + cq * 4), sh = load4(shift + cq * 4);
+  __syncthreads();
+  for (int r = rlane; r < nrows; r += rl) {
+    const f32x4 acc = point_dot<CP>(w, xs + r * CP);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = elu_t<T>(acc[e] * sc[e] + sh[e]);
+    store4(a + (r0 + r) * cout + cq * 4, o);
+  }
+}
+
+// MODE 0: statistics {sum dz, sum dz*yhat}; MODE 1: dW += dy^T . x with dy = c0*dz + c1*y + c2
+template <typename T, int MODE, int CP>
+__global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restrict__ da, const float* __restrict__ x,
+                                                              int C, const float* __restrict__ W,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              const float* __restrict__ mean,     // MODE 0
+                                                              const float* __restrict__ rstd,     // MODE 0
+                                                              const float* __restrict__ coef,     // MODE 1: [3][cout]
+                                                              double* __restrict__ stats, int nrep,
+                                                              float* __restrict__ dW, long P, int cout) {
+  __shared__ float xs[1024 * CP];     // points [WG_ROWS][CP], later the [rl][cout][CP] row-lane combine (rl*cout = 1024)
+  const int qpr = cout >> 2, rl = 256 / qpr;
+  const int cq = threadIdx.x % qpr, rlane = threadIdx.x / qpr;
+  const long r0 = (long)blockIdx.x * BWD_ROWS;
+  const int nrows = (int)min((long)BWD_ROWS, P - r0);
+  stage_points<CP>(xs, x, C, r0, nrows, BWD_ROWS);
+  float w[4][CP];
+  load_weights<CP>(w, W, C, cq);
+  const f32x4 sc = load4(scale + cq * 4), sh = load4(shift + cq * 4);
+  f32x4 p0, p1, p2 = {0.f, 0.f, 0.f, 0.f};
+  if (MODE == 0) { p0 = load4(mean + cq * 4); p1 = load4(rstd + cq * 4); }
+  else { p0 = load4(coef + cq * 4); p1 = load4(coef + cout + cq * 4); p2 = load4(coef + 2 * cout + cq * 4); }
+  __syncthreads();
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  float acc[4][CP];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < CP; ++c) acc[j][c] = 0.f;
+  // 4 rows per trip: four independent gradient loads in flight per lane
+  for (int r = rlane; r < nrows; r += 4 * rl) {
+    f32x4 g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      g[u] = (r + u * rl < nrows) ? load4(da + (r0 + r + u * rl) * cout + cq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r + u * rl >= nrows) break;
+      const float* xr = xs + (r + u * rl) * CP;
+      const f32x4 yv = point_dot<CP>(w, xr);
+      f32x4 d;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = g[u][e] * elu_grad_from_pre_t<T>(yv[e] * sc[e] + sh[e]);
+      if (MODE == 0) {
+        s1 += d;
+        s2 += d * ((yv - p0) * p1);
+      } else {
+        const f32x4 dy = p0 * d + p1 * yv + p2;
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+          const float xv = xr[c];
+          acc[0][c] = fmaf(dy.x, xv, acc[0][c]);
+          acc[1][c] = fmaf(dy.y, xv, acc[1][c]);
+          acc[2][c] = fmaf(dy.z, xv, acc[2][c]);
+          acc[3][c] = fmaf(dy.w, xv, acc[3][c]);
+        }
+      }
+    }
+  }
+  __syncthreads();                       // xs is reused for the row-lane combine
+  if (MODE == 0) {
+    f32x4* red = reinterpret_cast<f32x4*>(xs);      // [2][256]
+    red[threadIdx.x] = s1;
+    red[256 + threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = threadIdx.x; o < 2 * cout; o += 256) {
+      const int stat = o / cout, cc = o - stat * cout;
+      double v = 0.0;
+      for (int l = 0; l < rl; ++l) v += (double)red[stat * 256 + l * qpr + (cc >> 2)][cc & 3];
+      unsafeAtomicAdd(&stats[((long)(blockIdx.x % nrep) * 2 + stat) * cout + cc], v);
+    }
+  } else {
+    float* red = xs;                     // [rl][cout][CP]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int c = 0; c < CP; ++c) red[(rlane * cout + cq * 4 + j) * CP + c] = acc[j][c];
+    __syncthreads();
+    for (int o = threadIdx.x; o < cout * C; o += 256) {
+      const int ch = o / C, c = o - ch * C;
+      float v = 0.f;
+      for (int l = 0; l < rl; ++l) v += red[(l * cout + ch) * CP + c];
+      atomicAdd(&dW[o], v);
     }
   }
 }
@@ -152,7 +302,7 @@ inline bool shape_ok(int C, int cout) {
 
 extern "C" int pcaa_pointnet_in_fwd(const float* x, int C, const float* W, const float* bias, void* y,
                                     int y_dtype, long P, int cout, double* stats, int nrep, void* stream) {
-  PCAA_CHECK_ARG(x && W && y && P >= 1, "pcaa_pointnet_in_fwd: bad args");
+  PCAA_CHECK_ARG(x && W && (y || stats) && P >= 1, "pcaa_pointnet_in_fwd: bad args");
   PCAA_CHECK_ARG(shape_ok(C, cout), "pcaa_pointnet_in_fwd: need C<=%d and cout/4 dividing 256 (C=%d cout=%d)", MAXC, C, cout);
   PCAA_CHECK_ARG(!stats || nrep >= 1, "pcaa_pointnet_in_fwd: bad nrep");
   const unsigned grid = (unsigned)cdiv(P, FWD_ROWS);
@@ -179,6 +329,61 @@ extern "C" int pcaa_pointnet_in_wgrad(const void* dy, int dy_dtype, const float*
                        (const bf16_t*)dy, x, C, dW, P, cout);
   else { pcaa_set_error("pcaa_pointnet_in_wgrad: bad dtype"); return PCAA_ERR_INVALID_ARG; }
   PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_wgrad");
+}
+
+// the point-feature loops are unrolled to CP = 4 (C <= 4: xyz+v, the reference's default) or 8
+#define LAUNCH_CP(kern, T, ...)                                                                              \
+  do {                                                                                                       \
+    if (C <= 4) hipLaunchKernelGGL((kern<T, 4>), dim3(grid), dim3(256), 0, as_stream(stream), __VA_ARGS__);  \
+    else hipLaunchKernelGGL((kern<T, 8>), dim3(grid), dim3(256), 0, as_stream(stream), __VA_ARGS__);         \
+  } while (0)
+#define LAUNCH_BWD(T, MODE, ...)                                                                                          \
+  do {                                                                                                                    \
+    if (C <= 4) hipLaunchKernelGGL((pointnet_in_bwd_kernel<T, MODE, 4>), dim3(grid), dim3(256), 0, as_stream(stream), __VA_ARGS__); \
+    else hipLaunchKernelGGL((pointnet_in_bwd_kernel<T, MODE, 8>), dim3(grid), dim3(256), 0, as_stream(stream), __VA_ARGS__);        \
+  } while (0)
+
+extern "C" int pcaa_pointnet_in_apply(const float* x, int C, const float* W, const float* scale, const float* shift,
+                                      void* a, int a_dtype, long P, int cout, void* stream) {
+  PCAA_CHECK_ARG(x && W && scale && shift && a && P >= 1, "pcaa_pointnet_in_apply: bad args");
+  PCAA_CHECK_ARG(shape_ok(C, cout), "pcaa_pointnet_in_apply: need C<=%d and cout/4 dividing 256 (C=%d cout=%d)", MAXC, C, cout);
+  const unsigned grid = (unsigned)cdiv(P, FWD_ROWS);
+  if (a_dtype == PCAA_F32)
+    LAUNCH_CP(pointnet_in_apply_kernel, float, x, C, W, scale, shift, (float*)a, P, cout);
+  else if (a_dtype == PCAA_BF16)
+    LAUNCH_CP(pointnet_in_apply_kernel, bf16_t, x, C, W, scale, shift, (bf16_t*)a, P, cout);
+  else { pcaa_set_error("pcaa_pointnet_in_apply: bad dtype"); return PCAA_ERR_INVALID_ARG; }
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_apply");
+}
+
+extern "C" int pcaa_pointnet_in_bwd_stats(const void* da, int dtype, const float* x, int C, const float* W,
+                                          const float* scale, const float* shift, const float* mean,
+                                          const float* rstd, double* stats, int nrep, long P, int cout,
+                                          void* stream) {
+  PCAA_CHECK_ARG(da && x && W && scale && shift && mean && rstd && stats && P >= 1 && nrep >= 1,
+                 "pcaa_pointnet_in_bwd_stats: bad args");
+  PCAA_CHECK_ARG(shape_ok(C, cout), "pcaa_pointnet_in_bwd_stats: need C<=%d and cout/4 dividing 256 (C=%d cout=%d)", MAXC, C, cout);
+  const unsigned grid = (unsigned)cdiv(P, BWD_ROWS);
+  if (dtype == PCAA_F32)
+    LAUNCH_BWD(float, 0, (const float*)da, x, C, W, scale, shift, mean, rstd, nullptr, stats, nrep, nullptr, P, cout);
+  else if (dtype == PCAA_BF16)
+    LAUNCH_BWD(bf16_t, 0, (const bf16_t*)da, x, C, W, scale, shift, mean, rstd, nullptr, stats, nrep, nullptr, P, cout);
+  else { pcaa_set_error("pcaa_pointnet_in_bwd_stats: bad dtype"); return PCAA_ERR_INVALID_ARG; }
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_bwd_stats");
+}
+
+extern "C" int pcaa_pointnet_in_bwd_wgrad(const void* da, int dtype, const float* x, int C, const float* W,
+                                          const float* scale, const float* shift, const float* coef, float* dW,
+                                          long P, int cout, void* stream) {
+  PCAA_CHECK_ARG(da && x && W && scale && shift && coef && dW && P >= 1, "pcaa_pointnet_in_bwd_wgrad: bad args");
+  PCAA_CHECK_ARG(shape_ok(C, cout), "pcaa_pointnet_in_bwd_wgrad: need C<=%d and cout/4 dividing 256 (C=%d cout=%d)", MAXC, C, cout);
+  const unsigned grid = (unsigned)cdiv(P, BWD_ROWS);
+  if (dtype == PCAA_F32)
+    LAUNCH_BWD(float, 1, (const float*)da, x, C, W, scale, shift, nullptr, nullptr, coef, nullptr, 1, dW, P, cout);
+  else if (dtype == PCAA_BF16)
+    LAUNCH_BWD(bf16_t, 1, (const bf16_t*)da, x, C, W, scale, shift, nullptr, nullptr, coef, nullptr, 1, dW, P, cout);
+  else { pcaa_set_error("pcaa_pointnet_in_bwd_wgrad: bad dtype"); return PCAA_ERR_INVALID_ARG; }
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_bwd_wgrad");
 }
 
 extern "C" int pcaa_cast_bf16(const float* src, void* dst, void* dst_t, int R, int C, void* stream) {

@@ -125,6 +125,26 @@ def pointnet_forward(xp2d, layers, training, mode, pool_rows=0):
         conv, bn = layer.module[0], layer.module[1]
         cout, cin = conv.weight.shape[0], conv.weight.shape[1]
         W2d = conv.weight.view(cout, cin)
+        if (a.dtype == torch.float32 and cin <= 8 and ops.pointnet_in_ok(cin, cout)
+                and not (li == nl - 1 and pool_rows)):
+            # raw points -> first layer: y = x.W^T costs cin FMAs per element, less than reading it back, so
+            # it is never stored: statistics pass, then a = ELU(BN(y)) straight from the points
+            rows = a.shape[0]
+            if training:
+                stats = ops.new_stats(cout, a.device)
+                ops.pointnet_in_fwd(a, W2d, None, None, stats)
+                count = _sync_stats(stats, rows)
+                scale, shift, mean, rstd = ops.bn_finalize(stats, count, conv.bias, bn, cout)
+            else:
+                scale, shift = ops.bn_eval_coeffs(bn, cout, conv.bias)
+                mean = rstd = None
+                count = rows
+            s = _LayerSave()
+            s.a_in, s.col, s.y, s.scale, s.shift, s.mean, s.rstd = a, None, None, scale, shift, mean, rstd
+            s.rows, s.cin, s.cout, s.dil = count, cin, cout, 0
+            saves.append(s)
+            a = ops.pointnet_in_apply(a, W2d, scale, shift, torch.bfloat16 if mode == "bf16" else torch.float32)
+            continue
         y, scale, shift, mean, rstd, count = _linear_bn(a, W2d, conv.bias, bn, training, mode, True)
         s = _LayerSave()
         s.a_in, s.col, s.y, s.scale, s.shift, s.mean, s.rstd = a, None, y, scale, shift, mean, rstd
@@ -213,11 +233,22 @@ def pointnet_backward(saves, layers, mode, d_last=None, dpool=None, pool_rows=0,
         W2d = conv.weight.view(s.cout, s.cin)
         need_in = li > 0 or need_dx
         outs = _layer_outs(gout, f"{prefix}{li + 1}.", "module.0.weight", "module.1.weight", "module.1.bias")
-        if li == len(layers) - 1 and dpool is not None:
+        if s.y is None and da is not None and not need_in:
+            # recompute path of the first layer: two passes over da, nothing else is read or written
+            stats = ops.pointnet_in_bwd_stats(da, s.a_in, W2d, s.scale, s.shift, s.mean, s.rstd)
+            _sync_stats(stats, 0)
+            coef, dg, db = ops.bn_bwd_finalize(stats, s.rows, bn, s.mean, s.rstd, s.cout,
+                                               dgamma=outs[1] if outs else None, dbeta=outs[2] if outs else None)
+            dW = ops.pointnet_in_bwd_wgrad(da, s.a_in, W2d, s.scale, s.shift, coef,
+                                           out=outs[0].view(s.cout, s.cin) if outs else None, out_is_zero=True)
+            dprev = None
+        elif li == len(layers) - 1 and dpool is not None:
             dW, dg, db, dprev = _bn_layer_backward(s, bn, W2d, mode, dpool=dpool, group_rows=pool_rows,
                                                    pool_scale=1.0 / pool_rows, need_dinput=need_in, lhs=s.a_in,
                                                    outs=outs)
         else:
+            if s.y is None:      # recompute layer, but the caller wants the gradient w.r.t. the points: rebuild y
+                s.y = ops.pointnet_in_fwd(s.a_in, W2d, None, da.dtype)
             dW, dg, db, dprev = _bn_layer_backward(s, bn, W2d, mode, da=da, need_dinput=need_in, lhs=s.a_in,
                                                    outs=outs)
         # the conv bias gradient is analytically zero (BatchNorm removes the mean)

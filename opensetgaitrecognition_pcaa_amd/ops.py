@@ -260,10 +260,60 @@ def pointnet_in_fwd(x2d, W2d, bias, out_dtype, stats=None):
     cout = W2d.shape[0]
     if W2d.shape[1] != C or not pointnet_in_ok(C, cout):
         raise ValueError(f"pointnet_in_fwd: unsupported shape C={C} cout={cout}")
+    if out_dtype is None:                    # statistics only (recompute path): y is never stored
+        if stats is None:
+            raise ValueError("pointnet_in_fwd: statistics-only call needs stats")
+        check(_lib.load().pcaa_pointnet_in_fwd(_p(x2d), C, _p(W2d), None, None, PCAA_F32, P, cout, _p(stats), NREP,
+                                               _s()), "pcaa_pointnet_in_fwd(stats)")
+        return None
     y = torch.empty((P, cout), dtype=out_dtype, device=x2d.device)
     check(_lib.load().pcaa_pointnet_in_fwd(_p(x2d), C, _p(W2d), _p(bias), _p(y), _dt(y), P, cout, _p(stats), NREP, _s()),
           "pcaa_pointnet_in_fwd")
     return y
+
+
+def pointnet_in_apply(x2d, W2d, scale, shift, out_dtype):
+    """a[P,cout] = ELU((x2d . W2d^T) * scale + shift): first PointNet layer, y recomputed, not read."""
+    _chk(x2d, "pointnet_in_apply.x", torch.float32, 2)
+    _chk(W2d, "pointnet_in_apply.W", torch.float32, 2)
+    P, C = x2d.shape
+    cout = W2d.shape[0]
+    if W2d.shape[1] != C or not pointnet_in_ok(C, cout):
+        raise ValueError(f"pointnet_in_apply: unsupported shape C={C} cout={cout}")
+    a = torch.empty((P, cout), dtype=out_dtype, device=x2d.device)
+    check(_lib.load().pcaa_pointnet_in_apply(_p(x2d), C, _p(W2d), _p(scale), _p(shift), _p(a), _dt(a), P, cout, _s()),
+          "pcaa_pointnet_in_apply")
+    return a
+
+
+def pointnet_in_bwd_stats(da, x2d, W2d, scale, shift, mean, rstd):
+    _chk(da, "pointnet_in_bwd_stats.da", dim=2)
+    _chk(x2d, "pointnet_in_bwd_stats.x", torch.float32, 2)
+    P, cout = da.shape
+    C = x2d.shape[1]
+    if x2d.shape[0] != P or tuple(W2d.shape) != (cout, C) or not pointnet_in_ok(C, cout):
+        raise ValueError("pointnet_in_bwd_stats: unsupported shape")
+    stats = new_stats(cout, da.device)
+    check(_lib.load().pcaa_pointnet_in_bwd_stats(_p(da), _dt(da), _p(x2d), C, _p(W2d), _p(scale), _p(shift), _p(mean),
+                                                 _p(rstd), _p(stats), NREP, P, cout, _s()),
+          "pcaa_pointnet_in_bwd_stats")
+    return stats
+
+
+def pointnet_in_bwd_wgrad(da, x2d, W2d, scale, shift, coef, out=None, out_is_zero=False):
+    _chk(da, "pointnet_in_bwd_wgrad.da", dim=2)
+    _chk(x2d, "pointnet_in_bwd_wgrad.x", torch.float32, 2)
+    P, cout = da.shape
+    C = x2d.shape[1]
+    if x2d.shape[0] != P or tuple(W2d.shape) != (cout, C) or not pointnet_in_ok(C, cout):
+        raise ValueError("pointnet_in_bwd_wgrad: unsupported shape")
+    if out is None:
+        out = torch.zeros((cout, C), dtype=torch.float32, device=da.device)
+    elif not out_is_zero:
+        out.zero_()
+    check(_lib.load().pcaa_pointnet_in_bwd_wgrad(_p(da), _dt(da), _p(x2d), C, _p(W2d), _p(scale), _p(shift), _p(coef),
+                                                 _p(out), P, cout, _s()), "pcaa_pointnet_in_bwd_wgrad")
+    return out
 
 
 def pointnet_in_wgrad(dy, x2d, out=None, out_is_zero=False):

@@ -399,3 +399,26 @@ def test_pointnet_input_layer_kernels(P, C, cout, dtype):
     dW = ops.pointnet_in_wgrad(dy, x)
     refw = dy.float().cpu().double().t() @ x.cpu().double()
     assert (dW.cpu().double() - refw).abs().max().item() <= 2e-6 * refw.abs().max().item() * P ** 0.5 / 10 + 1e-5
+    # recompute path (y never stored): statistics-only forward, apply, and the two backward passes over
+    # da must agree with the materialised chain y -> bn_act_fwd ; bn_act_bwd_stats -> dy -> wgrad
+    bn = _BN(cout, 84)
+    st_r = ops.new_stats(cout, DEV)
+    assert ops.pointnet_in_fwd(x, W, None, None, st_r) is None
+    assert torch.allclose(st_r.sum(0).cpu(), s, rtol=1e-12, atol=1e-9)
+    y0 = ops.pointnet_in_fwd(x, W, None, torch.float32)                  # bias-free pre-activation
+    scale, shift, mean, rstd = ops.bn_finalize(st_r, P, b, bn, cout)
+    a_ref = ops.bn_act_fwd(y0, scale, shift)
+    a_rec = ops.pointnet_in_apply(x, W, scale, shift, dtype)
+    atol_ = 1e-6 if dtype == torch.float32 else 1e-2
+    assert (a_rec.float() - a_ref).abs().max().item() <= atol_ * max(1.0, a_ref.abs().max().item())
+    da = _rand((P, cout), 85).to(DEV).to(dtype)
+    st_a = ops.bn_act_bwd_stats(y0, scale, shift, mean, rstd, da=da.float())
+    st_b = ops.pointnet_in_bwd_stats(da, x, W, scale, shift, mean, rstd)
+    sa, sb = st_a.sum(0).cpu(), st_b.sum(0).cpu()
+    assert (sa - sb).abs().max().item() <= (2e-6 if dtype == torch.float32 else 2e-3) * max(1.0, sa.abs().max().item())
+    coef, _, _ = ops.bn_bwd_finalize(st_a, P, bn, mean, rstd, cout)
+    dy_ref = ops.bn_bwd_dy_fused(y0, scale, shift, coef, da=da.float())
+    dW_ref = ops.pointnet_in_wgrad(dy_ref, x).cpu().double()
+    dW_rec = ops.pointnet_in_bwd_wgrad(da, x, W, scale, shift, coef).cpu().double()
+    wtol = 2e-5 if dtype == torch.float32 else 2e-3
+    assert (dW_rec - dW_ref).abs().max().item() <= wtol * max(1e-3, dW_ref.abs().max().item())
