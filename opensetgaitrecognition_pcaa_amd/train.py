@@ -155,6 +155,9 @@ class PCAATrainer:
         # the GEMMs lose more to the extra HBM stream than the update costs on its own
         self._side_adam_at = os.environ.get("PCAA_SIDE_ADAM_AT", "dtc")
         self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        # second stream for the critic branch of the step (see step()); PCAA_AUX_STREAM=0: everything inline
+        self._aux = (torch.cuda.Stream(device=self.device)
+                     if self.device.type == "cuda" and os.environ.get("PCAA_AUX_STREAM", "1") != "0" else None)
         self.overlap_allreduce = os.environ.get("PCAA_DP_OVERLAP", "1") != "0"
         # PCAA_DP_FORCE=1 issues the collectives even on a 1-rank group (exercises the RCCL path on one GPU)
         self._force_collectives = os.environ.get("PCAA_DP_FORCE", "0") == "1"
@@ -199,14 +202,40 @@ class PCAATrainer:
         # (2) cross-entropy, its gradient and the predicted labels in one launch
         sup_loss, dlogits, preds = ops.cross_entropy(logits, gt, want_loss=True, want_grad=supervise,
                                                      grad_scale=1.0, want_preds=True)
-        # (3) D-step: prior sample, WGAN-GP loss + closed-form gradients, Adam
-        z, oh = ops.prior_sample(z0, self.discriminator_means, gt, self.K)
-        d_losses, _ = ops.disc_wgan_gp(z, sup_fv, oh, alphas.reshape(-1).contiguous(), self._d_params,
-                                       cfg["GP_WEIGHT"], grads_out=self._d_grads)
-        self._allreduce(self.flat_d.g)
-        self.flat_d.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs)
+        # (3) D-step: prior sample, WGAN-GP loss + closed-form gradients, Adam; then the adversarial
+        # term of the G-step with the UPDATED critic.  ~10 launches of one wave per batch row: they run
+        # on a second stream beside the HBM-bound decoder forward / Chamfer / decoder backward, which do
+        # not depend on the critic, and join where the adversarial gradient enters the G backward.
+        adv = float(cfg["ADV_WEIGHT"])
 
-        # (4) G-step forward: decoder + Chamfer (+ fused gradient), adversarial term with the UPDATED critic
+        def critic_branch():
+            z, oh = ops.prior_sample(z0, self.discriminator_means, gt, self.K)
+            dl, _ = ops.disc_wgan_gp(z, sup_fv, oh, alphas.reshape(-1).contiguous(), self._d_params,
+                                     cfg["GP_WEIGHT"], grads_out=self._d_grads)
+            self._allreduce(self.flat_d.g)
+            self.flat_d.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs)
+            synth = ops.disc_forward(sup_fv, oh, self._d_params)
+            lg = ops.total(synth, -adv / B)
+            gout = torch.full((B,), -adv / B, dtype=torch.float32, device=self.device)
+            ds, _, _ = ops.disc_backward(sup_fv, oh, self._d_params, gout, want_dx=True, want_params=False)
+            return dl, lg, ds
+
+        joined = None
+        if self._aux is not None:
+            main = torch.cuda.current_stream()
+            fork = torch.cuda.Event()
+            fork.record(main)
+            with torch.cuda.stream(self._aux):
+                self._aux.wait_event(fork)
+                d_losses, loss_g, dsup = critic_branch()
+                joined = torch.cuda.Event()
+                joined.record(self._aux)
+            for t in (d_losses[0], d_losses[1], loss_g, dsup):
+                t.record_stream(main)          # allocated on the aux stream, consumed on the main one
+        else:
+            d_losses, loss_g, dsup = critic_branch()
+
+        # (4) G-step forward: decoder + Chamfer (+ fused gradient)
         if self.decoder_projection_head is not None:
             hproj = F_hip.linear_act_forward(sup_fv, self.decoder_projection_head[0], ACT_ELU)
         else:
@@ -216,15 +245,15 @@ class PCAATrainer:
         inv_bt = 1.0 / (B * self.T)
         frame_loss, drec = ops.chamfer(rec4, pcs, want_grad=True, grad_scale=inv_bt)
         rec_loss = ops.total(frame_loss, inv_bt)
-        adv = float(cfg["ADV_WEIGHT"])
-        synth = ops.disc_forward(sup_fv, oh, self._d_params)
-        loss_g = ops.total(synth, -adv / B)
-        gout = torch.full((B,), -adv / B, dtype=torch.float32, device=self.device)
-        dsup, _, _ = ops.disc_backward(sup_fv, oh, self._d_params, gout, want_dx=True, want_params=False)
 
         # (5) G-step backward (the adversarial gradient w.r.t. sup_fvs seeds the accumulation)
+        if joined is not None and self.decoder_projection_head is None:
+            torch.cuda.current_stream().wait_event(joined)
+            joined = None
         if self.decoder_projection_head is not None:
             _, dh = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads, mode=mode)
+            if joined is not None:
+                torch.cuda.current_stream().wait_event(joined)
             gv = self.flat_g.grad_views
             _, _, dsup = F_hip.linear_act_backward(sup_fv, hproj, self.decoder_projection_head[0], ACT_ELU, dh,
                                                    dx_init=dsup, dW_out=gv["GPH.0.weight"], db_out=gv["GPH.0.bias"])
