@@ -72,6 +72,10 @@ int pcaa_gemm(int math,
  * out (=|+=).  pcaa_gemm_num_splits tells how many splits pcaa_gemm / pcaa_gemm_slabs will
  * actually run for a requested split_k (K is cut into multiples of the kernel's K step). */
 int pcaa_gemm_num_splits(int math, int K, int split_k);
+/* Diagnostics (PCAA_GEMM_DIAG=20 build of the bf16 LDS-DMA kernel): per-workgroup s_memtime stamps of
+ * its phases, host_out[workgroup*8 + slot], slots 0 start, 1 first stage issued, 4 first stage landed,
+ * 2 K loop done, 3 C stores issued, 5 statistics issued, 6 stores retired, 7 s_memrealtime at start. */
+int pcaa_debug_gemm_stamps(unsigned long long* host_out, int n);
 int pcaa_gemm_slabs(int math,
                     const void* A, int a_dtype, int a_layout, long lda,
                     const void* B, int b_dtype, int b_layout, long ldb,

@@ -381,6 +381,25 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ base, long l
   }
 }
 
+// one of the 4 pieces a wave moves per tile (dma_tile = pieces 0..3)
+template <int LAY>
+__device__ __forceinline__ void dma_piece(const bf16_t* __restrict__ base, long ld, int row0, int R, int k0,
+                                          bf16_t* s_tile, int wave, int lane, int j) {
+  const int p = wave * 4 + j;
+  const bf16_t* src;
+  if (LAY == KC) {
+    const int r = 8 * p + (lane >> 3);
+    const int g = (lane & 7) ^ ((r >> 1) & 7);
+    src = base + (long)min(row0 + r, R - 1) * ld + k0 + 8 * g;
+  } else {
+    const int k = 2 * p + (lane >> 5);
+    const int c = (lane & 31) ^ (4 * (k & 3));
+    src = base + (long)(k0 + k) * ld + row0 + 8 * c;
+  }
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)(s_tile + p * 512), 16, 0, 0);
+}
+
 // per-lane element offset of fragment rows [row_base, row_base+32) at k-step 0 (row_base % 32 == 0)
 template <int LAY>
 __device__ __forceinline__ int dma_frag_offset(int row_base, int lane) {
@@ -402,15 +421,31 @@ __device__ __forceinline__ bf16x8 dma_load_frag(const bf16_t* s, int off, int ks
   return u.v;
 }
 
+// DIAG 20: correct results + s_memtime / s_memrealtime stamps of the workgroup's phases (wave 0
+// only) into a buffer of its own, read back with pcaa_debug_gemm_stamps (tools/gemm_l2.py --stamps)
+constexpr int STAMP_SLOTS = 12, STAMP_WGS = 8192;   // 8..11: per-step sums (issue, MFMA, vmcnt wait, barrier)
+__device__ unsigned long long g_gemm_stamps[STAMP_WGS * STAMP_SLOTS];
+#define GEMM_STAMP(slot)                                                                         \
+  do {                                                                                           \
+    if (DIAG == 20 && tid == 0 && blockIdx.x < STAMP_WGS)                                        \
+      g_gemm_stamps[blockIdx.x * STAMP_SLOTS + (slot)] =                                         \
+          (slot) == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();         \
+  } while (0)
+
 // DIAG != 0: timing-only builds (WRONG results) used to attribute the loop time:
 //   1 no DMA inside the loop, 2 no MFMA, 3 no epilogue.  Selected with PCAA_GEMM_DIAG.
 template <typename TC, int ALAY, int BLAY, int DIAG = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
+  // DIAG 23: front-loaded DMA issue; it stays the order of the RC x RC (wgrad) instantiation, where the
+  // interleaved order measured 0-8 % slower (transpose reads: two ds_read_b64_tr_b16 per fragment)
+  constexpr bool kFine = ALAY == KC && (DIAG == 0 || DIAG == 20 || DIAG == 21);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, half = lane >> 5;
+  GEMM_STAMP(0);      // workgroup start
+  GEMM_STAMP(7);      // wall clock (100 MHz) of the same instant
   int tm, tn;
   const int split = block_coords(p, p.M / BM, p.N / BN, tm, tn);
 
@@ -443,7 +478,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
     dma_tile<ALAY>(A, p.lda, tm * BM, p.M, kbeg, smem, wave, lane);
     dma_tile<BLAY>(B, p.ldb, tn * BN, p.N, kbeg, smem + D_TILE, wave, lane);
   }
+  GEMM_STAMP(1);      // first stage issued
   __syncthreads();
+  GEMM_STAMP(4);      // first stage landed (prologue over); slot order: 0 1 4 2 3 5 6
+  unsigned long long loop_sum[4] = {0, 0, 0, 0};
 
   if (DIAG >= 11 && DIAG <= 13) {
     // timing only: the DMA stream alone (no MFMA, no LDS reads), three source-address patterns
@@ -487,12 +525,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   for (int t = 0; t < nt; ++t) {
     const bf16_t* sA = smem + (t & 1) * 2 * D_TILE;
     const bf16_t* sB = sA + D_TILE;
-    if (t + 1 < nt && DIAG != 1) {
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+    if (DIAG == 20) ts0 = __builtin_amdgcn_s_memtime();
+    if (t + 1 < nt && DIAG != 1 && !kFine && DIAG != 22) {
       bf16_t* nA = smem + ((t + 1) & 1) * 2 * D_TILE;
       const int k0 = kbeg + (t + 1) * BK;
       dma_tile<ALAY>(A, p.lda, tm * BM, p.M, k0, nA, wave, lane);
       dma_tile<BLAY>(B, p.ldb, tn * BN, p.N, k0, nA + D_TILE, wave, lane);
     }
+    if (DIAG == 20) ts1 = __builtin_amdgcn_s_memtime();
     // software-pipelined fragment reads: the 6 ds_reads of k-step ks+1 are issued before the 8
     // MFMAs of k-step ks, so only the first read group of a stage exposes LDS latency (the
     // compiler's own schedule was "read; s_waitcnt lgkmcnt(0); mfma" per group)
@@ -513,7 +554,51 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
       // pin: next step's reads stay ABOVE this step's MFMAs (the machine scheduler otherwise sinks
       // them to just before their use and waits lgkmcnt(0))
       __builtin_amdgcn_sched_barrier(0);
-      if (DIAG != 2) {
+      if (DIAG == 22) {
+        // loader waves: waves 0-3 (one per SIMD) issue ALL 64 pieces of the step, two in front of every
+        // 4 of their MFMAs; waves 4-7 (their SIMD partners) only compute and keep the MFMA pipe busy
+        // while the loaders sit in the vector-memory issue queue
+        bf16_t* nA = smem + ((t + 1) & 1) * 2 * D_TILE;
+        const int k0 = kbeg + (t + 1) * BK;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          if (t + 1 < nt && wave < 4) {
+            const int slot = 2 * ks + g;                  // 0..7
+            const int vw = wave + 4 * (slot >> 2);        // slots 0-3: own pieces, 4-7: the partner's
+            const int j = slot & 3;
+            dma_piece<ALAY>(A, p.lda, tm * BM, p.M, k0, nA, vw, lane, j);
+            dma_piece<BLAY>(B, p.ldb, tn * BN, p.N, k0, nA + D_TILE, vw, lane, j);
+          }
+#pragma unroll
+          for (int i = 2 * g; i < 2 * g + 2; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if (kFine) {
+        // fine interleave (default): one DMA piece in front of every 4 MFMAs, 8 pieces over the 32 MFMAs of
+        // a step.  Per-step stamps of the front-loaded order (DIAG 23): the wave spent ~700 cycles issuing
+        // its 8 pieces, ~1370 issuing MFMAs, ~100 waiting for vmcnt(0) and ~1400 at the barrier waiting for
+        // the waves that got through the CU's vector-memory queue last.  Interleaved, the queueing overlaps
+        // the other waves' MFMAs: +4-5 % on all three PointNet shapes; dedicated loader waves (DIAG 22) -5 %.
+        bf16_t* nA = smem + ((t + 1) & 1) * 2 * D_TILE;
+        const int k0 = kbeg + (t + 1) * BK;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          if (t + 1 < nt) {
+            const int pc = 2 * ks + g;
+            if (pc < 4) dma_piece<ALAY>(A, p.lda, tm * BM, p.M, k0, nA, wave, lane, pc);
+            else dma_piece<BLAY>(B, p.ldb, tn * BN, p.N, k0, nA + D_TILE, wave, lane, pc - 4);
+          }
+#pragma unroll
+          for (int i = 2 * g; i < 2 * g + 2; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if (DIAG != 2) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -527,14 +612,30 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
+    if (DIAG == 20) {
+      // MFMA results are not waited for here: ts2 is "all MFMAs ISSUED"; the s_nop keeps the stamp after them
+      ts2 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ts3 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const unsigned long long ts4 = __builtin_amdgcn_s_memtime();
+      loop_sum[0] += ts1 - ts0; loop_sum[1] += ts2 - ts1; loop_sum[2] += ts3 - ts2; loop_sum[3] += ts4 - ts3;
+    } else {
+      __syncthreads();
+    }
+  }
+  if (DIAG == 20 && tid == 0 && blockIdx.x < STAMP_WGS) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g_gemm_stamps[blockIdx.x * STAMP_SLOTS + 8 + i] = loop_sum[i];
   }
 
   if (DIAG == 3) {
     if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = 1.f;   // keep the accumulators live
     return;
   }
+  GEMM_STAMP(2);      // K loop done
   epilogue_full_tile<TC>(p, acc, smem, tm, tn, tid, split);
+  GEMM_STAMP(3);      // C stores issued
   if (p.colstats != nullptr) {
     float* red = reinterpret_cast<float*>(smem_raw);
 #pragma unroll
@@ -561,7 +662,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
     const double v = (double)red[(stat * 2 + 0) * 256 + col] + (double)red[(stat * 2 + 1) * 256 + col];
     unsafeAtomicAdd(&p.colstats[((long)(tm % p.nrep) * 2 + stat) * p.N + tn * BN + col], v);
   }
+  GEMM_STAMP(5);      // statistics atomics issued
+  if (DIAG == 20) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GEMM_STAMP(6);    // all stores / atomics of this wave retired
+  }
 }
+
+}  // namespace
+
+// host side of the DIAG 20 stamps: n <= STAMP_WGS * STAMP_SLOTS values, [workgroup][slot]
+extern "C" int pcaa_debug_gemm_stamps(unsigned long long* host_out, int n) {
+  if (!host_out || n < 1 || n > STAMP_WGS * STAMP_SLOTS) return PCAA_ERR_INVALID_ARG;
+  const hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * n);
+  return e == hipSuccess ? PCAA_OK : PCAA_ERR_LAUNCH;
+}
+namespace {
 
 // ===========================================================================
 // Persistent LDS-DMA kernel (forward / dgrad: thousands of 256x256 tiles, K only 512-1024).
@@ -981,6 +1097,146 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma4_kernel(GemmParams p) 
   }
 }
 
+// ===========================================================================
+// 5-tile ring (all 160 KB of LDS): A double-buffered, B TRIPLE-buffered.
+// Phase stamps of the 2-stage kernel (PCAA_GEMM_DIAG=20) put a 64-deep step at ~3730 shader cycles
+// against 2048 of MFMA: the CU's vector-memory path moves the step's 64 KB of LDS-DMA in ~2750
+// cycles (~24 B/clk, DMA-only build), and in the 2-stage ring it sits idle from "stage landed" to
+// the next issue after the barrier.  Here step t issues A(t+1) and then B(t+2): the wait at the
+// end of the step is s_waitcnt vmcnt(4) -- everything but the four youngest pieces, B(t+2) -- so
+// there is always half a stage queued behind the data the next step needs and the memory path never
+// drains.  Same fragment reads, MFMA schedule and epilogue as the 2-stage kernel; raw s_barrier
+// (__syncthreads would wait vmcnt(0)).
+// ===========================================================================
+constexpr int R5_LDS_BYTES = 5 * D_TILE * 2;           // 163840
+
+__device__ __forceinline__ void r5_wait_barrier(bool keep_b_in_flight) {
+  if (keep_b_in_flight) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <typename TC, int ALAY, int BLAY>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_r5_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  bf16_t* sAbuf = smem;                      // 2 tiles
+  bf16_t* sBbuf = smem + 2 * D_TILE;         // 3 tiles
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, half = lane >> 5;
+  int tm, tn;
+  const int split = block_coords(p, p.M / BM, p.N / BN, tm, tn);
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nt = (kend - kbeg) / BK;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int offA[FM], offB[FN], kofs[4];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) offA[i] = dma_frag_offset<ALAY>(wm * 128 + i * 32, lane);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) offB[j] = dma_frag_offset<BLAY>(wn * 64 + j * 32, lane);
+  {
+    const int swz = (l31 >> 1) & 7;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kofs[s] = ((2 * s + half) ^ swz) * 8;
+  }
+
+  // prologue: A(0), B(0), then B(1) which may stay in flight
+  if (nt > 0) {
+    dma_tile<ALAY>(A, p.lda, tm * BM, p.M, kbeg, sAbuf, wave, lane);
+    dma_tile<BLAY>(B, p.ldb, tn * BN, p.N, kbeg, sBbuf, wave, lane);
+    if (nt > 1) dma_tile<BLAY>(B, p.ldb, tn * BN, p.N, kbeg + BK, sBbuf + D_TILE, wave, lane);
+  }
+  r5_wait_barrier(nt > 1);
+
+  int bcur = 0;                                // B buffer of step t (t % 3 without the division)
+  for (int t = 0; t < nt; ++t) {
+    const bf16_t* sA = sAbuf + (t & 1) * D_TILE;
+    const bf16_t* sB = sBbuf + bcur * D_TILE;
+    const int bnext2 = bcur == 0 ? 2 : bcur - 1;            // (t + 2) % 3
+    if (t + 1 < nt) dma_tile<ALAY>(A, p.lda, tm * BM, p.M, kbeg + (t + 1) * BK, sAbuf + ((t + 1) & 1) * D_TILE, wave, lane);
+    if (t + 2 < nt) dma_tile<BLAY>(B, p.ldb, tn * BN, p.N, kbeg + (t + 2) * BK, sBbuf + bnext2 * D_TILE, wave, lane);
+    bf16x8 af[2][FM], bfr[2][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) af[0][i] = dma_load_frag<ALAY>(sA, offA[i], 0, kofs);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bfr[0][j] = dma_load_frag<BLAY>(sB, offB[j], 0, kofs);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks < 3) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[nxt][i] = dma_load_frag<ALAY>(sA, offA[i], ks + 1, kofs);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bfr[nxt][j] = dma_load_frag<BLAY>(sB, offB[j], ks + 1, kofs);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // A(t+1) and B(t+1) must have landed; B(t+2) (the 4 youngest pieces of this wave) may not
+    r5_wait_barrier(t + 2 < nt);
+    bcur = bcur == 2 ? 0 : bcur + 1;
+  }
+
+  epilogue_full_tile<TC>(p, acc, smem, tm, tn, tid, split);
+  if (p.colstats != nullptr) {
+    float* red = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[i][j][r];
+          s1 += v;
+          s2 += v * v;
+        }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (half == 0) {
+        const int col = wn * 64 + j * 32 + l31;
+        red[(0 * 2 + wm) * 256 + col] = s1;
+        red[(1 * 2 + wm) * 256 + col] = s2;
+      }
+    }
+    __syncthreads();
+    const int stat = tid >> 8, col = tid & 255;
+    const double v = (double)red[(stat * 2 + 0) * 256 + col] + (double)red[(stat * 2 + 1) * 256 + col];
+    unsafeAtomicAdd(&p.colstats[((long)(tm % p.nrep) * 2 + stat) * p.N + tn * BN + col], v);
+  }
+}
+
+template <typename TC, int ALAY, int BLAY>
+bool launch_r5(const GemmParams& p, dim3 grid, hipStream_t s) {
+  static bool configured = false;
+  auto kern = gemm_bf16_r5_kernel<TC, ALAY, BLAY>;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            R5_LDS_BYTES) != hipSuccess)
+      return false;
+    configured = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), R5_LDS_BYTES, s, p);
+  return true;
+}
+
 template <typename TC, int ALAY, int BLAY>
 bool launch_dma4(const GemmParams& p, dim3 grid, hipStream_t s) {
   static bool configured = false;
@@ -1064,11 +1320,17 @@ bool pcaa_launch_gemm_bf16_big(const GemmParams& p_in, int a_dtype, int a_layout
         if (p.diag == 11) return launch_dma<bf16_t, KC, KC, 11>(p, grid, stream);
         if (p.diag == 12) return launch_dma<bf16_t, KC, KC, 12>(p, grid, stream);
         if (p.diag == 13) return launch_dma<bf16_t, KC, KC, 13>(p, grid, stream);
+        if (p.diag == 20) return launch_dma<bf16_t, KC, KC, 20>(p, grid, stream);   // correct results + phase stamps
+        if (p.diag == 21) return launch_dma<bf16_t, KC, KC, 21>(p, grid, stream);   // correct results, fine DMA interleave
+        if (p.diag == 22) return launch_dma<bf16_t, KC, KC, 22>(p, grid, stream);   // correct results, loader waves
+        if (p.diag == 23) return launch_dma<bf16_t, KC, KC, 23>(p, grid, stream);   // correct results, front-loaded issue
         return launch_dma<bf16_t, KC, KC, 3>(p, grid, stream);
       }
       if (a_layout == RC && cf) {
         if (p.diag == 1) return launch_dma<float, RC, RC, 1>(p, grid, stream);
         if (p.diag == 2) return launch_dma<float, RC, RC, 2>(p, grid, stream);
+        if (p.diag == 23) return launch_dma<float, RC, RC, 23>(p, grid, stream);  // correct results, front-loaded issue
+        if (p.diag >= 20) return launch_dma<float, RC, RC>(p, grid, stream);      // KC-only diagnostics: default kernel
         return launch_dma<float, RC, RC, 3>(p, grid, stream);
       }
     }
@@ -1081,6 +1343,13 @@ bool pcaa_launch_gemm_bf16_big(const GemmParams& p_in, int a_dtype, int a_layout
         ((uintptr_t)p.C % 16) == 0) {
       if (a_layout == KC) return launch_dmap<KC, KC>(p, stream);
       return launch_dmap<RC, RC>(p, stream);
+    }
+    static const bool r5 = getenv("PCAA_GEMM_R5") != nullptr && atoi(getenv("PCAA_GEMM_R5")) != 0;
+    if (r5) {
+      bool ok = false;
+      if (a_layout == KC) ok = cf ? launch_r5<float, KC, KC>(p, grid, stream) : launch_r5<bf16_t, KC, KC>(p, grid, stream);
+      else if (cf) ok = launch_r5<float, RC, RC>(p, grid, stream);
+      if (ok) return true;
     }
     if (two_stage) {
       if (a_layout == KC) return cf ? launch_dma<float, KC, KC>(p, grid, stream) : launch_dma<bf16_t, KC, KC>(p, grid, stream);

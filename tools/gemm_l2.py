@@ -47,3 +47,23 @@ torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
 print(f"{a.mode} cin={a.cin} cout={a.cout} stagger={os.environ.get('PCAA_GEMM_STAGGER', '0')}: {ms:.3f} ms "
       f"{2.0 * P * a.cin * a.cout / ms / 1e9:.0f} TFLOP/s", flush=True)
+
+if os.environ.get("PCAA_GEMM_DIAG") == "20" and a.mode == "fwd":
+    # phase stamps of the LAST launch (cycles of the shader clock; slot 7 = 100 MHz wall clock)
+    import ctypes
+    import numpy as np
+    from opensetgaitrecognition_pcaa_amd import _lib
+    nwg = min(8192, (P // 256) * (a.cout // 256))
+    buf = np.zeros(nwg * 12, dtype=np.uint64)
+    rc = _lib.load().pcaa_debug_gemm_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.size)
+    assert rc == 0
+    s = buf.reshape(nwg, 12).astype(np.int64)
+    ph = {"launch->first DMA issued": s[:, 1] - s[:, 0], "first stage landed": s[:, 4] - s[:, 1],
+          "K loop": s[:, 2] - s[:, 4], "epilogue (LDS transpose + C stores issued)": s[:, 3] - s[:, 2],
+          "  per step: DMA issue": s[:, 8] // (a.cin // 64), "  per step: ds_read + MFMA issue": s[:, 9] // (a.cin // 64),
+          "  per step: wait vmcnt(0)": s[:, 10] // (a.cin // 64), "  per step: barrier": s[:, 11] // (a.cin // 64),
+          "statistics": s[:, 5] - s[:, 3], "stores retired": s[:, 6] - s[:, 5], "whole workgroup": s[:, 6] - s[:, 0]}
+    for k, v in ph.items():
+        print(f"  {k:46s} median {np.median(v):9.0f} cyc   p10 {np.percentile(v, 10):9.0f}   p90 {np.percentile(v, 90):9.0f}")
+    wall = (s[:, 7].max() - s[:, 7].min()) / 100.0      # us between first and last workgroup start
+    print(f"  workgroup starts span {wall:.1f} us; K steps per tile {a.cin // 64}")
