@@ -1165,8 +1165,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_r5_kernel(GemmParams p) {
     const bf16_t* sA = sAbuf + (t & 1) * D_TILE;
     const bf16_t* sB = sBbuf + bcur * D_TILE;
     const int bnext2 = bcur == 0 ? 2 : bcur - 1;            // (t + 2) % 3
-    if (t + 1 < nt) dma_tile<ALAY>(A, p.lda, tm * BM, p.M, kbeg + (t + 1) * BK, sAbuf + ((t + 1) & 1) * D_TILE, wave, lane);
-    if (t + 2 < nt) dma_tile<BLAY>(B, p.ldb, tn * BN, p.N, kbeg + (t + 2) * BK, sBbuf + bnext2 * D_TILE, wave, lane);
+    constexpr bool kFine = ALAY == KC;          // as in the 2-stage kernel: interleave the pieces with the MFMAs
+    if (!kFine) {
+      if (t + 1 < nt) dma_tile<ALAY>(A, p.lda, tm * BM, p.M, kbeg + (t + 1) * BK, sAbuf + ((t + 1) & 1) * D_TILE, wave, lane);
+      if (t + 2 < nt) dma_tile<BLAY>(B, p.ldb, tn * BN, p.N, kbeg + (t + 2) * BK, sBbuf + bnext2 * D_TILE, wave, lane);
+    }
     bf16x8 af[2][FM], bfr[2][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i) af[0][i] = dma_load_frag<ALAY>(sA, offA[i], 0, kofs);
@@ -1182,12 +1185,30 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_r5_kernel(GemmParams p) {
         for (int j = 0; j < FN; ++j) bfr[nxt][j] = dma_load_frag<BLAY>(sB, offB[j], ks + 1, kofs);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (kFine) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+        for (int g = 0; g < 2; ++g) {
+          const int pc = 2 * ks + g;                    // pieces 0-3: A(t+1), 4-7: B(t+2) -- B stays youngest
+          if (pc < 4) {
+            if (t + 1 < nt) dma_piece<ALAY>(A, p.lda, tm * BM, p.M, kbeg + (t + 1) * BK, sAbuf + ((t + 1) & 1) * D_TILE, wave, lane, pc);
+          } else {
+            if (t + 2 < nt) dma_piece<BLAY>(B, p.ldb, tn * BN, p.N, kbeg + (t + 2) * BK, sBbuf + bnext2 * D_TILE, wave, lane, pc - 4);
+          }
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+          for (int i = 2 * g; i < 2 * g + 2; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     // A(t+1) and B(t+1) must have landed; B(t+2) (the 4 youngest pieces of this wave) may not
     r5_wait_barrier(t + 2 < nt);
