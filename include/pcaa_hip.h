@@ -80,6 +80,15 @@ int pcaa_gemm_slabs(int math,
                     const void* A, int a_dtype, int a_layout, long lda,
                     const void* B, int b_dtype, int b_layout, long ldb,
                     float* slabs, long slab_stride, int M, int N, int K, int split_k, void* stream);
+/* dgrad of a PointNet layer fused with the BatchNorm+ELU backward of the layer BELOW it
+ * (models.py:20-29 backward): da = dy[M,K] . Wt[N,K]^T never reaches memory; the epilogue reads that
+ * layer's stored pre-activation y[M,N] and writes  dz = da * ELU'(y*scale+shift)  (bf16, same ld as y)
+ * while adding {sum dz, sum dz*(y-mean)*rstd} per column into stats (as pcaa_bn_act_bwd_dz does in a
+ * separate pass).  All operands bf16, M and N multiples of 256, K of 64. */
+int pcaa_gemm_dgrad_bn_supported(int M, int N, int K);
+int pcaa_gemm_dgrad_bn(const void* dy, long lddy, const void* Wt, long ldw, const void* y, void* dz, long ld,
+                       const float* scale, const float* shift, const float* mean, const float* rstd,
+                       double* stats, int nrep, int M, int N, int K, void* stream);
 int pcaa_splitk_reduce(const float* slabs, int nsplit, long slab_stride, long n, float* out,
                        int accumulate, void* stream);
 /* same, for out[rows, ch], plus the BatchNorm column statistics of out (stats as in pcaa_gemm) */

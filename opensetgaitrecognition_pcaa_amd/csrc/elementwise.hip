@@ -274,17 +274,14 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ stats, int nre
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_dy_kernel(const T* __restrict__ dz, const T* __restrict__ y,
                                                         T* __restrict__ dy, const float* __restrict__ coef,
-                                                        long nquads, int qpr, int ch) {
-  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (long)gridDim.x * 256) {
-    const int c = (int)(q % qpr) << 2;
-    const f32x4 d = load4(dz + q * 4), yv = load4(y + q * 4);
-    const f32x4 k0 = load4(coef + c), k1 = load4(coef + ch + c), k2 = load4(coef + 2 * ch + c);
-    f32x4 o;
-    o.x = k0.x * d.x + k1.x * yv.x + k2.x;
-    o.y = k0.y * d.y + k1.y * yv.y + k2.y;
-    o.z = k0.z * d.z + k1.z * yv.z + k2.z;
-    o.w = k0.w * d.w + k1.w * yv.w + k2.w;
-    store4(dy + q * 4, o);
+                                                        unsigned nquads, unsigned qpr, unsigned ch) {
+  // column-invariant grid (see bn_act_fwd_kernel): the thread's coefficients live in registers
+  const unsigned q0 = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+  const unsigned c = (q0 % qpr) << 2;
+  const f32x4 k0 = load4(coef + c), k1 = load4(coef + ch + c), k2 = load4(coef + 2 * ch + c);
+  for (unsigned q = q0; q < nquads; q += stride) {
+    const f32x4 d = load4(dz + (size_t)q * 4), yv = load4(y + (size_t)q * 4);
+    store4(dy + (size_t)q * 4, k0 * d + k1 * yv + k2);
   }
 }
 
@@ -645,13 +642,14 @@ extern "C" int pcaa_bn_bwd_dy(const void* dz, const void* y, void* dy, int dtype
   PCAA_CHECK_ARG(dz && y && dy && coef, "pcaa_bn_bwd_dy: null pointer");
   PCAA_CHECK_ARG(rows >= 1 && ch >= 4 && (ch & 3) == 0, "pcaa_bn_bwd_dy: ch must be a multiple of 4");
   const long nq = rows * (ch >> 2);
-  const int grid = grid_for(nq);
+  PCAA_CHECK_ARG(nq < (1L << 31), "pcaa_bn_bwd_dy: tensor too large for 32-bit quad indices");
+  const int grid = col_invariant_grid(nq, ch >> 2);
   if (dtype == PCAA_F32)
-    hipLaunchKernelGGL(bn_bwd_dy_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream),
-                       (const float*)dz, (const float*)y, (float*)dy, coef, nq, ch >> 2, ch);
+    hipLaunchKernelGGL(bn_bwd_dy_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), (const float*)dz,
+                       (const float*)y, (float*)dy, coef, (unsigned)nq, (unsigned)(ch >> 2), (unsigned)ch);
   else if (dtype == PCAA_BF16)
-    hipLaunchKernelGGL(bn_bwd_dy_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream),
-                       (const bf16_t*)dz, (const bf16_t*)y, (bf16_t*)dy, coef, nq, ch >> 2, ch);
+    hipLaunchKernelGGL(bn_bwd_dy_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t*)dz,
+                       (const bf16_t*)y, (bf16_t*)dy, coef, (unsigned)nq, (unsigned)(ch >> 2), (unsigned)ch);
   else { pcaa_set_error("pcaa_bn_bwd_dy: bad dtype"); return PCAA_ERR_INVALID_ARG; }
   PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_bwd_dy");
 }

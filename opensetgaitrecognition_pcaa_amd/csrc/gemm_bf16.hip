@@ -237,6 +237,103 @@ __device__ __forceinline__ void epilogue_full_tile(const GemmParams& p, f32x16 (
   }
 }
 
+// dgrad epilogue fused with the BatchNorm+ELU backward of the layer BELOW (pcaa_gemm_dgrad_bn):
+// the tile of da = dy.Wt never reaches HBM as such -- on its way out (row-contiguous, after the LDS
+// transpose) each lane loads the same 16 B of that layer's stored pre-activation y and writes
+//   dz = da * ELU'(y*scale + shift)
+// while accumulating the column sums {dz, dz * (y-mean)*rstd} the BatchNorm backward needs.  That
+// replaces a separate pass that re-read da and y (0.31 ms per step for PointNet layers 2-3).
+__device__ __forceinline__ void unpack8(const uint4 v, float (&f)[8]) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+__device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p, f32x16 (&acc)[FM][FN], bf16_t* smem,
+                                                  int tm, int tn, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, half = lane >> 5;
+  constexpr int PITCH = 64;
+  uint32_t* w32 = reinterpret_cast<uint32_t*>(smem + wave * 128 * PITCH);
+  const bool odd = lane & 1;
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int colw = (j * 32 + (l31 & ~1)) >> 1;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float va = acc[i][j][r], vb = acc[i][j][r + 1];
+        const float got = dpp_swap_neighbour(odd ? va : vb);
+        const uint32_t packed = odd ? pack2(got, vb) : pack2(va, got);
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + (odd ? 1 : 0);
+        w32[row * (PITCH / 2) + colw] = packed;
+      }
+  }
+  __syncthreads();
+  const int cg = (lane & 7) * 8, r0 = lane >> 3;
+  const long tile_off = (long)(tm * BM + wm * 128) * p.ldc + tn * BN + wn * 64;
+  bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + tile_off;
+  const bf16_t* Y = reinterpret_cast<const bf16_t*>(p.ep_y) + tile_off;       // same shape and ld as C
+  const bf16_t* w = smem + wave * 128 * PITCH;
+  const int gcol = tn * BN + wn * 64 + cg;
+  float sc[8], sh[8], mu[8], rs[8];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const f32x4 a = load4(p.ep_scale + gcol + 4 * q), b = load4(p.ep_shift + gcol + 4 * q);
+    const f32x4 c = load4(p.ep_mean + gcol + 4 * q), d = load4(p.ep_rstd + gcol + 4 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sc[4 * q + e] = a[e]; sh[4 * q + e] = b[e]; mu[4 * q + e] = c[e]; rs[4 * q + e] = d[e]; }
+  }
+  uint4 yv[16];
+#pragma unroll
+  for (int pass = 0; pass < 16; ++pass)
+    yv[pass] = *reinterpret_cast<const uint4*>(Y + (long)(pass * 8 + r0) * p.ldc + cg);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+#pragma unroll
+  for (int pass = 0; pass < 16; ++pass) {
+    const int row = pass * 8 + r0;
+    float da[8], yy[8], dz[8];
+    unpack8(*reinterpret_cast<const uint4*>(&w[row * PITCH + cg]), da);
+    unpack8(yv[pass], yy);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float z = yy[c] * sc[c] + sh[c];
+      dz[c] = da[c] * (z > 0.f ? 1.f : __expf(z));
+      s1[c] += dz[c];
+      s2[c] += dz[c] * ((yy[c] - mu[c]) * rs[c]);
+    }
+    uint4 o;
+    o.x = pack2(dz[0], dz[1]); o.y = pack2(dz[2], dz[3]); o.z = pack2(dz[4], dz[5]); o.w = pack2(dz[6], dz[7]);
+    *reinterpret_cast<uint4*>(C + (long)row * p.ldc + cg) = o;
+  }
+  // lanes with equal (lane & 7) hold the same 8 columns: fold the 8 row lanes
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      s1[c] += __shfl_xor(s1[c], o, 64);
+      s2[c] += __shfl_xor(s2[c], o, 64);
+    }
+  }
+  __syncthreads();                       // every wave is done with its LDS image
+  float* red = reinterpret_cast<float*>(smem);      // [2 stats][2 wm][256 cols]
+  if (lane < 8) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      red[(0 * 2 + wm) * 256 + wn * 64 + cg + c] = s1[c];
+      red[(1 * 2 + wm) * 256 + wn * 64 + cg + c] = s2[c];
+    }
+  }
+  __syncthreads();
+  const int stat = tid >> 8, col = tid & 255;
+  const double v = (double)red[(stat * 2 + 0) * 256 + col] + (double)red[(stat * 2 + 1) * 256 + col];
+  unsafeAtomicAdd(&p.colstats[((long)(tm % p.nrep) * 2 + stat) * p.N + tn * BN + col], v);
+}
+
 template <typename TA, typename TB, typename TC, int ALAY, int BLAY>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_big_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -438,7 +535,7 @@ template <typename TC, int ALAY, int BLAY, int DIAG = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   // DIAG 23: front-loaded DMA issue; it stays the order of the RC x RC (wgrad) instantiation, where the
   // interleaved order measured 0-8 % slower (transpose reads: two ds_read_b64_tr_b16 per fragment)
-  constexpr bool kFine = ALAY == KC && (DIAG == 0 || DIAG == 20 || DIAG == 21);
+  constexpr bool kFine = ALAY == KC && (DIAG == 0 || DIAG == 20 || DIAG == 21 || DIAG == 30);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
 
@@ -634,6 +731,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
     return;
   }
   GEMM_STAMP(2);      // K loop done
+  if constexpr (DIAG == 30) {       // dgrad fused with the BatchNorm+ELU backward of the layer below
+    epilogue_dgrad_bn(p, acc, smem, tm, tn, tid);
+    return;
+  }
   epilogue_full_tile<TC>(p, acc, smem, tm, tn, tid, split);
   GEMM_STAMP(3);      // C stores issued
   if (p.colstats != nullptr) {
@@ -1301,6 +1402,21 @@ bool launch(const GemmParams& p, dim3 grid, hipStream_t s) {
 }
 
 }  // namespace
+
+// dgrad + BatchNorm/ELU backward of the layer below (pcaa_gemm_dgrad_bn): whole 256x256 tiles, bf16 KC x KC
+bool pcaa_launch_gemm_dgrad_bn(const GemmParams& p_in, hipStream_t stream) {
+  GemmParams p = p_in;
+  if ((p.M % BM) || (p.N % BN) || (p.K % BK)) return false;
+  p.nsplit = 1;
+  p.split_fast = 0;
+  p.diag = 0;
+  p.k_per_split = p.K;
+  p.atomic = 0;
+  p.c_split_stride = 0;
+  const long ntiles = (long)(p.M / BM) * (p.N / BN);
+  if (ntiles >= (1L << 31)) return false;
+  return launch_dma<bf16_t, KC, KC, 30>(p, dim3((unsigned)ntiles, 1, 1), stream);
+}
 
 bool pcaa_launch_gemm_bf16_big(const GemmParams& p_in, int a_dtype, int a_layout, int b_dtype, int b_layout,
                                int c_dtype, int nsplit, hipStream_t stream) {

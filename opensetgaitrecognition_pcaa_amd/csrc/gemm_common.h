@@ -15,6 +15,8 @@ struct GemmParams {
   int nsplit;       // number of K splits
   int split_fast;   // 1: 1-D grid, block b -> split b % nsplit, tile b / nsplit (see block_coords)
   long c_split_stride;   // slab split-K: split s stores its partial tile at C + s * c_split_stride (no atomics)
+  // dgrad fused with the BatchNorm+ELU backward of the layer below (pcaa_gemm_dgrad_bn)
+  const void* ep_y; const float* ep_scale; const float* ep_shift; const float* ep_mean; const float* ep_rstd;
   int diag;       // timing-only diagnostics of the 2-stage DMA kernel (WRONG results): 1 no DMA in the loop, 2 no MFMA, 3 no epilogue
 };
 
@@ -49,3 +51,4 @@ __device__ __forceinline__ int block_coords(const GemmParams& p, int nbm, int nb
 // combination is not served by it (caller falls back to the small-tile kernel).
 bool pcaa_launch_gemm_bf16_big(const GemmParams& p, int a_dtype, int a_layout, int b_dtype, int b_layout,
                                int c_dtype, int nsplit, hipStream_t stream);
+bool pcaa_launch_gemm_dgrad_bn(const GemmParams& p, hipStream_t stream);

@@ -12,6 +12,8 @@ Numerics modes (``set_precision``):
   * ``"bf16"``  -- PointNet activations stored in bf16, PointNet GEMMs on the
     bf16 MFMA pipe with fp32 accumulation; everything else fp32.
 """
+import os
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -160,31 +162,53 @@ def pointnet_forward(xp2d, layers, training, mode, pool_rows=0):
     return a, saves
 
 
+class _FusedGrad:
+    """What the fused dgrad (ops.gemm_dgrad_bn) hands to the layer below instead of da:
+    dz = da * ELU'(z) and that layer's BatchNorm-backward statistics."""
+    __slots__ = ("dz", "stats")
+
+    def __init__(self, dz, stats):
+        self.dz, self.stats = dz, stats
+
+
+_FUSE_DGRAD_BN = os.environ.get("PCAA_FUSE_DGRAD_BN", "1") != "0"
+
+
 def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool_scale=1.0,
-                       need_dinput=True, lhs=None, outs=None):
+                       need_dinput=True, lhs=None, outs=None, below=None):
     """Backward of one (linear, BN, ELU) layer.  ``lhs`` is the GEMM's left
     operand ([rows, K]: the input activation or the im2col matrix).  ``outs`` =
     (dW, dgamma, dbeta) destination views (dW PRE-ZEROED: the trainer's flat
-    gradient buffer) or None to allocate.
+    gradient buffer) or None to allocate.  ``da`` may be a _FusedGrad (the dgrad of the layer
+    above already applied ELU' and reduced the statistics).  ``below``: the saved state of the
+    layer that produced ``lhs`` -- if it qualifies, this layer's dgrad is fused with the first
+    half of ITS backward and a _FusedGrad is returned as d_lhs.
     Returns (dW2d, dgamma, dbeta, d_lhs or None)."""
     y = s.y
     rows_local, cout = y.shape
-    # pass 1: statistics only (reads da/dpool and y, writes nothing); pass 2: dy directly, with
-    # dz = da*ELU'(z) recomputed in registers -- dz is never materialised
-    if da is not None and da.dtype != y.dtype:
-        da = da.to(y.dtype)
-    pool_e = getattr(s, "pool_e", None)
-    if dpool is not None and pool_e is not None:
-        # mean-pooled layer: the statistics follow from the forward's per-group sums, y is not re-read
-        stats = ops.bn_pool_bwd_stats(dpool, pool_e, pool_scale)
+    if isinstance(da, _FusedGrad):
+        stats = da.stats
+        _sync_stats(stats, 0)
+        coef, dgamma, dbeta = ops.bn_bwd_finalize(stats, s.rows, bn, s.mean, s.rstd, cout,
+                                                  dgamma=outs[1] if outs else None, dbeta=outs[2] if outs else None)
+        dy = ops.bn_bwd_dy(da.dz, y, coef, out=da.dz)
     else:
-        stats = ops.bn_act_bwd_stats(y, s.scale, s.shift, s.mean, s.rstd, da=da, dpool=dpool,
-                                     group_rows=group_rows, pool_scale=pool_scale)
-    _sync_stats(stats, 0)
-    coef, dgamma, dbeta = ops.bn_bwd_finalize(stats, s.rows, bn, s.mean, s.rstd, cout,
-                                              dgamma=outs[1] if outs else None, dbeta=outs[2] if outs else None)
-    dy = ops.bn_bwd_dy_fused(y, s.scale, s.shift, coef, da=da, dpool=dpool, group_rows=group_rows,
-                             pool_scale=pool_scale, out=da)
+        # pass 1: statistics only (reads da/dpool and y, writes nothing); pass 2: dy directly, with
+        # dz = da*ELU'(z) recomputed in registers -- dz is never materialised
+        if da is not None and da.dtype != y.dtype:
+            da = da.to(y.dtype)
+        pool_e = getattr(s, "pool_e", None)
+        if dpool is not None and pool_e is not None:
+            # mean-pooled layer: the statistics follow from the forward's per-group sums, y is not re-read
+            stats = ops.bn_pool_bwd_stats(dpool, pool_e, pool_scale)
+        else:
+            stats = ops.bn_act_bwd_stats(y, s.scale, s.shift, s.mean, s.rstd, da=da, dpool=dpool,
+                                         group_rows=group_rows, pool_scale=pool_scale)
+        _sync_stats(stats, 0)
+        coef, dgamma, dbeta = ops.bn_bwd_finalize(stats, s.rows, bn, s.mean, s.rstd, cout,
+                                                  dgamma=outs[1] if outs else None, dbeta=outs[2] if outs else None)
+        dy = ops.bn_bwd_dy_fused(y, s.scale, s.shift, coef, da=da, dpool=dpool, group_rows=group_rows,
+                                 pool_scale=pool_scale, out=da)
     K = lhs.shape[1]
     dW_out = outs[0].view(cout, K) if outs else None
     # dW[cout, K] = dy^T . lhs   (contraction over the rows: both operands row-contiguous)
@@ -208,7 +232,14 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
             Wt = _W16_CACHE.pop(W2d.data_ptr(), None)      # bf16 [K, cout] made by the forward pass
             if Wt is None or tuple(Wt.shape) != (K, cout):
                 _, Wt = ops.cast_bf16(W2d, False, True)
-            d_lhs = ops.gemm(dy, KC, Wt, KC, rows_local, K, cout, out_dtype=torch.bfloat16, math=PCAA_BF16)
+            if (_FUSE_DGRAD_BN and below is not None and below.y is not None and below.y.dtype == torch.bfloat16
+                    and below.mean is not None and tuple(below.y.shape) == (rows_local, K)
+                    and ops.gemm_dgrad_bn_supported(rows_local, K, cout)):
+                # dgrad fused with ELU' and the BatchNorm-backward statistics of the layer below
+                d_lhs = _FusedGrad(*ops.gemm_dgrad_bn(dy, Wt, below.y, below.scale, below.shift, below.mean,
+                                                      below.rstd))
+            else:
+                d_lhs = ops.gemm(dy, KC, Wt, KC, rows_local, K, cout, out_dtype=torch.bfloat16, math=PCAA_BF16)
         else:
             d_lhs = ops.gemm(dy, KC, W2d, RC, rows_local, K, cout,
                              out_dtype=torch.float32)
@@ -245,12 +276,12 @@ def pointnet_backward(saves, layers, mode, d_last=None, dpool=None, pool_rows=0,
         elif li == len(layers) - 1 and dpool is not None:
             dW, dg, db, dprev = _bn_layer_backward(s, bn, W2d, mode, dpool=dpool, group_rows=pool_rows,
                                                    pool_scale=1.0 / pool_rows, need_dinput=need_in, lhs=s.a_in,
-                                                   outs=outs)
+                                                   outs=outs, below=saves[li - 1] if li > 0 else None)
         else:
             if s.y is None:      # recompute layer, but the caller wants the gradient w.r.t. the points: rebuild y
                 s.y = ops.pointnet_in_fwd(s.a_in, W2d, None, da.dtype)
             dW, dg, db, dprev = _bn_layer_backward(s, bn, W2d, mode, da=da, need_dinput=need_in, lhs=s.a_in,
-                                                   outs=outs)
+                                                   outs=outs, below=saves[li - 1] if li > 0 else None)
         # the conv bias gradient is analytically zero (BatchNorm removes the mean)
         zb = gout[f"{prefix}{li + 1}.module.0.bias"] if gout is not None else torch.zeros_like(conv.bias)
         grads.append({"module.0.weight": dW.view_as(conv.weight), "module.0.bias": zb,

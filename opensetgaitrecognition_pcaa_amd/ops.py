@@ -230,6 +230,39 @@ def gemm_slabs(A, a_layout, B, b_layout, M, N, K, split_k, out=None, accumulate=
     return out
 
 
+def gemm_dgrad_bn_supported(M, N, K):
+    return bool(_lib.load().pcaa_gemm_dgrad_bn_supported(int(M), int(N), int(K)))
+
+
+def gemm_dgrad_bn(dy, Wt, y, scale, shift, mean, rstd):
+    """dz[M,N] = (dy[M,K] @ Wt[N,K]^T) * ELU'(y*scale+shift) plus the BatchNorm-backward statistics of
+    the layer that owns y -- the dgrad of the layer above fused with the first half of this layer's
+    backward.  Returns (dz bf16, stats)."""
+    for t, nm in ((dy, "dy"), (Wt, "Wt"), (y, "y")):
+        _chk(t, f"gemm_dgrad_bn.{nm}", torch.bfloat16, 2)
+    M, K = dy.shape
+    N = Wt.shape[0]
+    if Wt.shape[1] != K or tuple(y.shape) != (M, N):
+        raise ValueError("gemm_dgrad_bn: shape mismatch")
+    dz = torch.empty_like(y)
+    stats = new_stats(N, dy.device)
+    timer = TIMER
+    key = _dma_key(torch.bfloat16, KC)
+    timer = timer if (timer is not None and timer.wants(key)) else None
+    if timer is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_lib.load().pcaa_gemm_dgrad_bn(_p(dy), dy.stride(0), _p(Wt), Wt.stride(0), _p(y), _p(dz), y.stride(0),
+                                         _p(scale), _p(shift), _p(mean), _p(rstd), _p(stats), NREP, M, N, K, _s()),
+          "pcaa_gemm_dgrad_bn")
+    if timer is not None:
+        e1.record()
+        nbytes = 2 * (M * K + N * K + 2 * M * N)
+        timer.records.append((key, 2.0 * M * N * K, float(nbytes), e0, e1))
+    return dz, stats
+
+
 def pick_split_k(M, N, K, target_blocks=1024, bk=32, tile=128):
     tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
     if tiles >= target_blocks:

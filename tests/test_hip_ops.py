@@ -197,6 +197,35 @@ def test_skinny_linear_layers_random_bf16_rounding():
     assert (dW - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 256, 256), (768, 512, 1024), (1024, 1024, 512)])
+def test_gemm_dgrad_bn_fused_epilogue(M, N, K):
+    """dgrad fused with ELU' and the BatchNorm-backward statistics of the layer below: must agree with
+    the separate chain  da = dy.Wt^T (bf16) ; stats = bn_act_bwd_stats(y, da) ; dz = da*ELU'(z)."""
+    assert ops.gemm_dgrad_bn_supported(M, N, K)
+    rng = np.random.default_rng(41)
+    dy = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(DEV).bfloat16()
+    Wt = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(DEV).bfloat16()
+    y = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(DEV).bfloat16()
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, N).astype(np.float32)).to(DEV)
+    shift = torch.from_numpy(rng.uniform(-0.5, 0.5, N).astype(np.float32)).to(DEV)
+    mean = torch.from_numpy(rng.uniform(-0.2, 0.2, N).astype(np.float32)).to(DEV)
+    rstd = torch.from_numpy(rng.uniform(0.5, 2.0, N).astype(np.float32)).to(DEV)
+    dz, st = ops.gemm_dgrad_bn(dy, Wt, y, scale, shift, mean, rstd)
+    da = ops.gemm(dy, KC, Wt, KC, M, N, K, out_dtype=torch.bfloat16, math=PCAA_BF16)
+    dz_ref, st_ref = ops.bn_act_bwd_dz(y, scale, shift, mean, rstd, da=da)
+    assert (dz.float() - dz_ref.float()).abs().max().item() <= 1e-2 * max(1.0, dz_ref.float().abs().max().item())
+    sa, sb = st.sum(0).cpu(), st_ref.sum(0).cpu()
+    assert (sa - sb).abs().max().item() <= 2e-3 * max(1.0, sb.abs().max().item())
+    # exact fp64 check of the statistics against the dz the kernel itself wrote is not possible (they are
+    # accumulated before the bf16 rounding); against fp64 of the unrounded product instead
+    da64 = dy.float().cpu().double() @ Wt.float().cpu().double().t()
+    z = y.float().cpu().double() * scale.cpu().double() + shift.cpu().double()
+    dz64 = da64 * torch.where(z > 0, torch.ones_like(z), torch.exp(z))
+    yh = (y.float().cpu().double() - mean.cpu().double()) * rstd.cpu().double()
+    assert (sa[0] - dz64.sum(0)).abs().max().item() <= 5e-3 * max(1.0, dz64.sum(0).abs().max().item())
+    assert (sa[1] - (dz64 * yh).sum(0)).abs().max().item() <= 5e-3 * max(1.0, (dz64 * yh).sum(0).abs().max().item())
+
+
 def test_skinny_rejects_unsupported_shapes():
     assert not ops.skinny_supported(65, 1920, 960)
     assert not ops.skinny_supported(64, 1200, 960)
