@@ -84,11 +84,14 @@ int pcaa_gemm_slabs(int math,
  * (models.py:20-29 backward): da = dy[M,K] . Wt[N,K]^T never reaches memory; the epilogue reads that
  * layer's stored pre-activation y[M,N] and writes  dz = da * ELU'(y*scale+shift)  (bf16, same ld as y)
  * while adding {sum dz, sum dz*(y-mean)*rstd} per column into stats (as pcaa_bn_act_bwd_dz does in a
- * separate pass).  All operands bf16, M and N multiples of 256, K of 64. */
+ * separate pass).  All operands bf16, M and N multiples of 256, K of 64.
+ * y == NULL: the layer below is the first PointNet layer on its recompute path; its pre-activation is
+ * rebuilt as x[M,xc] . W1[N,xc]^T (fp32, xc <= 8) and dz feeds pcaa_pointnet_in_bwd_wgrad(dz_is_pre). */
 int pcaa_gemm_dgrad_bn_supported(int M, int N, int K);
 int pcaa_gemm_dgrad_bn(const void* dy, long lddy, const void* Wt, long ldw, const void* y, void* dz, long ld,
                        const float* scale, const float* shift, const float* mean, const float* rstd,
-                       double* stats, int nrep, int M, int N, int K, void* stream);
+                       double* stats, int nrep, int M, int N, int K,
+                       const float* x, int xc, const float* W1, void* stream);
 int pcaa_splitk_reduce(const float* slabs, int nsplit, long slab_stride, long n, float* out,
                        int accumulate, void* stream);
 /* same, for out[rows, ch], plus the BatchNorm column statistics of out (stats as in pcaa_gemm) */
@@ -115,7 +118,8 @@ int pcaa_pointnet_in_bwd_stats(const void* da, int dtype, const float* x, int C,
                                double* stats, int nrep, long P, int cout, void* stream);
 int pcaa_pointnet_in_bwd_wgrad(const void* da, int dtype, const float* x, int C, const float* W,
                                const float* scale, const float* shift, const float* coef, float* dW,
-                               long P, int cout, void* stream);
+                               long P, int cout, int dz_is_pre /* da already is dz (pcaa_gemm_dgrad_bn) */,
+                               void* stream);
 
 /* bf16 shadow of an fp32 weight matrix src[R,C]: dst[R,C] and/or its transpose dst_t[C,R]
  * (either may be NULL).  Lets the bf16 GEMM stream both operands by LDS-DMA. */

@@ -483,13 +483,17 @@ extern "C" int pcaa_gemm_dgrad_bn_supported(int M, int N, int K) {
 
 extern "C" int pcaa_gemm_dgrad_bn(const void* dy, long lddy, const void* Wt, long ldw, const void* y, void* dz,
                                   long ld, const float* scale, const float* shift, const float* mean,
-                                  const float* rstd, double* stats, int nrep, int M, int N, int K, void* stream) {
-  PCAA_CHECK_ARG(dy && Wt && y && dz && scale && shift && mean && rstd && stats, "pcaa_gemm_dgrad_bn: null pointer");
+                                  const float* rstd, double* stats, int nrep, int M, int N, int K,
+                                  const float* x, int xc, const float* W1, void* stream) {
+  PCAA_CHECK_ARG(dy && Wt && dz && scale && shift && mean && rstd && stats, "pcaa_gemm_dgrad_bn: null pointer");
+  PCAA_CHECK_ARG((y != nullptr) != (x != nullptr), "pcaa_gemm_dgrad_bn: exactly one of y / x");
+  PCAA_CHECK_ARG(!x || (W1 && xc >= 1 && xc <= 8 && ((uintptr_t)x % 16) == 0),
+                 "pcaa_gemm_dgrad_bn: recompute needs W1, 1 <= xc <= 8 and a 16-B aligned x");
   PCAA_CHECK_ARG(pcaa_gemm_dgrad_bn_supported(M, N, K), "pcaa_gemm_dgrad_bn: M, N must be multiples of 256 and K of 64 "
                  "(M=%d N=%d K=%d)", M, N, K);
   PCAA_CHECK_ARG(lddy >= K && ldw >= K && ld >= N && (lddy % 8) == 0 && (ldw % 8) == 0 && (ld % 8) == 0 && nrep >= 1,
                  "pcaa_gemm_dgrad_bn: bad leading dimension / nrep");
-  PCAA_CHECK_ARG(((uintptr_t)dy % 16) == 0 && ((uintptr_t)Wt % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+  PCAA_CHECK_ARG(((uintptr_t)dy % 16) == 0 && ((uintptr_t)Wt % 16) == 0 && (!y || ((uintptr_t)y % 16) == 0) &&
                  ((uintptr_t)dz % 16) == 0 && ((uintptr_t)scale % 16) == 0 && ((uintptr_t)shift % 16) == 0 &&
                  ((uintptr_t)mean % 16) == 0 && ((uintptr_t)rstd % 16) == 0, "pcaa_gemm_dgrad_bn: 16-B alignment");
   GemmParams p;
@@ -499,6 +503,7 @@ extern "C" int pcaa_gemm_dgrad_bn(const void* dy, long lddy, const void* Wt, lon
   p.M = M; p.N = N; p.K = K;
   p.colstats = stats; p.nrep = nrep;
   p.ep_y = y; p.ep_scale = scale; p.ep_shift = shift; p.ep_mean = mean; p.ep_rstd = rstd;
+  p.ep_x = x; p.ep_w1 = W1; p.ep_xc = xc;
   if (!pcaa_launch_gemm_dgrad_bn(p, as_stream(stream))) {
     pcaa_set_error("pcaa_gemm_dgrad_bn: launch configuration failed");
     return PCAA_ERR_LAUNCH;

@@ -250,6 +250,9 @@ __device__ __forceinline__ void unpack8(const uint4 v, float (&f)[8]) {
   f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
 }
 
+// POINTS: the layer below is the first PointNet layer on its recompute path -- its pre-activation was
+// never stored, y[row][col] = sum_c x[row][c] * W1[col][c] (C <= 8 point features) is rebuilt here.
+template <bool POINTS>
 __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p, f32x16 (&acc)[FM][FN], bf16_t* smem,
                                                   int tm, int tn, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
@@ -287,9 +290,29 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p, f32x16 (&
     for (int e = 0; e < 4; ++e) { sc[4 * q + e] = a[e]; sh[4 * q + e] = b[e]; mu[4 * q + e] = c[e]; rs[4 * q + e] = d[e]; }
   }
   uint4 yv[16];
+  f32x4 xv[16][2];
+  float w1[8][8];
+  const int xc = p.ep_xc;
+  if (POINTS) {
+    const float* X = p.ep_x + (long)(tm * BM + wm * 128) * xc;
 #pragma unroll
-  for (int pass = 0; pass < 16; ++pass)
-    yv[pass] = *reinterpret_cast<const uint4*>(Y + (long)(pass * 8 + r0) * p.ldc + cg);
+    for (int pass = 0; pass < 16; ++pass) {
+      const float* xr = X + (long)(pass * 8 + r0) * xc;
+      if (xc == 4) { xv[pass][0] = load4(xr); xv[pass][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xv[pass][c >> 2][c & 3] = c < xc ? xr[c] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) w1[j][c] = c < xc ? p.ep_w1[(long)(gcol + j) * xc + c] : 0.f;
+  } else {
+#pragma unroll
+    for (int pass = 0; pass < 16; ++pass)
+      yv[pass] = *reinterpret_cast<const uint4*>(Y + (long)(pass * 8 + r0) * p.ldc + cg);
+  }
   float s1[8], s2[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
@@ -298,7 +321,17 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p, f32x16 (&
     const int row = pass * 8 + r0;
     float da[8], yy[8], dz[8];
     unpack8(*reinterpret_cast<const uint4*>(&w[row * PITCH + cg]), da);
-    unpack8(yv[pass], yy);
+    if (POINTS) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a = fmaf(w1[j][c], xv[pass][c >> 2][c & 3], a);   // same order as pointnet_in.hip
+        yy[j] = a;
+      }
+    } else {
+      unpack8(yv[pass], yy);
+    }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const float z = yy[c] * sc[c] + sh[c];
@@ -535,7 +568,7 @@ template <typename TC, int ALAY, int BLAY, int DIAG = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   // DIAG 23: front-loaded DMA issue; it stays the order of the RC x RC (wgrad) instantiation, where the
   // interleaved order measured 0-8 % slower (transpose reads: two ds_read_b64_tr_b16 per fragment)
-  constexpr bool kFine = ALAY == KC && (DIAG == 0 || DIAG == 20 || DIAG == 21 || DIAG == 30);
+  constexpr bool kFine = ALAY == KC && (DIAG == 0 || DIAG == 20 || DIAG == 21 || DIAG == 30 || DIAG == 31);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
 
@@ -731,8 +764,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
     return;
   }
   GEMM_STAMP(2);      // K loop done
-  if constexpr (DIAG == 30) {       // dgrad fused with the BatchNorm+ELU backward of the layer below
-    epilogue_dgrad_bn(p, acc, smem, tm, tn, tid);
+  if constexpr (DIAG == 30 || DIAG == 31) {       // dgrad fused with the BatchNorm+ELU backward of the layer below
+    epilogue_dgrad_bn<DIAG == 31>(p, acc, smem, tm, tn, tid);
     return;
   }
   epilogue_full_tile<TC>(p, acc, smem, tm, tn, tid, split);
@@ -1415,6 +1448,7 @@ bool pcaa_launch_gemm_dgrad_bn(const GemmParams& p_in, hipStream_t stream) {
   p.c_split_stride = 0;
   const long ntiles = (long)(p.M / BM) * (p.N / BN);
   if (ntiles >= (1L << 31)) return false;
+  if (p.ep_y == nullptr) return launch_dma<bf16_t, KC, KC, 31>(p, dim3((unsigned)ntiles, 1, 1), stream);
   return launch_dma<bf16_t, KC, KC, 30>(p, dim3((unsigned)ntiles, 1, 1), stream);
 }
 

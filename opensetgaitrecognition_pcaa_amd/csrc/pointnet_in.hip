@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void pointnet_in_apply_kernel(const float* __r
   }
 }
 
-// MODE 0: statistics {sum dz, sum dz*yhat}; MODE 1: dW += dy^T . x with dy = c0*dz + c1*y + c2
+// MODE 0: statistics {sum dz, sum dz*yhat}; MODE 1: dW += dy^T . x with dy = c0*dz + c1*y + c2;
+// MODE 2: as 1 with the incoming tensor already dz (ELU' applied by the fused dgrad epilogue)
 template <typename T, int MODE, int CP>
 __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restrict__ da, const float* __restrict__ x,
                                                               int C, const float* __restrict__ W,
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restric
       const f32x4 yv = point_dot<CP>(w, xr);
       f32x4 d;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) d[e] = g[u][e] * elu_grad_from_pre_t<T>(yv[e] * sc[e] + sh[e]);
+      for (int e = 0; e < 4; ++e)
+        d[e] = MODE == 2 ? g[u][e] : g[u][e] * elu_grad_from_pre_t<T>(yv[e] * sc[e] + sh[e]);   // MODE 2: da is already dz
       if (MODE == 0) {
         s1 += d;
         s2 += d * ((yv - p0) * p1);
@@ -374,14 +376,18 @@ extern "C" int pcaa_pointnet_in_bwd_stats(const void* da, int dtype, const float
 
 extern "C" int pcaa_pointnet_in_bwd_wgrad(const void* da, int dtype, const float* x, int C, const float* W,
                                           const float* scale, const float* shift, const float* coef, float* dW,
-                                          long P, int cout, void* stream) {
+                                          long P, int cout, int dz_is_pre, void* stream) {
   PCAA_CHECK_ARG(da && x && W && scale && shift && coef && dW && P >= 1, "pcaa_pointnet_in_bwd_wgrad: bad args");
   PCAA_CHECK_ARG(shape_ok(C, cout), "pcaa_pointnet_in_bwd_wgrad: need C<=%d and cout/4 dividing 256 (C=%d cout=%d)", MAXC, C, cout);
   const unsigned grid = (unsigned)cdiv(P, BWD_ROWS);
-  if (dtype == PCAA_F32)
+  if (dtype == PCAA_F32 && !dz_is_pre)
     LAUNCH_BWD(float, 1, (const float*)da, x, C, W, scale, shift, nullptr, nullptr, coef, nullptr, 1, dW, P, cout);
-  else if (dtype == PCAA_BF16)
+  else if (dtype == PCAA_F32)
+    LAUNCH_BWD(float, 2, (const float*)da, x, C, W, scale, shift, nullptr, nullptr, coef, nullptr, 1, dW, P, cout);
+  else if (dtype == PCAA_BF16 && !dz_is_pre)
     LAUNCH_BWD(bf16_t, 1, (const bf16_t*)da, x, C, W, scale, shift, nullptr, nullptr, coef, nullptr, 1, dW, P, cout);
+  else if (dtype == PCAA_BF16)
+    LAUNCH_BWD(bf16_t, 2, (const bf16_t*)da, x, C, W, scale, shift, nullptr, nullptr, coef, nullptr, 1, dW, P, cout);
   else { pcaa_set_error("pcaa_pointnet_in_bwd_wgrad: bad dtype"); return PCAA_ERR_INVALID_ARG; }
   PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_bwd_wgrad");
 }

@@ -172,10 +172,14 @@ class _FusedGrad:
 
 
 _FUSE_DGRAD_BN = os.environ.get("PCAA_FUSE_DGRAD_BN", "1") != "0"
+# the same fusion into the dgrad above the FIRST layer (y rebuilt from the points in the epilogue) is correct
+# but measured slower: the layer-2 dgrad went 0.195 -> 0.361 ms (64 FMAs + 192 live registers per lane in the
+# epilogue) to save a 0.10 ms statistics pass.  Opt-in.
+_FUSE_DGRAD_POINTS = os.environ.get("PCAA_FUSE_DGRAD_POINTS", "0") == "1"
 
 
 def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool_scale=1.0,
-                       need_dinput=True, lhs=None, outs=None, below=None):
+                       need_dinput=True, lhs=None, outs=None, below=None, below_W=None):
     """Backward of one (linear, BN, ELU) layer.  ``lhs`` is the GEMM's left
     operand ([rows, K]: the input activation or the im2col matrix).  ``outs`` =
     (dW, dgamma, dbeta) destination views (dW PRE-ZEROED: the trainer's flat
@@ -238,6 +242,12 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
                 # dgrad fused with ELU' and the BatchNorm-backward statistics of the layer below
                 d_lhs = _FusedGrad(*ops.gemm_dgrad_bn(dy, Wt, below.y, below.scale, below.shift, below.mean,
                                                       below.rstd))
+            elif (_FUSE_DGRAD_BN and below is not None and below.y is None and below_W is not None
+                  and below.mean is not None and below.a_in.dtype == torch.float32
+                  and below.a_in.shape[0] == rows_local and ops.gemm_dgrad_bn_supported(rows_local, K, cout)):
+                # the layer below is the first PointNet layer on its recompute path: y is rebuilt in the epilogue
+                d_lhs = _FusedGrad(*ops.gemm_dgrad_bn(dy, Wt, None, below.scale, below.shift, below.mean, below.rstd,
+                                                      points=below.a_in, W1=below_W))
             else:
                 d_lhs = ops.gemm(dy, KC, Wt, KC, rows_local, K, cout, out_dtype=torch.bfloat16, math=PCAA_BF16)
         else:
@@ -264,24 +274,34 @@ def pointnet_backward(saves, layers, mode, d_last=None, dpool=None, pool_rows=0,
         W2d = conv.weight.view(s.cout, s.cin)
         need_in = li > 0 or need_dx
         outs = _layer_outs(gout, f"{prefix}{li + 1}.", "module.0.weight", "module.1.weight", "module.1.bias")
+        # weight of the layer below when that layer is a recompute layer whose backward will not need dx
+        below_W = None
+        if _FUSE_DGRAD_POINTS and li == 1 and saves[0].y is None and not need_dx:
+            c0 = layers[0].module[0]
+            below_W = c0.weight.view(saves[0].cout, saves[0].cin)
         if s.y is None and da is not None and not need_in:
-            # recompute path of the first layer: two passes over da, nothing else is read or written
-            stats = ops.pointnet_in_bwd_stats(da, s.a_in, W2d, s.scale, s.shift, s.mean, s.rstd)
+            # recompute path of the first layer: two passes over da (one, when the dgrad above already applied
+            # ELU' and reduced the statistics), nothing else is read or written
+            fused = isinstance(da, _FusedGrad)
+            stats = da.stats if fused else ops.pointnet_in_bwd_stats(da, s.a_in, W2d, s.scale, s.shift, s.mean, s.rstd)
             _sync_stats(stats, 0)
             coef, dg, db = ops.bn_bwd_finalize(stats, s.rows, bn, s.mean, s.rstd, s.cout,
                                                dgamma=outs[1] if outs else None, dbeta=outs[2] if outs else None)
-            dW = ops.pointnet_in_bwd_wgrad(da, s.a_in, W2d, s.scale, s.shift, coef,
-                                           out=outs[0].view(s.cout, s.cin) if outs else None, out_is_zero=True)
+            dW = ops.pointnet_in_bwd_wgrad(da.dz if fused else da, s.a_in, W2d, s.scale, s.shift, coef,
+                                           out=outs[0].view(s.cout, s.cin) if outs else None, out_is_zero=True,
+                                           dz_is_pre=fused)
             dprev = None
         elif li == len(layers) - 1 and dpool is not None:
             dW, dg, db, dprev = _bn_layer_backward(s, bn, W2d, mode, dpool=dpool, group_rows=pool_rows,
                                                    pool_scale=1.0 / pool_rows, need_dinput=need_in, lhs=s.a_in,
-                                                   outs=outs, below=saves[li - 1] if li > 0 else None)
+                                                   outs=outs, below=saves[li - 1] if li > 0 else None,
+                                                   below_W=below_W)
         else:
             if s.y is None:      # recompute layer, but the caller wants the gradient w.r.t. the points: rebuild y
                 s.y = ops.pointnet_in_fwd(s.a_in, W2d, None, da.dtype)
             dW, dg, db, dprev = _bn_layer_backward(s, bn, W2d, mode, da=da, need_dinput=need_in, lhs=s.a_in,
-                                                   outs=outs, below=saves[li - 1] if li > 0 else None)
+                                                   outs=outs, below=saves[li - 1] if li > 0 else None,
+                                                   below_W=below_W)
         # the conv bias gradient is analytically zero (BatchNorm removes the mean)
         zb = gout[f"{prefix}{li + 1}.module.0.bias"] if gout is not None else torch.zeros_like(conv.bias)
         grads.append({"module.0.weight": dW.view_as(conv.weight), "module.0.bias": zb,

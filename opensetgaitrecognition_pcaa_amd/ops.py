@@ -234,17 +234,30 @@ def gemm_dgrad_bn_supported(M, N, K):
     return bool(_lib.load().pcaa_gemm_dgrad_bn_supported(int(M), int(N), int(K)))
 
 
-def gemm_dgrad_bn(dy, Wt, y, scale, shift, mean, rstd):
+def gemm_dgrad_bn(dy, Wt, y, scale, shift, mean, rstd, points=None, W1=None):
     """dz[M,N] = (dy[M,K] @ Wt[N,K]^T) * ELU'(y*scale+shift) plus the BatchNorm-backward statistics of
     the layer that owns y -- the dgrad of the layer above fused with the first half of this layer's
     backward.  Returns (dz bf16, stats)."""
-    for t, nm in ((dy, "dy"), (Wt, "Wt"), (y, "y")):
-        _chk(t, f"gemm_dgrad_bn.{nm}", torch.bfloat16, 2)
+    _chk(dy, "gemm_dgrad_bn.dy", torch.bfloat16, 2)
+    _chk(Wt, "gemm_dgrad_bn.Wt", torch.bfloat16, 2)
     M, K = dy.shape
     N = Wt.shape[0]
-    if Wt.shape[1] != K or tuple(y.shape) != (M, N):
+    if Wt.shape[1] != K:
         raise ValueError("gemm_dgrad_bn: shape mismatch")
-    dz = torch.empty_like(y)
+    xc = 0
+    if y is None:
+        # layer below = first PointNet layer on its recompute path: y = points . W1^T is rebuilt in the epilogue
+        _chk(points, "gemm_dgrad_bn.points", torch.float32, 2)
+        _chk(W1, "gemm_dgrad_bn.W1", torch.float32, 2)
+        xc = points.shape[1]
+        if points.shape[0] != M or tuple(W1.shape) != (N, xc) or not 1 <= xc <= 8:
+            raise ValueError("gemm_dgrad_bn: points / W1 shape mismatch")
+        dz = torch.empty((M, N), dtype=torch.bfloat16, device=dy.device)
+    else:
+        _chk(y, "gemm_dgrad_bn.y", torch.bfloat16, 2)
+        if tuple(y.shape) != (M, N):
+            raise ValueError("gemm_dgrad_bn: shape mismatch")
+        dz = torch.empty_like(y)
     stats = new_stats(N, dy.device)
     timer = TIMER
     key = _dma_key(torch.bfloat16, KC)
@@ -253,8 +266,9 @@ def gemm_dgrad_bn(dy, Wt, y, scale, shift, mean, rstd):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(_lib.load().pcaa_gemm_dgrad_bn(_p(dy), dy.stride(0), _p(Wt), Wt.stride(0), _p(y), _p(dz), y.stride(0),
-                                         _p(scale), _p(shift), _p(mean), _p(rstd), _p(stats), NREP, M, N, K, _s()),
+    check(_lib.load().pcaa_gemm_dgrad_bn(_p(dy), dy.stride(0), _p(Wt), Wt.stride(0), _p(y), _p(dz), dz.stride(0),
+                                         _p(scale), _p(shift), _p(mean), _p(rstd), _p(stats), NREP, M, N, K,
+                                         _p(points) if y is None else None, xc, _p(W1) if y is None else None, _s()),
           "pcaa_gemm_dgrad_bn")
     if timer is not None:
         e1.record()
@@ -333,7 +347,7 @@ def pointnet_in_bwd_stats(da, x2d, W2d, scale, shift, mean, rstd):
     return stats
 
 
-def pointnet_in_bwd_wgrad(da, x2d, W2d, scale, shift, coef, out=None, out_is_zero=False):
+def pointnet_in_bwd_wgrad(da, x2d, W2d, scale, shift, coef, out=None, out_is_zero=False, dz_is_pre=False):
     _chk(da, "pointnet_in_bwd_wgrad.da", dim=2)
     _chk(x2d, "pointnet_in_bwd_wgrad.x", torch.float32, 2)
     P, cout = da.shape
@@ -345,7 +359,8 @@ def pointnet_in_bwd_wgrad(da, x2d, W2d, scale, shift, coef, out=None, out_is_zer
     elif not out_is_zero:
         out.zero_()
     check(_lib.load().pcaa_pointnet_in_bwd_wgrad(_p(da), _dt(da), _p(x2d), C, _p(W2d), _p(scale), _p(shift), _p(coef),
-                                                 _p(out), P, cout, _s()), "pcaa_pointnet_in_bwd_wgrad")
+                                                 _p(out), P, cout, int(bool(dz_is_pre)), _s()),
+          "pcaa_pointnet_in_bwd_wgrad")
     return out
 
 

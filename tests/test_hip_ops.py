@@ -226,6 +226,35 @@ def test_gemm_dgrad_bn_fused_epilogue(M, N, K):
     assert (sa[1] - (dz64 * yh).sum(0)).abs().max().item() <= 5e-3 * max(1.0, (dz64 * yh).sum(0).abs().max().item())
 
 
+@pytest.mark.parametrize("C", [4, 5])
+def test_gemm_dgrad_bn_recomputed_points_layer(C):
+    """fused dgrad whose 'layer below' is the first PointNet layer on its recompute path: y is rebuilt
+    from the points in the epilogue; (dz, statistics) must match the stored-y variant on that same y,
+    and the dz-consuming wgrad must match the da-consuming one."""
+    M, N, K = 768, 512, 512
+    rng = np.random.default_rng(42)
+    x = torch.from_numpy(rng.standard_normal((M, C)).astype(np.float32)).to(DEV)
+    W1 = torch.from_numpy((rng.standard_normal((N, C)) * 0.5).astype(np.float32)).to(DEV)
+    dy = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(DEV).bfloat16()
+    Wt = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(DEV).bfloat16()
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, N).astype(np.float32)).to(DEV)
+    shift = torch.from_numpy(rng.uniform(-0.5, 0.5, N).astype(np.float32)).to(DEV)
+    mean = torch.from_numpy(rng.uniform(-0.2, 0.2, N).astype(np.float32)).to(DEV)
+    rstd = torch.from_numpy(rng.uniform(0.5, 2.0, N).astype(np.float32)).to(DEV)
+    dz, st = ops.gemm_dgrad_bn(dy, Wt, None, scale, shift, mean, rstd, points=x, W1=W1)
+    y32 = ops.pointnet_in_fwd(x, W1, None, torch.float32)
+    da = ops.gemm(dy, KC, Wt, KC, M, N, K, out_dtype=torch.bfloat16, math=PCAA_BF16)
+    dz_ref, st_ref = ops.bn_act_bwd_dz(y32, scale, shift, mean, rstd, da=da.float())
+    assert (dz.float() - dz_ref).abs().max().item() <= 1e-2 * max(1.0, dz_ref.abs().max().item())
+    sa, sb = st.sum(0).cpu(), st_ref.sum(0).cpu()
+    assert (sa - sb).abs().max().item() <= 2e-3 * max(1.0, sb.abs().max().item())
+    bn = _BN(N, 43)
+    coef, _, _ = ops.bn_bwd_finalize(st_ref, M, bn, mean, rstd, N)
+    dW_a = ops.pointnet_in_bwd_wgrad(da, x, W1, scale, shift, coef).cpu().double()
+    dW_b = ops.pointnet_in_bwd_wgrad(dz, x, W1, scale, shift, coef, dz_is_pre=True).cpu().double()
+    assert (dW_a - dW_b).abs().max().item() <= 5e-3 * max(1e-3, dW_a.abs().max().item())
+
+
 def test_skinny_rejects_unsupported_shapes():
     assert not ops.skinny_supported(65, 1920, 960)
     assert not ops.skinny_supported(64, 1200, 960)
