@@ -29,6 +29,27 @@ inline bool ch_ok(int ch) {
   return (256 % q) == 0;
 }
 
+// sum of the nrep replicas of one channel's two statistics; 8 replicas (16 loads) in flight per trip --
+// the one-at-a-time loop made these single-workgroup kernels 8-10 us of pure load latency
+__device__ __forceinline__ void replica_sums(const double* __restrict__ stats, int nrep, int ch, int c, double& s1,
+                                             double& s2) {
+  int r = 0;
+  for (; r + 8 <= nrep; r += 8) {
+    double a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = stats[((long)(r + u) * 2 + 0) * ch + c];
+      b[u] = stats[((long)(r + u) * 2 + 1) * ch + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s1 += a[u]; s2 += b[u]; }
+  }
+  for (; r < nrep; ++r) {
+    s1 += stats[((long)r * 2 + 0) * ch + c];
+    s2 += stats[((long)r * 2 + 1) * ch + c];
+  }
+}
+
 // ---------------------------------------------------------------- BN finalize (forward)
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, int nrep, double inv_count,
                                    double unbias, const float* __restrict__ lin_bias,
@@ -40,10 +61,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int nrep, d
   if (c == 0 && nbt) *nbt += 1;
   if (c >= ch) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < nrep; ++r) {
-    s1 += stats[((long)r * 2 + 0) * ch + c];
-    s2 += stats[((long)r * 2 + 1) * ch + c];
-  }
+  replica_sums(stats, nrep, ch, c, s1, s2);
   const double m0 = s1 * inv_count;                 // mean of the bias-free linear output
   double var = s2 * inv_count - m0 * m0;            // biased variance
   if (var < 0.0) var = 0.0;
@@ -257,10 +275,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ stats, int nre
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ch) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < nrep; ++r) {
-    s1 += stats[((long)r * 2 + 0) * ch + c];
-    s2 += stats[((long)r * 2 + 1) * ch + c];
-  }
+  replica_sums(stats, nrep, ch, c, s1, s2);
   if (dbeta) dbeta[c] = (float)s1;
   if (dgamma) dgamma[c] = (float)s2;
   const double c1 = s1 * inv_count, c2 = s2 * inv_count;
@@ -305,8 +320,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   const int cl = threadIdx.x & 63, rlane = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   float acc = 0.f;
-  if (c < cols)
-    for (long r = rlane; r < rows; r += 4) acc += x[r * cols + c];
+  if (c < cols) {
+    long r = rlane;
+    for (; r + 28 < rows; r += 32) {      // 8 rows in flight per trip (these launches are pure load latency)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = x[(r + 4 * u) * cols + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; r < rows; r += 4) acc += x[r * cols + c];
+  }
   red[threadIdx.x] = acc;
   __syncthreads();
   if (rlane == 0 && c < cols) out[c] = red[cl] + red[64 + cl] + red[128 + cl] + red[192 + cl];
