@@ -150,6 +150,7 @@ class PCAATrainer:
         self._dec_start = self.flat_g.offsets[dec_names[0]] if dec_names else self.flat_g.total
         self.early_decoder_adam = os.environ.get("PCAA_EARLY_ADAM", "1") != "0"
         self._side_adam_blocks = int(os.environ.get("PCAA_SIDE_ADAM_BLOCKS", "256"))
+        self._dp_chunks = max(1, int(os.environ.get("PCAA_DP_CHUNKS", "4")))
         # measured (same box, ms/step): no side stream 8.08-8.26 | beside the temporal-conv/head backward
         # 7.90 (256 blocks), 7.99 (128) | beside the PointNet backward GEMMs 8.29 (256) .. 9.03 (32):
         # the GEMMs lose more to the extra HBM stream than the update costs on its own
@@ -259,9 +260,22 @@ class PCAATrainer:
                                                    dx_init=dsup, dW_out=gv["GPH.0.weight"], db_out=gv["GPH.0.bias"])
         else:
             _, dsup = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads, dz_init=dsup, mode=mode)
-        pending = None
+        # [GPH | decoder] gradients are final here.  Data-parallel: their all-reduce goes out now, in a few
+        # chunks (the collectives of one communicator run in order), so that the side-stream Adam of chunk i
+        # overlaps the all-reduce of chunk i+1 instead of waiting for all 628 MB.
+        pending = []                               # (lo, hi, work) in flat_g coordinates
         if self.overlap_allreduce:
-            pending = self._allreduce(self._tail_region, async_op=True)
+            enc_end = self._enc_region.numel()
+            bounds = [enc_end, self._dec_start] if self._dec_start > enc_end else [enc_end]
+            collective = self.pg is not None and (self.world > 1 or self._force_collectives)
+            nchunk = self._dp_chunks if collective else 1
+            dec_n = self.flat_g.total - self._dec_start
+            for i in range(1, nchunk + 1):
+                b = self._dec_start + (dec_n * i // nchunk) // _ALIGN * _ALIGN if i < nchunk else self.flat_g.total
+                if b > bounds[-1]:
+                    bounds.append(b)
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                pending.append((lo, hi, self._allreduce(self.flat_g.g[lo:hi], async_op=True)))
         early = self.early_decoder_adam and self.overlap_allreduce and self._side is not None
         hook = None
         if early:
@@ -273,10 +287,13 @@ class PCAATrainer:
                 ready.record(torch.cuda.current_stream())
                 with torch.cuda.stream(self._side):
                     self._side.wait_event(ready)        # everything enqueued on the main stream so far
-                    if pending is not None:
-                        pending.wait()                  # side stream waits for the decoder-region all-reduce
-                    self.flat_g.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs, lo=self._dec_start,
-                                     advance=False, max_blocks=self._side_adam_blocks)
+                    for lo, hi, work in pending:
+                        if hi <= self._dec_start:
+                            continue                    # the projection-head slice is updated on the main stream
+                        if work is not None:
+                            work.wait()                 # side stream waits for THIS chunk's all-reduce only
+                        self.flat_g.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs, lo=max(lo, self._dec_start),
+                                         hi=hi, advance=False, max_blocks=self._side_adam_blocks)
                     ev = torch.cuda.Event()
                     ev.record(self._side)
                     done.append(ev)
@@ -289,8 +306,9 @@ class PCAATrainer:
                                before_pointnet=hook)
         if self.overlap_allreduce:
             self._allreduce(self._enc_region)
-            if pending is not None:
-                pending.wait()          # stream-side wait, no host block
+            for _, _, work in pending:
+                if work is not None:
+                    work.wait()         # stream-side wait, no host block
         else:
             self._allreduce(self.flat_g.g)
         if early:
