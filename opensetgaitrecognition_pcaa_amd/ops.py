@@ -260,7 +260,7 @@ def gemm_dgrad_bn(dy, Wt, y, scale, shift, mean, rstd, points=None, W1=None):
         dz = torch.empty_like(y)
     stats = new_stats(N, dy.device)
     timer = TIMER
-    key = _dma_key(torch.bfloat16, KC)
+    key = "gemm_bf16_dma_kernel<bf16,KC,KC,dgrad_bn>"       # its own instantiation (epilogue carries ELU' + statistics)
     timer = timer if (timer is not None and timer.wants(key)) else None
     if timer is not None:
         e0 = torch.cuda.Event(enable_timing=True)

@@ -17,15 +17,17 @@ def key_of(name):
         ln = int(m.group(1))
         base, rest = name[m.end():m.end() + ln], name[m.end() + ln:]
         if base == "gemm_bf16_dma_kernel":
-            t = re.match(r"I(DF16b|f)Li(\d)ELi(\d)E", rest)
+            t = re.match(r"I(DF16b|f)Li(\d)ELi(\d)ELi(\d+)E", rest)
             lay = "KC" if t.group(2) == "0" else "RC"
-            return f"gemm_bf16_dma_kernel<{'bf16' if t.group(1) == 'DF16b' else 'f32'},{lay},{lay}>"
+            tail = ",dgrad_bn" if t.group(4) in ("30", "31") else ""
+            return f"gemm_bf16_dma_kernel<{'bf16' if t.group(1) == 'DF16b' else 'f32'},{lay},{lay}{tail}>"
         return base + ("<bf16>" if rest.startswith("IDF16b") else "")
     n = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"gemm_bf16_dma_kernel<(__bf16|float), (\d), (\d)", n)
+    m = re.match(r"gemm_bf16_dma_kernel<(__bf16|float), (\d), (\d), (\d+)", n)
     if m:
         lay = "KC" if m.group(2) == "0" else "RC"
-        return f"gemm_bf16_dma_kernel<{'bf16' if m.group(1) == '__bf16' else 'f32'},{lay},{lay}>"
+        tail = ",dgrad_bn" if m.group(4) in ("30", "31") else ""
+        return f"gemm_bf16_dma_kernel<{'bf16' if m.group(1) == '__bf16' else 'f32'},{lay},{lay}{tail}>"
     n = re.sub(r"\(.*", "", n)
     n = re.sub(r"<.*", "", n)
     return n
