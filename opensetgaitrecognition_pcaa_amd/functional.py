@@ -171,6 +171,46 @@ class _FusedGrad:
         self.dz, self.stats = dz, stats
 
 
+# Side stream for the SMALL weight-gradient products (temporal block, MLP heads): they only feed the
+# optimizer at the end of the step, are 10-50 us launches on a handful of CUs, and are independent of the
+# dgrad that continues the chain -- run beside it they leave the backward's critical path.  Set per step by
+# the trainer (set_wgrad_stream), which joins the stream before the encoder-gradient all-reduce / Adam.
+_WGRAD_STREAM = None
+
+
+def set_wgrad_stream(stream):
+    global _WGRAD_STREAM
+    _WGRAD_STREAM = stream
+
+
+class _on_wgrad_stream:
+    """``with _on_wgrad_stream(t1, t2, ...)``: run the body on the wgrad side stream after everything
+    enqueued so far; the listed tensors (inputs allocated on the main stream) are kept alive for it."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+        self.ctx = None
+
+    def __enter__(self):
+        st = _WGRAD_STREAM
+        if st is None:
+            return self
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.ctx = torch.cuda.stream(st)
+        self.ctx.__enter__()
+        st.wait_event(ev)
+        for t in self.tensors:
+            if t is not None:
+                t.record_stream(st)
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 _FUSE_DGRAD_BN = os.environ.get("PCAA_FUSE_DGRAD_BN", "1") != "0"
 # the same fusion into the dgrad above the FIRST layer (y rebuilt from the points in the epilogue) is correct
 # but measured slower: the layer-2 dgrad went 0.195 -> 0.361 ms (64 FMAs + 192 live registers per lane in the
@@ -228,8 +268,11 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
             dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, math=PCAA_BF16)
     else:
         sk = ops.pick_split_k(cout, K, rows_local)
-        dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, split_k=sk,
-                      accumulate=sk > 1 or dW_out is not None)
+        if dW_out is not None:
+            with _on_wgrad_stream(dy, lhs):
+                dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, split_k=sk, accumulate=True)
+        else:
+            dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, split_k=sk, accumulate=sk > 1)
     d_lhs = None
     if need_dinput:
         if mode == "bf16" and dy.dtype == torch.bfloat16 and cout % 8 == 0:
@@ -416,7 +459,11 @@ def linear_act_backward(x, a_out, lin, act, d_out, need_dx=True, dW_out=None, db
     if fuse_elu_in:
         raise RuntimeError("linear_act_backward: fuse_elu_in is only served by the skinny path")
     wide = _wide_bf16(mode, M, N, K)
-    dW = ops.gemm(dz2, RC, x, RC, N, K, M, out=dW_out, math=PCAA_BF16 if wide else PCAA_F32)
+    if dW_out is not None and not wide:
+        with _on_wgrad_stream(dz2, x):
+            dW = ops.gemm(dz2, RC, x, RC, N, K, M, out=dW_out, math=PCAA_F32)
+    else:
+        dW = ops.gemm(dz2, RC, x, RC, N, K, M, out=dW_out, math=PCAA_BF16 if wide else PCAA_F32)
     dx = None
     if need_dx:
         if wide:

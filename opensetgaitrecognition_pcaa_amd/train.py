@@ -159,6 +159,9 @@ class PCAATrainer:
         # second stream for the critic branch of the step (see step()); PCAA_AUX_STREAM=0: everything inline
         self._aux = (torch.cuda.Stream(device=self.device)
                      if self.device.type == "cuda" and os.environ.get("PCAA_AUX_STREAM", "1") != "0" else None)
+        # third stream: the small weight-gradient products of the temporal block / heads (functional._WGRAD_STREAM)
+        self._wg = (torch.cuda.Stream(device=self.device)
+                    if self.device.type == "cuda" and os.environ.get("PCAA_WGRAD_STREAM", "1") != "0" else None)
         self.overlap_allreduce = os.environ.get("PCAA_DP_OVERLAP", "1") != "0"
         # PCAA_DP_FORCE=1 issues the collectives even on a 1-rank group (exercises the RCCL path on one GPU)
         self._force_collectives = os.environ.get("PCAA_DP_FORCE", "0") == "1"
@@ -302,8 +305,14 @@ class PCAATrainer:
                 hook = launch_side_adam                 # beside the MFMA-bound PointNet backward
             else:
                 launch_side_adam()                      # beside the temporal-conv / head backward
-        F_hip.encoder_backward(enc, st, dlogits if supervise else None, dsup, gout=self._enc_grads,
-                               before_pointnet=hook)
+        F_hip.set_wgrad_stream(self._wg)
+        try:
+            F_hip.encoder_backward(enc, st, dlogits if supervise else None, dsup, gout=self._enc_grads,
+                                   before_pointnet=hook)
+        finally:
+            F_hip.set_wgrad_stream(None)
+        if self._wg is not None:
+            torch.cuda.current_stream().wait_stream(self._wg)       # its products feed the all-reduce / Adam below
         if self.overlap_allreduce:
             self._allreduce(self._enc_region)
             for _, _, work in pending:
