@@ -448,9 +448,15 @@ def linear_act_backward(x, a_out, lin, act, d_out, need_dx=True, dW_out=None, db
     N = lin.weight.shape[0]
     dz = ops.elu_bwd_from_out(d_out, a_out) if (act == ACT_ELU and not d_is_pre) else d_out
     dz2 = dz.view(M, N)
-    db = ops.colsum(dz2, out=db_out)
     if _skinny(mode, M, N, K):
-        dW = ops.skinny_linear_wgrad(dz2, x, out=dW_out)
+        if dW_out is not None and db_out is not None:
+            # the weight-gradient write stream (and the bias gradient) beside the dgrad read stream of the same layer
+            with _on_wgrad_stream(dz2, x):
+                db = ops.colsum(dz2, out=db_out)
+                dW = ops.skinny_linear_wgrad(dz2, x, out=dW_out)
+        else:
+            db = ops.colsum(dz2, out=db_out)
+            dW = ops.skinny_linear_wgrad(dz2, x, out=dW_out)
         dx = None
         if need_dx:
             dx = ops.skinny_linear_dgrad(dz2, lin.weight, a_prev=x if fuse_elu_in else None, out=dx_init,
@@ -458,6 +464,7 @@ def linear_act_backward(x, a_out, lin, act, d_out, need_dx=True, dW_out=None, db
         return dW, db, dx
     if fuse_elu_in:
         raise RuntimeError("linear_act_backward: fuse_elu_in is only served by the skinny path")
+    db = ops.colsum(dz2, out=db_out)
     wide = _wide_bf16(mode, M, N, K)
     if dW_out is not None and not wide:
         with _on_wgrad_stream(dz2, x):

@@ -251,6 +251,7 @@ class PCAATrainer:
         rec_loss = ops.total(frame_loss, inv_bt)
 
         # (5) G-step backward (the adversarial gradient w.r.t. sup_fvs seeds the accumulation)
+        F_hip.set_wgrad_stream(self._wg)
         if joined is not None and self.decoder_projection_head is None:
             torch.cuda.current_stream().wait_event(joined)
             joined = None
@@ -271,6 +272,8 @@ class PCAATrainer:
             enc_end = self._enc_region.numel()
             bounds = [enc_end, self._dec_start] if self._dec_start > enc_end else [enc_end]
             collective = self.pg is not None and (self.world > 1 or self._force_collectives)
+            if collective and self._wg is not None:
+                torch.cuda.current_stream().wait_stream(self._wg)   # the decoder's dW/db were written on that stream
             nchunk = self._dp_chunks if collective else 1
             dec_n = self.flat_g.total - self._dec_start
             for i in range(1, nchunk + 1):
@@ -290,6 +293,8 @@ class PCAATrainer:
                 ready.record(torch.cuda.current_stream())
                 with torch.cuda.stream(self._side):
                     self._side.wait_event(ready)        # everything enqueued on the main stream so far
+                    if self._wg is not None:
+                        self._side.wait_stream(self._wg)   # ... and the decoder weight gradients on the wgrad stream
                     for lo, hi, work in pending:
                         if hi <= self._dec_start:
                             continue                    # the projection-head slice is updated on the main stream
@@ -305,7 +310,6 @@ class PCAATrainer:
                 hook = launch_side_adam                 # beside the MFMA-bound PointNet backward
             else:
                 launch_side_adam()                      # beside the temporal-conv / head backward
-        F_hip.set_wgrad_stream(self._wg)
         try:
             F_hip.encoder_backward(enc, st, dlogits if supervise else None, dsup, gout=self._enc_grads,
                                    before_pointnet=hook)
