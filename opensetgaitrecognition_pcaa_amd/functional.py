@@ -12,6 +12,7 @@ Numerics modes (``set_precision``):
   * ``"bf16"``  -- PointNet activations stored in bf16, PointNet GEMMs on the
     bf16 MFMA pipe with fp32 accumulation; everything else fp32.
 """
+import contextlib
 import os
 
 import torch
@@ -211,6 +212,7 @@ class _on_wgrad_stream:
         return False
 
 
+_BIG_WGRAD_ASIDE = os.environ.get("PCAA_BIG_WGRAD_ASIDE", "0") == "1"    # experiment: PointNet wgrads on that stream too
 _FUSE_DGRAD_BN = os.environ.get("PCAA_FUSE_DGRAD_BN", "1") != "0"
 # the same fusion into the dgrad above the FIRST layer (y rebuilt from the points in the epilogue) is correct
 # but measured slower: the layer-2 dgrad went 0.195 -> 0.361 ms (64 FMAs + 192 live registers per lane in the
@@ -262,10 +264,11 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
         dW = ops.pointnet_in_wgrad(dy, lhs, out=dW_out, out_is_zero=True)
     elif wgrad_bf16:
         sk = ops.pick_split_k(cout, K, rows_local, target_blocks=256, bk=64, tile=256)
-        if sk > 1:
-            dW = ops.gemm_slabs(dy, RC, lhs, RC, cout, K, rows_local, sk, out=dW_out, math=PCAA_BF16)
-        else:
-            dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, math=PCAA_BF16)
+        with _on_wgrad_stream(dy, lhs) if (_BIG_WGRAD_ASIDE and dW_out is not None) else contextlib.nullcontext():
+            if sk > 1:
+                dW = ops.gemm_slabs(dy, RC, lhs, RC, cout, K, rows_local, sk, out=dW_out, math=PCAA_BF16)
+            else:
+                dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, math=PCAA_BF16)
     else:
         sk = ops.pick_split_k(cout, K, rows_local)
         if dW_out is not None:
