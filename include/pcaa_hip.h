@@ -29,6 +29,8 @@
 extern "C" {
 #endif
 
+#define PCAA_ABI_VERSION 2 /* pcaa_abi_version() of a library built from this header */
+
 #define PCAA_OK 0
 #define PCAA_ERR_INVALID_ARG 1
 #define PCAA_ERR_LAUNCH 2

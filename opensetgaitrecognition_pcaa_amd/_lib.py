@@ -14,6 +14,16 @@ HEADER = os.path.join(os.path.dirname(PKG), "include", "pcaa_hip.h")
 LIB_PATH = os.path.join(PKG, "libpcaa_hip.so")
 
 PCAA_F32, PCAA_BF16 = 0, 1
+
+
+def _header_abi_version():
+    import re
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "pcaa_hip.h")
+    with open(hdr) as f:
+        return int(re.search(r"#define\s+PCAA_ABI_VERSION\s+(\d+)", f.read()).group(1))
+
+
+ABI_VERSION = _header_abi_version()        # what include/pcaa_hip.h declares; load() checks the library against it
 KC, RC = 0, 1
 ACT_NONE, ACT_ELU = 0, 1
 

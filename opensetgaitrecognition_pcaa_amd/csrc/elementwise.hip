@@ -16,7 +16,7 @@ void pcaa_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* pcaa_last_error(void) { return g_err; }
-extern "C" int pcaa_abi_version(void) { return 2; }
+extern "C" int pcaa_abi_version(void) { return PCAA_ABI_VERSION; }
 
 namespace {
 
