@@ -74,6 +74,11 @@ def load():
                 f"{LIB_PATH} is missing: the PCAA HIP extension has not been built. "
                 "Run `python -m opensetgaitrecognition_pcaa_amd.build` (needs hipcc). "
                 "There is no CPU fallback for this package.")
+        # torch first: it ships its own libamdhip64, and the HIP runtime that owns the device context and the
+        # streams we launch on must be the one libpcaa_hip.so binds to.  Loaded the other way round (this
+        # library before torch, e.g. build() then smoke() in one process) the process ends up with two HIP
+        # runtimes and every launch fails with "no ROCm-capable device is detected".
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (ret, args) in parse_header().items():
             fn = getattr(lib, name)     # AttributeError if the .so does not export it
