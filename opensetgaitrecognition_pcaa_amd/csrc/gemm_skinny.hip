@@ -141,6 +141,75 @@ __global__ __launch_bounds__(256) void skinny_dgrad_kernel(const float* __restri
   store_acc(acc, slabs + (long)blockIdx.y * slab_stride, K, M, col, K, h);
 }
 
+// dgrad, two columns per lane: the same structure with 8-B loads -- lane l of a wave reads W[n][c0+2l, +1], the
+// even columns feed one MFMA B-fragment and the odd ones a second (a column permutation the store undoes), so
+// a wave covers 64 columns with HALF the vector-memory instructions per byte.  The one-column kernel was bound
+// by those (7200 dword wave-loads per CU on the 7680x15360 layer: 3.2 TB/s against 4.5-5 of the other two).
+// grid (ceil(K/256), nsplit)
+__global__ __launch_bounds__(256) void skinny_dgrad2_kernel(const float* __restrict__ dz, long lddz,
+                                                            const float* __restrict__ W, long ldw,
+                                                            float* __restrict__ slabs, long slab_stride, int M,
+                                                            int N, int K, int cps) {
+  __shared__ __attribute__((aligned(16))) bf16_t sbuf[2][64 * SP];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int col = blockIdx.x * 256 + wave * 64 + 2 * l31;          // this lane's column pair
+  const int c0 = blockIdx.y * cps;
+  const int nch = min(cps, N / CH - c0);
+  if (nch <= 0) return;
+  const int lane_off = 8 * h * (int)ldw + min(col, K - 2);
+  const float* Wc = W + (long)c0 * CH * ldw;
+
+  f32x2 wr[4][8];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wr[s][e] = *reinterpret_cast<const f32x2*>(Wc + (long)(s * 16 + e) * ldw + lane_off);
+  SmallStage st;
+  small_load(st, dz, lddz, M, c0 * CH, tid);
+  small_store(st, sbuf[0], tid);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mf][f][r] = 0.f;
+  lds_barrier();
+
+  for (int c = 0; c < nch; ++c) {
+    const bool more = c + 1 < nch;
+    const bf16_t* cur = sbuf[c & 1];
+    if (more) small_load(st, dz, lddz, M, (c0 + c + 1) * CH, tid);
+    const float* Wn = Wc + (long)min(c + 1, nch - 1) * CH * ldw;     // last trip: harmless re-read
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float ev[8], od[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { ev[e] = wr[s][e].x; od[e] = wr[s][e].y; }
+      const bf16x8 b0 = pack8(ev), b1 = pack8(od);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wr[s][e] = *reinterpret_cast<const f32x2*>(Wn + (long)(s * 16 + e) * ldw + lane_off);
+      const bf16x8 a0 = small_frag(cur, 0, s, l31, h), a1 = small_frag(cur, 1, s, l31, h);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) small_store(st, sbuf[(c + 1) & 1], tid);
+    lds_barrier();
+  }
+  if (col >= K) return;
+  float* out = slabs + (long)blockIdx.y * slab_stride;
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m < M) *reinterpret_cast<f32x2*>(out + (long)m * K + col) = f32x2{acc[mf][0][r], acc[mf][1][r]};
+    }
+}
+
 // ------------------------------------------------------------------ forward: y = x . W^T
 // grid (ceil(N/128), nsplit); wave w owns output columns (rows of W) [128 bx + 32 w, +32)
 __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, long ldx,
@@ -389,8 +458,13 @@ extern "C" int pcaa_skinny_linear_dgrad(const float* dz, long lddz, const float*
   const long stride = (long)M * K;
   PCAA_CHECK_ARG(ws_floats >= stride * nsplit, "pcaa_skinny_linear_dgrad: workspace too small");
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(skinny_dgrad_kernel, dim3((unsigned)cdiv(K, 128), nsplit), dim3(256), 0, s, dz, lddz, W, ldw, ws,
-                     stride, M, N, K, cps);
+  static const bool narrow = getenv("PCAA_SKINNY_DGRAD_NARROW") != nullptr;      // the one-column-per-lane kernel
+  if (!narrow && (ldw % 2) == 0 && ((uintptr_t)W % 8) == 0)
+    hipLaunchKernelGGL(skinny_dgrad2_kernel, dim3((unsigned)cdiv(K, 256), nsplit), dim3(256), 0, s, dz, lddz, W, ldw,
+                       ws, stride, M, N, K, cps);
+  else
+    hipLaunchKernelGGL(skinny_dgrad_kernel, dim3((unsigned)cdiv(K, 128), nsplit), dim3(256), 0, s, dz, lddz, W, ldw,
+                       ws, stride, M, N, K, cps);
   reduce_launch(ws, nsplit, stride, dx, nullptr, PCAA_ACT_NONE, a_prev, accumulate, M, K, s);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_dgrad");
 }
