@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--graph", default=os.environ.get("PCAA_GRAPH", "off"), choices=["on", "off"],
+                    help="replay the step as a captured hipGraph (PCAATrainer.step_graphed).  Measured SLOWER than "
+                         "eager enqueue on this stack (7.48 vs 6.99 ms/step: the 4-stream step is GPU-bound, and "
+                         "graph replay loses some of the cross-stream overlap), so it is opt-in")
     return ap.parse_args()
 
 
@@ -130,8 +134,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    use_graph = a.graph == "on"
+    run_step = tr.step
     for _ in range(a.warmup):
         out = tr.step(pcs, gt, z0, al)
+    if use_graph:
+        # capture (the step is recorded, then replayed once: one more real, untimed step)
+        out = tr.step_graphed(pcs, gt, z0, al, warmup=0)
+        run_step = tr.step_graphed
     barrier()
     timer = None
     if not a.no_kernel_timing:
@@ -141,12 +151,14 @@ def main():
         ops.set_timer(timer)
     # the launches of the first `timed_steps` steps of the timed region carry the events: every timed
     # launch drains the queue around itself (two marker packets), ~20 us of bubbles per step for 9 launches
-    timed_steps = min(a.steps, 4) if timer is not None else 0
+    # (graph mode: those steps run eagerly -- events cannot be read back from inside a replayed graph --
+    # and the remaining steps of the timed region are graph replays)
+    timed_steps = min(a.steps, 2 if use_graph else 4) if timer is not None else 0
     t0 = time.perf_counter()
     for i in range(a.steps):
         if i == timed_steps:
             ops.set_timer(None)
-        out = tr.step(pcs, gt, z0, al)
+        out = tr.step(pcs, gt, z0, al) if i < timed_steps else run_step(pcs, gt, z0, al)
     barrier()
     dt = time.perf_counter() - t0
     ops.set_timer(None)
@@ -167,7 +179,8 @@ def main():
             "config": {"workload": f"PCAA V4 train step (enc+dec+disc fwd/bwd, WGAN-GP, Chamfer, 2x Adam), "
                                    f"B={B}/GPU T={T} N={N} C={C} K={K}, BASELINE config[1]",
                        "global_batch": B * world, "precision": a.precision,
-                       "parallelism": f"dp{world}", "sync_bn": bool(a.sync_bn), "finite_loss": loss_ok},
+                       "parallelism": f"dp{world}", "sync_bn": bool(a.sync_bn), "finite_loss": loss_ok,
+                       "hip_graph": bool(use_graph)},
         }
         if timer is not None:
             agg = timer.summary()

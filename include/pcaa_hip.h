@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PCAA_ABI_VERSION 2 /* pcaa_abi_version() of a library built from this header */
+#define PCAA_ABI_VERSION 3 /* pcaa_abi_version() of a library built from this header */
 
 #define PCAA_OK 0
 #define PCAA_ERR_INVALID_ARG 1
@@ -290,6 +290,15 @@ int pcaa_skinny_linear_wgrad(const float* dz, long lddz, const float* x, long ld
 int pcaa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
                    float lr, float beta1, float beta2, float eps, int step, float grad_scale,
                    int max_blocks, void* stream);
+/* The same update with the step count kept ON THE DEVICE, so that a captured hipGraph of the
+ * train step replays without per-step host arguments: pcaa_adam_advance does
+ * `*step_dev += 1; coef_dev[0] = lr / (1 - beta1^step); coef_dev[1] = 1 / sqrt(1 - beta2^step)`
+ * (fp64, the arithmetic of pcaa_adam_step) once per optimizer step; pcaa_adam_step_dev applies the
+ * update to any sub-range of the flat buffer with those two scalars read from coef_dev. */
+int pcaa_adam_advance(int* step_dev, float* coef_dev, float lr, float beta1, float beta2, void* stream);
+int pcaa_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                       float beta1, float beta2, float eps, const float* coef_dev, float grad_scale,
+                       int max_blocks, void* stream);
 
 #ifdef __cplusplus
 }

@@ -440,7 +440,12 @@ template <int U>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n,
                                                    float b1, float b2, float eps, float step_size,
-                                                   float inv_bc2_sqrt, float grad_scale) {
+                                                   float inv_bc2_sqrt, float grad_scale,
+                                                   const float* __restrict__ coef) {
+  if (coef) {            // step-dependent scalars kept on the device (hipGraph replay: no host argument changes)
+    step_size = coef[0];
+    inv_bc2_sqrt = coef[1];
+  }
   const long nq = n >> 2;
   const long stride = (long)gridDim.x * 256;
   for (long q0 = (long)blockIdx.x * 256 + threadIdx.x; q0 < nq; q0 += stride * U) {
@@ -477,6 +482,17 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     v[i] = vv;
     p[i] -= step_size * (mm / (sqrtf(vv) * inv_bc2_sqrt + eps));
   }
+}
+
+// one thread: advance the device-side step count and derive the two step-dependent Adam scalars in fp64,
+// exactly as the host launcher does
+__global__ void adam_coef_kernel(int* __restrict__ step, float* __restrict__ coef, float lr, float b1, float b2) {
+  const int t = *step + 1;
+  *step = t;
+  const double bc1 = 1.0 - pow((double)b1, (double)t);
+  const double bc2 = 1.0 - pow((double)b2, (double)t);
+  coef[0] = (float)((double)lr / bc1);
+  coef[1] = (float)(1.0 / sqrt(bc2));
 }
 
 inline int grid_for(long work_items, int per_block = 256, int cap = 256 * 8) {
@@ -833,24 +849,44 @@ extern "C" int pcaa_splitk_reduce(const float* slabs, int nsplit, long slab_stri
   PCAA_RETURN_LAUNCH_STATUS("pcaa_splitk_reduce");
 }
 
+static int launch_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float beta1,
+                       float beta2, float eps, float step_size, float inv_bc2_sqrt, const float* coef,
+                       float grad_scale, int max_blocks, void* stream, const char* what) {
+  PCAA_CHECK_ARG(((uintptr_t)param % 16) == 0 && ((uintptr_t)grad % 16) == 0 && ((uintptr_t)exp_avg % 16) == 0 &&
+                 ((uintptr_t)exp_avg_sq % 16) == 0, "pcaa_adam_step: buffers must be 16-B aligned");
+  static const int env_cap = getenv("PCAA_ADAM_BLOCKS") ? atoi(getenv("PCAA_ADAM_BLOCKS")) : 0;
+  const int cap = env_cap > 0 ? env_cap : (max_blocks > 0 ? max_blocks : 256 * 16);
+  if (cap <= 1024)
+    hipLaunchKernelGGL(adam_kernel<4>, dim3(grid_for(n >> 4, 256, cap)), dim3(256), 0, as_stream(stream), param, grad,
+                       exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size, inv_bc2_sqrt, grad_scale, coef);
+  else
+    hipLaunchKernelGGL(adam_kernel<1>, dim3(grid_for(n >> 2, 256, cap)), dim3(256), 0, as_stream(stream), param, grad,
+                       exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size, inv_bc2_sqrt, grad_scale, coef);
+  PCAA_RETURN_LAUNCH_STATUS(what);
+}
+
 extern "C" int pcaa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
                               float lr, float beta1, float beta2, float eps, int step, float grad_scale,
                               int max_blocks, void* stream) {
   PCAA_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n >= 1 && step >= 1 && max_blocks >= 0,
                  "pcaa_adam_step: bad args");
-  PCAA_CHECK_ARG(((uintptr_t)param % 16) == 0 && ((uintptr_t)grad % 16) == 0 && ((uintptr_t)exp_avg % 16) == 0 &&
-                 ((uintptr_t)exp_avg_sq % 16) == 0, "pcaa_adam_step: buffers must be 16-B aligned");
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  const float step_size = (float)((double)lr / bc1);
-  const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-  static const int env_cap = getenv("PCAA_ADAM_BLOCKS") ? atoi(getenv("PCAA_ADAM_BLOCKS")) : 0;
-  const int cap = env_cap > 0 ? env_cap : (max_blocks > 0 ? max_blocks : 256 * 16);
-  if (cap <= 1024)
-    hipLaunchKernelGGL(adam_kernel<4>, dim3(grid_for(n >> 4, 256, cap)), dim3(256), 0, as_stream(stream), param, grad,
-                       exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size, inv_bc2_sqrt, grad_scale);
-  else
-    hipLaunchKernelGGL(adam_kernel<1>, dim3(grid_for(n >> 2, 256, cap)), dim3(256), 0, as_stream(stream), param, grad,
-                       exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size, inv_bc2_sqrt, grad_scale);
-  PCAA_RETURN_LAUNCH_STATUS("pcaa_adam_step");
+  return launch_adam(param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, (float)((double)lr / bc1),
+                     (float)(1.0 / sqrt(bc2)), nullptr, grad_scale, max_blocks, stream, "pcaa_adam_step");
+}
+
+extern "C" int pcaa_adam_advance(int* step_dev, float* coef_dev, float lr, float beta1, float beta2, void* stream) {
+  PCAA_CHECK_ARG(step_dev && coef_dev, "pcaa_adam_advance: bad args");
+  hipLaunchKernelGGL(adam_coef_kernel, dim3(1), dim3(1), 0, as_stream(stream), step_dev, coef_dev, lr, beta1, beta2);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_adam_advance");
+}
+
+extern "C" int pcaa_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                                  float beta1, float beta2, float eps, const float* coef_dev, float grad_scale,
+                                  int max_blocks, void* stream) {
+  PCAA_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && coef_dev && n >= 1 && max_blocks >= 0,
+                 "pcaa_adam_step_dev: bad args");
+  return launch_adam(param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, 0.f, 0.f, coef_dev, grad_scale,
+                     max_blocks, stream, "pcaa_adam_step_dev");
 }

@@ -780,3 +780,28 @@ def adam_step_(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0, max_blocks=0):
         raise ValueError("adam_step_: size mismatch")
     check(_lib.load().pcaa_adam_step(_p(p), _p(g), _p(m), _p(v), n, float(lr), float(b1), float(b2), float(eps),
                                      int(step), float(grad_scale), int(max_blocks), _s()), "pcaa_adam_step")
+
+
+def adam_advance_(step_dev, coef_dev, lr, b1, b2):
+    """Device-side optimizer step count: ``step_dev`` int32[1] += 1 and ``coef_dev`` float32[2] =
+    (lr / (1 - b1^step), 1 / sqrt(1 - b2^step)) -- see pcaa_adam_advance."""
+    _chk(step_dev, "adam.step_dev", torch.int32)
+    _chk(coef_dev, "adam.coef_dev", torch.float32)
+    if step_dev.numel() != 1 or coef_dev.numel() != 2:
+        raise ValueError("adam_advance_: step_dev is int32[1], coef_dev float32[2]")
+    check(_lib.load().pcaa_adam_advance(_p(step_dev), _p(coef_dev), float(lr), float(b1), float(b2), _s()),
+          "pcaa_adam_advance")
+
+
+def adam_step_dev_(p, g, m, v, b1, b2, eps, coef_dev, grad_scale=1.0, max_blocks=0):
+    """adam_step_ with the step-dependent scalars read from ``coef_dev`` (adam_advance_)."""
+    for nm, t in (("p", p), ("g", g), ("m", m), ("v", v)):
+        _chk(t, f"adam.{nm}", torch.float32)
+    _chk(coef_dev, "adam.coef_dev", torch.float32)
+    n = p.numel()
+    if not (g.numel() == m.numel() == v.numel() == n) or coef_dev.numel() != 2:
+        raise ValueError("adam_step_dev_: size mismatch")
+    check(_lib.load().pcaa_adam_step_dev(_p(p), _p(g), _p(m), _p(v), n, float(b1), float(b2), float(eps),
+                                         _p(coef_dev), float(grad_scale), int(max_blocks), _s()),
+          "pcaa_adam_step_dev")
+

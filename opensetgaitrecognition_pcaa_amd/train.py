@@ -54,16 +54,30 @@ class FlatBuffer:
                 p.data = self.p[o:o + n].view(p.shape)
                 self.grad_views[name] = self.g[o:o + n].view(p.shape)
         self.step = 0
+        # The optimizer's step count also lives on the device (int32 + the two bias-correction scalars
+        # derived from it by pcaa_adam_advance), so that a captured hipGraph of the train step replays
+        # without per-step host arguments; ``step`` is the host mirror (replays bump it).
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        self.coef_dev = torch.zeros(2, dtype=torch.float32, device=device)
+
+    def advance(self, lr, b1, b2):
+        """Begin the next optimizer step (once per step, before any adam() range of it)."""
+        self.step += 1
+        ops.adam_advance_(self.step_dev, self.coef_dev, lr, b1, b2)
+
+    def set_step(self, step):
+        self.step = int(step)
+        self.step_dev.fill_(self.step)
 
     def adam(self, lr, b1, b2, eps=1e-8, grad_scale=1.0, lo=0, hi=None, advance=True, max_blocks=0):
         """One Adam update of the elements [lo, hi) (default: everything).  ``advance=False``:
         a further range of the SAME optimizer step (the step count is shared)."""
         if advance:
-            self.step += 1
+            self.advance(lr, b1, b2)
         hi = self.total if hi is None else hi
         if hi > lo:
-            ops.adam_step_(self.p[lo:hi], self.g[lo:hi], self.m[lo:hi], self.v[lo:hi], lr, b1, b2, eps, self.step,
-                           grad_scale, max_blocks)
+            ops.adam_step_dev_(self.p[lo:hi], self.g[lo:hi], self.m[lo:hi], self.v[lo:hi], b1, b2, eps,
+                               self.coef_dev, grad_scale, max_blocks)
 
 
 class PCAATrainer:
@@ -103,6 +117,7 @@ class PCAATrainer:
             self.discriminator_projection_head = None
         self.discriminator_means = None
         self._flat_ready = False
+        self._graphs = {}
 
     # ------------------------------------------------------------------ setup
     def set_prior_means(self, means):
@@ -285,7 +300,7 @@ class PCAATrainer:
         early = self.early_decoder_adam and self.overlap_allreduce and self._side is not None
         hook = None
         if early:
-            self.flat_g.step += 1
+            self.flat_g.advance(cfg["LR"], cfg["B1"], cfg["B2"])
             done = []
 
             def launch_side_adam():
@@ -333,6 +348,46 @@ class PCAATrainer:
         tot = rec_loss + loss_g + (sup_loss if supervise else 0.0)
         return {"d_loss": d_losses[0], "gp": d_losses[1], "rec_loss": rec_loss, "loss_g": loss_g,
                 "sup_loss": sup_loss, "tot_loss": tot, "preds": preds, "out_labels": logits, "sup_fvs": sup_fv}
+
+    # ------------------------------------------------------------------ hipGraph replay of the step
+    def step_graphed(self, pcs, gt, z0, alphas, supervise=True, warmup=2):
+        """step() through a captured hipGraph.  The step is a fixed sequence of ~200 launches on four
+        streams with no host synchronisation and no per-step host scalar (the Adam step count lives on
+        the device), so it is captured once per (batch shape, supervise) and replayed: one graph launch
+        per step instead of ~200 enqueues, and the latency-bound parts (temporal block, heads, critic)
+        no longer wait for the host.  The first ``warmup`` calls of a shape run eagerly (lazy
+        initialisation, allocator warm-up), the next one captures; every call performs exactly one real
+        train step.  The returned tensors are the graph's static outputs: they are overwritten by the
+        next replay (clone what must survive)."""
+        key = (tuple(pcs.shape), tuple(pcs.stride()), bool(supervise))
+        ent = self._graphs.setdefault(key, {"eager": 0, "graph": None})
+        if ent["graph"] is None:
+            if ent["eager"] < warmup:
+                ent["eager"] += 1
+                return self.step(pcs, gt, z0, alphas, supervise)
+            static = [torch.empty_like(pcs), torch.empty_like(gt), torch.empty_like(z0), torch.empty_like(alphas)]
+            for dst, src in zip(static, (pcs, gt, z0, alphas)):
+                dst.copy_(src)
+            steps0 = (self.flat_g.step, self.flat_d.step)
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(self.device)
+            # capture records the launches without running them: parameters, Adam state, BatchNorm
+            # running statistics and the device-side step counts are untouched until the first replay
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                out = self.step(*static, supervise)
+            # the Python side of step() ran once during capture: that bump of the host step mirrors
+            # stands for the replay below
+            assert (self.flat_g.step, self.flat_d.step) == (steps0[0] + 1, steps0[1] + 1)
+            ent.update(graph=graph, static=static, out=out)
+            graph.replay()
+            return out
+        for dst, src in zip(ent["static"], (pcs, gt, z0, alphas)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        self.flat_g.step += 1
+        self.flat_d.step += 1
+        ent["graph"].replay()
+        return ent["out"]
 
     @torch.no_grad()
     def evaluate_batch(self, pcs, gt):

@@ -227,6 +227,50 @@ def test_v4_train_steps_vs_golden():
                     check_against_record(g, f"s{s}.param.{nm}.", name, v, 5e-5)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_v4_graphed_steps_match_eager_and_golden(precision):
+    """step_graphed (hipGraph capture + replay, device-side Adam step count) performs exactly the
+    steps step() does: same golden trajectory (fp32), and the same state as an eagerly stepped twin
+    after 4 steps (1 eager warm-up, 1 capture+replay, 2 replays with fresh inputs)."""
+    g, m = load_golden("v4_B6_N32_C4_K4")
+    B, N, C, K, steps = m["B"], m["N"], m["C"], m["K"], m["steps"]
+    twins = [_trainer_from_golden(m, precision), _trainer_from_golden(m, precision)]
+    for tr in twins:
+        tr.set_prior_means(torch.from_numpy(g["means"]))
+    keys = ("d_loss", "gp", "rec_loss", "loss_g", "sup_loss", "tot_loss")
+    for s in range(4):
+        pcs = syn.synthetic_pcs(B, T, N, C, seed=m["pcs_seed0"] + s).to(DEV).permute(0, 3, 1, 2)
+        gt = syn.synthetic_labels(B, K, seed=m["gt_seed0"] + s).to(DEV)
+        z0 = syn.synthetic_z0(B, 32, seed=m["z0_seed0"] + s).to(DEV)
+        al = syn.synthetic_alphas(B, seed=m["alpha_seed0"] + s).to(DEV)
+        ref = twins[0].step(pcs, gt, z0, al)
+        ref = {k: v.clone() for k, v in ref.items()}
+        out = twins[1].step_graphed(pcs, gt, z0, al, warmup=1)
+        got = np.array([out[k].item() for k in keys])
+        want = np.array([ref[k].item() for k in keys])
+        # both twins run the same kernels; only the order of the fp64 statistics atomics may differ.  In
+        # bf16 mode that noise decides bf16 roundings, which Adam's sign-like first steps amplify: the two
+        # trajectories agree to the bf16-mode tolerance (2e-2), not to round-off
+        assert np.allclose(got, want, rtol=1e-5 if precision == "fp32" else 2e-2, atol=1e-6 if precision == "fp32" else 2e-2), (s, got, want)
+        if precision == "fp32":
+            assert torch.equal(out["preds"], ref["preds"])
+            if s < steps:
+                tol = TOL if s == 0 else 5e-4 * s
+                assert np.allclose(got, g[f"s{s}.losses"], rtol=tol, atol=1e-5), (s, got, g[f"s{s}.losses"])
+                assert np.array_equal(out["preds"].cpu().numpy(), g[f"s{s}.preds"])
+    assert twins[1].flat_g.step == twins[0].flat_g.step == 4
+    assert int(twins[1].flat_g.step_dev.item()) == 4 and int(twins[1].flat_d.step_dev.item()) == 4
+    if precision == "fp32":
+        for a, b in ((twins[0].flat_g, twins[1].flat_g), (twins[0].flat_d, twins[1].flat_d)):
+            # Adam moves a parameter by at most lr per step: elements whose gradient is rounding noise
+            # may differ by a fraction of that, everything else agrees to fp32 round-off
+            assert float((a.p - b.p).abs().max()) <= 0.5e-4 * 4
+            assert float((a.p - b.p).abs().mean()) <= 1e-7
+        for (n0, v0), (n1, v1) in zip(twins[0].encoder.state_dict().items(), twins[1].encoder.state_dict().items()):
+            if n0.endswith("num_batches_tracked"):
+                assert int(v0) == int(v1) == 4, n0
+
+
 def test_v4_step_bf16_mode_close_to_fp32():
     """bf16-MFMA throughput mode: fp32 accumulation, bf16 PointNet activations.
     Stated tolerance: losses within 2e-2 relative, embeddings within 5e-2 of
