@@ -154,11 +154,14 @@ def main():
     # (graph mode: those steps run eagerly -- events cannot be read back from inside a replayed graph --
     # and the remaining steps of the timed region are graph replays)
     timed_steps = min(a.steps, 2 if use_graph else 4) if timer is not None else 0
+    host_s = 0.0
     t0 = time.perf_counter()
     for i in range(a.steps):
         if i == timed_steps:
             ops.set_timer(None)
+        h0 = time.perf_counter()
         out = tr.step(pcs, gt, z0, al) if i < timed_steps else run_step(pcs, gt, z0, al)
+        host_s += time.perf_counter() - h0
     barrier()
     dt = time.perf_counter() - t0
     ops.set_timer(None)
@@ -180,7 +183,9 @@ def main():
                                    f"B={B}/GPU T={T} N={N} C={C} K={K}, BASELINE config[1]",
                        "global_batch": B * world, "precision": a.precision,
                        "parallelism": f"dp{world}", "sync_bn": bool(a.sync_bn), "finite_loss": loss_ok,
-                       "hip_graph": bool(use_graph)},
+                       "hip_graph": bool(use_graph),
+                       # time the host spends enqueueing one step (no synchronisation inside step())
+                       "host_enqueue_ms_per_step": host_s / a.steps * 1e3},
         }
         if timer is not None:
             agg = timer.summary()

@@ -282,6 +282,26 @@ int pcaa_skinny_linear_dgrad(const float* dz, long lddz, const float* W, long ld
 int pcaa_skinny_linear_wgrad(const float* dz, long lddz, const float* x, long ldx, float* dW, long lddw,
                              int M, int N, int K, void* stream);
 
+/* ------------------------------------------------------------------ MLP heads, fused
+ * CGEncoder's MLP_sup1 / MLP_head / MLP_sup2 (models.py:252-277, applied at :285-292) and the
+ * decoder projection head Sequential(Linear(32,64), ELU) (PCAA_ablation.py:778-781) as one forward
+ * and one backward launch (fp32 FMAs, exact in both precision modes):
+ *   sup_fv = ELU(W1 x4 + b1)  [B,32];   h = ELU(Wh sup_fv + bh)  [B,16]   (Wh null: no projection head)
+ *   logits = ELU(W2 (h | sup_fv) + b2)  [B,K];   hproj = ELU(Wg sup_fv + bg)  [B,64]   (Wg null: skipped)
+ * Backward: d_logits / d_hproj are gradients w.r.t. those (post-ELU) outputs, d_sup is whatever else
+ * arrives at sup_fv (critic, decoder without head); any of the three may be null.  All weight / bias
+ * gradients and dx4 [B,512] are WRITTEN (not accumulated).  pcaa_heads_supported: widths
+ * 512/32/(16|0)/(64|0); the backward keeps all rows in LDS: B <= 64, K <= 8. */
+int pcaa_heads_supported(int B, int K, int d_in, int d_sup, int d_head, int d_proj, int backward);
+int pcaa_heads_fwd(const float* x4, const float* W1, const float* b1, const float* Wh, const float* bh,
+                   const float* W2, const float* b2, const float* Wg, const float* bg, float* sup_fv,
+                   float* h, float* logits, float* hproj, int B, int K, void* stream);
+int pcaa_heads_bwd(const float* x4, const float* sup_fv, const float* h, const float* logits,
+                   const float* hproj, const float* W1, const float* Wh, const float* W2,
+                   const float* Wg, const float* d_logits, const float* d_sup, const float* d_hproj,
+                   float* dW1, float* db1, float* dWh, float* dbh, float* dW2, float* db2, float* dWg,
+                   float* dbg, float* dx4, int B, int K, void* stream);
+
 /* ------------------------------------------------------------------ optimizer
  * torch.optim.Adam (no weight decay, no amsgrad; PCAA_ablation.py:820-833) on a
  * flat fp32 buffer. `step` is the 1-based step count after this update.  max_blocks (0 =

@@ -26,6 +26,24 @@ _PRECISION = {"mode": "fp32"}
 _SYNC_BN = {"group": None}
 
 
+# Optional section marks: with a list installed (set_marks), mark(name) records a timing event on the
+# current stream at a few section boundaries of the step (tools/step_sections.py prints the elapsed
+# times between them).  Off by default: no events, no cost.
+_MARKS = None
+
+
+def set_marks(lst):
+    global _MARKS
+    _MARKS = lst
+
+
+def mark(name):
+    if _MARKS is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        _MARKS.append((name, ev))
+
+
 def set_precision(mode: str):
     if mode not in ("fp32", "bf16"):
         raise ValueError("precision must be 'fp32' or 'bf16'")
@@ -496,7 +514,32 @@ class EncoderState:
     pass
 
 
-def encoder_forward(enc, x, training, mode=None):
+_FUSE_HEADS = os.environ.get("PCAA_FUSE_HEADS", "1") != "0"
+
+
+def _heads_mods(enc, gph):
+    l1 = enc.MLP_sup1[0]
+    lh = enc.MLP_head[0] if enc.use_projection_head else None
+    l2 = enc.MLP_sup2[0]
+    lg = gph[0] if gph is not None else None
+    return l1, lh, l2, lg
+
+
+def _heads_fusable(enc, gph, B, backward):
+    if not _FUSE_HEADS:
+        return False
+    l1, lh, l2, lg = _heads_mods(enc, gph)
+    return ops.heads_supported(B, l2.weight.shape[0], l1.weight.shape[1], l1.weight.shape[0],
+                               lh.weight.shape[0] if lh is not None else 0,
+                               lg.weight.shape[0] if lg is not None else 0, backward) and \
+        l2.weight.shape[1] == (lh.weight.shape[0] if lh is not None else l1.weight.shape[0]) and \
+        (lg is None or lg.weight.shape[1] == l1.weight.shape[0]) and \
+        (lh is None or lh.weight.shape[1] == l1.weight.shape[0])
+
+
+def encoder_forward(enc, x, training, mode=None, gph=None):
+    """``gph``: optional decoder projection head ``Sequential(Linear(32,64), ELU)`` evaluated in the
+    same launch as the MLP heads (``st.hproj``)."""
     mode = get_precision() if mode is None else mode
     _require_gpu(x, "CGEncoder")
     if x.dim() != 4:
@@ -512,23 +555,39 @@ def encoder_forward(enc, x, training, mode=None):
     st.B, st.C, st.T, st.N, st.mode, st.training = B, C, T, N, mode, training
     xp = _point_major(x).view(B * T * N, C)
     st.xp = xp
+    mark("enc_fwd.begin")
     x2, st.pn = pointnet_forward(xp, enc.pc_block.layers(), training, mode, pool_rows=N)   # [B*T, 1024]
     st.x2 = x2
+    mark("enc_fwd.pointnet")
     x4, st.dtc = dtc_forward(x2, B, T, enc.tc_block.layers(), training, pool_time=True)     # [B, 512]
     st.x4 = x4
+    mark("enc_fwd.dtc")
+    st.h = st.hproj = None
+    if _heads_fusable(enc, gph, B, False):
+        m1, mh, m2, mg = _heads_mods(enc, gph)
+        st.sup_fv, st.h, st.logits, st.hproj = ops.heads_fwd(
+            x4, m1.weight, m1.bias, mh.weight if mh is not None else None, mh.bias if mh is not None else None,
+            m2.weight, m2.bias, mg.weight if mg is not None else None, mg.bias if mg is not None else None)
+        return st.logits, st.sup_fv, st
     st.sup_fv = linear_act_forward(x4, enc.MLP_sup1[0], ACT_ELU)
     h = st.sup_fv
     if enc.use_projection_head:
         st.h = linear_act_forward(st.sup_fv, enc.MLP_head[0], ACT_ELU)
         h = st.h
     st.logits = linear_act_forward(h, enc.MLP_sup2[0], ACT_ELU)
+    if gph is not None:
+        st.hproj = linear_act_forward(st.sup_fv, gph[0], ACT_ELU)
     return st.logits, st.sup_fv, st
 
 
-def encoder_backward(enc, st, d_logits, d_supfv, need_dx=False, gout=None, before_pointnet=None):
+def encoder_backward(enc, st, d_logits, d_supfv, need_dx=False, gout=None, before_pointnet=None,
+                     gph=None, d_hproj=None, gph_gout=None, after_heads=None):
     """Returns ({state_dict-style name: grad}, dx [B,C,T,N] view or None).
     ``gout``: optional {name: gradient view}; split-K products accumulate into
-    them, so they must arrive ZEROED (the trainer zeroes its flat buffer once)."""
+    them, so they must arrive ZEROED (the trainer zeroes its flat buffer once).
+    ``gph`` / ``d_hproj`` / ``gph_gout``: the decoder projection head evaluated by encoder_forward(gph=...),
+    the gradient w.r.t. its output and optional (dW, db) destinations: its backward runs in the heads'
+    launch; its gradients are returned under "GPH.0.weight" / "GPH.0.bias"."""
     if not st.training:
         raise RuntimeError("CGEncoder backward in eval mode is not implemented on the HIP path "
                            "(the reference only differentiates the train-mode encoder)")
@@ -538,32 +597,65 @@ def encoder_backward(enc, st, d_logits, d_supfv, need_dx=False, gout=None, befor
     def dst(name):
         return (gout[name + ".weight"], gout[name + ".bias"]) if gout is not None else (None, None)
 
-    dsup = d_supfv.contiguous().clone() if d_supfv is not None else torch.zeros_like(st.sup_fv)
-    if d_logits is not None:
-        h = st.h if enc.use_projection_head else st.sup_fv
-        w_o, b_o = dst("MLP_sup2.0")
-        if enc.use_projection_head:
-            dW, db, dh = linear_act_backward(h, st.logits, enc.MLP_sup2[0], ACT_ELU, d_logits.contiguous(),
-                                             dW_out=w_o, db_out=b_o)
-            g["MLP_sup2.0.weight"], g["MLP_sup2.0.bias"] = dW, db
-            w_o, b_o = dst("MLP_head.0")
-            dW, db, dsup = linear_act_backward(st.sup_fv, st.h, enc.MLP_head[0], ACT_ELU, dh, dx_init=dsup,
-                                               dW_out=w_o, db_out=b_o)
-            g["MLP_head.0.weight"], g["MLP_head.0.bias"] = dW, db
-        else:
-            dW, db, dsup = linear_act_backward(h, st.logits, enc.MLP_sup2[0], ACT_ELU, d_logits.contiguous(),
-                                               dx_init=dsup, dW_out=w_o, db_out=b_o)
-            g["MLP_sup2.0.weight"], g["MLP_sup2.0.bias"] = dW, db
+    if d_hproj is not None and (gph is None or st.hproj is None):
+        raise RuntimeError("encoder_backward: d_hproj needs the head passed to encoder_forward(gph=...)")
+    if _heads_fusable(enc, gph if d_hproj is not None else None, B, True):
+        m1, mh, m2, mg = _heads_mods(enc, gph if d_hproj is not None else None)
+        outs = {}
+        outs["dW1"], outs["db1"] = dst("MLP_sup1.0")
+        outs["dW2"], outs["db2"] = dst("MLP_sup2.0")
+        if mh is not None:
+            outs["dWh"], outs["dbh"] = dst("MLP_head.0")
+        if mg is not None and gph_gout is not None:
+            outs["dWg"], outs["dbg"] = gph_gout
+        outs, dx4 = ops.heads_bwd(
+            st.x4, st.sup_fv, st.h, st.logits, st.hproj if mg is not None else None, m1.weight,
+            mh.weight if mh is not None else None, m2.weight, mg.weight if mg is not None else None,
+            d_logits.contiguous() if d_logits is not None else None,
+            d_supfv.contiguous() if d_supfv is not None else None,
+            d_hproj.contiguous() if mg is not None else None, outs)
+        g["MLP_sup1.0.weight"], g["MLP_sup1.0.bias"] = outs["dW1"], outs["db1"]
+        g["MLP_sup2.0.weight"], g["MLP_sup2.0.bias"] = outs["dW2"], outs["db2"]
+        if mh is not None:
+            g["MLP_head.0.weight"], g["MLP_head.0.bias"] = outs["dWh"], outs["dbh"]
+        if mg is not None:
+            g["GPH.0.weight"], g["GPH.0.bias"] = outs["dWg"], outs["dbg"]
     else:
-        for nm in ("MLP_sup2.0", "MLP_head.0"):
-            mod = getattr(enc, nm.split(".")[0], None)
-            if mod is not None:
-                g[nm + ".weight"] = gout[nm + ".weight"] if gout is not None else torch.zeros_like(mod[0].weight)
-                g[nm + ".bias"] = gout[nm + ".bias"] if gout is not None else torch.zeros_like(mod[0].bias)
-    w_o, b_o = dst("MLP_sup1.0")
-    dW, db, dx4 = linear_act_backward(st.x4, st.sup_fv, enc.MLP_sup1[0], ACT_ELU, dsup, dW_out=w_o, db_out=b_o)
-    g["MLP_sup1.0.weight"], g["MLP_sup1.0.bias"] = dW, db
+        dsup = d_supfv.contiguous().clone() if d_supfv is not None else torch.zeros_like(st.sup_fv)
+        if d_hproj is not None:
+            gw, gb = gph_gout if gph_gout is not None else (None, None)
+            dW, db, dsup = linear_act_backward(st.sup_fv, st.hproj, gph[0], ACT_ELU, d_hproj.contiguous(),
+                                               dx_init=dsup, dW_out=gw, db_out=gb)
+            g["GPH.0.weight"], g["GPH.0.bias"] = dW, db
+        if d_logits is not None:
+            h = st.h if enc.use_projection_head else st.sup_fv
+            w_o, b_o = dst("MLP_sup2.0")
+            if enc.use_projection_head:
+                dW, db, dh = linear_act_backward(h, st.logits, enc.MLP_sup2[0], ACT_ELU, d_logits.contiguous(),
+                                                 dW_out=w_o, db_out=b_o)
+                g["MLP_sup2.0.weight"], g["MLP_sup2.0.bias"] = dW, db
+                w_o, b_o = dst("MLP_head.0")
+                dW, db, dsup = linear_act_backward(st.sup_fv, st.h, enc.MLP_head[0], ACT_ELU, dh, dx_init=dsup,
+                                                   dW_out=w_o, db_out=b_o)
+                g["MLP_head.0.weight"], g["MLP_head.0.bias"] = dW, db
+            else:
+                dW, db, dsup = linear_act_backward(h, st.logits, enc.MLP_sup2[0], ACT_ELU, d_logits.contiguous(),
+                                                   dx_init=dsup, dW_out=w_o, db_out=b_o)
+                g["MLP_sup2.0.weight"], g["MLP_sup2.0.bias"] = dW, db
+        else:
+            for nm in ("MLP_sup2.0", "MLP_head.0"):
+                mod = getattr(enc, nm.split(".")[0], None)
+                if mod is not None:
+                    g[nm + ".weight"] = gout[nm + ".weight"] if gout is not None else torch.zeros_like(mod[0].weight)
+                    g[nm + ".bias"] = gout[nm + ".bias"] if gout is not None else torch.zeros_like(mod[0].bias)
+        w_o, b_o = dst("MLP_sup1.0")
+        dW, db, dx4 = linear_act_backward(st.x4, st.sup_fv, enc.MLP_sup1[0], ACT_ELU, dsup, dW_out=w_o, db_out=b_o)
+        g["MLP_sup1.0.weight"], g["MLP_sup1.0.bias"] = dW, db
+    mark("enc_bwd.heads")
+    if after_heads is not None:
+        after_heads()            # trainer hook: the heads' backward is enqueued, the temporal block follows
     dg, dx2 = dtc_backward(st.dtc, enc.tc_block.layers(), B, T, dpool=dx4, need_dx=True, gout=gout)
+    mark("enc_bwd.dtc")
     for i, d in enumerate(dg, start=1):
         for k, v in d.items():
             g[f"tc_block.dtc{i}.{k}"] = v
@@ -574,6 +666,7 @@ def encoder_backward(enc, st, d_logits, d_supfv, need_dx=False, gout=None, befor
     for i, d in enumerate(pg, start=1):
         for k, v in d.items():
             g[f"pc_block.pointnet{i}.{k}"] = v
+    mark("enc_bwd.pointnet")
     dx = None
     if need_dx:
         dx = dxp.float().view(B, T, N, st.C).permute(0, 3, 1, 2)

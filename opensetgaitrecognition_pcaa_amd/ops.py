@@ -805,3 +805,62 @@ def adam_step_dev_(p, g, m, v, b1, b2, eps, coef_dev, grad_scale=1.0, max_blocks
                                          _p(coef_dev), float(grad_scale), int(max_blocks), _s()),
           "pcaa_adam_step_dev")
 
+
+# ------------------------------------------------------------------ fused MLP heads (heads.hip)
+def heads_supported(B, K, d_in, d_sup, d_head, d_proj, backward):
+    return bool(_lib.load().pcaa_heads_supported(int(B), int(K), int(d_in), int(d_sup), int(d_head), int(d_proj),
+                                                 1 if backward else 0))
+
+
+def heads_fwd(x4, W1, b1, Wh, bh, W2, b2, Wg=None, bg=None):
+    """One launch for MLP_sup1 -> (MLP_head) -> MLP_sup2 and, if given, the decoder projection head.
+    Returns (sup_fv [B,32], h [B,16] or None, logits [B,K], hproj [B,64] or None)."""
+    _chk(x4, "heads_fwd.x4", torch.float32, 2)
+    for nm, t in (("W1", W1), ("b1", b1), ("W2", W2), ("b2", b2)):
+        _chk(t, f"heads_fwd.{nm}", torch.float32)
+    B, K = x4.shape[0], W2.shape[0]
+    d_head = Wh.shape[0] if Wh is not None else 0
+    d_proj = Wg.shape[0] if Wg is not None else 0
+    if (tuple(W1.shape) != (32, x4.shape[1]) or W2.shape[1] != (d_head or 32)
+            or not heads_supported(B, K, x4.shape[1], 32, d_head, d_proj, False)):
+        raise ValueError(f"heads_fwd: unsupported shapes x4 {tuple(x4.shape)} W1 {tuple(W1.shape)} W2 {tuple(W2.shape)}")
+    dev = x4.device
+    sup = torch.empty((B, 32), dtype=torch.float32, device=dev)
+    h = torch.empty((B, d_head), dtype=torch.float32, device=dev) if Wh is not None else None
+    logits = torch.empty((B, K), dtype=torch.float32, device=dev)
+    hproj = torch.empty((B, d_proj), dtype=torch.float32, device=dev) if Wg is not None else None
+    check(_lib.load().pcaa_heads_fwd(_p(x4), _p(W1), _p(b1), _p(Wh), _p(bh), _p(W2), _p(b2), _p(Wg), _p(bg),
+                                     _p(sup), _p(h), _p(logits), _p(hproj), B, K, _s()), "pcaa_heads_fwd")
+    return sup, h, logits, hproj
+
+
+def heads_bwd(x4, sup_fv, h, logits, hproj, W1, Wh, W2, Wg, d_logits, d_sup, d_hproj, outs=None):
+    """One launch for the backward of heads_fwd.  ``outs``: optional dict of destination views
+    (dW1, db1, dWh, dbh, dW2, db2, dWg, dbg) -- missing ones are allocated.  Returns (grads dict, dx4)."""
+    B, K = x4.shape[0], W2.shape[0]
+    for nm, t in (("x4", x4), ("sup_fv", sup_fv), ("logits", logits), ("W1", W1), ("W2", W2)):
+        _chk(t, f"heads_bwd.{nm}", torch.float32)
+    for nm, t, shape in (("d_logits", d_logits, (B, K)), ("d_sup", d_sup, (B, 32)), ("d_hproj", d_hproj, (B, 64))):
+        if t is not None:
+            _chk(t, f"heads_bwd.{nm}", torch.float32)
+            if tuple(t.shape) != shape:
+                raise ValueError(f"heads_bwd.{nm}: shape {tuple(t.shape)}, expected {shape}")
+    outs = dict(outs or {})
+    dev = x4.device
+    want = {"dW1": W1, "db1": W1.shape[0], "dW2": W2, "db2": K}
+    if Wh is not None:
+        want.update(dWh=Wh, dbh=Wh.shape[0])
+    if d_hproj is not None:
+        want.update(dWg=Wg, dbg=Wg.shape[0])
+    for k, like in want.items():
+        if outs.get(k) is None:
+            outs[k] = (torch.empty_like(like) if isinstance(like, torch.Tensor)
+                       else torch.empty(like, dtype=torch.float32, device=dev))
+        _chk(outs[k], f"heads_bwd.{k}", torch.float32)
+    dx4 = torch.empty_like(x4)
+    check(_lib.load().pcaa_heads_bwd(_p(x4), _p(sup_fv), _p(h), _p(logits), _p(hproj), _p(W1), _p(Wh), _p(W2),
+                                     _p(Wg), _p(d_logits), _p(d_sup), _p(d_hproj), _p(outs["dW1"]), _p(outs["db1"]),
+                                     _p(outs.get("dWh")), _p(outs.get("dbh")), _p(outs["dW2"]), _p(outs["db2"]),
+                                     _p(outs.get("dWg")), _p(outs.get("dbg")), _p(dx4), B, K, _s()), "pcaa_heads_bwd")
+    return outs, dx4
+

@@ -217,7 +217,9 @@ class PCAATrainer:
         self._enc_region.zero_()
 
         # (1) encoder forward (train-mode BatchNorm)
-        logits, sup_fv, st = F_hip.encoder_forward(enc, pcs, True, mode)
+        # (the decoder projection head rides in the launch of the MLP heads)
+        logits, sup_fv, st = F_hip.encoder_forward(enc, pcs, True, mode, gph=self.decoder_projection_head)
+        F_hip.mark("heads_fwd")
         # (2) cross-entropy, its gradient and the predicted labels in one launch
         sup_loss, dlogits, preds = ops.cross_entropy(logits, gt, want_loss=True, want_grad=supervise,
                                                      grad_scale=1.0, want_preds=True)
@@ -255,37 +257,36 @@ class PCAATrainer:
             d_losses, loss_g, dsup = critic_branch()
 
         # (4) G-step forward: decoder + Chamfer (+ fused gradient)
-        if self.decoder_projection_head is not None:
-            hproj = F_hip.linear_act_forward(sup_fv, self.decoder_projection_head[0], ACT_ELU)
-        else:
-            hproj = sup_fv
+        hproj = st.hproj if self.decoder_projection_head is not None else sup_fv
         rec, acts = F_hip.decoder_forward(dec, hproj, mode)
+        F_hip.mark("dec_fwd")
         rec4 = rec.view(B, self.C, self.T, self.N)
         inv_bt = 1.0 / (B * self.T)
         frame_loss, drec = ops.chamfer(rec4, pcs, want_grad=True, grad_scale=inv_bt)
         rec_loss = ops.total(frame_loss, inv_bt)
 
+        F_hip.mark("chamfer")
         # (5) G-step backward (the adversarial gradient w.r.t. sup_fvs seeds the accumulation)
         F_hip.set_wgrad_stream(self._wg)
         if joined is not None and self.decoder_projection_head is None:
             torch.cuda.current_stream().wait_event(joined)
             joined = None
+        dh = None
         if self.decoder_projection_head is not None:
+            # the head's own backward (dh -> dsup, dW, db) runs inside the heads' backward launch below
             _, dh = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads, mode=mode)
             if joined is not None:
                 torch.cuda.current_stream().wait_event(joined)
-            gv = self.flat_g.grad_views
-            _, _, dsup = F_hip.linear_act_backward(sup_fv, hproj, self.decoder_projection_head[0], ACT_ELU, dh,
-                                                   dx_init=dsup, dW_out=gv["GPH.0.weight"], db_out=gv["GPH.0.bias"])
         else:
             _, dsup = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads, dz_init=dsup, mode=mode)
-        # [GPH | decoder] gradients are final here.  Data-parallel: their all-reduce goes out now, in a few
-        # chunks (the collectives of one communicator run in order), so that the side-stream Adam of chunk i
-        # overlaps the all-reduce of chunk i+1 instead of waiting for all 628 MB.
+        # The decoder's gradients are final here (the projection head's follow with the encoder's: its backward
+        # runs in the MLP heads' launch).  Data-parallel: their all-reduce goes out now, in a few chunks (the
+        # collectives of one communicator run in order), so that the side-stream Adam of chunk i overlaps the
+        # all-reduce of chunk i+1 instead of waiting for all 628 MB.
+        F_hip.mark("dec_bwd")
         pending = []                               # (lo, hi, work) in flat_g coordinates
         if self.overlap_allreduce:
-            enc_end = self._enc_region.numel()
-            bounds = [enc_end, self._dec_start] if self._dec_start > enc_end else [enc_end]
+            bounds = [self._dec_start]
             collective = self.pg is not None and (self.world > 1 or self._force_collectives)
             if collective and self._wg is not None:
                 torch.cuda.current_stream().wait_stream(self._wg)   # the decoder's dW/db were written on that stream
@@ -298,7 +299,7 @@ class PCAATrainer:
             for lo, hi in zip(bounds[:-1], bounds[1:]):
                 pending.append((lo, hi, self._allreduce(self.flat_g.g[lo:hi], async_op=True)))
         early = self.early_decoder_adam and self.overlap_allreduce and self._side is not None
-        hook = None
+        hook = hook_heads = None
         if early:
             self.flat_g.advance(cfg["LR"], cfg["B1"], cfg["B2"])
             done = []
@@ -323,17 +324,22 @@ class PCAATrainer:
 
             if self._side_adam_at == "pointnet":
                 hook = launch_side_adam                 # beside the MFMA-bound PointNet backward
+            elif self._side_adam_at == "dtc":
+                hook_heads = launch_side_adam           # beside the temporal-conv backward, after the heads' launch
             else:
-                launch_side_adam()                      # beside the temporal-conv / head backward
+                launch_side_adam()                      # right after the decoder backward
         try:
+            gv = self.flat_g.grad_views
             F_hip.encoder_backward(enc, st, dlogits if supervise else None, dsup, gout=self._enc_grads,
-                                   before_pointnet=hook)
+                                   before_pointnet=hook, after_heads=hook_heads,
+                                   gph=self.decoder_projection_head, d_hproj=dh,
+                                   gph_gout=(gv["GPH.0.weight"], gv["GPH.0.bias"]) if dh is not None else None)
         finally:
             F_hip.set_wgrad_stream(None)
         if self._wg is not None:
             torch.cuda.current_stream().wait_stream(self._wg)       # its products feed the all-reduce / Adam below
         if self.overlap_allreduce:
-            self._allreduce(self._enc_region)
+            self._allreduce(self.flat_g.g[:self._dec_start])      # encoder + projection head
             for _, _, work in pending:
                 if work is not None:
                     work.wait()         # stream-side wait, no host block
@@ -345,6 +351,7 @@ class PCAATrainer:
         else:
             self.flat_g.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs)
 
+        F_hip.mark("adam+join")
         tot = rec_loss + loss_g + (sup_loss if supervise else 0.0)
         return {"d_loss": d_losses[0], "gp": d_losses[1], "rec_loss": rec_loss, "loss_g": loss_g,
                 "sup_loss": sup_loss, "tot_loss": tot, "preds": preds, "out_labels": logits, "sup_fvs": sup_fv}

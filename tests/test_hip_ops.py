@@ -480,3 +480,71 @@ def test_pointnet_input_layer_kernels(P, C, cout, dtype):
     dW_rec = ops.pointnet_in_bwd_wgrad(da, x, W, scale, shift, coef).cpu().double()
     wtol = 2e-5 if dtype == torch.float32 else 2e-3
     assert (dW_rec - dW_ref).abs().max().item() <= wtol * max(1e-3, dW_ref.abs().max().item())
+
+
+# ---------------------------------------------------------------- fused MLP heads (heads.hip)
+@pytest.mark.parametrize("B,K,head,proj,sup", [(64, 8, True, True, True), (6, 4, True, True, True),
+                                               (16, 6, False, False, True), (37, 2, True, False, False),
+                                               (5, 8, False, True, True)])
+def test_heads_fwd_bwd_vs_fp64_autograd(B, K, head, proj, sup):
+    """One-launch forward / backward of MLP_sup1 -> (MLP_head) -> MLP_sup2 (+ decoder projection head)
+    against fp64 torch autograd of the same layers (reference models.py:285-292, PCAA_ablation.py:778-781)."""
+    d2 = 16 if head else 32
+    x4 = _rand((B, 512), 1)
+    P = {"W1": _rand((32, 512), 2, 512 ** -0.5), "b1": _rand((32,), 3, 0.1),
+         "W2": _rand((K, d2), 4, d2 ** -0.5), "b2": _rand((K,), 5, 0.1)}
+    if head:
+        P.update(Wh=_rand((16, 32), 6, 32 ** -0.5), bh=_rand((16,), 7, 0.1))
+    if proj:
+        P.update(Wg=_rand((64, 32), 8, 32 ** -0.5), bg=_rand((64,), 9, 0.1))
+    d_logits, d_sup, d_hproj = _rand((B, K), 10), _rand((B, 32), 11) if sup else None, _rand((B, 64), 12) if proj else None
+    # fp64 reference
+    R = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    xr = x4.double().requires_grad_(True)
+    elu = torch.nn.functional.elu
+    sup_r = elu(xr @ R["W1"].t() + R["b1"])
+    h_r = elu(sup_r @ R["Wh"].t() + R["bh"]) if head else sup_r
+    log_r = elu(h_r @ R["W2"].t() + R["b2"])
+    obj = (log_r * d_logits.double()).sum()
+    if sup:
+        obj = obj + (sup_r * d_sup.double()).sum()
+    if proj:
+        hp_r = elu(sup_r @ R["Wg"].t() + R["bg"])
+        obj = obj + (hp_r * d_hproj.double()).sum()
+    obj.backward()
+    # HIP
+    G = {k: v.to(DEV) for k, v in P.items()}
+    xg = x4.to(DEV)
+    s, h, lg, hp = ops.heads_fwd(xg, G["W1"], G["b1"], G.get("Wh"), G.get("bh"), G["W2"], G["b2"], G.get("Wg"), G.get("bg"))
+
+    def close(a, ref, what, tol=2e-5):
+        err = (a.cpu().double() - ref.detach()).abs().max().item()
+        assert err <= tol * max(ref.detach().abs().max().item(), 1e-3), (what, err)
+
+    close(s, sup_r, "sup_fv"); close(lg, log_r, "logits")
+    if head:
+        close(h, h_r, "h")
+    if proj:
+        close(hp, hp_r, "hproj")
+    if B > 64:
+        return
+    outs, dx4 = ops.heads_bwd(xg, s, h, lg, hp, G["W1"], G.get("Wh"), G["W2"], G.get("Wg"), d_logits.to(DEV),
+                              d_sup.to(DEV) if sup else None, d_hproj.to(DEV) if proj else None)
+    close(dx4, xr.grad, "dx4")
+    for k, nm in (("dW1", "W1"), ("db1", "b1"), ("dW2", "W2"), ("db2", "b2"), ("dWh", "Wh"), ("dbh", "bh"),
+                  ("dWg", "Wg"), ("dbg", "bg")):
+        if nm in R:
+            close(outs[k], R[nm].grad, k)
+
+
+def test_heads_fwd_large_batch_and_unsupported_backward():
+    B, K = 1024, 8
+    x4 = _rand((B, 512), 21).to(DEV)
+    W1, b1 = _rand((32, 512), 22, 0.05).to(DEV), _rand((32,), 23, 0.1).to(DEV)
+    W2, b2 = _rand((K, 32), 24, 0.2).to(DEV), _rand((K,), 25, 0.1).to(DEV)
+    s, h, lg, hp = ops.heads_fwd(x4, W1, b1, None, None, W2, b2)
+    ref = torch.nn.functional.elu(x4.double() @ W1.double().t() + b1.double())
+    assert (s.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    assert h is None and hp is None and tuple(lg.shape) == (B, K)
+    assert not ops.heads_supported(B, K, 512, 32, 0, 0, True)      # backward keeps all rows in LDS: B <= 64
+    assert not ops.heads_supported(8, K, 256, 32, 0, 0, False)
