@@ -282,6 +282,23 @@ int pcaa_skinny_linear_dgrad(const float* dz, long lddz, const float* W, long ld
 int pcaa_skinny_linear_wgrad(const float* dz, long lddz, const float* x, long ldx, float* dW, long lddw,
                              int M, int N, int K, void* stream);
 
+/* ------------------------------------------------------------------ temporal block, fused forward
+ * One DilTempConv1d layer (models.py:37-79) in one launch: implicit im2col of the causal dilated
+ * convolution, the previous layer's BatchNorm+ELU applied while its bias-free output `src` is staged
+ * (scale/shift null: src is the block input, used as is), y[B*T,cout] = bias-free pre-BN output,
+ * BatchNorm statistics of y (fp64 sums into stats[nrep][2][cout], as pcaa_gemm's colstats) and,
+ * if col != null, the im2col matrix col[B*T, cin*3] (layout of pcaa_dtc_im2col) that the weight
+ * gradient contracts with.  W = conv1d.weight viewed [cout, cin*3].  Exact-fp32 MFMA.
+ * ksplit > 1 cuts the input channels over workgroups: split z writes its partial product to
+ * y + z*slab_stride (y then holds ksplit slabs, stats must be null) and pcaa_splitk_reduce_stats
+ * finishes the sum and the statistics.
+ * pcaa_dtc_conv_supported: T <= 32, cin % 4 == 0, cout % 16 == 0. */
+int pcaa_dtc_conv_supported(int T, int cin, int cout);
+int pcaa_dtc_conv_ksplit(int B, int cin, int cout);   /* the ksplit to pass: >= cin/256, 8 for few long tiles */
+int pcaa_dtc_conv_fwd(const float* src, const float* scale, const float* shift, const float* W, float* y,
+                      float* col, double* stats, int nrep, int B, int T, int cin, int cout, int dilation,
+                      int ksplit, long slab_stride, void* stream);
+
 /* ------------------------------------------------------------------ MLP heads, fused
  * CGEncoder's MLP_sup1 / MLP_head / MLP_sup2 (models.py:252-277, applied at :285-292) and the
  * decoder projection head Sequential(Linear(32,64), ELU) (PCAA_ablation.py:778-781) as one forward

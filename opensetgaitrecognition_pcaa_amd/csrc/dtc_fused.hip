@@ -1,0 +1,224 @@
+// TemporalConvolutionBlock forward (reference models.py:37-79, 108-160), one launch per layer:
+//
+//   y_l[(b,t)][co] = sum_{ci,tap} W_l[co][ci][tap] * a_{l-1}[b][t-(2-tap)*d][ci]      (causal, zero for t<0)
+//   a_{l-1} = ELU(scale_{l-1} * y_{l-1} + shift_{l-1})   applied once, while the sequence is staged (layer 1: the input as is)
+//
+// The block holds 0.08 % of the step's FLOPs (2.2 GFLOP forward at B=64) in six layers that each need
+// the BatchNorm statistics of ALL B*T rows of the layer before: the unfused path spent 310 us here in 29
+// launches (im2col, 128x128-tile MFMA GEMM, split-K reduction, finalize, BN+ELU pass per layer).  This
+// kernel does BN/ELU-on-load + implicit im2col + the contraction + the BatchNorm statistics of its own
+// output in one launch on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: an fmaf chain, so fp32 mode keeps
+// its parity and bf16 mode shares the path).  One workgroup = one sequence (T <= 32 rows) x 32 output
+// channels:
+//   * the activated sequence tile a[T][channels] is staged in LDS ONCE (coalesced 16-B loads, one ELU per
+//     element); the causal shifts of the three taps are row offsets of the MFMA's A-fragment reads into
+//     that tile (a dedicated zero row serves t < 0), so im2col never exists as data on the forward path;
+//   * the contraction runs tap-major inside 32-channel chunks (k' = tap*32 + ci: any order is valid as
+//     long as both operands share it), so a lane's four consecutive k' are four consecutive channels:
+//     one 16-B LDS read per operand feeds four MFMAs;
+//   * per chunk only the weights move: 32 x 96 floats, contiguous in HBM, scattered tap-major into LDS;
+//   * the four waves split each chunk's contraction on the same 32x32 tile and are combined through
+//     LDS at the end, where the tile is stored and its column sums go to the fp64 statistics.
+// Earlier forms, measured at B=64 (us for the 256->512 layer): gathering im2col elements one by one
+// with BN+ELU per gathered element 50-80 (24 scalar loads per thread and chunk: load-issue bound, not
+// the expm1f), plain-FMA register tiles 80 (the non-packed fp32 VALU peaks at half the fp32-MFMA rate).
+// The first column tile also writes the im2col matrix the BACKWARD's weight gradient contracts with.
+#include "common.h"
+
+namespace {
+
+constexpr int ROWS = 32;   // rows (time steps) per workgroup, T <= ROWS
+
+struct DtcFwdParams {
+  const float* src;     // [B*T, cin]: block input (layer 1) or the previous layer's bias-free pre-BN output
+  const float* scale;   // [cin] BatchNorm+ELU of the previous layer applied on load; null: src used as is
+  const float* shift;
+  const float* W;       // [cout, cin*3], k = ci*3 + tap
+  float* y;             // [B*T, cout]
+  float* col;           // [B*T, cin*3] (im2col of the activated input) or null
+  double* stats;        // [nrep][2][cout] fp64 sums (sum, sum of squares) or null
+  int B, T, cin, cout, dil, nrep;
+  long slab_stride;     // gridDim.z > 1: split z writes its partial product to y + z*slab_stride
+};
+
+constexpr int CC = 32;              // input channels per chunk: 3*CC = 96-deep contraction per trip
+constexpr int WP = 3 * CC + 4;      // weight tile pitch: 36*row mod 64 walks all 16 four-bank groups
+constexpr int MAX_CR = 256;         // channels of the activated sequence tile one workgroup keeps in LDS
+constexpr int ZROW = ROWS;          // index of the all-zero row of that tile
+
+// ELU for the staging path.  Relative error <= 3e-7 over the whole range: a degree-6 Taylor polynomial
+// where exp(z)-1 would cancel (|z| < 0.25, truncation z^7/5040), v_exp_f32 elsewhere (|result| >= 0.22).
+__device__ __forceinline__ float elu_stage(float z) {
+  if (z > 0.f) return z;
+  const float poly = z * (1.f + z * (0.5f + z * (1.f / 6 + z * (1.f / 24 + z * (1.f / 120 + z * (1.f / 720))))));
+  return z > -0.25f ? poly : __expf(z) - 1.f;
+}
+
+// gridDim.z > 1 splits the input channels over workgroups (the 1024->16 layer: 64 workgroups walking
+// K = 3072 was one long chain of load latencies): split z writes its partial tile to y + z*slab_stride
+// and pcaa_splitk_reduce_stats finishes the sum and the statistics.
+__global__ __launch_bounds__(256) void dtc_fwd_kernel(DtcFwdParams p) {
+  __shared__ __attribute__((aligned(16))) float a_lds[(ROWS + 1) * (MAX_CR + 4)];   // later: the 4 partial tiles
+  __shared__ __attribute__((aligned(16))) float Ws[32 * WP];
+  __shared__ float red[2][8][32];
+  static_assert(4 * ROWS * 33 <= (ROWS + 1) * (MAX_CR + 4), "partial tiles alias the sequence tile");
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x, n0 = blockIdx.y * 32;
+  const int T = p.T, cin = p.cin, K = cin * 3, d = p.dil;
+  const bool split = gridDim.z > 1;
+  float* yout = p.y + (long)blockIdx.z * p.slab_stride;
+  // this workgroup's input-channel range [cz0, cz0+cr)
+  const int per_z = ((cin + CC - 1) / CC + (int)gridDim.z - 1) / (int)gridDim.z * CC;
+  const int cz0 = blockIdx.z * per_z;
+  const int cr = max(0, min(cin, cz0 + per_z) - cz0);
+  const int AP = cr + 4;
+
+  // ---- the activated sequence tile, once
+  {
+    const int q4 = cr >> 2;
+    const bool act = p.scale != nullptr;
+    for (int q = tid; q < T * q4; q += 256) {
+      const int r = q / q4, c4 = (q - r * q4) << 2;
+      f32x4 v = load4(p.src + ((long)b * T + r) * cin + cz0 + c4);
+      if (act) {
+        const f32x4 sc = load4(p.scale + cz0 + c4), sh = load4(p.shift + cz0 + c4);
+        v.x = elu_stage(fmaf(sc.x, v.x, sh.x));
+        v.y = elu_stage(fmaf(sc.y, v.y, sh.y));
+        v.z = elu_stage(fmaf(sc.z, v.z, sh.z));
+        v.w = elu_stage(fmaf(sc.w, v.w, sh.w));
+      }
+      *reinterpret_cast<f32x4*>(&a_lds[r * AP + c4]) = v;
+    }
+    for (int q = tid; q < (ROWS + 1 - T) * AP; q += 256) a_lds[T * AP + q] = 0.f;     // rows T..31 and the zero row
+  }
+  f32x4 rw[3];
+  auto load_w = [&](int c0) {
+    // 32 columns x 96 contiguous floats W[n0+c][(cz0+c0)*3 ...]: float4 q -> (column c = q / 24, run offset f)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int q = tid + j * 256;
+      const int c = q / 24, f = (q - c * 24) << 2;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n0 + c < p.cout && c0 * 3 + f < cr * 3) v = load4(p.W + (long)(n0 + c) * K + (long)(cz0 + c0) * 3 + f);
+      rw[j] = v;
+    }
+  };
+  auto store_w = [&]() {
+    // scatter tap-major: run element kk = ci_l*3 + tap -> Ws[c][tap*CC + ci_l]
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int q = tid + j * 256;
+      const int c = q / 24, f = (q - c * 24) << 2;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int kk = f + m, ci_l = kk / 3, tap = kk - ci_l * 3;
+        Ws[c * WP + tap * CC + ci_l] = rw[j][m];
+      }
+    }
+  };
+  if (cr > 0) load_w(0);
+  __syncthreads();
+  if (p.col != nullptr && blockIdx.y == 0) {
+    // im2col of the activated input for the backward: col[(b,t)][ci*3+tap] = a[t-(2-tap)*d][ci]
+    const int run = cr * 3;
+    for (int q = tid; q < T * run; q += 256) {
+      const int r = q / run, kk = q - r * run;
+      const int ci = kk / 3, tap = kk - ci * 3;
+      const int ts = r - (2 - tap) * d;
+      p.col[((long)b * T + r) * K + (long)cz0 * 3 + kk] = ts >= 0 ? a_lds[ts * AP + ci] : 0.f;
+    }
+  }
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int c0 = 0; c0 < cr; c0 += CC) {
+    if (c0 > 0) __syncthreads();          // previous trip's readers are done with the weight tile
+    store_w();
+    __syncthreads();
+    if (c0 + CC < cr) load_w(c0 + CC);    // in flight while this chunk is consumed
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const int gg = wave * 3 + g;        // 12 groups of 8 per chunk: tap = gg / 4, 8 channels each
+      const int tap = gg >> 2, ci_l = ((gg & 3) << 3) + (half << 2);
+      const int rs = l31 - (2 - tap) * d;
+      const float* ap = (rs >= 0 && c0 + ci_l < cr) ? &a_lds[rs * AP + c0 + ci_l] : &a_lds[ZROW * AP];
+      const f32x4 av = *reinterpret_cast<const f32x4*>(ap);
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(&Ws[l31 * WP + tap * CC + ci_l]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wv.w, acc, 0, 0, 0);
+    }
+  }
+  // combine the four waves' partial tiles (accumulator i of lane (l31, half) is row (i&3) + 8*(i>>2) + 4*half,
+  // column l31); the sequence tile is dead by now
+  __syncthreads();
+  float (*part)[ROWS][33] = reinterpret_cast<float (*)[ROWS][33]>(a_lds);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) part[wave][(i & 3) + 8 * (i >> 2) + 4 * half][l31] = acc[i];
+  __syncthreads();
+  const int colx = tid & 31, rg = tid >> 5, gn = n0 + colx;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = rg + 8 * i;
+    const float v = (part[0][r][colx] + part[1][r][colx]) + (part[2][r][colx] + part[3][r][colx]);
+    if (r < T && gn < p.cout) {
+      yout[((long)b * T + r) * p.cout + gn] = v;
+      s1 += v;
+      s2 += v * v;
+    }
+  }
+  if (p.stats != nullptr && !split) {
+    red[0][rg][colx] = s1;
+    red[1][rg][colx] = s2;
+    __syncthreads();
+    if (tid < 64) {
+      const int stat = tid >> 5, c = tid & 31;
+      if (n0 + c < p.cout) {
+        double v = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) v += (double)red[stat][g][c];
+        unsafeAtomicAdd(&p.stats[((long)(b % p.nrep) * 2 + stat) * p.cout + n0 + c], v);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int pcaa_dtc_conv_supported(int T, int cin, int cout) {
+  return (T >= 1 && T <= ROWS && cin >= 4 && cin % 4 == 0 && cout >= 16 && cout % 16 == 0) ? 1 : 0;
+}
+
+/* smallest / recommended split of the input channels over workgroups: a workgroup keeps at most MAX_CR
+ * channels of its sequence in LDS; few workgroups with a long contraction are cut further */
+extern "C" int pcaa_dtc_conv_ksplit(int B, int cin, int cout) {
+  const int chunks = (cin + CC - 1) / CC;
+  int ks = (cin + MAX_CR - 1) / MAX_CR;
+  if ((long)B * ((cout + 31) / 32) <= 128 && chunks >= 16) ks = ks > 8 ? ks : 8;
+  return ks < chunks ? ks : chunks;
+}
+
+extern "C" int pcaa_dtc_conv_fwd(const float* src, const float* scale, const float* shift, const float* W, float* y,
+                                 float* col, double* stats, int nrep, int B, int T, int cin, int cout, int dilation,
+                                 int ksplit, long slab_stride, void* stream) {
+  PCAA_CHECK_ARG(src && W && y && B >= 1 && dilation >= 1 && ksplit >= 1, "pcaa_dtc_conv_fwd: bad args");
+  PCAA_CHECK_ARG(pcaa_dtc_conv_supported(T, cin, cout), "pcaa_dtc_conv_fwd: needs T <= %d, cin %% 4 == 0, cout %% 16 == 0",
+                 ROWS);
+  PCAA_CHECK_ARG((scale == nullptr) == (shift == nullptr), "pcaa_dtc_conv_fwd: scale and shift go together");
+  PCAA_CHECK_ARG(stats == nullptr || nrep >= 1, "pcaa_dtc_conv_fwd: nrep");
+  PCAA_CHECK_ARG(((uintptr_t)W % 16) == 0 && ((uintptr_t)src % 16) == 0 && (scale == nullptr || (((uintptr_t)scale % 16) == 0 &&
+                 ((uintptr_t)shift % 16) == 0)), "pcaa_dtc_conv_fwd: src, W, scale, shift must be 16-B aligned");
+  const int chunks = (cin + CC - 1) / CC;
+  const int per_z = (chunks + ksplit - 1) / ksplit * CC;
+  PCAA_CHECK_ARG(ksplit <= chunks && per_z <= MAX_CR, "pcaa_dtc_conv_fwd: ksplit must keep <= %d channels per workgroup "
+                 "(pcaa_dtc_conv_ksplit)", MAX_CR);
+  PCAA_CHECK_ARG(ksplit == 1 || (stats == nullptr && slab_stride >= (long)B * T * cout),
+                 "pcaa_dtc_conv_fwd: ksplit > 1 writes slabs (no statistics): slab_stride >= B*T*cout");
+  DtcFwdParams p{src, scale, shift, W, y, col, stats, B, T, cin, cout, dilation, nrep, ksplit > 1 ? slab_stride : 0};
+  hipLaunchKernelGGL(dtc_fwd_kernel, dim3(B, (cout + 31) / 32, ksplit), dim3(256), 0, as_stream(stream), p);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_dtc_conv_fwd");
+}

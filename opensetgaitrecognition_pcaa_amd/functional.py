@@ -375,19 +375,40 @@ def pointnet_backward(saves, layers, mode, d_last=None, dpool=None, pool_rows=0,
     return grads, da
 
 
+_FUSE_DTC = os.environ.get("PCAA_FUSE_DTC", "1") != "0"
+
+
 def dtc_forward(a2d, B, T, layers, training, pool_time):
-    """a2d: [B*T, Cin] fp32 rows (b,t).  Causal dilated conv = im2col + GEMM."""
+    """a2d: [B*T, Cin] fp32 rows (b,t).  Causal dilated conv = (implicit) im2col + contraction."""
     saves = []
     a = a2d
     nl = len(layers)
+    fused = _FUSE_DTC and a2d.dtype == torch.float32 and all(
+        ops.dtc_conv_supported(T, l.conv1d.weight.shape[1], l.conv1d.weight.shape[0]) for l in layers)
+    prev = None          # (scale, shift) of the layer whose bias-free output `a` is (fused path)
     for li, layer in enumerate(layers):
         conv, bn = layer.conv1d, layer.batch_norm
         cout, cin = conv.weight.shape[0], conv.weight.shape[1]
-        col = ops.dtc_im2col(a, B, T, cin, layer.dilation)
         W2d = conv.weight.view(cout, cin * 3)
-        y, scale, shift, mean, rstd, count = _linear_bn(col, W2d, conv.bias, bn, training, "fp32", None)
+        if fused:
+            # one launch: implicit im2col + BN/ELU of the previous layer on load + contraction + statistics
+            stats = ops.new_stats(cout, a.device) if training else None
+            y, col = ops.dtc_conv_fwd(a, prev[0] if prev else None, prev[1] if prev else None, W2d, B, T,
+                                      layer.dilation, stats=stats, want_col=training)
+            if training:
+                count = _sync_stats(stats, y.shape[0])
+                scale, shift, mean, rstd = ops.bn_finalize(stats, count, conv.bias, bn, cout)
+            else:
+                scale, shift = ops.bn_eval_coeffs(bn, cout, conv.bias)
+                mean = rstd = None
+                count = y.shape[0]
+            a_in = None
+        else:
+            col = ops.dtc_im2col(a, B, T, cin, layer.dilation)
+            y, scale, shift, mean, rstd, count = _linear_bn(col, W2d, conv.bias, bn, training, "fp32", None)
+            a_in = a
         s = _LayerSave()
-        s.a_in, s.col, s.y, s.scale, s.shift, s.mean, s.rstd = a, col, y, scale, shift, mean, rstd
+        s.a_in, s.col, s.y, s.scale, s.shift, s.mean, s.rstd = a_in, col, y, scale, shift, mean, rstd
         s.rows, s.cin, s.cout, s.dil = count, cin, cout, layer.dilation
         saves.append(s)
         if li == nl - 1 and pool_time:
@@ -395,7 +416,10 @@ def dtc_forward(a2d, B, T, layers, training, pool_time):
                 out, s.pool_e = ops.bn_act_meanpool_fwd(y, scale, shift, B, T, mean, rstd)
                 return out, saves
             return ops.bn_act_meanpool_fwd(y, scale, shift, B, T), saves
-        a = ops.bn_act_fwd(y, scale, shift)
+        if fused and li < nl - 1:
+            a, prev = y, (scale, shift)
+        else:
+            a = ops.bn_act_fwd(y, scale, shift)
     return a, saves
 
 

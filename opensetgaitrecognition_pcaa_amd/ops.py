@@ -864,3 +864,44 @@ def heads_bwd(x4, sup_fv, h, logits, hproj, W1, Wh, W2, Wg, d_logits, d_sup, d_h
                                      _p(outs.get("dWg")), _p(outs.get("dbg")), _p(dx4), B, K, _s()), "pcaa_heads_bwd")
     return outs, dx4
 
+
+# ------------------------------------------------------------------ fused temporal-block forward (dtc_fused.hip)
+def dtc_conv_supported(T, cin, cout):
+    return bool(_lib.load().pcaa_dtc_conv_supported(int(T), int(cin), int(cout)))
+
+
+def dtc_conv_fwd(src, scale, shift, W2d, B, T, dilation, stats=None, want_col=False):
+    """One DilTempConv1d layer forward in one launch (see pcaa_dtc_conv_fwd): returns (y, col or None)."""
+    _chk(src, "dtc_conv_fwd.src", torch.float32, 2)
+    _chk(W2d, "dtc_conv_fwd.W", torch.float32, 2)
+    rows, cin = src.shape
+    cout = W2d.shape[0]
+    if rows != B * T or W2d.shape[1] != cin * 3 or not dtc_conv_supported(T, cin, cout):
+        raise ValueError(f"dtc_conv_fwd: unsupported shapes src {tuple(src.shape)} W {tuple(W2d.shape)} B={B} T={T}")
+    if scale is not None:
+        _chk(scale, "dtc_conv_fwd.scale", torch.float32)
+        _chk(shift, "dtc_conv_fwd.shift", torch.float32)
+        if scale.numel() != cin or shift.numel() != cin:
+            raise ValueError("dtc_conv_fwd: scale/shift length")
+    if stats is not None:
+        _chk(stats, "dtc_conv_fwd.stats", torch.float64)
+        if tuple(stats.shape) != (NREP, 2, cout):
+            raise ValueError("dtc_conv_fwd: stats shape")
+    y = torch.empty((rows, cout), dtype=torch.float32, device=src.device)
+    col = torch.empty((rows, cin * 3), dtype=torch.float32, device=src.device) if want_col else None
+    lib = _lib.load()
+    ksplit = lib.pcaa_dtc_conv_ksplit(B, cin, cout)
+    if ksplit > 1:
+        stride = rows * cout
+        slabs = torch.empty(ksplit * stride, dtype=torch.float32, device=src.device)
+        check(lib.pcaa_dtc_conv_fwd(_p(src), _p(scale), _p(shift), _p(W2d), _p(slabs), _p(col), None, NREP,
+                                    B, T, cin, cout, int(dilation), ksplit, stride, _s()), "pcaa_dtc_conv_fwd")
+        if stats is not None:
+            check(lib.pcaa_splitk_reduce_stats(_p(slabs), ksplit, stride, _p(y), _p(stats), NREP, rows, cout, _s()),
+                  "pcaa_splitk_reduce_stats")
+        else:
+            check(lib.pcaa_splitk_reduce(_p(slabs), ksplit, stride, stride, _p(y), 0, _s()), "pcaa_splitk_reduce")
+        return y, col
+    check(lib.pcaa_dtc_conv_fwd(_p(src), _p(scale), _p(shift), _p(W2d), _p(y), _p(col), _p(stats), NREP,
+                                B, T, cin, cout, int(dilation), 1, 0, _s()), "pcaa_dtc_conv_fwd")
+    return y, col

@@ -548,3 +548,32 @@ def test_heads_fwd_large_batch_and_unsupported_backward():
     assert h is None and hp is None and tuple(lg.shape) == (B, K)
     assert not ops.heads_supported(B, K, 512, 32, 0, 0, True)      # backward keeps all rows in LDS: B <= 64
     assert not ops.heads_supported(8, K, 256, 32, 0, 0, False)
+
+
+# ---------------------------------------------------------------- fused temporal-block layer (dtc_fused.hip)
+@pytest.mark.parametrize("B,T,cin,cout,d,act", [(3, 30, 16, 32, 2, True), (2, 30, 1024, 16, 1, False),
+                                                (5, 30, 256, 512, 4, True), (4, 7, 64, 128, 1, True),
+                                                (64, 30, 32, 64, 4, True)])
+def test_dtc_conv_fwd_vs_fp64_conv1d(B, T, cin, cout, d, act):
+    """Implicit-im2col causal dilated Conv1d (models.py:59-68, 75-76: padding 2d both sides, last 2d
+    outputs dropped) with the previous layer's BatchNorm+ELU applied on load, against fp64 torch."""
+    src = _rand((B * T, cin), 31)
+    W = _rand((cout, cin, 3), 32, (3 * cin) ** -0.5)
+    scale = (_rand((cin,), 33, 0.3) + 1.0) if act else None
+    shift = _rand((cin,), 34, 0.3) if act else None
+    a = src.double()
+    if act:
+        a = torch.nn.functional.elu(a * scale.double() + shift.double())
+    x = a.view(B, T, cin).permute(0, 2, 1)                                # [B, cin, T]
+    ref = torch.nn.functional.conv1d(x, W.double(), padding=2 * d, dilation=d)[:, :, :-2 * d]
+    ref = ref.permute(0, 2, 1).reshape(B * T, cout)
+    stats = torch.zeros((ops.NREP, 2, cout), dtype=torch.float64, device=DEV)
+    y, col = ops.dtc_conv_fwd(src.to(DEV), scale.to(DEV) if act else None, shift.to(DEV) if act else None,
+                              W.view(cout, cin * 3).to(DEV), B, T, d, stats=stats, want_col=True)
+    scl = ref.abs().max().item()
+    assert (y.cpu().double() - ref).abs().max().item() <= 2e-6 * (3 * cin) ** 0.5 * scl + 1e-6
+    st = stats.sum(0).cpu()
+    assert torch.allclose(st[0], ref.sum(0), rtol=1e-4, atol=1e-4 * scl * (B * T) ** 0.5)
+    assert torch.allclose(st[1], (ref * ref).sum(0), rtol=1e-4, atol=1e-6)
+    col_ref = ops.dtc_im2col(a.float().to(DEV).contiguous(), B, T, cin, d)
+    assert (col - col_ref).abs().max().item() <= 1e-6 * max(a.abs().max().item(), 1.0)
