@@ -145,12 +145,12 @@ def main():
     barrier()
     timer = None
     if not a.no_kernel_timing:
-        # HIP events only around the kernel family the roofline reports (each timed launch puts two
-        # event packets on the stream; timing all ~45 GEMM launches cost 0.3 ms per step)
+        # HIP events on the kernel family the roofline reports: the start/stop events ride on the launch
+        # itself (hipExtLaunchKernelGGL through pcaa_time_next_gemm), i.e. they are the kernel's own begin/end
+        # timestamps -- the quantity rocprofv3's kernel trace reports -- on the stream it is launched on
         timer = ops.LaunchTimer(only_prefix="gemm_bf16_dma_kernel" if a.precision == "bf16" else "gemm_f32_kernel")
         ops.set_timer(timer)
-    # the launches of the first `timed_steps` steps of the timed region carry the events: every timed
-    # launch drains the queue around itself (two marker packets), ~20 us of bubbles per step for 9 launches
+    # the launches of the first `timed_steps` steps of the timed region carry the events
     # (graph mode: those steps run eagerly -- events cannot be read back from inside a replayed graph --
     # and the remaining steps of the timed region are graph replays)
     timed_steps = min(a.steps, 2 if use_graph else 4) if timer is not None else 0

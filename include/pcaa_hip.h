@@ -94,6 +94,17 @@ int pcaa_gemm_dgrad_bn(const void* dy, long lddy, const void* Wt, long ldw, cons
                        const float* scale, const float* shift, const float* mean, const float* rstd,
                        double* stats, int nrep, int M, int N, int K,
                        const float* x, int xc, const float* W1, void* stream);
+/* Kernel-exact timing of one LDS-DMA GEMM launch (bench.py's roofline figure): events made by
+ * pcaa_timing_events_create and armed with pcaa_time_next_gemm ride on the NEXT such launch of the
+ * calling thread (hipExtLaunchKernelGGL start/stop events: the timestamps of the kernel's own dispatch
+ * packet, what rocprofv3 reports).  pcaa_timing_pending: 1 while armed events have not been consumed
+ * (the call did not reach that kernel); pcaa_time_next_gemm(NULL, NULL) disarms.  pcaa_timing_elapsed_ms
+ * after the stream has been synchronised. */
+int pcaa_timing_events_create(void** start, void** stop);
+int pcaa_timing_events_destroy(void* start, void* stop);
+int pcaa_time_next_gemm(void* start, void* stop);
+int pcaa_timing_pending(void);
+int pcaa_timing_elapsed_ms(void* start, void* stop, float* ms);
 int pcaa_splitk_reduce(const float* slabs, int nsplit, long slab_stride, long n, float* out,
                        int accumulate, void* stream);
 /* same, for out[rows, ch], plus the BatchNorm column statistics of out (stats as in pcaa_gemm) */

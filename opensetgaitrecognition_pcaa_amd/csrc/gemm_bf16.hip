@@ -19,6 +19,8 @@
 //               chunks) and the MFMA fragment -- 8 consecutive k of one row -- is
 //               gathered by two ds_read_b64_tr_b16 transpose reads; with that pitch
 //               the 32 lanes of a half cover all 64 banks exactly once.
+#include <hip/hip_ext.h>
+
 #include "gemm_common.h"
 
 namespace {
@@ -1416,7 +1418,11 @@ bool launch_dma(const GemmParams& p, dim3 grid, hipStream_t s) {
       return false;
     configured = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), D_LDS_BYTES, s, p);
+  const PcaaLaunchEvents ev = pcaa_take_launch_events();
+  if (ev.start != nullptr)
+    hipExtLaunchKernelGGL(kern, grid, dim3(NTHREADS), D_LDS_BYTES, s, ev.start, ev.stop, 0, p);
+  else
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), D_LDS_BYTES, s, p);
   return true;
 }
 
@@ -1551,4 +1557,45 @@ bool pcaa_launch_gemm_bf16_big(const GemmParams& p_in, int a_dtype, int a_layout
     return false;
   }
   return false;
+}
+
+// ------------------------------------------------------------------ kernel-exact launch timing
+namespace {
+thread_local PcaaLaunchEvents g_armed = {nullptr, nullptr};
+}
+PcaaLaunchEvents pcaa_take_launch_events() {
+  const PcaaLaunchEvents e = g_armed;
+  g_armed = {nullptr, nullptr};
+  return e;
+}
+extern "C" int pcaa_timing_events_create(void** start, void** stop) {
+  PCAA_CHECK_ARG(start && stop, "pcaa_timing_events_create: null");
+  hipEvent_t a = nullptr, b = nullptr;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+    pcaa_set_error("pcaa_timing_events_create: hipEventCreate failed");
+    return PCAA_ERR_LAUNCH;
+  }
+  *start = a;
+  *stop = b;
+  return PCAA_OK;
+}
+extern "C" int pcaa_timing_events_destroy(void* start, void* stop) {
+  if (start) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(start));
+  if (stop) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(stop));
+  return PCAA_OK;
+}
+extern "C" int pcaa_time_next_gemm(void* start, void* stop) {
+  PCAA_CHECK_ARG((start == nullptr) == (stop == nullptr), "pcaa_time_next_gemm: both events or none");
+  g_armed = {reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)};
+  return PCAA_OK;
+}
+extern "C" int pcaa_timing_pending(void) { return g_armed.start != nullptr ? 1 : 0; }
+extern "C" int pcaa_timing_elapsed_ms(void* start, void* stop, float* ms) {
+  PCAA_CHECK_ARG(start && stop && ms, "pcaa_timing_elapsed_ms: null");
+  const hipError_t e = hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop));
+  if (e != hipSuccess) {
+    pcaa_set_error("pcaa_timing_elapsed_ms: %s", hipGetErrorString(e));
+    return PCAA_ERR_LAUNCH;
+  }
+  return PCAA_OK;
 }

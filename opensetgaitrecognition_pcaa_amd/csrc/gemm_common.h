@@ -48,6 +48,13 @@ __device__ __forceinline__ int block_coords(const GemmParams& p, int nbm, int nb
   return blockIdx.z;
 }
 
+// Kernel-exact timing of ONE launch (bench.py's roofline figure): start/stop events armed by
+// pcaa_time_next_gemm are attached to the next LDS-DMA GEMM launch of this thread through
+// hipExtLaunchKernelGGL, i.e. they carry the timestamps of the kernel's own dispatch packet (what rocprofv3
+// reports) instead of bracketing it with two marker packets that each drain the queue (+25 us per launch).
+struct PcaaLaunchEvents { hipEvent_t start, stop; };
+PcaaLaunchEvents pcaa_take_launch_events();      // returns {nullptr, nullptr} when nothing is armed; disarms
+
 // 256x256-tile bf16 kernel (gemm_bf16.hip).  Returns false if the shape/dtype
 // combination is not served by it (caller falls back to the small-tile kernel).
 bool pcaa_launch_gemm_bf16_big(const GemmParams& p, int a_dtype, int a_layout, int b_dtype, int b_layout,

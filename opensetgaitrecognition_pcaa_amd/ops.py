@@ -52,7 +52,7 @@ class LaunchTimer:
     events are recorded on the stream the kernels are launched on)."""
 
     def __init__(self, only_prefix=None):
-        self.records = []      # (key, flops, bytes, start_event, end_event)
+        self.records = []      # (key, flops, bytes, events)
         # every timed launch costs two event packets on the stream (~0.3 ms per step when all ~45
         # GEMM launches are timed); bench.py restricts the timing to the kernel it reports
         self.only_prefix = only_prefix
@@ -63,13 +63,71 @@ class LaunchTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for key, flops, nbytes, e0, e1 in self.records:
+        for key, flops, nbytes, ev in self.records:
+            if not ev.valid():
+                continue
             a = agg.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             a["launches"] += 1
-            a["ms"] += e0.elapsed_time(e1)
+            a["ms"] += ev.elapsed_ms()
             a["flops"] += flops
             a["bytes"] += nbytes
         return agg
+
+
+class _TorchEvents:
+    """two marker events around a call (each drains the queue: ~25 us on top of the kernel)"""
+
+    def __init__(self):
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e1 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+
+    def end(self):
+        self.e1.record()
+        return self
+
+    def valid(self):
+        return True
+
+    def elapsed_ms(self):
+        return self.e0.elapsed_time(self.e1)
+
+
+class _KernelEvents:
+    """start/stop events attached to the next LDS-DMA GEMM launch itself (pcaa_time_next_gemm): the
+    kernel's own begin/end timestamps, as rocprofv3 reports them."""
+
+    def __init__(self):
+        lib = _lib.load()
+        self.a, self.b = ctypes.c_void_p(), ctypes.c_void_p()
+        check(lib.pcaa_timing_events_create(ctypes.byref(self.a), ctypes.byref(self.b)), "pcaa_timing_events_create")
+        check(lib.pcaa_time_next_gemm(self.a, self.b), "pcaa_time_next_gemm")
+        self.ok = False
+
+    def end(self):
+        lib = _lib.load()
+        self.ok = not lib.pcaa_timing_pending()       # consumed by the launch?
+        if not self.ok:
+            lib.pcaa_time_next_gemm(None, None)
+        return self
+
+    def valid(self):
+        return self.ok
+
+    def elapsed_ms(self):
+        ms = ctypes.c_float()
+        check(_lib.load().pcaa_timing_elapsed_ms(self.a, self.b, ctypes.byref(ms)), "pcaa_timing_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            _lib.load().pcaa_timing_events_destroy(self.a, self.b)
+        except Exception:
+            pass
+
+
+def _begin_timing(key):
+    return _KernelEvents() if key.startswith("gemm_bf16_dma_kernel") else _TorchEvents()
 
 
 TIMER = None
@@ -169,16 +227,14 @@ def gemm(A, a_layout, B, b_layout, M, N, K, *, lda=None, ldb=None, out=None, out
             key = "gemm_bf16_big_kernel"
         timer = timer if timer.wants(key) else None
     if timer is not None:
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+        ev = _begin_timing(key)
     check(lib.pcaa_gemm(math, _p(A), _dt(A), a_layout, lda, _p(B), _dt(B), b_layout, ldb,
                         _p(out), _dt(out), N, M, N, K, _p(bias), _p(colstats), NREP,
                         int(split_k), int(bool(accumulate)), _s()), "pcaa_gemm")
     if timer is not None:
-        e1.record()
+        ev.end()
         nbytes = A.numel() * A.element_size() + B.numel() * B.element_size() + out.numel() * out.element_size()
-        timer.records.append((key, 2.0 * M * N * K, float(nbytes), e0, e1))
+        timer.records.append((key, 2.0 * M * N * K, float(nbytes), ev))
     return out
 
 
@@ -208,15 +264,13 @@ def gemm_slabs(A, a_layout, B, b_layout, M, N, K, split_k, out=None, accumulate=
         key = _dma_key(torch.float32, a_layout) if dma else ("gemm_bf16_big_kernel" if math == PCAA_BF16 else "gemm_f32_kernel")
         timer = timer if timer.wants(key) else None
     if timer is not None:
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+        ev = _begin_timing(key)
     check(lib.pcaa_gemm_slabs(math, _p(A), _dt(A), a_layout, A.stride(0), _p(B), _dt(B), b_layout, B.stride(0),
                               _p(slabs), stride, M, N, K, int(split_k), _s()), "pcaa_gemm_slabs")
     if timer is not None:
-        e1.record()
+        ev.end()
         nbytes = A.numel() * A.element_size() + B.numel() * B.element_size() + ns * stride * 4
-        timer.records.append((key, 2.0 * M * N * K, float(nbytes), e0, e1))
+        timer.records.append((key, 2.0 * M * N * K, float(nbytes), ev))
     if colstats is not None:
         # reduction fused with the BatchNorm column statistics of the result
         if accumulate:
@@ -263,17 +317,15 @@ def gemm_dgrad_bn(dy, Wt, y, scale, shift, mean, rstd, points=None, W1=None):
     key = "gemm_bf16_dma_kernel<bf16,KC,KC,dgrad_bn>"       # its own instantiation (epilogue carries ELU' + statistics)
     timer = timer if (timer is not None and timer.wants(key)) else None
     if timer is not None:
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+        ev = _begin_timing(key)
     check(_lib.load().pcaa_gemm_dgrad_bn(_p(dy), dy.stride(0), _p(Wt), Wt.stride(0), _p(y), _p(dz), dz.stride(0),
                                          _p(scale), _p(shift), _p(mean), _p(rstd), _p(stats), NREP, M, N, K,
                                          _p(points) if y is None else None, xc, _p(W1) if y is None else None, _s()),
           "pcaa_gemm_dgrad_bn")
     if timer is not None:
-        e1.record()
+        ev.end()
         nbytes = 2 * (M * K + N * K + 2 * M * N)
-        timer.records.append((key, 2.0 * M * N * K, float(nbytes), e0, e1))
+        timer.records.append((key, 2.0 * M * N * K, float(nbytes), ev))
     return dz, stats
 
 
@@ -534,12 +586,10 @@ def _skinny_timed(fn, flops, nbytes):
     timer = TIMER
     if timer is None or not timer.wants("gemm_skinny_kernel"):
         return fn()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
+    ev = _TorchEvents()
     fn()
-    e1.record()
-    timer.records.append(("gemm_skinny_kernel", flops, float(nbytes), e0, e1))
+    ev.end()
+    timer.records.append(("gemm_skinny_kernel", flops, float(nbytes), ev))
 
 
 def skinny_linear_fwd(x, W, bias, act):
