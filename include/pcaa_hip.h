@@ -213,6 +213,13 @@ int pcaa_prior_sample(const float* z0, const float* means, const long long* gt, 
 int pcaa_pack_points(const float* src, long sb, long sc, long st, long sn,
                      float* dst, int B, int C, int T, int N, void* stream);
 
+/* Batch assembly from a packed crop store resident in HBM (replaces the per-sample np.load + default collate
+ * of MSRadarDataset.__getitem__ / DataLoader, datasets.py:466-479, PCAA_ablation.py:794-800):
+ * dst[r] = src[idx[r]], rows of row_bytes bytes (multiple of 16).  An index outside [0, n_src_rows)
+ * zero-fills its row and sets *err_flag (device int, may be NULL) to 1. */
+int pcaa_gather_rows(const void* src, long n_src_rows, long row_bytes, const long long* idx, void* dst,
+                     long n_rows, int* err_flag, void* stream);
+
 /* causal dilated Conv1d (k=3) as a GEMM: col[(b,t)][ci*3+tap] = a[b][t-(2-tap)*d][ci] or 0
  * (models.py:59-68,75-76) and its adjoint */
 int pcaa_dtc_im2col(const float* a, float* col, int B, int T, int Cin, int dilation, void* stream);

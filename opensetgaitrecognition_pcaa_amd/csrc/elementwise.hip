@@ -755,6 +755,37 @@ extern "C" int pcaa_pack_points(const float* src, long sb, long sc, long st, lon
   PCAA_RETURN_LAUNCH_STATUS("pcaa_pack_points");
 }
 
+namespace {
+// dst[r] = src[idx[r]] for rows of row_vec 16-B vectors: the device-side batch assembly of the packed crop
+// store (batcher.py).  Pure byte movement, coalesced 16-B copies; an index outside [0, n_src) zero-fills
+// its row and raises the error flag instead of reading out of bounds.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, const long long* __restrict__ idx,
+                                                          long n_src, uint4* __restrict__ dst, long n_rows,
+                                                          long row_vec, int* __restrict__ err) {
+  const long total = n_rows * row_vec;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long)gridDim.x * 256) {
+    const long r = v / row_vec, off = v - r * row_vec;
+    const long long i = idx[r];
+    uint4 val = {0u, 0u, 0u, 0u};
+    if (i >= 0 && i < n_src) val = src[i * row_vec + off];
+    else if (err != nullptr && off == 0) atomicOr(err, 1);
+    dst[v] = val;
+  }
+}
+}  // namespace
+
+extern "C" int pcaa_gather_rows(const void* src, long n_src_rows, long row_bytes, const long long* idx, void* dst,
+                                long n_rows, int* err_flag, void* stream) {
+  PCAA_CHECK_ARG(src && idx && dst && n_src_rows >= 1 && n_rows >= 1 && row_bytes >= 16 && row_bytes % 16 == 0,
+                 "pcaa_gather_rows: bad args (rows are multiples of 16 bytes)");
+  PCAA_CHECK_ARG(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "pcaa_gather_rows: 16-B alignment");
+  const long row_vec = row_bytes / 16;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n_rows * row_vec, 256, 256 * 16)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const uint4*>(src), idx, n_src_rows, reinterpret_cast<uint4*>(dst), n_rows,
+                     row_vec, err_flag);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_gather_rows");
+}
+
 extern "C" int pcaa_dtc_im2col(const float* a, float* col, int B, int T, int Cin, int dilation, void* stream) {
   PCAA_CHECK_ARG(a && col && B >= 1 && T >= 1 && Cin >= 1 && dilation >= 1, "pcaa_dtc_im2col: bad args");
   const long n = (long)B * T * Cin * 3;

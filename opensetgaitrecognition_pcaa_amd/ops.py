@@ -714,6 +714,27 @@ def pack_points(x):
     return out
 
 
+def gather_rows(src, idx, out=None, err_flag=None):
+    """out[r] = src[idx[r]] along dim 0 (device-side batch assembly; rows must be multiples of 16 bytes)."""
+    if not (isinstance(src, torch.Tensor) and src.is_cuda and src.is_contiguous() and src.dim() >= 1):
+        raise RuntimeError("gather_rows: src must be a contiguous tensor on the HIP device (this package has no CPU path)")
+    _chk(idx, "gather_rows.idx", torch.int64, 1)
+    row_bytes = src[0].numel() * src.element_size() if src.dim() > 1 else src.element_size()
+    if row_bytes % 16:
+        raise ValueError(f"gather_rows: rows of {row_bytes} bytes are not a multiple of 16")
+    n = idx.numel()
+    if out is None:
+        out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    elif out.shape != (n,) + tuple(src.shape[1:]) or out.dtype != src.dtype or not out.is_contiguous():
+        raise ValueError("gather_rows: out does not match")
+    if err_flag is not None:
+        _chk(err_flag, "gather_rows.err_flag", torch.int32)
+    if n:
+        check(_lib.load().pcaa_gather_rows(_p(src), src.shape[0], row_bytes, _p(idx), _p(out), n, _p(err_flag), _s()),
+              "pcaa_gather_rows")
+    return out
+
+
 def dtc_im2col(a, B, T, Cin, d):
     _chk(a, "im2col.a", torch.float32, 2)
     col = torch.empty((B * T, 3 * Cin), dtype=torch.float32, device=a.device)

@@ -448,10 +448,17 @@ def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=
     dev = trainer.device
     make = dataset_factory or (lambda split: MSRadarDataset(split, subsample_factor=config["SUBSAMPLE_FACTOR"]))
     train_set, valid_set = make(SPLIT.TRAIN), make(SPLIT.VALID)
-    loader_train = torch.utils.data.DataLoader(train_set, batch_size=config["BATCH_SIZE"], drop_last=True,
-                                               shuffle=True, num_workers=0)
-    loader_valid = torch.utils.data.DataLoader(valid_set, batch_size=config["BATCH_SIZE"], drop_last=True,
-                                               shuffle=False, num_workers=0)
+    if os.environ.get("PCAA_DEVICE_BATCHER", "1") != "0" and len(train_set) and len(valid_set):
+        # packed store in HBM + device-side batch assembly; same batches (and the same consumption of
+        # torch's global RNG) as the DataLoaders of the reference (batcher.py)
+        from .batcher import batcher_for
+        loader_train = batcher_for(train_set, config["BATCH_SIZE"], dev, shuffle=True)
+        loader_valid = batcher_for(valid_set, config["BATCH_SIZE"], dev, shuffle=False)
+    else:
+        loader_train = torch.utils.data.DataLoader(train_set, batch_size=config["BATCH_SIZE"], drop_last=True,
+                                                   shuffle=True, num_workers=0)
+        loader_valid = torch.utils.data.DataLoader(valid_set, batch_size=config["BATCH_SIZE"], drop_last=True,
+                                                   shuffle=False, num_workers=0)
     _ = make(SPLIT.UNSEEN) if dataset_factory is None else None
 
     wb = _wandb()
