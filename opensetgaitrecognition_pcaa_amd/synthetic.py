@@ -98,3 +98,22 @@ def checksum(t: torch.Tensor, nsample: int = 16) -> dict:
         "samples": f[idx].numpy().copy(),
         "sample_idx": idx.numpy().copy(),
     }
+
+
+def synthetic_raw_track(seed: int, n_frames: int, max_points: int = 40) -> list:
+    """A raw radar track in the reference's on-disk format (``datasets.py:95-103``: a pickled list of
+    per-frame dicts ``cardinality [1]``, ``elements [n,2]``, ``z_coord [n]``, ``dopplers [n]``,
+    ``powers [n]`` (linear, positive)), with per-frame cardinalities on both sides of typical NMAX values."""
+    rng = np.random.default_rng(seed)
+    frames = []
+    for _ in range(n_frames):
+        n = int(rng.integers(3, max_points + 1))
+        frames.append({
+            "cardinality": np.array([n]),
+            "elements": rng.standard_normal((n, 2)) * 0.4 + rng.standard_normal(2),
+            "z_coord": rng.standard_normal(n) * 0.5 + 1.0,
+            "dopplers": rng.standard_normal(n) * 0.8,
+            "powers": np.exp(rng.standard_normal(n) * 1.5),
+        })
+    return frames
+
