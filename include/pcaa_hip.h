@@ -89,6 +89,15 @@ int pcaa_gemm_slabs(int math,
  * separate pass).  All operands bf16, M and N multiples of 256, K of 64.
  * y == NULL: the layer below is the first PointNet layer on its recompute path; its pre-activation is
  * rebuilt as x[M,xc] . W1[N,xc]^T (fp32, xc <= 8) and dz feeds pcaa_pointnet_in_bwd_wgrad(dz_is_pre). */
+/* Eval-mode PointNet layer in one launch (models.py:6-34 with BatchNorm2d in eval mode: a per-channel affine map
+ * known before the product): out[M,N] bf16 = ELU(scale[n] * (A[M,K] . W[N,K]^T) + shift[n]), A and W bf16,
+ * contraction contiguous; same shape rule as pcaa_gemm_dgrad_bn_supported.  pool_rows in {32, 64, 128}: the
+ * activation is additionally averaged over groups of pool_rows consecutive rows (AvgPool2d((1,N)) over the
+ * points of a frame, models.py:242-243) and out is fp32 [M/pool_rows, N] -- the [M,N] activation never
+ * exists.  The inference path (inference_PCAA.py:196-231, BASELINE config[4]) uses both forms. */
+int pcaa_gemm_affine_elu(const void* A, long lda, const void* W, long ldw, void* out, long ldo,
+                         const float* scale, const float* shift, int M, int N, int K, int pool_rows,
+                         void* stream);
 int pcaa_gemm_dgrad_bn_supported(int M, int N, int K);
 int pcaa_gemm_dgrad_bn(const void* dy, long lddy, const void* Wt, long ldw, const void* y, void* dz, long ld,
                        const float* scale, const float* shift, const float* mean, const float* rstd,

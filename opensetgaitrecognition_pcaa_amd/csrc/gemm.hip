@@ -510,3 +510,31 @@ extern "C" int pcaa_gemm_dgrad_bn(const void* dy, long lddy, const void* Wt, lon
   }
   PCAA_RETURN_LAUNCH_STATUS("pcaa_gemm_dgrad_bn");
 }
+
+extern "C" int pcaa_gemm_affine_elu(const void* A, long lda, const void* W, long ldw, void* out, long ldo,
+                                    const float* scale, const float* shift, int M, int N, int K, int pool_rows,
+                                    void* stream) {
+  PCAA_CHECK_ARG(A && W && out && scale && shift, "pcaa_gemm_affine_elu: null pointer");
+  PCAA_CHECK_ARG(pool_rows == 0 || pool_rows == 32 || pool_rows == 64 || pool_rows == 128,
+                 "pcaa_gemm_affine_elu: pool_rows must be 0, 32, 64 or 128");
+  PCAA_CHECK_ARG(pcaa_gemm_dgrad_bn_supported(M, N, K), "pcaa_gemm_affine_elu: M, N must be multiples of 256 and K of 64 "
+                 "(M=%d N=%d K=%d)", M, N, K);
+  PCAA_CHECK_ARG(lda >= K && ldw >= K && ldo >= N && (lda % 8) == 0 && (ldw % 8) == 0 && (pool_rows != 0 || (ldo % 8) == 0),
+                 "pcaa_gemm_affine_elu: bad leading dimension");
+  PCAA_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                 "pcaa_gemm_affine_elu: 16-B alignment");
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.B = W; p.C = out;
+  p.lda = lda; p.ldb = ldw; p.ldc = ldo;
+  p.M = M; p.N = N; p.K = K;
+  p.nrep = 1;
+  p.ep_scale = scale; p.ep_shift = shift;
+  p.ep_xc = pool_rows;
+  if (!pcaa_launch_gemm_affine_elu(p, as_stream(stream))) {
+    pcaa_set_error("pcaa_gemm_affine_elu: launch configuration failed");
+    return PCAA_ERR_LAUNCH;
+  }
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_gemm_affine_elu");
+}
+

@@ -184,7 +184,10 @@ __device__ __forceinline__ float dpp_swap_neighbour(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 
-template <typename TC>
+// AFFINE (bf16 out, eval-mode BatchNorm): the stored value is ELU(scale[col]*acc + shift[col]) -- with running
+// statistics the BatchNorm is a per-channel affine map known BEFORE the product, so the activation leaves the
+// GEMM directly and the separate BN+ELU pass over [P, ch] (read + write) of the train-mode path is gone.
+template <typename TC, bool AFFINE = false>
 __device__ __forceinline__ void epilogue_full_tile(const GemmParams& p, f32x16 (&acc)[FM][FN], bf16_t* smem,
                                                    int tm, int tn, int tid, int split) {
   const int lane = tid & 63, wave = tid >> 6;
@@ -197,12 +200,19 @@ __device__ __forceinline__ void epilogue_full_tile(const GemmParams& p, f32x16 (
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const float bv = add_bias ? p.bias[tn * BN + wn * 64 + j * 32 + l31] : 0.f;
+      const float esc = AFFINE ? p.ep_scale[tn * BN + wn * 64 + j * 32 + l31] : 1.f;
+      const float esh = AFFINE ? p.ep_shift[tn * BN + wn * 64 + j * 32 + l31] : 0.f;
       const int colw = (j * 32 + (l31 & ~1)) >> 1;            // 32-bit word index of the column pair
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const float va = acc[i][j][r] + bv, vb = acc[i][j][r + 1] + bv;   // rows R and R+1, my column
+          float va = acc[i][j][r] + bv, vb = acc[i][j][r + 1] + bv;   // rows R and R+1, my column
+          if constexpr (AFFINE) {
+            va = fmaf(va, esc, esh); vb = fmaf(vb, esc, esh);
+            va = va > 0.f ? va : __expf(va) - 1.f;
+            vb = vb > 0.f ? vb : __expf(vb) - 1.f;
+          }
           const float got = dpp_swap_neighbour(odd ? va : vb);
           // even lane: row R, (mine, right neighbour's) ; odd lane: row R+1, (left neighbour's, mine)
           const uint32_t packed = odd ? pack2(got, vb) : pack2(va, got);
@@ -235,6 +245,40 @@ __device__ __forceinline__ void epilogue_full_tile(const GemmParams& p, f32x16 (
           if (p.atomic) atomicAdd(dst, v);
           else *dst = v;
         }
+    }
+  }
+}
+
+// Eval-mode LAST PointNet layer: BatchNorm (affine) + ELU + the mean over the N points of a frame
+// (AvgPool2d((1,N)), models.py:242-243, :282) straight from the accumulators: a wave holds 128 rows x 64
+// columns of the tile = IPG-block groups of 32*IPG consecutive rows (IPG = N/32 in {1,2,4}), so a group's
+// column mean is a sum over the lane's registers plus one cross-half shuffle; the [P, ch] activation is never
+// written or re-read (2 x 8 GB per 1024 sequences at N=128).  out fp32 [P/N, ch].
+template <int IPG>
+__device__ __forceinline__ void epilogue_affine_meanpool(const GemmParams& p, f32x16 (&acc)[FM][FN], int tm, int tn,
+                                                         int tid) {
+  static_assert(FM % IPG == 0, "groups must not straddle waves");
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, half = lane >> 5;
+  float* out = reinterpret_cast<float*>(p.C);
+  const float inv_n = 1.f / (32 * IPG);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int col = tn * BN + wn * 64 + j * 32 + l31;
+    const float esc = p.ep_scale[col], esh = p.ep_shift[col];
+#pragma unroll
+    for (int g0 = 0; g0 < FM; g0 += IPG) {
+      float sum = 0.f;
+#pragma unroll
+      for (int i = g0; i < g0 + IPG; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float z = fmaf(acc[i][j][r], esc, esh);
+          sum += z > 0.f ? z : __expf(z) - 1.f;
+        }
+      sum += __shfl_xor(sum, 32, 64);
+      const long grp = ((long)tm * BM + wm * 128 + g0 * 32) / (32 * IPG);
+      if (half == 0) out[grp * p.ldc + col] = sum * inv_n;
     }
   }
 }
@@ -570,7 +614,7 @@ template <typename TC, int ALAY, int BLAY, int DIAG = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   // DIAG 23: front-loaded DMA issue; it stays the order of the RC x RC (wgrad) instantiation, where the
   // interleaved order measured 0-8 % slower (transpose reads: two ds_read_b64_tr_b16 per fragment)
-  constexpr bool kFine = ALAY == KC && (DIAG == 0 || DIAG == 20 || DIAG == 21 || DIAG == 30 || DIAG == 31);
+  constexpr bool kFine = ALAY == KC && (DIAG == 0 || DIAG == 20 || DIAG == 21 || DIAG == 30 || DIAG == 31 || DIAG == 40 || DIAG == 41 || DIAG == 42 || DIAG == 44);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
 
@@ -768,6 +812,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   GEMM_STAMP(2);      // K loop done
   if constexpr (DIAG == 30 || DIAG == 31) {       // dgrad fused with the BatchNorm+ELU backward of the layer below
     epilogue_dgrad_bn<DIAG == 31>(p, acc, smem, tm, tn, tid);
+    return;
+  }
+  if constexpr (DIAG == 40) {
+    epilogue_full_tile<TC, true>(p, acc, smem, tm, tn, tid, split);
+    return;
+  }
+  if constexpr (DIAG == 41 || DIAG == 42 || DIAG == 44) {
+    epilogue_affine_meanpool<DIAG - 40>(p, acc, tm, tn, tid);
     return;
   }
   epilogue_full_tile<TC>(p, acc, smem, tm, tn, tid, split);
@@ -1456,6 +1508,29 @@ bool pcaa_launch_gemm_dgrad_bn(const GemmParams& p_in, hipStream_t stream) {
   if (ntiles >= (1L << 31)) return false;
   if (p.ep_y == nullptr) return launch_dma<bf16_t, KC, KC, 31>(p, dim3((unsigned)ntiles, 1, 1), stream);
   return launch_dma<bf16_t, KC, KC, 30>(p, dim3((unsigned)ntiles, 1, 1), stream);
+}
+
+// product + eval-mode BatchNorm + ELU (pcaa_gemm_affine_elu): whole 256x256 tiles, bf16 KC x KC -> bf16
+bool pcaa_launch_gemm_affine_elu(const GemmParams& p_in, hipStream_t stream) {
+  GemmParams p = p_in;
+  if ((p.M % BM) || (p.N % BN) || (p.K % BK)) return false;
+  p.nsplit = 1;
+  p.split_fast = 0;
+  p.diag = 0;
+  p.k_per_split = p.K;
+  p.atomic = 0;
+  p.c_split_stride = 0;
+  p.colstats = nullptr;
+  const long ntiles = (long)(p.M / BM) * (p.N / BN);
+  if (ntiles >= (1L << 31)) return false;
+  // p.ep_xc: rows per mean-pool group (0: plain activation output)
+  switch (p.ep_xc) {
+    case 0: return launch_dma<bf16_t, KC, KC, 40>(p, dim3((unsigned)ntiles, 1, 1), stream);
+    case 32: return launch_dma<float, KC, KC, 41>(p, dim3((unsigned)ntiles, 1, 1), stream);
+    case 64: return launch_dma<float, KC, KC, 42>(p, dim3((unsigned)ntiles, 1, 1), stream);
+    case 128: return launch_dma<float, KC, KC, 44>(p, dim3((unsigned)ntiles, 1, 1), stream);
+    default: return false;
+  }
 }
 
 bool pcaa_launch_gemm_bf16_big(const GemmParams& p_in, int a_dtype, int a_layout, int b_dtype, int b_layout,

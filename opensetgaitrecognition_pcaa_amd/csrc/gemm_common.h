@@ -60,3 +60,4 @@ PcaaLaunchEvents pcaa_take_launch_events();      // returns {nullptr, nullptr} w
 bool pcaa_launch_gemm_bf16_big(const GemmParams& p, int a_dtype, int a_layout, int b_dtype, int b_layout,
                                int c_dtype, int nsplit, hipStream_t stream);
 bool pcaa_launch_gemm_dgrad_bn(const GemmParams& p, hipStream_t stream);
+bool pcaa_launch_gemm_affine_elu(const GemmParams& p, hipStream_t stream);

@@ -166,6 +166,23 @@ def pointnet_forward(xp2d, layers, training, mode, pool_rows=0):
             saves.append(s)
             a = ops.pointnet_in_apply(a, W2d, scale, shift, torch.bfloat16 if mode == "bf16" else torch.float32)
             continue
+        last_pool = li == nl - 1 and pool_rows
+        if (_FUSE_EVAL_EPILOGUE and not training and mode == "bf16" and a.dtype == torch.bfloat16
+                and (not last_pool or pool_rows in (32, 64, 128))
+                and ops.gemm_dgrad_bn_supported(a.shape[0], cout, cin)):
+            # eval mode: BatchNorm is a fixed per-channel affine map -> BN + ELU (and the mean over the frame's
+            # points for the last layer) in the GEMM epilogue: no stored y, no separate pass
+            scale, shift = ops.bn_eval_coeffs(bn, cout, conv.bias)
+            w16, _ = ops.cast_bf16(W2d, True, False)
+            a_next = ops.gemm_affine_elu(a, w16, scale, shift, pool_rows if last_pool else 0)
+            s = _LayerSave()
+            s.a_in, s.col, s.y, s.scale, s.shift, s.mean, s.rstd = a, None, None, scale, shift, None, None
+            s.rows, s.cin, s.cout, s.dil = a.shape[0], cin, cout, 0
+            saves.append(s)
+            if last_pool:
+                return a_next, saves
+            a = a_next
+            continue
         y, scale, shift, mean, rstd, count = _linear_bn(a, W2d, conv.bias, bn, training, mode, True)
         s = _LayerSave()
         s.a_in, s.col, s.y, s.scale, s.shift, s.mean, s.rstd = a, None, y, scale, shift, mean, rstd
@@ -539,6 +556,7 @@ class EncoderState:
 
 
 _FUSE_HEADS = os.environ.get("PCAA_FUSE_HEADS", "1") != "0"
+_FUSE_EVAL_EPILOGUE = os.environ.get("PCAA_FUSE_EVAL_EPILOGUE", "1") != "0"
 
 
 def _heads_mods(enc, gph):

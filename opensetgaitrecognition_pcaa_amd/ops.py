@@ -284,6 +284,28 @@ def gemm_slabs(A, a_layout, B, b_layout, M, N, K, split_k, out=None, accumulate=
     return out
 
 
+def gemm_affine_elu(a, W16, scale, shift, pool_rows=0):
+    """ELU(scale * (a[M,K] @ W16[N,K]^T) + shift) in one launch (eval-mode BatchNorm+ELU in the GEMM
+    epilogue): bf16 [M,N], or with pool_rows in {32,64,128} its mean over groups of pool_rows consecutive
+    rows, fp32 [M/pool_rows, N].  a, W16 bf16; shapes as gemm_dgrad_bn_supported."""
+    _chk(a, "gemm_affine_elu.a", torch.bfloat16, 2)
+    _chk(W16, "gemm_affine_elu.W16", torch.bfloat16, 2)
+    _chk(scale, "gemm_affine_elu.scale", torch.float32)
+    _chk(shift, "gemm_affine_elu.shift", torch.float32)
+    M, K = a.shape
+    N = W16.shape[0]
+    if (W16.shape[1] != K or scale.numel() != N or shift.numel() != N or not gemm_dgrad_bn_supported(M, N, K)
+            or pool_rows not in (0, 32, 64, 128)):
+        raise ValueError(f"gemm_affine_elu: unsupported shapes a {tuple(a.shape)} W {tuple(W16.shape)} pool {pool_rows}")
+    if pool_rows:
+        out = torch.empty((M // pool_rows, N), dtype=torch.float32, device=a.device)
+    else:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    check(_lib.load().pcaa_gemm_affine_elu(_p(a), a.stride(0), _p(W16), W16.stride(0), _p(out), N, _p(scale),
+                                           _p(shift), M, N, K, int(pool_rows), _s()), "pcaa_gemm_affine_elu")
+    return out
+
+
 def gemm_dgrad_bn_supported(M, N, K):
     return bool(_lib.load().pcaa_gemm_dgrad_bn_supported(int(M), int(N), int(K)))
 

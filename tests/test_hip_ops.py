@@ -577,3 +577,35 @@ def test_dtc_conv_fwd_vs_fp64_conv1d(B, T, cin, cout, d, act):
     assert torch.allclose(st[1], (ref * ref).sum(0), rtol=1e-4, atol=1e-6)
     col_ref = ops.dtc_im2col(a.float().to(DEV).contiguous(), B, T, cin, d)
     assert (col - col_ref).abs().max().item() <= 1e-6 * max(a.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 1024, 512), (3840, 512, 512)])
+def test_gemm_affine_elu_epilogue(M, N, K):
+    """Eval-mode PointNet layer in one launch: ELU(scale * (a @ W^T) + shift), bf16 in/out, fp32 accumulate."""
+    a = _rand((M, K), 61).to(DEV).to(torch.bfloat16)
+    W = (_rand((N, K), 62, K ** -0.5)).to(DEV).to(torch.bfloat16)
+    scale = (_rand((N,), 63, 0.3) + 1.0).to(DEV)
+    shift = _rand((N,), 64, 0.5).to(DEV)
+    out = ops.gemm_affine_elu(a, W, scale, shift)
+    ref = torch.nn.functional.elu((a.double() @ W.double().t()) * scale.double() + shift.double())
+    assert out.dtype == torch.bfloat16 and tuple(out.shape) == (M, N)
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 2 ** -7 * ref.abs().max().item(), err           # one bf16 rounding of the output
+    # and it equals the two-pass path (GEMM -> bf16 y -> BN+ELU pass) up to y's extra bf16 rounding
+    y = ops.gemm(a, KC, W, KC, M, N, K, out_dtype=torch.bfloat16, math=PCAA_BF16)
+    two = ops.bn_act_fwd(y, scale, shift)
+    assert (out.float() - two.float()).abs().max().item() <= 2 ** -6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("M,N,K,pool", [(512, 256, 64, 32), (1024, 1024, 512, 64), (3840, 1024, 1024, 128)])
+def test_gemm_affine_elu_meanpool_epilogue(M, N, K, pool):
+    """Last eval-mode PointNet layer: BN (affine) + ELU + mean over the frame's points in the GEMM epilogue."""
+    a = _rand((M, K), 71).to(DEV).to(torch.bfloat16)
+    W = (_rand((N, K), 72, K ** -0.5)).to(DEV).to(torch.bfloat16)
+    scale = (_rand((N,), 73, 0.3) + 1.0).to(DEV)
+    shift = _rand((N,), 74, 0.5).to(DEV)
+    out = ops.gemm_affine_elu(a, W, scale, shift, pool_rows=pool)
+    act = torch.nn.functional.elu((a.double() @ W.double().t()) * scale.double() + shift.double())
+    ref = act.view(M // pool, pool, N).mean(1)
+    assert out.dtype == torch.float32 and tuple(out.shape) == (M // pool, N)
+    assert (out.double() - ref).abs().max().item() <= 2e-5 * max(act.abs().max().item(), 1.0)
