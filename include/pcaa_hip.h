@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PCAA_ABI_VERSION 3 /* pcaa_abi_version() of a library built from this header */
+#define PCAA_ABI_VERSION 4 /* pcaa_abi_version() of a library built from this header */
 
 #define PCAA_OK 0
 #define PCAA_ERR_INVALID_ARG 1
@@ -267,14 +267,16 @@ int pcaa_disc_backward(const float* x, const float* label, int B, int K,
 /* WGAN-GP critic step (PCAA_ablation.py:939-976): d_loss = mean D(fv) - mean D(z)
  * + gp_weight * mean (|dD/dx(z + alpha (fv - z))| - 1)^2 with the closed-form
  * second-order gradient.  losses[0]=d_loss, losses[1]=gp.
- * Parameter grads are OVERWRITTEN. */
+ * Parameter grads are OVERWRITTEN.  dz (or NULL): d(d_loss)/dz [B,32] -- ablation variant 1
+ * (PCAA_ablation.py:28-378) learns the prior centroids, z = z0 + GaussianMeanLearner(onehot) (:170-186),
+ * so the critic loss is differentiated w.r.t. z too (real pass + the penalty through the interpolates). */
 size_t pcaa_disc_workspace_bytes(int B, int K);
 int pcaa_disc_wgan_gp(const float* z, const float* fv, const float* label, const float* alphas,
                       int B, int K,
                       const float* W1, const float* b1, const float* W2, const float* b2,
                       const float* W3, const float* b3, float gp_weight, float* losses,
                       float* dW1, float* db1, float* dW2, float* db2, float* dW3, float* db3,
-                      float* workspace, size_t workspace_bytes, void* stream);
+                      float* dz, float* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ open-set scoring
  * joint_likelihood (inference_PCAA.py:129-136): lik[b] = (1/K) sum_k N(x_b; mu_k, I_D), float64,

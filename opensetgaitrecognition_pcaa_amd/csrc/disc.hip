@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64) void disc_rows_kernel(const float* __restrict__
   s.u[t] = (t < XD) ? zv : lab;
   __syncthreads();
   Fwd fr = forward_pass(s, IN, P1, t);
-  (void)first_order(s, fr, -invB, IN, P1, t, recs + ((long)0 * B + row) * REC);
+  const float du_real = first_order(s, fr, -invB, IN, P1, t, recs + ((long)0 * B + row) * REC);
   __syncthreads();
   // fake pass: c = +1/B
   s.u[t] = (t < XD) ? fvv : lab;
@@ -205,6 +205,19 @@ __global__ __launch_bounds__(64) void disc_rows_kernel(const float* __restrict__
   rec[R_D1 + t] = ab1;
   rec[R_H1 + t] = fi.h1;
   rec[R_U + t] = (t < IN) ? s.u[t] : 0.f;
+  if (dx != nullptr) {
+    // d(d_loss)/dz (variant 1: z = z0 + GaussianMeanLearner(onehot) carries a gradient): the real pass's input
+    // gradient plus the penalty's, which reaches z through interp = z + alpha (fv - z), i.e. times (1 - alpha);
+    // ab1 is d(gp_weight * gp)/d(layer-1 pre-activation) of the interpolate pass
+    s.d1[t] = ab1;
+    __syncthreads();
+    if (t < XD) {
+      float dgp = 0.f;
+#pragma unroll 8
+      for (int o = 0; o < H1; ++o) dgp = fmaf(s.W1[o * P1 + t], s.d1[o], dgp);
+      dx[(long)row * XD + t] = fmaf(1.f - alpha, dgp, du_real);
+    }
+  }
   if (t == 0) {
     rec[R_C] = 0.f;
     out[(long)row * 3 + 0] = fr.D;
@@ -341,7 +354,7 @@ extern "C" int pcaa_disc_wgan_gp(const float* z, const float* fv, const float* l
                                  int B, int K, const float* W1, const float* b1, const float* W2,
                                  const float* b2, const float* W3, const float* b3, float gp_weight,
                                  float* losses, float* dW1, float* db1, float* dW2, float* db2, float* dW3,
-                                 float* db3, float* workspace, size_t workspace_bytes, void* stream) {
+                                 float* db3, float* dz, float* workspace, size_t workspace_bytes, void* stream) {
   PCAA_CHECK_ARG(disc_args_ok(B, K), "pcaa_disc_wgan_gp: bad B=%d K=%d", B, K);
   PCAA_CHECK_ARG(z && fv && (label || K == 0) && alphas && W1 && b1 && W2 && b2 && W3 && b3 && losses,
                  "pcaa_disc_wgan_gp: null pointer");
@@ -352,7 +365,7 @@ extern "C" int pcaa_disc_wgan_gp(const float* z, const float* fv, const float* l
   float* gpx = recs + (size_t)3 * B * REC;
   float* rowvals = gpx + (size_t)B * GPX;
   hipLaunchKernelGGL(disc_rows_kernel<2>, dim3(B), dim3(64), 0, s, z, fv, label, alphas, B, K, p, gp_weight,
-                     rowvals, (float*)nullptr, (float*)nullptr, recs, gpx);
+                     rowvals, dz, (float*)nullptr, recs, gpx);
   const int total = H1 * (XD + K) + H1 + H2 * H1 + H2 + H2 + 1;
   hipLaunchKernelGGL(disc_param_grad_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, recs, gpx, 3, B,
                      K, dW1, db1, dW2, db2, dW3, db3);

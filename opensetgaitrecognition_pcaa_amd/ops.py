@@ -848,7 +848,7 @@ def disc_backward(x, label, params, gout, want_dx=True, want_dlabel=False, want_
     return dx, dl, (grads if want_params else None)
 
 
-def disc_wgan_gp(z, fv, label, alphas, params, gp_weight, grads_out=None):
+def disc_wgan_gp(z, fv, label, alphas, params, gp_weight, grads_out=None, want_dz=False):
     for t, nm in ((z, "z"), (fv, "fv"), (label, "label"), (alphas, "alphas")):
         _chk(t, f"wgan.{nm}", torch.float32)
     B, K = label.shape
@@ -858,9 +858,12 @@ def disc_wgan_gp(z, fv, label, alphas, params, gp_weight, grads_out=None):
     losses = torch.empty(2, dtype=torch.float32, device=dev)
     grads = grads_out if grads_out is not None else [torch.empty_like(p) for p in params]
     ws = disc_workspace(B, K, dev)
+    dz = torch.empty_like(z) if want_dz else None
     check(_lib.load().pcaa_disc_wgan_gp(_p(z), _p(fv), _p(label), _p(alphas), B, K, *[_p(p) for p in params],
-                                        float(gp_weight), _p(losses), *[_p(g) for g in grads], _p(ws),
+                                        float(gp_weight), _p(losses), *[_p(g) for g in grads], _p(dz), _p(ws),
                                         ws.numel() * 4, _s()), "pcaa_disc_wgan_gp")
+    if want_dz:
+        return losses, grads, dz          # dz = d(d_loss)/dz (variant 1: learned centroids)
     return losses, grads
 
 

@@ -4,6 +4,8 @@
   -- the paper's PCAA (reference ``PCAA_ablation.py:746-1122``)
 * ``train_CGAAE(config)`` / ``train_variant2`` -- base loop without projection
   heads (``train_AAE.py:25-364``, ``PCAA_ablation.py:381-389``)
+* ``train_variant1(config, wandb_mode="online")`` -- ablation with the ``GaussianMeanLearner``
+  producing the prior centroids (``PCAA_ablation.py:28-378``)
 
 Both drive :class:`PCAATrainer`, which owns the five modules, flat fp32
 parameter / gradient / Adam buffers (one fused Adam launch per optimiser, one
@@ -23,7 +25,7 @@ from . import constants
 from . import functional as F_hip
 from . import ops
 from ._lib import ACT_ELU
-from .models import CGDecoder, CGDiscriminator, CGEncoder
+from .models import CGDecoder, CGDiscriminator, CGEncoder, GaussianMeanLearner
 from .utils import sample_distant_points, save_model
 
 _ALIGN = 64  # floats; keeps every parameter view 256-B aligned inside the flat buffers
@@ -82,10 +84,17 @@ class FlatBuffer:
 
 class PCAATrainer:
     """One process = one GPU.  ``variant`` "v4" (projection heads, the paper's
-    PCAA) or "base" (train_CGAAE / variant 2)."""
+    PCAA), "base" (train_CGAAE / variant 2) or "v1" (variant 4's networks without the inert discriminator
+    head, prior centroids = GaussianMeanLearner(one_hot), PCAA_ablation.py:28-378).
+
+    Variant 1 as the reference EXECUTES it: ``z = Variable(z0 + mus)`` (:186) detaches, so the mean learner
+    never receives a gradient -- its parameters stay at their initial values (they sit in optimizer_D with
+    ``grad=None``), only its BatchNorm running statistics move (golden: tests/golden/v1_*.npz).
+    ``learn_centroids=True`` is the variant's stated intent instead (NOT the reference's behaviour): z stays
+    attached, ``pcaa_disc_wgan_gp`` returns d(d_loss)/dz and the learner is trained by optimizer_D."""
 
     def __init__(self, config, n_classes=None, device="cuda", variant="v4", precision=None,
-                 process_group=None, sync_bn=False):
+                 process_group=None, sync_bn=False, learn_centroids=False):
         self.cfg = dict(config)
         self.K = n_classes if n_classes is not None else len(config["TRAIN_CLASSES"])
         self.N = config["NMAX"]
@@ -102,19 +111,27 @@ class PCAATrainer:
             self.world = dist.get_world_size(process_group)
             if sync_bn:
                 F_hip.set_sync_bn_group(process_group)
-        head = variant == "v4"
+        if variant not in ("v4", "base", "v1"):
+            raise ValueError(f"PCAATrainer: unknown variant {variant!r}")
+        head = variant in ("v4", "v1")
+        self.learn_centroids = bool(learn_centroids) and variant == "v1"
         # construction order = the reference's (PCAA_ablation.py:764-786): same draws from torch's RNG
         self.encoder = CGEncoder(n_out_labels=self.K, use_projection_head=head, nmax_points=self.N).to(self.device).float()
         self.decoder = CGDecoder(input_dim=self.L * 2 if head else self.L, nmax_points=self.N).to(self.device).float()
-        self.discriminator = CGDiscriminator(self.K).to(self.device).float()
-        if head:
+        if variant != "v1":
+            self.discriminator = CGDiscriminator(self.K).to(self.device).float()
+        self.decoder_projection_head = self.discriminator_projection_head = self.mean_learner = None
+        if variant == "v1":
+            # PCAA_ablation.py:44-64: encoder, decoder, decoder head, discriminator, mean learner
+            self.decoder_projection_head = torch.nn.Sequential(
+                torch.nn.Linear(self.L, self.L * 2), torch.nn.ELU()).to(self.device).float()
+            self.discriminator = CGDiscriminator(self.K).to(self.device).float()
+            self.mean_learner = GaussianMeanLearner(self.K).to(self.device).float()
+        elif head:
             self.decoder_projection_head = torch.nn.Sequential(
                 torch.nn.Linear(self.L, self.L * 2), torch.nn.ELU()).to(self.device).float()
             self.discriminator_projection_head = torch.nn.Sequential(
                 torch.nn.Linear(self.L * 2, self.L), torch.nn.ELU()).to(self.device).float()
-        else:
-            self.decoder_projection_head = None
-            self.discriminator_projection_head = None
         self.discriminator_means = None
         self._flat_ready = False
         self._graphs = {}
@@ -131,7 +148,10 @@ class PCAATrainer:
         d = {"E": self.encoder, "G": self.decoder, "D": self.discriminator}
         if self.decoder_projection_head is not None:
             d["GPH"] = self.decoder_projection_head
+        if self.discriminator_projection_head is not None:
             d["DPH"] = self.discriminator_projection_head
+        if self.mean_learner is not None:
+            d["ML"] = self.mean_learner
         return d
 
     def finalize(self):
@@ -143,7 +163,16 @@ class PCAATrainer:
         g_named += [("G." + n, p) for n, p in self.decoder.named_parameters() if n.startswith("dense")]
         self.flat_g = FlatBuffer(g_named, self.device)
         # the inert discriminator projection head is in optimizer_D but never gets a gradient
-        self.flat_d = FlatBuffer([("D." + n, p) for n, p in self.discriminator.named_parameters()], self.device)
+        d_named = [("D." + n, p) for n, p in self.discriminator.named_parameters()]
+        if self.learn_centroids:
+            # optimizer_D = Adam(chain(mean_learner, discriminator)) (PCAA_ablation.py:104-108); in the reference's
+            # executed behaviour the learner's gradients are None (Adam skips them), so it stays out of the buffer
+            d_named = [("ML." + n, p) for n, p in self.mean_learner.named_parameters()] + d_named
+        self.flat_d = FlatBuffer(d_named, self.device)
+        if self.variant == "v1":
+            self._zero_means = torch.zeros((self.K, self.L), dtype=torch.float32, device=self.device)
+            ml = [i for i, nm in enumerate(self.flat_d.names) if nm.startswith("ML.")]
+            self._ml_end = self.flat_d.offsets[len(ml)] if ml and len(ml) < len(self.flat_d.offsets) else 0
         self._d_params = ops._disc_params(self.discriminator)
         self._d_grads = [self.flat_d.grad_views["D." + n] for n, _ in self.discriminator.named_parameters()]
         self._dec_grads = {n: self.flat_g.grad_views["G." + n] for n, _ in self.decoder.named_parameters()
@@ -205,7 +234,7 @@ class PCAATrainer:
         Returns a dict of DEVICE tensors (no host sync)."""
         if not self._flat_ready:
             self.finalize()
-        if self.discriminator_means is None:
+        if self.discriminator_means is None and self.variant != "v1":
             raise RuntimeError("prior means not set: call sample_prior_means() / set_prior_means()")
         cfg = self.cfg
         B = pcs.shape[0]
@@ -230,9 +259,27 @@ class PCAATrainer:
         adv = float(cfg["ADV_WEIGHT"])
 
         def critic_branch():
-            z, oh = ops.prior_sample(z0, self.discriminator_means, gt, self.K)
-            dl, _ = ops.disc_wgan_gp(z, sup_fv, oh, alphas.reshape(-1).contiguous(), self._d_params,
-                                     cfg["GP_WEIGHT"], grads_out=self._d_grads)
+            if self.variant == "v1":
+                # centroids from the mean learner (train-mode BatchNorm over the batch's one-hots, :170)
+                _, oh = ops.prior_sample(z0, self._zero_means, gt, self.K)
+                if self.learn_centroids:
+                    for n, p in self.mean_learner.named_parameters():
+                        p.grad = self.flat_d.grad_views["ML." + n]
+                    self.flat_d.g[:self._ml_end].zero_()
+                    mus = self.mean_learner(oh)
+                    z = z0 + mus.detach()
+                    dl, _, dz = ops.disc_wgan_gp(z, sup_fv, oh, alphas.reshape(-1).contiguous(), self._d_params,
+                                                 cfg["GP_WEIGHT"], grads_out=self._d_grads, want_dz=True)
+                    mus.backward(dz)
+                else:
+                    with torch.no_grad():
+                        z = z0 + self.mean_learner(oh)
+                    dl, _ = ops.disc_wgan_gp(z, sup_fv, oh, alphas.reshape(-1).contiguous(), self._d_params,
+                                             cfg["GP_WEIGHT"], grads_out=self._d_grads)
+            else:
+                z, oh = ops.prior_sample(z0, self.discriminator_means, gt, self.K)
+                dl, _ = ops.disc_wgan_gp(z, sup_fv, oh, alphas.reshape(-1).contiguous(), self._d_params,
+                                         cfg["GP_WEIGHT"], grads_out=self._d_grads)
             self._allreduce(self.flat_d.g)
             self.flat_d.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs)
             synth = ops.disc_forward(sup_fv, oh, self._d_params)
@@ -414,9 +461,18 @@ class PCAATrainer:
 
     # ------------------------------------------------------------------ checkpoints (format of the reference)
     def save_checkpoints(self, folder, model_name):
-        suffix = {"E": "_E", "G": "_G", "D": "_D", "GPH": "_GPH", "DPH": "_DPH"}
+        suffix = {"E": "_E", "G": "_G", "D": "_D", "GPH": "_GPH", "DPH": "_DPH", "ML": "_ML"}
         for key, mod in self.modules().items():
             save_model(mod, os.path.join(folder, f"{model_name}{suffix[key]}.pt"))
+        if self.mean_learner is not None:
+            torch.save(self.learned_centroids(), os.path.join(folder, "discriminator_means.pt"))
+
+    @torch.no_grad()
+    def learned_centroids(self):
+        """Variant 1's ``discriminator_means.pt`` (PCAA_ablation.py:367-375): the mean learner applied to the K
+        one-hot labels -- in whatever mode it is in; the reference never leaves train mode here, so the
+        BatchNorm statistics are those of the K one-hots (and the running statistics move)."""
+        return self.mean_learner(torch.eye(self.K, dtype=torch.float32, device=self.device))
 
 
 # ----------------------------------------------------------------------
@@ -468,8 +524,9 @@ def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=
         run = wb.init(project=constants.WANDB_PROJECT, config=config, name=config["MODEL_NAME"],
                       notes=config["NOTES"], reinit=True, mode=constants.WANDB_MODE)
 
-    means = trainer.sample_prior_means()
-    torch.save(means, os.path.join("models", config["MODEL_NAME"], "discriminator_means.pt"))
+    if variant != "v1":
+        means = trainer.sample_prior_means()
+        torch.save(means, os.path.join("models", config["MODEL_NAME"], "discriminator_means.pt"))
     trainer.finalize()
 
     best_valid_accuracy = 0
@@ -535,6 +592,12 @@ def train_variant4(config, wandb_mode="online", proj_head_on_discriminator=False
             "proj_head_on_discriminator=True is never used by the reference's drivers and would fail "
             "there too (Linear(64,32) applied to the 32-wide sup_fvs, PCAA_ablation.py:783-786, :934)")
     return _run_loop(config, "v4", **kw)
+
+
+def train_variant1(config, wandb_mode="online", **kw):
+    """Variant 1: the prior centroids come from a GaussianMeanLearner (PCAA_ablation.py:28-378); see
+    PCAATrainer for what the reference executes vs. what the variant intends."""
+    return _run_loop(config, "v1", **kw)
 
 
 def train_CGAAE(config=None, **kw):

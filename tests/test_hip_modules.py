@@ -383,3 +383,93 @@ def test_full_size_properties_config2():
     assert abs(loss_fn(x, x).item()) < 1e-3
     a = loss_fn(x[:, :, :, perm], x).item()
     assert abs(a) < 1e-3
+
+
+# ---------------------------------------------------------------- ablation variant 1 (GaussianMeanLearner centroids)
+def _v1_trainer(m, learn=False):
+    B, N, C, K = m["B"], m["N"], m["C"], m["K"]
+    constants.NFEATURES = C
+    cfg = dict(constants.CONFIG)
+    cfg.update(NMAX=N, TRAIN_CLASSES=list(range(K)), BATCH_SIZE=B, LR=1e-4, B1=0.9, B2=0.99,
+               GP_WEIGHT=15, ADV_WEIGHT=1, SUP_LATENT_DIM=32)
+    tr = PCAATrainer(cfg, precision="fp32", variant="v1", learn_centroids=learn)
+    for mod, seed in zip((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head, tr.mean_learner),
+                         m["fill_seeds"]):
+        syn.deterministic_fill_(mod, seed)
+    tr.finalize()
+    tr.train()
+    return tr
+
+
+def _v1_inputs(m, s):
+    B, N, C, K = m["B"], m["N"], m["C"], m["K"]
+    return (syn.synthetic_pcs(B, T, N, C, seed=m["pcs_seed0"] + s), syn.synthetic_labels(B, K, seed=m["gt_seed0"] + s),
+            syn.synthetic_z0(B, 32, seed=m["z0_seed0"] + s), syn.synthetic_alphas(B, seed=m["alpha_seed0"] + s))
+
+
+def test_v1_train_steps_vs_golden():
+    """train_variant1's step as the reference executes it (the mean learner gets no gradient: its
+    Variable(z0 + mus) detaches) against the trajectory generated from the reference's own modules."""
+    g, m = load_golden("v1_B6_N32_C4_K4")
+    steps = m["steps"]
+    tr = _v1_trainer(m)
+    ml0 = {k: v.detach().clone() for k, v in tr.mean_learner.state_dict().items()}
+    for s in range(steps):
+        pcs, gt, z0, al = _v1_inputs(m, s)
+        out = tr.step(pcs.to(DEV).permute(0, 3, 1, 2), gt.to(DEV), z0.to(DEV), al.to(DEV))
+        got = np.array([out[k].item() for k in ("d_loss", "gp", "rec_loss", "loss_g", "sup_loss", "tot_loss")])
+        tol = TOL if s == 0 else 5e-4 * s
+        assert np.allclose(got, g[f"s{s}.losses"], rtol=tol, atol=1e-5), (s, got, g[f"s{s}.losses"])
+        assert np.array_equal(out["preds"].cpu().numpy(), g[f"s{s}.preds"])
+        _close(out["sup_fvs"], g[f"s{s}.sup_fvs"], tol, what=f"sup_fvs step {s}")
+    for name, v in tr.discriminator.state_dict().items():
+        check_against_record(g, f"s{steps - 1}.param.D.", name, v, 5e-5, scale_floor=1.0)
+    for name, v in tr.mean_learner.state_dict().items():
+        if name.endswith("weight") or name.endswith("bias"):
+            assert torch.equal(v, ml0[name]), f"{name}: the reference never updates the mean learner"
+        elif name.endswith("running_var"):
+            check_against_record(g, f"s{steps - 1}.param.ML.", name, v, 1e-4, scale_floor=1.0)
+        elif name.endswith("num_batches_tracked"):
+            assert int(v) == steps
+    cent = tr.learned_centroids()
+    _close(cent, g["centroids_train_mode"], 1e-3, floor=1e-3, what="learned centroids (train-mode BN over the K one-hots)")
+
+
+def test_v1_learn_centroids_option_vs_oracle():
+    """learn_centroids=True (the variant's stated intent, not the reference's behaviour): z stays attached,
+    pcaa_disc_wgan_gp returns d(d_loss)/dz and the mean learner is trained -- against the oracle's autograd."""
+    g, m = load_golden("v1_B6_N32_C4_K4")
+    K, C, N = m["K"], m["C"], m["N"]
+    tr = _v1_trainer(m, learn=True)
+
+    def sd_cpu(mod):
+        return {k: v.detach().cpu().clone() for k, v in mod.state_dict().items()}
+
+    st = O.V1State(sd_cpu(tr.encoder), sd_cpu(tr.decoder), sd_cpu(tr.discriminator), sd_cpu(tr.decoder_projection_head),
+                   sd_cpu(tr.mean_learner), C, T, N, K)
+    cfg = dict(LR=1e-4, B1=0.9, B2=0.99, GP_WEIGHT=15, ADV_WEIGHT=1)
+    pcs, gt, z0, al = _v1_inputs(m, 0)
+    ref = O.v1_train_step(st, pcs.permute(0, 3, 1, 2), gt, z0, al, cfg, attach_centroids=True)
+    out = tr.step(pcs.to(DEV).permute(0, 3, 1, 2), gt.to(DEV), z0.to(DEV), al.to(DEV))
+    for k in ("d_loss", "gp", "rec_loss", "loss_g", "sup_loss", "tot_loss"):
+        assert abs(out[k].item() - ref[k].item()) <= TOL * abs(ref[k].item()) + 1e-5, (k, out[k].item(), ref[k].item())
+    # the gradient shrinks ~100x per BatchNorm layer on the way down (6 rows, one-hot inputs: 0.28 at the output
+    # layer, 1e-6 at the first), each BatchNorm backward cancelling O(1) terms: the error is judged against the
+    # scale of the chain's gradient, not each tensor's own
+    gscale = max(float(v.abs().max()) for k, v in ref["d_grads"].items() if k.startswith("ML.") and v is not None)
+    for name, _ in tr.mean_learner.named_parameters():
+        gr = ref["d_grads"]["ML." + name]
+        got = tr.flat_d.grad_views["ML." + name]
+        if name in ("model.0.bias", "model.3.bias", "model.6.bias"):       # feed a BatchNorm: analytically zero
+            assert float(got.abs().max()) == 0.0
+            continue
+        err = float((got.cpu().double() - gr.double()).abs().max())
+        assert err <= 5e-5 * gscale, (name, err, gscale)
+    for name, v in tr.mean_learner.state_dict().items():
+        if name.endswith("weight") and v.dim() == 2:
+            err = (v.cpu() - st.gml[name]).abs().max().item()
+            # one Adam step moves an element by lr in the direction of its gradient's sign: a noise-level
+            # gradient can send the two sides opposite ways (2 lr); the mean must agree far better
+            assert err <= 2.1e-4, (name, err)
+            if name in ("model.6.weight", "model.9.weight"):     # gradients well above Adam's eps: signs agree
+                assert (v.cpu() - st.gml[name]).abs().mean().item() <= 1e-5, name

@@ -609,3 +609,23 @@ def test_gemm_affine_elu_meanpool_epilogue(M, N, K, pool):
     ref = act.view(M // pool, pool, N).mean(1)
     assert out.dtype == torch.float32 and tuple(out.shape) == (M // pool, N)
     assert (out.double() - ref).abs().max().item() <= 2e-5 * max(act.abs().max().item(), 1.0)
+
+
+def test_wgan_gp_dz_vs_autograd():
+    """d(d_loss)/dz of the critic step (the gradient variant 1 would send into the mean learner) against
+    autograd through the oracle's loss (double backward through the gradient penalty)."""
+    B, K = 16, 8
+    disc = {k: v for k, v in zip(("model.0.weight", "model.0.bias", "model.2.weight", "model.2.bias", "model.4.weight",
+                                  "model.4.bias"),
+                                 (_rand((64, 32 + K), 81, 0.2), _rand((64,), 82, 0.1), _rand((32, 64), 83, 0.2),
+                                  _rand((32,), 84, 0.1), _rand((1, 32), 85, 0.3), _rand((1,), 86, 0.1)))}
+    z = _rand((B, 32), 87); fv = _rand((B, 32), 88)
+    oh = torch.nn.functional.one_hot(torch.arange(B) % K, K).float()
+    al = torch.from_numpy(np.random.default_rng(89).random((B, 1), dtype=np.float32))
+    zr = z.clone().requires_grad_(True)
+    d_loss, gp = O.wgan_gp_d_loss(disc, fv, oh, zr, al, 15.0)
+    ref = torch.autograd.grad(d_loss, zr)[0]
+    losses, grads, dz = ops.disc_wgan_gp(z.to(DEV), fv.to(DEV), oh.to(DEV), al.reshape(-1).to(DEV),
+                                         [v.to(DEV) for v in disc.values()], 15.0, want_dz=True)
+    assert abs(losses[0].item() - d_loss.item()) <= 1e-4 * abs(d_loss.item()) + 1e-6
+    assert (dz.cpu() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-7

@@ -207,3 +207,47 @@ def test_inference_scoring():
     for k in (1, 2, 4, 6):
         votes = O.k_vote(g["lk_known"], g["preds"], thr, k, 6)
         assert np.array_equal(votes, g[f"votes_k{k}"])
+
+
+def _is_gml_pre_bn_bias(name):
+    # GaussianMeanLearner: Linear biases model.0/3/6 feed a BatchNorm1d (analytically zero gradient)
+    return name in ("model.0.bias", "model.3.bias", "model.6.bias")
+
+
+def test_v1_train_steps_learned_centroids():
+    """Ablation variant 1 (PCAA_ablation.py:28-378): the oracle's restatement against the golden trajectory
+    produced by the reference's own modules (tests/golden/make_golden_v1.py)."""
+    g, m = load_golden("v1_B6_N32_C4_K4")
+    B, N, C, K, steps = m["B"], m["N"], m["C"], m["K"], m["steps"]
+    s0, s1, s2, s3, s4 = m["fill_seeds"]
+    enc, dec, disc, gph = make_encoder(K, N, C, True, s0), make_decoder(64, N, C, s1), make_disc(K, s2), make_head(32, 64, s3)
+    gml = models.GaussianMeanLearner(K).float()
+    syn.deterministic_fill_(gml, s4)
+    st = O.V1State(sd_clone(enc), sd_clone(dec), sd_clone(disc), sd_clone(gph), sd_clone(gml), C, T, N, K)
+    cfg = dict(LR=1e-4, B1=0.9, B2=0.99, GP_WEIGHT=15, ADV_WEIGHT=1)
+    for s in range(steps):
+        pcs = syn.synthetic_pcs(B, T, N, C, seed=m["pcs_seed0"] + s).permute(0, 3, 1, 2)
+        gt = syn.synthetic_labels(B, K, seed=m["gt_seed0"] + s)
+        z0 = syn.synthetic_z0(B, 32, seed=m["z0_seed0"] + s)
+        al = syn.synthetic_alphas(B, seed=m["alpha_seed0"] + s)
+        out = O.v1_train_step(st, pcs, gt, z0, al, cfg)
+        got = np.array([out[k].item() for k in ("d_loss", "gp", "rec_loss", "loss_g", "sup_loss", "tot_loss")])
+        assert np.allclose(got, g[f"s{s}.losses"], rtol=5e-5 * (s + 1), atol=1e-6), (s, got, g[f"s{s}.losses"])
+        assert np.array_equal(out["preds"].numpy(), g[f"s{s}.preds"])
+        assert torch.allclose(out["mus"], torch.from_numpy(g[f"s{s}.mus"]), rtol=1e-4, atol=2e-5 * (s + 1))
+        if s == 0:
+            for name, gr in out["d_grads"].items():
+                nm, pname = name.split(".", 1)
+                if nm == "ML":
+                    # the reference's Variable(z0 + mus) detaches: the mean learner gets NO gradient
+                    assert gr is None and f"s0.dgrad.ML.{pname}::none" in g.files
+                    continue
+                check_against_record(g, f"s0.dgrad.{nm}.", pname, gr, 2e-4, scale_floor=1e-3)
+        if s in (0, steps - 1):
+            for nm, sd in (("D", st.disc), ("ML", st.gml)):
+                for name, v in sd.items():
+                    if nm == "ML" and (_is_gml_pre_bn_bias(name) or name.endswith("running_mean")):
+                        continue
+                    check_against_record(g, f"s{s}.param.{nm}.", name, v, 5e-5, scale_floor=1.0)
+    cent = O.gaussian_mean_learner_forward(torch.eye(K), st.gml, training=True, update_stats=False)
+    assert torch.allclose(cent, torch.from_numpy(g["centroids_train_mode"]), rtol=1e-3, atol=2e-4)
