@@ -814,17 +814,31 @@ def decoder_forward(dec, z, mode=None):
     if z.dim() != 2 or z.shape[1] != dec.dense1.weight.shape[1]:
         raise RuntimeError(f"CGDecoder: expected [B,{dec.dense1.weight.shape[1]}], got {tuple(z.shape)}")
     acts = [z.contiguous().float()]
-    layers = dec.dense_layers()
+    # _pcaa_pad (set by PCAATrainer.finalize for ragged widths): the layers as zero-padded [Np,Kp] weights;
+    # the chain then runs in the padded widths (padded activations are exactly 0) and the output is cut back
+    layers = getattr(dec, "_pcaa_pad", None) or dec.dense_layers()
     for i, lin in enumerate(layers):
         acts.append(linear_act_forward(acts[-1], lin, ACT_ELU if i < 4 else ACT_NONE, mode))
-    return acts[-1], acts
+    out = acts[-1]
+    S = dec.dense5.weight.shape[0]
+    if out.shape[1] != S:
+        out = out[:, :S].contiguous()
+    return out, acts
 
 
 def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=None, mode=None):
+    """``grads_out`` {"denseI.weight"/"denseI.bias": destination}: for a padded decoder (see decoder_forward)
+    these are the PADDED gradient tensors; without grads_out the returned gradients are cut to the parameter
+    shapes."""
     mode = get_precision() if mode is None else mode
-    layers = dec.dense_layers()
+    padded = getattr(dec, "_pcaa_pad", None)
+    layers = padded or dec.dense_layers()
     g = {}
-    d = d_out.contiguous().view(acts[-1].shape)
+    d = d_out.contiguous().view(d_out.shape[0], -1)
+    if d.shape[1] != acts[-1].shape[1]:
+        dp = torch.zeros_like(acts[-1])                  # padded output columns carry no gradient
+        dp[:, :d.shape[1]].copy_(d)
+        d = dp
     pre = False           # d is w.r.t. the layer's pre-activation (ELU' already applied by the dgrad above)
     for i in range(4, -1, -1):
         lin = layers[i]
@@ -838,7 +852,11 @@ def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=Non
                                         dx_init=dz_init if i == 0 else None, mode=mode, d_is_pre=pre,
                                         fuse_elu_in=fuse)
         pre = fuse
-        g[nm + ".weight"], g[nm + ".bias"] = dW.view_as(lin.weight), db
+        dW = dW.view_as(lin.weight)
+        if padded and grads_out is None:
+            ref = dec.dense_layers()[i]                  # cut the padding off: gradients in the parameter shapes
+            dW, db = dW[:ref.weight.shape[0], :ref.weight.shape[1]], db[:ref.bias.shape[0]]
+        g[nm + ".weight"], g[nm + ".bias"] = dW, db
     return g, d
 
 

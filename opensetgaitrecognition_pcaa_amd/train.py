@@ -35,23 +35,38 @@ class FlatBuffer:
     """Parameters re-pointed into one contiguous fp32 buffer (+ matching
     gradient and Adam moment buffers)."""
 
-    def __init__(self, named_params, device):
+    def __init__(self, named_params, device, padded_shapes=None):
+        """``padded_shapes``: optional {name: padded shape}: that parameter is stored zero-padded to the
+        given shape and exposed as the strided ``[:n0, :n1]`` view of it (same values, same ``state_dict``);
+        ``self.padded[name]`` holds the full (parameter, gradient) tensors for kernels that want whole tiles."""
         self.names, self.offsets, self.sizes, self.params = [], [], [], []
+        padded_shapes = padded_shapes or {}
         total = 0
         for name, p in named_params:
             self.names.append(name)
             self.offsets.append(total)
-            self.sizes.append(p.numel())
+            n = int(torch.Size(padded_shapes[name]).numel()) if name in padded_shapes else p.numel()
+            self.sizes.append(n)
             self.params.append(p)
-            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            total += (n + _ALIGN - 1) // _ALIGN * _ALIGN
         self.total = total
         self.p = torch.zeros(total, dtype=torch.float32, device=device)
         self.g = torch.zeros(total, dtype=torch.float32, device=device)
         self.m = torch.zeros(total, dtype=torch.float32, device=device)
         self.v = torch.zeros(total, dtype=torch.float32, device=device)
         self.grad_views = {}
+        self.padded = {}
         with torch.no_grad():
             for name, p, o, n in zip(self.names, self.params, self.offsets, self.sizes):
+                if name in padded_shapes:
+                    shp = tuple(padded_shapes[name])
+                    full_p, full_g = self.p[o:o + n].view(shp), self.g[o:o + n].view(shp)
+                    window = tuple(slice(0, d) for d in p.shape)
+                    full_p[window].copy_(p.detach())
+                    p.data = full_p[window]
+                    self.grad_views[name] = full_g[window]
+                    self.padded[name] = (full_p, full_g)
+                    continue
                 self.p[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = self.p[o:o + n].view(p.shape)
                 self.grad_views[name] = self.g[o:o + n].view(p.shape)
@@ -161,7 +176,29 @@ class PCAATrainer:
             g_named += [("GPH." + n, p) for n, p in self.decoder_projection_head.named_parameters()]
         # bn1..bn4 of the decoder never receive a gradient: torch.optim.Adam skips them
         g_named += [("G." + n, p) for n, p in self.decoder.named_parameters() if n.startswith("dense")]
-        self.flat_g = FlatBuffer(g_named, self.device)
+        # Decoder widths that are not multiples of 64 (N=150, the reference's default: 1125 ... 18000) keep the
+        # weight-streaming kernels away -- rows of 1125 floats are not even 16-B aligned.  The weights are then
+        # STORED zero-padded to multiples of 64 in both dimensions and the decoder runs in the padded widths
+        # (functional.decoder_forward): padded outputs are ELU(0) = 0, padded rows / columns get exactly zero
+        # gradients (their operands are zero), so Adam leaves the padding at zero and the [:N,:K] windows the
+        # modules expose are bit-for-bit what an unpadded run of the same kernels would hold.
+        pads = {}
+        if os.environ.get("PCAA_PAD_DECODER", "1") != "0":
+            r64 = lambda v: (v + 63) // 64 * 64
+            lins = self.decoder.dense_layers()
+            if any(l.weight.shape[0] % 64 for l in lins):
+                for i, l in enumerate(lins, start=1):
+                    n_out, n_in = l.weight.shape
+                    kp = n_in if i == 1 else r64(n_in)             # the first layer's input is the latent itself
+                    pads[f"G.dense{i}.weight"] = (r64(n_out), kp)
+                    pads[f"G.dense{i}.bias"] = (r64(n_out),)
+        self.flat_g = FlatBuffer(g_named, self.device, padded_shapes=pads)
+        if pads:
+            from types import SimpleNamespace
+            self.decoder._pcaa_pad = [
+                SimpleNamespace(weight=self.flat_g.padded[f"G.dense{i}.weight"][0],
+                                bias=self.flat_g.padded[f"G.dense{i}.bias"][0])
+                for i in range(1, len(self.decoder.dense_layers()) + 1)]
         # the inert discriminator projection head is in optimizer_D but never gets a gradient
         d_named = [("D." + n, p) for n, p in self.discriminator.named_parameters()]
         if self.learn_centroids:
@@ -175,8 +212,9 @@ class PCAATrainer:
             self._ml_end = self.flat_d.offsets[len(ml)] if ml and len(ml) < len(self.flat_d.offsets) else 0
         self._d_params = ops._disc_params(self.discriminator)
         self._d_grads = [self.flat_d.grad_views["D." + n] for n, _ in self.discriminator.named_parameters()]
-        self._dec_grads = {n: self.flat_g.grad_views["G." + n] for n, _ in self.decoder.named_parameters()
-                           if n.startswith("dense")}
+        self._dec_grads = {n: (self.flat_g.padded["G." + n][1] if "G." + n in self.flat_g.padded
+                               else self.flat_g.grad_views["G." + n])
+                           for n, _ in self.decoder.named_parameters() if n.startswith("dense")}
         # encoder gradients are produced straight into the flat buffer; the split-K products
         # accumulate, so that (leading) region is cleared by one fill per step
         self._enc_grads = {n: self.flat_g.grad_views["E." + n] for n, _ in self.encoder.named_parameters()}

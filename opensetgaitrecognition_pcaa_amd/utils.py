@@ -23,7 +23,10 @@ class SeqChamferLoss(torch.nn.Module):
 
 
 def save_model(_model: torch.nn.Module, _path):
-    torch.save(_model.state_dict(), _path)
+    """``torch.save(model.state_dict(), path)`` (reference utils.py:160-161).  The trainer re-points parameters
+    into its flat buffers (train.FlatBuffer): saved as they are, every tensor would drag the whole 0.6 GB
+    storage into each checkpoint file, so each entry is saved as a compact copy -- same keys, shapes, values."""
+    torch.save({k: v.detach().clone() for k, v in _model.state_dict().items()}, _path)
 
 
 def sample_distant_points(dimension, n, min_dist, sphere_radius, seed=42, verbose=False):

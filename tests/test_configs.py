@@ -51,7 +51,7 @@ def test_point_sweep_train_step_vs_oracle_fp32(N, C, K):
     assert err <= 1e-4 * ref["sup_fvs"].abs().max().item()
 
 
-@pytest.mark.parametrize("N,B", [(32, 64), (64, 16), (128, 64), (256, 8)])
+@pytest.mark.parametrize("N,B", [(32, 64), (64, 16), (128, 64), (150, 16), (256, 8)])
 def test_point_sweep_bf16_mode_runs_and_tracks_fp32(N, B):
     """bf16 throughput mode (B=64, N=128 is the bench shape): finite, and within the stated
     bf16 tolerance of the fp32 mode from the same state."""

@@ -473,3 +473,22 @@ def test_v1_learn_centroids_option_vs_oracle():
             assert err <= 2.1e-4, (name, err)
             if name in ("model.6.weight", "model.9.weight"):     # gradients well above Adam's eps: signs agree
                 assert (v.cpu() - st.gml[name]).abs().mean().item() <= 1e-5, name
+
+
+def test_checkpoints_are_compact_and_reload(tmp_path):
+    """Checkpoint files of the reference's layout (<name>_{E,G,D,GPH,DPH}.pt, PCAA_ablation.py:1073-1117): after
+    finalize() parameters are views into the trainer's flat buffers, the files must still hold only their own
+    tensors and load into fresh modules of the reference's shapes."""
+    g, m = load_golden("v4_B6_N32_C4_K4")
+    tr = _trainer_from_golden(m)
+    tr.set_prior_means(torch.from_numpy(g["means"]))
+    tr.save_checkpoints(str(tmp_path), "mdl")
+    sizes = {k: (tmp_path / f"mdl_{k}.pt").stat().st_size for k in ("E", "G", "D", "GPH", "DPH")}
+    n_enc = sum(v.numel() * v.element_size() for v in tr.encoder.state_dict().values())
+    assert sizes["E"] <= n_enc + (1 << 16), sizes           # not the 40 MB flat buffer
+    assert sizes["D"] < (1 << 17) and sizes["GPH"] < (1 << 16)
+    constants.NFEATURES = m["C"]
+    enc2 = models.CGEncoder(m["K"], nmax_points=m["N"], use_projection_head=True)
+    enc2.load_state_dict(torch.load(tmp_path / "mdl_E.pt", map_location="cpu"))
+    for (k, a), (_, b) in zip(enc2.state_dict().items(), tr.encoder.state_dict().items()):
+        assert torch.equal(a, b.cpu()), k
