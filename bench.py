@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--backend", default=os.environ.get("PCAA_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on a one-GPU box "
+                         "together with PCAA_BENCH_DEVICE=0, which puts every rank on that GPU)")
     ap.add_argument("--graph", default=os.environ.get("PCAA_GRAPH", "off"), choices=["on", "off"],
                     help="replay the step as a captured hipGraph (PCAATrainer.step_graphed).  Measured SLOWER than "
                          "eager enqueue on this stack (7.48 vs 6.99 ms/step: the 4-stream step is GPU-bound, and "
@@ -102,13 +105,17 @@ def main():
     from opensetgaitrecognition_pcaa_amd.train import PCAATrainer
     from opensetgaitrecognition_pcaa_amd.utils import sample_distant_points
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = int(os.environ.get("PCAA_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     pg = None
     if world > 1 or os.environ.get("PCAA_DP_FORCE", "0") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
 
     B, N, C, K, T = a.batch, a.points, a.features, a.classes, constants.NSTEPS
