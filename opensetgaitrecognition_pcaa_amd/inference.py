@@ -106,19 +106,32 @@ class OpenSetScorer:
         return k_vote(lik, preds, self.threshold, k, n_labels)
 
 
-def CGAAE_inference_setup(model_name, loaders_batch_size=1, variation=False, generate_dataset=False,
+def _variation_uses_head(variation, model_name=""):
+    """Projection head on the encoder for variants 1, 2 and 4 (inference_PCAA.py:75-84); ``variation`` may be
+    the reference's VARIATION enum, its name ("V1"...), True/False, or be inferred from the model name's
+    ``...V4`` suffix (:402-414)."""
+    if variation is True:
+        return True
+    name = getattr(variation, "name", variation) if variation else model_name.split(".")[0][-2:]
+    return str(name).upper() in ("V1", "V2", "V4")
+
+
+def CGAAE_inference_setup(model_name, loaders_batch_size=1, variation=False, generate_dataset=True,
                           force_pc_subsampling=0, device=None):
     """Load ``models/<name>/config.pkl``, ``<name>_E.pt`` and ``discriminator_means.pt``
-    (checkpoint format of the reference) -> (encoder.eval(), means on the device).
-    Dataset regeneration (``generate_dataset``) is out of scope: the crops must exist."""
-    if generate_dataset:
-        raise NotImplementedError("dataset generation from raw radar tracks is out of scope (SURVEY.md 8f)")
+    (checkpoint format of the reference) -> (encoder.eval(), means on the device); with
+    ``generate_dataset`` the splits are regenerated from the raw tracks first for the model's
+    TRAIN_CLASSES / NMAX (inference_PCAA.py:66-72)."""
     folder = os.path.join("models", model_name)
     with open(os.path.join(folder, "config.pkl"), "rb") as f:
         config = pickle.load(f)
+    if generate_dataset:
+        from .datasets import generate_splits
+        generate_splits(train_classes=config["TRAIN_CLASSES"], seed=0, force_pc_subsampling=force_pc_subsampling,
+                        nmax_points=config["NMAX"], verbose=False)
     dev = torch.device(device or constants.DEVICE)
-    head = variation in ("V1", "V2", "V4", True) if variation is not False else False
-    enc = CGEncoder(n_out_labels=len(config["TRAIN_CLASSES"]), use_projection_head=head,
+    enc = CGEncoder(n_out_labels=len(config["TRAIN_CLASSES"]),
+                    use_projection_head=_variation_uses_head(variation, model_name),
                     nmax_points=config["NMAX"]).to(dev).float()
     enc.load_state_dict(torch.load(os.path.join(folder, f"{model_name}_E.pt"), map_location=dev))
     means = torch.load(os.path.join(folder, "discriminator_means.pt"), map_location=dev)
@@ -161,3 +174,66 @@ def naive_sequential_procedure(k, encoder, discriminator_means, known_pcs, known
     windows(k_lik, k_preds, known_labels, False)
     windows(u_lik, u_preds, unseen_labels, True)
     return np.asarray(preds), np.asarray(labels), thr
+
+
+def _sequential_split_on_device(split, scenarios_list, device):
+    """A split's crops in the sequential order of ``MSRadarDataset(sequential=True)`` as device tensors
+    ([M,C,T,N] view of the packed point-major store, labels [M])."""
+    from .batcher import PackedCrops, pack_split
+    from .datasets import MSRadarDataset
+    ds = MSRadarDataset(split, scenarios=scenarios_list, sequential=True)
+    cache = str(ds.dataset_dir).rstrip("/") + "_packed_seq"
+    pack_split(ds, cache)
+    crops, labels = PackedCrops(cache).to_device(device)
+    return crops.permute(0, 3, 1, 2), labels
+
+
+def CGAAE_inference(model_names, ks, force_pc_subsampling=0, scenarios_list=None, variation=False,
+                    generate_dataset=True, device=None):
+    """Open-set evaluation driver with the reference's call surface and output files
+    (inference_PCAA.py:382-469): for every model and k, the naive sequential procedure on the sequentially
+    ordered test / unseen splits; writes ``naive_seq_log_{k}*.json`` (accuracy, F1 micro / macro / weighted),
+    ``final_preds_{k}*.npy`` / ``final_labels_{k}*.npy`` and ``naive_seq_log_subsampled{n}.json`` under
+    ``models/<name>/``.  Not reproduced: the confusion-matrix PNG (plotting).  The splits are regenerated once per
+    call (the reference regenerates them for every (model, k) with identical arguments)."""
+    import json
+    from sklearn.metrics import f1_score
+    from .constants import SPLIT
+    scenarios_list = constants.TRAIN_SCENARIOS if scenarios_list is None else scenarios_list
+    default_scen = list(scenarios_list) == list(constants.TRAIN_SCENARIOS)
+    if force_pc_subsampling and not default_scen:
+        raise ValueError("force_pc_subsampling and scenarios_list cannot be both different from default")
+    dev = torch.device(device or constants.DEVICE)
+    if force_pc_subsampling and default_scen:
+        suffix = f"_subsampled{force_pc_subsampling}"
+    elif not force_pc_subsampling and not default_scen:
+        suffix = "_scenarios" + "_".join(sc.value for sc in scenarios_list)
+    else:
+        suffix = ""
+    out_log = {}
+    generated = not generate_dataset
+    for model_name in model_names:
+        folder = os.path.join("models", model_name)
+        os.makedirs(os.path.join("figures", model_name), exist_ok=True)
+        enc, means = CGAAE_inference_setup(model_name, 32, variation, generate_dataset=not generated,
+                                           force_pc_subsampling=force_pc_subsampling, device=dev)
+        generated = True
+        known_pcs, known_labels = _sequential_split_on_device(SPLIT.TEST, scenarios_list, dev)
+        unseen_pcs, unseen_labels = _sequential_split_on_device(SPLIT.UNSEEN, scenarios_list, dev)
+        for k in ks:
+            preds, labels, thr = naive_sequential_procedure(k, enc, means, known_pcs, known_labels, unseen_pcs,
+                                                            unseen_labels, seed=0, unseen_valid_ratio=0.2)
+            labels = labels.astype(int)
+            metrics = {"n_steps": k, "accuracy": float(np.equal(labels, preds).sum() / max(len(labels), 1)),
+                       "f1_micro": float(f1_score(labels, preds, average="micro")),
+                       "f1_macro": float(f1_score(labels, preds, average="macro")),
+                       "f1_weighted": float(f1_score(labels, preds, average="weighted"))}
+            with open(os.path.join(folder, f"naive_seq_log_{k}{suffix}.json"), "w") as f:
+                json.dump(metrics, f)
+            np.save(os.path.join(folder, f"final_preds_{k}{suffix}.npy"), preds)
+            np.save(os.path.join(folder, f"final_labels_{k}{suffix}.npy"), labels)
+            out_log[k] = {m: metrics[m] for m in ("f1_micro", "f1_macro", "f1_weighted")}
+        with open(os.path.join(folder, f"naive_seq_log_subsampled{force_pc_subsampling}.json"), "w") as f:
+            json.dump(out_log, f)
+    return out_log
+
