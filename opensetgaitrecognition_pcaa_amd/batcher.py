@@ -53,10 +53,26 @@ def pack_split(dataset, out_dir, chunk=256):
     np.save(os.path.join(out_dir, "labels.i64.npy"), labels)
     manifest = {"n": n, "T": T, "N": N, "C": C, "dtype": "float32", "layout": "[M,T,N,C] point-major",
                 "filenames": list(getattr(dataset, "filenames", [])),
-                "original_labels": [int(v) for v in getattr(dataset, "original_labels", [])]}
+                "original_labels": [int(v) for v in getattr(dataset, "original_labels", [])],
+                "source_signature": source_signature(dataset)}
     with open(os.path.join(out_dir, MANIFEST), "w") as f:
         json.dump(manifest, f)
     return manifest
+
+
+def source_signature(dataset):
+    """[number of files, total bytes, newest mtime in ns] of a file-backed dataset's crops: a regenerated split
+    (same file names, other contents -- e.g. generate_splits with another NMAX) must not be served from a
+    stale packed store."""
+    d, names = getattr(dataset, "dataset_dir", None), getattr(dataset, "filenames", None)
+    if d is None or names is None:
+        return None
+    size, newest = 0, 0
+    for f in names:
+        st = os.stat(os.path.join(d, f))
+        size += st.st_size
+        newest = max(newest, st.st_mtime_ns)
+    return [len(names), size, newest]
 
 
 class PackedCrops:
@@ -172,7 +188,9 @@ def batcher_for(dataset, batch_size, device, shuffle, drop_last=True, cache_dir=
     fresh = False
     if os.path.exists(os.path.join(cache_dir, MANIFEST)):
         with open(os.path.join(cache_dir, MANIFEST)) as f:
-            fresh = json.load(f).get("filenames") == list(dataset.filenames)
+            man = json.load(f)
+            fresh = (man.get("filenames") == list(dataset.filenames)
+                     and man.get("source_signature") == source_signature(dataset))
     if not fresh:
         pack_split(dataset, cache_dir)
     crops, labels = PackedCrops(cache_dir).to_device(device)

@@ -646,3 +646,39 @@ def train_CGAAE(config=None, **kw):
 def train_variant2(config, wandb_mode="online", **kw):
     """Variant 2 == train_CGAAE (PCAA_ablation.py:381-389)."""
     return train_CGAAE(config, **kw)
+
+
+def train_pointsubsampling(n_training_classes=(2, 4, 6, 8), n_points_subs=(50, 70, 90, 110, 130, 150), n_tests=5,
+                           ks=(1, 2, 4, 6), model_name_base="PCAA_npts_V4_", splits_seed=0, config=None):
+    """The point-subsampling study of the reference's ``train_pointsubsampling.py`` (its ``__main__``, :19-76;
+    BASELINE config[3]): for every number of training classes, ``n_tests`` distinct random class subsets
+    (``default_rng(splits_seed).choice``, as there); for every NMAX the splits are regenerated from the raw
+    tracks with that many points per frame, variant 4 is trained and evaluated open-set for each k.
+    Returns {model_name: CGAAE_inference's log}."""
+    from .datasets import LABEL_DICT, generate_splits
+    from .inference import CGAAE_inference
+    from .utils import openness
+    rng = np.random.default_rng(splits_seed)
+    results = {}
+    for n_tr in n_training_classes:
+        chosen = []
+        for i in range(n_tests):
+            while True:
+                classes = sorted(int(c) for c in rng.choice(len(LABEL_DICT), n_tr, replace=False))
+                if classes not in chosen:
+                    chosen.append(classes)
+                    break
+            cfg = dict(constants.CONFIG if config is None else config)
+            cfg["TRAIN_CLASSES"] = classes
+            cfg["Openness"] = openness(n_tr, len(LABEL_DICT))
+            for n_points in n_points_subs:
+                cfg["NMAX"] = n_points
+                generate_splits(train_classes=classes, seed=0, nmax_points=n_points, verbose=False)
+                name = f"{model_name_base}{n_points}.{n_tr}.{i + 1}"
+                cfg["MODEL_NAME"] = name
+                cfg["NOTES"] = f"Runs with different number of points ({n_points}.{n_tr}.{i + 1})"
+                train_variant4(dict(cfg), wandb_mode="disabled", proj_head_on_discriminator=False)
+                results[name] = CGAAE_inference(model_names=[name], ks=list(ks), variation="V4",
+                                                generate_dataset=False)
+    return results
+

@@ -104,3 +104,14 @@ def test_device_batcher_full_size_properties():
         lab += torch.bincount(y, minlength=8)
     assert abs(float(tot) - float(ds.pcs.double().sum())) <= 1e-6 * float(ds.pcs.double().abs().sum())
     assert torch.equal(lab.cpu(), torch.bincount(ds.labels, minlength=8))
+
+
+def test_packed_store_is_rebuilt_when_the_split_is_regenerated(tmp_path, monkeypatch):
+    """Same file names, new contents (generate_splits with another NMAX): the signature in the manifest differs."""
+    _make_split(tmp_path, monkeypatch)
+    ds = MSRadarDataset(SPLIT.TRAIN)
+    man = batcher.pack_split(ds, str(tmp_path / "packed"))
+    assert man["source_signature"] == batcher.source_signature(ds)
+    name = ds.filenames[0]
+    np.save(os.path.join(ds.dataset_dir, name), np.zeros((T, N + 4, C)))       # regenerated with more points
+    assert batcher.source_signature(MSRadarDataset(SPLIT.TRAIN)) != man["source_signature"]

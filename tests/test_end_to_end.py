@@ -11,7 +11,7 @@ import torch
 
 from opensetgaitrecognition_pcaa_amd import constants, datasets, inference, synthetic as syn
 from opensetgaitrecognition_pcaa_amd import functional as F_hip
-from opensetgaitrecognition_pcaa_amd.train import train_variant1, train_variant4
+from opensetgaitrecognition_pcaa_amd.train import train_pointsubsampling, train_variant1, train_variant4
 
 pytestmark = pytest.mark.gpu
 
@@ -73,3 +73,10 @@ def _flow(classes):
     assert os.path.exists("models/e2e_V1/e2e_V1_ML.pt")
     cent = torch.load("models/e2e_V1/discriminator_means.pt", map_location="cpu")
     assert tuple(cent.shape) == (len(classes), 32) and torch.isfinite(cent).all()
+    # the point-subsampling study (train_pointsubsampling.py), cut down to one class count, one subset, two NMAX
+    base = dict(cfg); base.update(EPOCHS=1, BATCH_SIZE=16)
+    res = train_pointsubsampling(n_training_classes=(4,), n_points_subs=(12, 20), n_tests=1, ks=(2,), config=base,
+                                 model_name_base="sweep_V4_")
+    assert set(res) == {"sweep_V4_12.4.1", "sweep_V4_20.4.1"}
+    for name, log in res.items():
+        assert 0.0 <= log[2]["f1_macro"] <= 1.0 and os.path.exists(f"models/{name}/final_preds_2.npy")
