@@ -328,6 +328,13 @@ int pcaa_dtc_conv_fwd(const float* src, const float* scale, const float* shift, 
                       float* col, double* stats, int nrep, int B, int T, int cin, int cout, int dilation,
                       int ksplit, long slab_stride, void* stream);
 
+/* The adjoint w.r.t. the layer input in one launch (replaces dcol = dy . W on the im2col layout followed by
+ * pcaa_dtc_col2im): da[(b,t)][ci] = sum_{co,tap} dy[b][t+(2-tap)*d][co] * W[co][ci][tap].  ksplit > 1 (cout > 256)
+ * writes slabs for pcaa_splitk_reduce, as the forward. */
+int pcaa_dtc_conv_dgrad_ksplit(int B, int cin, int cout);
+int pcaa_dtc_conv_dgrad(const float* dy, const float* W, float* da, int B, int T, int cin, int cout,
+                        int dilation, int ksplit, long slab_stride, void* stream);
+
 /* ------------------------------------------------------------------ MLP heads, fused
  * CGEncoder's MLP_sup1 / MLP_head / MLP_sup2 (models.py:252-277, applied at :285-292) and the
  * decoder projection head Sequential(Linear(32,64), ELU) (PCAA_ablation.py:778-781) as one forward

@@ -187,6 +187,104 @@ __global__ __launch_bounds__(256) void dtc_fwd_kernel(DtcFwdParams p) {
   }
 }
 
+// ------------------------------------------------------------------ backward w.r.t. the layer input
+//   da[(b,t)][ci] = sum_{co,tap} dy[b][t+(2-tap)*d][co] * W[co][ci][tap]        (rows past the sequence end: zero)
+// The adjoint of the forward as the same kernel shape: the gradient sequence tile dy[T][cout range] is staged in
+// LDS once, the taps are row offsets (now forwards in time) of the A-fragment reads, the contraction runs over
+// (tap, co) in 32-channel chunks and the weight tile of a chunk is the same 96-float run per co as in the
+// forward, scattered TRANSPOSED (row = input channel ci, k' = tap*32 + co).  Replaces a 128x128-tile GEMM on a
+// handful of workgroups (dcol = dy . W) plus the col2im pass that summed its three taps.
+struct DtcDgradParams {
+  const float* dy;      // [B*T, cout]
+  const float* W;       // [cout, cin*3]
+  float* da;            // [B*T, cin] (gridDim.z > 1: slabs, split z at da + z*slab_stride)
+  int B, T, cin, cout, dil;
+  long slab_stride;
+};
+
+__global__ __launch_bounds__(256) void dtc_dgrad_kernel(DtcDgradParams p) {
+  __shared__ __attribute__((aligned(16))) float a_lds[(ROWS + 1) * (MAX_CR + 4)];
+  __shared__ __attribute__((aligned(16))) float Ws[32 * WP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x, n0 = blockIdx.y * 32;                 // n0: first input channel (output column)
+  const int T = p.T, cin = p.cin, cout = p.cout, d = p.dil;
+  const long wrow = (long)cin * 3;
+  float* out = p.da + (long)blockIdx.z * p.slab_stride;
+  const int per_z = ((cout + CC - 1) / CC + (int)gridDim.z - 1) / (int)gridDim.z * CC;
+  const int cz0 = blockIdx.z * per_z;
+  const int cr = max(0, min(cout, cz0 + per_z) - cz0);
+  const int AP = cr + 4;
+  {
+    const int q4 = cr >> 2;
+    for (int q = tid; q < T * q4; q += 256) {
+      const int r = q / q4, c4 = (q - r * q4) << 2;
+      *reinterpret_cast<f32x4*>(&a_lds[r * AP + c4]) = load4(p.dy + ((long)b * T + r) * cout + cz0 + c4);
+    }
+    for (int q = tid; q < (ROWS + 1 - T) * AP; q += 256) a_lds[T * AP + q] = 0.f;
+  }
+  f32x4 rw[3];
+  auto load_w = [&](int c0) {
+    // 32 contraction channels co x 96 contiguous floats W[cz0+c0+co_l][(n0 ...)*3 ...]
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int q = tid + j * 256;
+      const int co_l = q / 24, f = (q - co_l * 24) << 2;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c0 + co_l < cr && (long)n0 * 3 + f < wrow) v = load4(p.W + (long)(cz0 + c0 + co_l) * wrow + (long)n0 * 3 + f);
+      rw[j] = v;
+    }
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int q = tid + j * 256;
+      const int co_l = q / 24, f = (q - co_l * 24) << 2;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int kk = f + m, ci_l = kk / 3, tap = kk - ci_l * 3;
+        Ws[ci_l * WP + tap * CC + co_l] = rw[j][m];
+      }
+    }
+  };
+  if (cr > 0) load_w(0);
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int c0 = 0; c0 < cr; c0 += CC) {
+    if (c0 > 0) __syncthreads();
+    store_w();
+    __syncthreads();
+    if (c0 + CC < cr) load_w(c0 + CC);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const int gg = wave * 3 + g;
+      const int tap = gg >> 2, co_l = ((gg & 3) << 3) + (half << 2);
+      const int rs = l31 + (2 - tap) * d;
+      const float* ap = (rs < T && c0 + co_l < cr) ? &a_lds[rs * AP + c0 + co_l] : &a_lds[ZROW * AP];
+      const f32x4 av = *reinterpret_cast<const f32x4*>(ap);
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(&Ws[l31 * WP + tap * CC + co_l]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wv.w, acc, 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  float (*part)[ROWS][33] = reinterpret_cast<float (*)[ROWS][33]>(a_lds);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) part[wave][(i & 3) + 8 * (i >> 2) + 4 * half][l31] = acc[i];
+  __syncthreads();
+  const int colx = tid & 31, rg = tid >> 5, gn = n0 + colx;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = rg + 8 * i;
+    if (r < T && gn < cin)
+      out[((long)b * T + r) * cin + gn] = (part[0][r][colx] + part[1][r][colx]) + (part[2][r][colx] + part[3][r][colx]);
+  }
+}
+
 }  // namespace
 
 extern "C" int pcaa_dtc_conv_supported(int T, int cin, int cout) {
@@ -222,3 +320,27 @@ extern "C" int pcaa_dtc_conv_fwd(const float* src, const float* scale, const flo
   hipLaunchKernelGGL(dtc_fwd_kernel, dim3(B, (cout + 31) / 32, ksplit), dim3(256), 0, as_stream(stream), p);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_dtc_conv_fwd");
 }
+
+/* channel split for the dgrad (its contraction runs over the OUTPUT channels of the convolution) */
+extern "C" int pcaa_dtc_conv_dgrad_ksplit(int B, int cin, int cout) {
+  (void)B; (void)cin;
+  const int ks = (cout + MAX_CR - 1) / MAX_CR;
+  return ks < 1 ? 1 : ks;
+}
+
+extern "C" int pcaa_dtc_conv_dgrad(const float* dy, const float* W, float* da, int B, int T, int cin, int cout,
+                                   int dilation, int ksplit, long slab_stride, void* stream) {
+  PCAA_CHECK_ARG(dy && W && da && B >= 1 && dilation >= 1 && ksplit >= 1, "pcaa_dtc_conv_dgrad: bad args");
+  PCAA_CHECK_ARG(T >= 1 && T <= ROWS && cin >= 4 && cin % 4 == 0 && cout >= 4 && cout % 4 == 0,
+                 "pcaa_dtc_conv_dgrad: needs T <= %d, cin %% 4 == 0, cout %% 4 == 0", ROWS);
+  PCAA_CHECK_ARG(((uintptr_t)W % 16) == 0 && ((uintptr_t)dy % 16) == 0, "pcaa_dtc_conv_dgrad: dy, W must be 16-B aligned");
+  const int chunks = (cout + CC - 1) / CC;
+  const int per_z = (chunks + ksplit - 1) / ksplit * CC;
+  PCAA_CHECK_ARG(ksplit <= chunks && per_z <= MAX_CR, "pcaa_dtc_conv_dgrad: ksplit must keep <= %d channels per workgroup "
+                 "(pcaa_dtc_conv_dgrad_ksplit)", MAX_CR);
+  PCAA_CHECK_ARG(ksplit == 1 || slab_stride >= (long)B * T * cin, "pcaa_dtc_conv_dgrad: slab_stride >= B*T*cin");
+  DtcDgradParams p{dy, W, da, B, T, cin, cout, dilation, ksplit > 1 ? slab_stride : 0};
+  hipLaunchKernelGGL(dtc_dgrad_kernel, dim3(B, (cin + 31) / 32, ksplit), dim3(256), 0, as_stream(stream), p);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_dtc_conv_dgrad");
+}
+

@@ -256,7 +256,7 @@ _FUSE_DGRAD_POINTS = os.environ.get("PCAA_FUSE_DGRAD_POINTS", "0") == "1"
 
 
 def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool_scale=1.0,
-                       need_dinput=True, lhs=None, outs=None, below=None, below_W=None):
+                       need_dinput=True, lhs=None, outs=None, below=None, below_W=None, dgrad_fn=None):
     """Backward of one (linear, BN, ELU) layer.  ``lhs`` is the GEMM's left
     operand ([rows, K]: the input activation or the im2col matrix).  ``outs`` =
     (dW, dgamma, dbeta) destination views (dW PRE-ZEROED: the trainer's flat
@@ -312,7 +312,9 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
         else:
             dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, split_k=sk, accumulate=sk > 1)
     d_lhs = None
-    if need_dinput:
+    if need_dinput and dgrad_fn is not None:
+        d_lhs = dgrad_fn(dy)              # the caller's own adjoint (temporal block: implicit col2im)
+    elif need_dinput:
         if mode == "bf16" and dy.dtype == torch.bfloat16 and cout % 8 == 0:
             Wt = _W16_CACHE.pop(W2d.data_ptr(), None)      # bf16 [K, cout] made by the forward pass
             if Wt is None or tuple(Wt.shape) != (K, cout):
@@ -449,16 +451,25 @@ def dtc_backward(saves, layers, B, T, d_last=None, dpool=None, need_dx=True, gou
         W2d = conv.weight.view(s.cout, s.cin * 3)
         need_in = li > 0 or need_dx
         outs = _layer_outs(gout, f"{prefix}{li + 1}.", "conv1d.weight", "batch_norm.weight", "batch_norm.bias")
+        fused = _FUSE_DTC and T <= 32 and s.cin % 4 == 0 and s.cout % 4 == 0
+        # the adjoint w.r.t. the layer input in one launch (implicit col2im); else dcol = dy . W, then col2im
+        dgrad_fn = (lambda dy, W2d=W2d, s=s: ops.dtc_conv_dgrad(dy, W2d, B, T, s.cin, s.dil)) if fused else None
         if li == len(layers) - 1 and dpool is not None:
             dW, dg, db, dcol = _bn_layer_backward(s, bn, W2d, "fp32", dpool=dpool, group_rows=T,
-                                                  pool_scale=1.0 / T, need_dinput=need_in, lhs=s.col, outs=outs)
+                                                  pool_scale=1.0 / T, need_dinput=need_in, lhs=s.col, outs=outs,
+                                                  dgrad_fn=dgrad_fn)
         else:
             dW, dg, db, dcol = _bn_layer_backward(s, bn, W2d, "fp32", da=da, need_dinput=need_in, lhs=s.col,
-                                                  outs=outs)
+                                                  outs=outs, dgrad_fn=dgrad_fn)
         zb = gout[f"{prefix}{li + 1}.conv1d.bias"] if gout is not None else torch.zeros_like(conv.bias)
         grads.append({"conv1d.weight": dW.view_as(conv.weight), "conv1d.bias": zb,
                       "batch_norm.weight": dg, "batch_norm.bias": db})
-        da = ops.dtc_col2im(dcol, B, T, s.cin, s.dil) if need_in else None
+        if not need_in:
+            da = None
+        elif fused:
+            da = dcol                       # already the gradient w.r.t. the layer's input
+        else:
+            da = ops.dtc_col2im(dcol, B, T, s.cin, s.dil)
     grads.reverse()
     return grads, da
 

@@ -1001,3 +1001,26 @@ def dtc_conv_fwd(src, scale, shift, W2d, B, T, dilation, stats=None, want_col=Fa
     check(lib.pcaa_dtc_conv_fwd(_p(src), _p(scale), _p(shift), _p(W2d), _p(y), _p(col), _p(stats), NREP,
                                 B, T, cin, cout, int(dilation), 1, 0, _s()), "pcaa_dtc_conv_fwd")
     return y, col
+
+
+def dtc_conv_dgrad(dy, W2d, B, T, cin, dilation):
+    """da[B*T, cin] = adjoint of the causal dilated convolution w.r.t. its input (see pcaa_dtc_conv_dgrad)."""
+    _chk(dy, "dtc_conv_dgrad.dy", torch.float32, 2)
+    _chk(W2d, "dtc_conv_dgrad.W", torch.float32, 2)
+    rows, cout = dy.shape
+    if rows != B * T or tuple(W2d.shape) != (cout, cin * 3) or T > 32 or cin % 4 or cout % 4:
+        raise ValueError(f"dtc_conv_dgrad: unsupported shapes dy {tuple(dy.shape)} W {tuple(W2d.shape)} B={B} T={T}")
+    lib = _lib.load()
+    da = torch.empty((rows, cin), dtype=torch.float32, device=dy.device)
+    ks = lib.pcaa_dtc_conv_dgrad_ksplit(B, cin, cout)
+    if ks > 1:
+        stride = rows * cin
+        slabs = torch.empty(ks * stride, dtype=torch.float32, device=dy.device)
+        check(lib.pcaa_dtc_conv_dgrad(_p(dy), _p(W2d), _p(slabs), B, T, cin, cout, int(dilation), ks, stride, _s()),
+              "pcaa_dtc_conv_dgrad")
+        check(lib.pcaa_splitk_reduce(_p(slabs), ks, stride, stride, _p(da), 0, _s()), "pcaa_splitk_reduce")
+        return da
+    check(lib.pcaa_dtc_conv_dgrad(_p(dy), _p(W2d), _p(da), B, T, cin, cout, int(dilation), 1, 0, _s()),
+          "pcaa_dtc_conv_dgrad")
+    return da
+

@@ -629,3 +629,23 @@ def test_wgan_gp_dz_vs_autograd():
                                          [v.to(DEV) for v in disc.values()], 15.0, want_dz=True)
     assert abs(losses[0].item() - d_loss.item()) <= 1e-4 * abs(d_loss.item()) + 1e-6
     assert (dz.cpu() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-7
+
+
+@pytest.mark.parametrize("B,T,cin,cout,d", [(3, 30, 16, 32, 2), (2, 30, 1024, 16, 1), (5, 30, 256, 512, 4),
+                                            (4, 7, 64, 128, 1), (64, 30, 32, 64, 4), (2, 30, 20, 36, 2)])
+def test_dtc_conv_dgrad_vs_fp64_autograd(B, T, cin, cout, d):
+    """Adjoint of the causal dilated convolution w.r.t. its input (implicit col2im) against fp64 autograd of
+    conv1d(padding=2d)[..., :-2d] (models.py:59-68, 75-76), and against the unfused dcol = dy.W + col2im."""
+    W = _rand((cout, cin, 3), 91, (3 * cin) ** -0.5)
+    dy = _rand((B * T, cout), 92)
+    x = torch.zeros((B, cin, T), dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv1d(x, W.double(), padding=2 * d, dilation=d)[:, :, :-2 * d]
+    y.backward(dy.double().view(B, T, cout).permute(0, 2, 1))
+    ref = x.grad.permute(0, 2, 1).reshape(B * T, cin)
+    W2d = W.view(cout, cin * 3).to(DEV)
+    da = ops.dtc_conv_dgrad(dy.to(DEV), W2d, B, T, cin, d)
+    scl = ref.abs().max().item()
+    assert (da.cpu().double() - ref).abs().max().item() <= 2e-6 * (3 * cout) ** 0.5 * scl + 1e-6
+    dcol = ops.gemm(dy.to(DEV), KC, W2d, RC, B * T, cin * 3, cout, out_dtype=torch.float32)
+    two = ops.dtc_col2im(dcol, B, T, cin, d)
+    assert (da - two).abs().max().item() <= 1e-5 * scl
