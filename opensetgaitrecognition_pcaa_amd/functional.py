@@ -395,6 +395,7 @@ def pointnet_backward(saves, layers, mode, d_last=None, dpool=None, pool_rows=0,
 
 
 _FUSE_DTC = os.environ.get("PCAA_FUSE_DTC", "1") != "0"
+_FUSE_DTC_BWD = os.environ.get("PCAA_FUSE_DTC_BWD", "1") != "0"
 
 
 def dtc_forward(a2d, B, T, layers, training, pool_time):
@@ -451,7 +452,7 @@ def dtc_backward(saves, layers, B, T, d_last=None, dpool=None, need_dx=True, gou
         W2d = conv.weight.view(s.cout, s.cin * 3)
         need_in = li > 0 or need_dx
         outs = _layer_outs(gout, f"{prefix}{li + 1}.", "conv1d.weight", "batch_norm.weight", "batch_norm.bias")
-        fused = _FUSE_DTC and T <= 32 and s.cin % 4 == 0 and s.cout % 4 == 0
+        fused = _FUSE_DTC and _FUSE_DTC_BWD and T <= 32 and s.cin % 4 == 0 and s.cout % 4 == 0
         # the adjoint w.r.t. the layer input in one launch (implicit col2im); else dcol = dy . W, then col2im
         dgrad_fn = (lambda dy, W2d=W2d, s=s: ops.dtc_conv_dgrad(dy, W2d, B, T, s.cin, s.dil)) if fused else None
         if li == len(layers) - 1 and dpool is not None:
