@@ -329,11 +329,20 @@ int pcaa_dtc_conv_fwd(const float* src, const float* scale, const float* shift, 
                       int ksplit, long slab_stride, void* stream);
 
 /* The adjoint w.r.t. the layer input in one launch (replaces dcol = dy . W on the im2col layout followed by
- * pcaa_dtc_col2im): da[(b,t)][ci] = sum_{co,tap} dy[b][t+(2-tap)*d][co] * W[co][ci][tap].  ksplit > 1 (cout > 256)
- * writes slabs for pcaa_splitk_reduce, as the forward. */
+ * pcaa_dtc_col2im): da[(b,t)][ci] = sum_{co,tap} dy[b][t+(2-tap)*d][co] * W[co][ci][tap].
+ *  - dy given, or formed on load from this layer's dz, y and the coefficients of pcaa_bn_bwd_finalize
+ *    (dy = coef0*dz + coef1*y + coef2: the second half of the BatchNorm backward, no separate pass); dy_out
+ *    (optional) receives the staged dy for the weight gradient;
+ *  - ep_stats given: `out` is dz of the layer BELOW, da * ELU'(ep_y*ep_scale + ep_shift), and its BatchNorm-
+ *    backward statistics {sum dz, sum dz*(ep_y-ep_mean)*ep_rstd} are accumulated into ep_stats[nrep][2][cin]
+ *    (the first half of that layer's backward, no separate pass); needs ksplit == 1.
+ * ksplit > 1 (cout > 512) writes slabs for pcaa_splitk_reduce, as the forward. */
 int pcaa_dtc_conv_dgrad_ksplit(int B, int cin, int cout);
-int pcaa_dtc_conv_dgrad(const float* dy, const float* W, float* da, int B, int T, int cin, int cout,
-                        int dilation, int ksplit, long slab_stride, void* stream);
+int pcaa_dtc_conv_dgrad(const float* dy, const float* dz, const float* y, const float* coef, float* dy_out,
+                        const float* W, float* out, const float* ep_y, const float* ep_scale,
+                        const float* ep_shift, const float* ep_mean, const float* ep_rstd, double* ep_stats,
+                        int nrep, int B, int T, int cin, int cout, int dilation, int ksplit, long slab_stride,
+                        void* stream);
 
 /* ------------------------------------------------------------------ MLP heads, fused
  * CGEncoder's MLP_sup1 / MLP_head / MLP_sup2 (models.py:252-277, applied at :285-292) and the

@@ -195,31 +195,56 @@ __global__ __launch_bounds__(256) void dtc_fwd_kernel(DtcFwdParams p) {
 // forward, scattered TRANSPOSED (row = input channel ci, k' = tap*32 + co).  Replaces a 128x128-tile GEMM on a
 // handful of workgroups (dcol = dy . W) plus the col2im pass that summed its three taps.
 struct DtcDgradParams {
-  const float* dy;      // [B*T, cout]
+  const float* dy;      // [B*T, cout], or null: dy = coef0*dz + coef1*y + coef2 is formed while the tile is staged
+  const float* dz;      // [B*T, cout]  d(loss)/d(pre-activation z) of THIS layer      (dy == null)
+  const float* y;       // [B*T, cout]  this layer's bias-free pre-BN output             (dy == null)
+  const float* coef;    // [3][cout]    pcaa_bn_bwd_finalize's coefficients             (dy == null)
+  float* dy_out;        // [B*T, cout] or null: the staged dy, written by the first column tile (for the wgrad)
   const float* W;       // [cout, cin*3]
-  float* da;            // [B*T, cin] (gridDim.z > 1: slabs, split z at da + z*slab_stride)
+  float* out;           // [B*T, cin]: da, or with the epilogue dz of the layer BELOW (gridDim.z > 1: slabs)
+  // epilogue (layer below): out = da * ELU'(ep_y*ep_scale + ep_shift), statistics {sum dz, sum dz*yhat}
+  const float* ep_y; const float* ep_scale; const float* ep_shift; const float* ep_mean; const float* ep_rstd;
+  double* ep_stats; int nrep;
   int B, T, cin, cout, dil;
   long slab_stride;
 };
 
-__global__ __launch_bounds__(256) void dtc_dgrad_kernel(DtcDgradParams p) {
-  __shared__ __attribute__((aligned(16))) float a_lds[(ROWS + 1) * (MAX_CR + 4)];
-  __shared__ __attribute__((aligned(16))) float Ws[32 * WP];
+constexpr int DG_MAX_CR = 512;                       // contraction channels per workgroup (dynamic LDS)
+constexpr int DG_PART_FLOATS = 4 * ROWS * 33;        // the four waves' partial tiles alias the sequence tile
+static inline int dg_tile_floats(int cr) { const int a = (ROWS + 1) * (cr + 4); return a > DG_PART_FLOATS ? a : DG_PART_FLOATS; }
+
+__global__ __launch_bounds__(256) void dtc_dgrad_kernel(DtcDgradParams p, int tile_floats) {
+  extern __shared__ __attribute__((aligned(16))) float dg_smem[];
+  float* a_lds = dg_smem;                            // [(ROWS+1)][cr+4], later part[4][ROWS][33]
+  float* Ws = dg_smem + tile_floats;                 // [32][WP]
+  float* red = Ws + 32 * WP;                         // [2][8][32]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
   const int b = blockIdx.x, n0 = blockIdx.y * 32;                 // n0: first input channel (output column)
   const int T = p.T, cin = p.cin, cout = p.cout, d = p.dil;
   const long wrow = (long)cin * 3;
-  float* out = p.da + (long)blockIdx.z * p.slab_stride;
+  float* out = p.out + (long)blockIdx.z * p.slab_stride;
   const int per_z = ((cout + CC - 1) / CC + (int)gridDim.z - 1) / (int)gridDim.z * CC;
   const int cz0 = blockIdx.z * per_z;
   const int cr = max(0, min(cout, cz0 + per_z) - cz0);
   const int AP = cr + 4;
   {
     const int q4 = cr >> 2;
+    const bool form = p.dy == nullptr;
+    const bool keep = p.dy_out != nullptr && blockIdx.y == 0;
     for (int q = tid; q < T * q4; q += 256) {
       const int r = q / q4, c4 = (q - r * q4) << 2;
-      *reinterpret_cast<f32x4*>(&a_lds[r * AP + c4]) = load4(p.dy + ((long)b * T + r) * cout + cz0 + c4);
+      const long g = ((long)b * T + r) * cout + cz0 + c4;
+      f32x4 v;
+      if (form) {
+        const f32x4 k0 = load4(p.coef + cz0 + c4), k1 = load4(p.coef + cout + cz0 + c4),
+                    k2 = load4(p.coef + 2 * cout + cz0 + c4);
+        v = k0 * load4(p.dz + g) + k1 * load4(p.y + g) + k2;
+      } else {
+        v = load4(p.dy + g);
+      }
+      *reinterpret_cast<f32x4*>(&a_lds[r * AP + c4]) = v;
+      if (keep) store4(p.dy_out + g, v);
     }
     for (int q = tid; q < (ROWS + 1 - T) * AP; q += 256) a_lds[T * AP + q] = 0.f;
   }
@@ -277,11 +302,39 @@ __global__ __launch_bounds__(256) void dtc_dgrad_kernel(DtcDgradParams p) {
   for (int i = 0; i < 16; ++i) part[wave][(i & 3) + 8 * (i >> 2) + 4 * half][l31] = acc[i];
   __syncthreads();
   const int colx = tid & 31, rg = tid >> 5, gn = n0 + colx;
+  const bool ep = p.ep_stats != nullptr;
+  float esc = 0.f, esh = 0.f, emu = 0.f, ers = 0.f;
+  if (ep && gn < cin) { esc = p.ep_scale[gn]; esh = p.ep_shift[gn]; emu = p.ep_mean[gn]; ers = p.ep_rstd[gn]; }
+  float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = rg + 8 * i;
-    if (r < T && gn < cin)
-      out[((long)b * T + r) * cin + gn] = (part[0][r][colx] + part[1][r][colx]) + (part[2][r][colx] + part[3][r][colx]);
+    if (r < T && gn < cin) {
+      float v = (part[0][r][colx] + part[1][r][colx]) + (part[2][r][colx] + part[3][r][colx]);
+      const long g = ((long)b * T + r) * cin + gn;
+      if (ep) {
+        // first half of the BatchNorm+ELU backward of the layer below: dz = da * ELU'(z), its two column sums
+        const float yb = p.ep_y[g];
+        v *= elu_grad_from_pre(fmaf(yb, esc, esh));
+        s1 += v;
+        s2 += v * ((yb - emu) * ers);
+      }
+      out[g] = v;
+    }
+  }
+  if (ep) {
+    red[(0 * 8 + rg) * 32 + colx] = s1;
+    red[(1 * 8 + rg) * 32 + colx] = s2;
+    __syncthreads();
+    if (tid < 64) {
+      const int stat = tid >> 5, c = tid & 31;
+      if (n0 + c < cin) {
+        double v = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) v += (double)red[(stat * 8 + g) * 32 + c];
+        unsafeAtomicAdd(&p.ep_stats[((long)(b % p.nrep) * 2 + stat) * cin + n0 + c], v);
+      }
+    }
   }
 }
 
@@ -321,26 +374,50 @@ extern "C" int pcaa_dtc_conv_fwd(const float* src, const float* scale, const flo
   PCAA_RETURN_LAUNCH_STATUS("pcaa_dtc_conv_fwd");
 }
 
-/* channel split for the dgrad (its contraction runs over the OUTPUT channels of the convolution) */
+/* channel split for the dgrad (its contraction runs over the OUTPUT channels of the convolution; a workgroup
+ * keeps up to 512 of them in LDS) */
 extern "C" int pcaa_dtc_conv_dgrad_ksplit(int B, int cin, int cout) {
   (void)B; (void)cin;
-  const int ks = (cout + MAX_CR - 1) / MAX_CR;
+  const int ks = (cout + DG_MAX_CR - 1) / DG_MAX_CR;
   return ks < 1 ? 1 : ks;
 }
 
-extern "C" int pcaa_dtc_conv_dgrad(const float* dy, const float* W, float* da, int B, int T, int cin, int cout,
-                                   int dilation, int ksplit, long slab_stride, void* stream) {
-  PCAA_CHECK_ARG(dy && W && da && B >= 1 && dilation >= 1 && ksplit >= 1, "pcaa_dtc_conv_dgrad: bad args");
+extern "C" int pcaa_dtc_conv_dgrad(const float* dy, const float* dz, const float* y, const float* coef, float* dy_out,
+                                   const float* W, float* out, const float* ep_y, const float* ep_scale,
+                                   const float* ep_shift, const float* ep_mean, const float* ep_rstd,
+                                   double* ep_stats, int nrep, int B, int T, int cin, int cout, int dilation,
+                                   int ksplit, long slab_stride, void* stream) {
+  PCAA_CHECK_ARG(W && out && B >= 1 && dilation >= 1 && ksplit >= 1, "pcaa_dtc_conv_dgrad: bad args");
+  PCAA_CHECK_ARG((dy != nullptr) != (dz != nullptr && y != nullptr && coef != nullptr),
+                 "pcaa_dtc_conv_dgrad: either dy, or dz + y + coef");
   PCAA_CHECK_ARG(T >= 1 && T <= ROWS && cin >= 4 && cin % 4 == 0 && cout >= 4 && cout % 4 == 0,
                  "pcaa_dtc_conv_dgrad: needs T <= %d, cin %% 4 == 0, cout %% 4 == 0", ROWS);
-  PCAA_CHECK_ARG(((uintptr_t)W % 16) == 0 && ((uintptr_t)dy % 16) == 0, "pcaa_dtc_conv_dgrad: dy, W must be 16-B aligned");
+  PCAA_CHECK_ARG(((uintptr_t)W % 16) == 0 && (!dy || ((uintptr_t)dy % 16) == 0) && (!dz || (((uintptr_t)dz % 16) == 0 &&
+                 ((uintptr_t)y % 16) == 0 && ((uintptr_t)coef % 16) == 0)) && (!dy_out || ((uintptr_t)dy_out % 16) == 0),
+                 "pcaa_dtc_conv_dgrad: 16-B alignment");
   const int chunks = (cout + CC - 1) / CC;
   const int per_z = (chunks + ksplit - 1) / ksplit * CC;
-  PCAA_CHECK_ARG(ksplit <= chunks && per_z <= MAX_CR, "pcaa_dtc_conv_dgrad: ksplit must keep <= %d channels per workgroup "
-                 "(pcaa_dtc_conv_dgrad_ksplit)", MAX_CR);
+  PCAA_CHECK_ARG(ksplit <= chunks && per_z <= DG_MAX_CR, "pcaa_dtc_conv_dgrad: ksplit must keep <= %d channels per "
+                 "workgroup (pcaa_dtc_conv_dgrad_ksplit)", DG_MAX_CR);
   PCAA_CHECK_ARG(ksplit == 1 || slab_stride >= (long)B * T * cin, "pcaa_dtc_conv_dgrad: slab_stride >= B*T*cin");
-  DtcDgradParams p{dy, W, da, B, T, cin, cout, dilation, ksplit > 1 ? slab_stride : 0};
-  hipLaunchKernelGGL(dtc_dgrad_kernel, dim3(B, (cin + 31) / 32, ksplit), dim3(256), 0, as_stream(stream), p);
+  const bool ep = ep_stats != nullptr;
+  PCAA_CHECK_ARG(!ep || (ksplit == 1 && ep_y && ep_scale && ep_shift && ep_mean && ep_rstd && nrep >= 1),
+                 "pcaa_dtc_conv_dgrad: the epilogue needs ksplit == 1 and ep_y, ep_scale, ep_shift, ep_mean, ep_rstd");
+  const int tile = dg_tile_floats(per_z);
+  const size_t lds = (size_t)(tile + 32 * WP + 2 * 8 * 32) * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    const size_t cap = (size_t)(dg_tile_floats(DG_MAX_CR) + 32 * WP + 2 * 8 * 32) * sizeof(float);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dtc_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)cap) != hipSuccess) {
+      pcaa_set_error("pcaa_dtc_conv_dgrad: cannot raise the dynamic LDS limit");
+      return PCAA_ERR_LAUNCH;
+    }
+    configured = true;
+  }
+  DtcDgradParams p{dy, dz, y, coef, dy_out, W, out, ep_y, ep_scale, ep_shift, ep_mean, ep_rstd, ep_stats, nrep,
+                   B, T, cin, cout, dilation, ksplit > 1 ? slab_stride : 0};
+  hipLaunchKernelGGL(dtc_dgrad_kernel, dim3(B, (cin + 31) / 32, ksplit), dim3(256), lds, as_stream(stream), p, tile);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_dtc_conv_dgrad");
 }
 

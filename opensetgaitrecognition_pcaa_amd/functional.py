@@ -453,8 +453,17 @@ def dtc_backward(saves, layers, B, T, d_last=None, dpool=None, need_dx=True, gou
         need_in = li > 0 or need_dx
         outs = _layer_outs(gout, f"{prefix}{li + 1}.", "conv1d.weight", "batch_norm.weight", "batch_norm.bias")
         fused = _FUSE_DTC and _FUSE_DTC_BWD and T <= 32 and s.cin % 4 == 0 and s.cout % 4 == 0
-        # the adjoint w.r.t. the layer input in one launch (implicit col2im); else dcol = dy . W, then col2im
-        dgrad_fn = (lambda dy, W2d=W2d, s=s: ops.dtc_conv_dgrad(dy, W2d, B, T, s.cin, s.dil)) if fused else None
+        # the adjoint w.r.t. the layer input in one launch (implicit col2im), with the first half of the
+        # BatchNorm+ELU backward of the layer below in its epilogue (dz and the two column sums: that layer then
+        # starts at bn_bwd_finalize); else dcol = dy . W, then col2im
+        dgrad_fn = None
+        if fused:
+            sb = saves[li - 1] if (li > 0 and s.cout <= 512 and saves[li - 1].mean is not None) else None
+
+            def dgrad_fn(dy, W2d=W2d, s=s, sb=sb):
+                out, stats, _ = ops.dtc_conv_dgrad(dy, W2d, B, T, s.cin, s.dil,
+                                                   below=(sb.y, sb.scale, sb.shift, sb.mean, sb.rstd) if sb else None)
+                return _FusedGrad(out, stats) if sb else out
         if li == len(layers) - 1 and dpool is not None:
             dW, dg, db, dcol = _bn_layer_backward(s, bn, W2d, "fp32", dpool=dpool, group_rows=T,
                                                   pool_scale=1.0 / T, need_dinput=need_in, lhs=s.col, outs=outs,

@@ -1003,24 +1003,48 @@ def dtc_conv_fwd(src, scale, shift, W2d, B, T, dilation, stats=None, want_col=Fa
     return y, col
 
 
-def dtc_conv_dgrad(dy, W2d, B, T, cin, dilation):
-    """da[B*T, cin] = adjoint of the causal dilated convolution w.r.t. its input (see pcaa_dtc_conv_dgrad)."""
-    _chk(dy, "dtc_conv_dgrad.dy", torch.float32, 2)
+def dtc_conv_dgrad(dy, W2d, B, T, cin, dilation, dz=None, y=None, coef=None, want_dy=False, below=None):
+    """Adjoint of the causal dilated convolution w.r.t. its input in one launch (pcaa_dtc_conv_dgrad).
+    ``dy`` [B*T,cout], or None with ``dz``, ``y``, ``coef``: dy is formed on load (``want_dy``: also returned).
+    ``below`` = (y, scale, shift, mean, rstd) of the layer below: the result is that layer's dz and its
+    BatchNorm-backward statistics come back too.  Returns (out [B*T,cin], stats or None, dy or None)."""
     _chk(W2d, "dtc_conv_dgrad.W", torch.float32, 2)
-    rows, cout = dy.shape
-    if rows != B * T or tuple(W2d.shape) != (cout, cin * 3) or T > 32 or cin % 4 or cout % 4:
-        raise ValueError(f"dtc_conv_dgrad: unsupported shapes dy {tuple(dy.shape)} W {tuple(W2d.shape)} B={B} T={T}")
+    cout = W2d.shape[0]
+    rows = B * T
+    src = dy if dy is not None else dz
+    _chk(src, "dtc_conv_dgrad.dy/dz", torch.float32, 2)
+    if tuple(src.shape) != (rows, cout) or tuple(W2d.shape) != (cout, cin * 3) or T > 32 or cin % 4 or cout % 4:
+        raise ValueError(f"dtc_conv_dgrad: unsupported shapes {tuple(src.shape)} W {tuple(W2d.shape)} B={B} T={T}")
+    if dy is None:
+        _chk(y, "dtc_conv_dgrad.y", torch.float32, 2)
+        _chk(coef, "dtc_conv_dgrad.coef", torch.float32, 2)
+        if tuple(y.shape) != (rows, cout) or tuple(coef.shape) != (3, cout):
+            raise ValueError("dtc_conv_dgrad: y / coef shapes")
     lib = _lib.load()
-    da = torch.empty((rows, cin), dtype=torch.float32, device=dy.device)
+    dev = src.device
+    out = torch.empty((rows, cin), dtype=torch.float32, device=dev)
+    dy_out = torch.empty((rows, cout), dtype=torch.float32, device=dev) if (want_dy and dy is None) else None
     ks = lib.pcaa_dtc_conv_dgrad_ksplit(B, cin, cout)
+    stats = None
+    ep = [None] * 5
+    if below is not None:
+        if ks > 1:
+            raise ValueError("dtc_conv_dgrad: the fused epilogue needs cout <= 512")
+        for t in below:
+            _chk(t, "dtc_conv_dgrad.below", torch.float32)
+        if tuple(below[0].shape) != (rows, cin) or any(t.numel() != cin for t in below[1:]):
+            raise ValueError("dtc_conv_dgrad: below shapes")
+        ep = list(below)
+        stats = new_stats(cin, dev)
     if ks > 1:
         stride = rows * cin
-        slabs = torch.empty(ks * stride, dtype=torch.float32, device=dy.device)
-        check(lib.pcaa_dtc_conv_dgrad(_p(dy), _p(W2d), _p(slabs), B, T, cin, cout, int(dilation), ks, stride, _s()),
+        slabs = torch.empty(ks * stride, dtype=torch.float32, device=dev)
+        check(lib.pcaa_dtc_conv_dgrad(_p(dy), _p(dz), _p(y), _p(coef), _p(dy_out), _p(W2d), _p(slabs), None, None, None,
+                                      None, None, None, NREP, B, T, cin, cout, int(dilation), ks, stride, _s()),
               "pcaa_dtc_conv_dgrad")
-        check(lib.pcaa_splitk_reduce(_p(slabs), ks, stride, stride, _p(da), 0, _s()), "pcaa_splitk_reduce")
-        return da
-    check(lib.pcaa_dtc_conv_dgrad(_p(dy), _p(W2d), _p(da), B, T, cin, cout, int(dilation), 1, 0, _s()),
-          "pcaa_dtc_conv_dgrad")
-    return da
-
+        check(lib.pcaa_splitk_reduce(_p(slabs), ks, stride, stride, _p(out), 0, _s()), "pcaa_splitk_reduce")
+    else:
+        check(lib.pcaa_dtc_conv_dgrad(_p(dy), _p(dz), _p(y), _p(coef), _p(dy_out), _p(W2d), _p(out), *[_p(t) for t in ep],
+                                      _p(stats), NREP, B, T, cin, cout, int(dilation), 1, 0, _s()),
+              "pcaa_dtc_conv_dgrad")
+    return out, stats, (dy if dy is not None else dy_out)

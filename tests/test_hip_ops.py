@@ -643,9 +643,35 @@ def test_dtc_conv_dgrad_vs_fp64_autograd(B, T, cin, cout, d):
     y.backward(dy.double().view(B, T, cout).permute(0, 2, 1))
     ref = x.grad.permute(0, 2, 1).reshape(B * T, cin)
     W2d = W.view(cout, cin * 3).to(DEV)
-    da = ops.dtc_conv_dgrad(dy.to(DEV), W2d, B, T, cin, d)
+    da, _, _ = ops.dtc_conv_dgrad(dy.to(DEV), W2d, B, T, cin, d)
     scl = ref.abs().max().item()
     assert (da.cpu().double() - ref).abs().max().item() <= 2e-6 * (3 * cout) ** 0.5 * scl + 1e-6
     dcol = ops.gemm(dy.to(DEV), KC, W2d, RC, B * T, cin * 3, cout, out_dtype=torch.float32)
     two = ops.dtc_col2im(dcol, B, T, cin, d)
     assert (da - two).abs().max().item() <= 1e-5 * scl
+
+
+@pytest.mark.parametrize("B,T,cin,cout,d", [(3, 30, 16, 32, 2), (5, 30, 256, 512, 4), (64, 30, 32, 64, 4)])
+def test_dtc_conv_dgrad_fused_bn_halves(B, T, cin, cout, d):
+    """dy formed on load (dy = c0*dz + c1*y + c2) and the epilogue for the layer below (dz_below = da*ELU'(z),
+    statistics {sum dz, sum dz*yhat}) against the separate passes."""
+    W2d = _rand((cout, cin * 3), 101, (3 * cin) ** -0.5).to(DEV)
+    dz, y = _rand((B * T, cout), 102).to(DEV), _rand((B * T, cout), 103).to(DEV)
+    coef = torch.stack([_rand((cout,), 104, 0.3) + 1.0, _rand((cout,), 105, 0.1), _rand((cout,), 106, 0.1)]).to(DEV).contiguous()
+    yb = _rand((B * T, cin), 107).to(DEV)
+    scale, shift = (_rand((cin,), 108, 0.3) + 1.0).to(DEV), _rand((cin,), 109, 0.3).to(DEV)
+    mean, rstd = _rand((cin,), 110, 0.2).to(DEV), (_rand((cin,), 111, 0.1).abs() + 0.8).to(DEV)
+    out, stats, dy = ops.dtc_conv_dgrad(None, W2d, B, T, cin, d, dz=dz, y=y, coef=coef, want_dy=True,
+                                        below=(yb, scale, shift, mean, rstd))
+    dy_ref = ops.bn_bwd_dy(dz, y, coef)
+    assert torch.equal(dy, dy_ref) or (dy - dy_ref).abs().max().item() <= 1e-6 * dy_ref.abs().max().item()
+    da_ref, _, _ = ops.dtc_conv_dgrad(dy_ref, W2d, B, T, cin, d)
+    z = yb.double() * scale.double() + shift.double()
+    dz_ref = da_ref.double() * torch.where(z > 0, torch.ones_like(z), torch.exp(z))
+    scl = dz_ref.abs().max().item()
+    assert (out.double() - dz_ref).abs().max().item() <= 2e-6 * scl + 1e-7
+    st = stats.sum(0)
+    yhat = (yb.double() - mean.double()) * rstd.double()
+    assert torch.allclose(st[0], dz_ref.sum(0), rtol=1e-4, atol=1e-5 * scl * (B * T) ** 0.5)
+    assert torch.allclose(st[1], (dz_ref * yhat).sum(0), rtol=1e-4, atol=1e-5 * scl * (B * T) ** 0.5 * yhat.abs().max().item())
+
