@@ -267,12 +267,20 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
     Returns (dW2d, dgamma, dbeta, d_lhs or None)."""
     y = s.y
     rows_local, cout = y.shape
+    d_lhs = None
+    dgrad_done = False
     if isinstance(da, _FusedGrad):
         stats = da.stats
         _sync_stats(stats, 0)
         coef, dgamma, dbeta = ops.bn_bwd_finalize(stats, s.rows, bn, s.mean, s.rstd, cout,
                                                   dgamma=outs[1] if outs else None, dbeta=outs[2] if outs else None)
-        dy = ops.bn_bwd_dy(da.dz, y, coef, out=da.dz)
+        if need_dinput and dgrad_fn is not None and getattr(dgrad_fn, "forms_dy", False):
+            # the adjoint kernel forms dy = c0*dz + c1*y + c2 while it stages its operand and hands it back
+            # for the weight gradient: no separate elementwise pass
+            d_lhs, dy = dgrad_fn(None, dz=da.dz, y=y, coef=coef)
+            dgrad_done = True
+        else:
+            dy = ops.bn_bwd_dy(da.dz, y, coef, out=da.dz)
     else:
         # pass 1: statistics only (reads da/dpool and y, writes nothing); pass 2: dy directly, with
         # dz = da*ELU'(z) recomputed in registers -- dz is never materialised
@@ -311,9 +319,12 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
                 dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, split_k=sk, accumulate=True)
         else:
             dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, split_k=sk, accumulate=sk > 1)
-    d_lhs = None
-    if need_dinput and dgrad_fn is not None:
+    if dgrad_done:
+        pass
+    elif need_dinput and dgrad_fn is not None:
         d_lhs = dgrad_fn(dy)              # the caller's own adjoint (temporal block: implicit col2im)
+        if isinstance(d_lhs, tuple):
+            d_lhs = d_lhs[0]
     elif need_dinput:
         if mode == "bf16" and dy.dtype == torch.bfloat16 and cout % 8 == 0:
             Wt = _W16_CACHE.pop(W2d.data_ptr(), None)      # bf16 [K, cout] made by the forward pass
@@ -460,10 +471,13 @@ def dtc_backward(saves, layers, B, T, d_last=None, dpool=None, need_dx=True, gou
         if fused:
             sb = saves[li - 1] if (li > 0 and s.cout <= 512 and saves[li - 1].mean is not None) else None
 
-            def dgrad_fn(dy, W2d=W2d, s=s, sb=sb):
-                out, stats, _ = ops.dtc_conv_dgrad(dy, W2d, B, T, s.cin, s.dil,
-                                                   below=(sb.y, sb.scale, sb.shift, sb.mean, sb.rstd) if sb else None)
-                return _FusedGrad(out, stats) if sb else out
+            def dgrad_fn(dy, dz=None, y=None, coef=None, W2d=W2d, s=s, sb=sb):
+                out, stats, dy_used = ops.dtc_conv_dgrad(
+                    dy, W2d, B, T, s.cin, s.dil, dz=dz, y=y, coef=coef, want_dy=dy is None,
+                    below=(sb.y, sb.scale, sb.shift, sb.mean, sb.rstd) if sb else None)
+                return (_FusedGrad(out, stats) if sb else out), dy_used
+
+            dgrad_fn.forms_dy = s.cout <= 512
         if li == len(layers) - 1 and dpool is not None:
             dW, dg, db, dcol = _bn_layer_backward(s, bn, W2d, "fp32", dpool=dpool, group_rows=T,
                                                   pool_scale=1.0 / T, need_dinput=need_in, lhs=s.col, outs=outs,
