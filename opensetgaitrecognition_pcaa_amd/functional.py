@@ -861,7 +861,7 @@ def decoder_forward(dec, z, mode=None):
     return out, acts
 
 
-def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=None, mode=None):
+def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=None, mode=None, after_layer=None):
     """``grads_out`` {"denseI.weight"/"denseI.bias": destination}: for a padded decoder (see decoder_forward)
     these are the PADDED gradient tensors; without grads_out the returned gradients are cut to the parameter
     shapes."""
@@ -887,6 +887,8 @@ def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=Non
                                         dx_init=dz_init if i == 0 else None, mode=mode, d_is_pre=pre,
                                         fuse_elu_in=fuse)
         pre = fuse
+        if after_layer is not None:
+            after_layer(i + 1)       # trainer hook: layer i+1's weight / bias gradients are enqueued
         dW = dW.view_as(lin.weight)
         if padded and grads_out is None:
             ref = dec.dense_layers()[i]                  # cut the padding off: gradients in the parameter shapes

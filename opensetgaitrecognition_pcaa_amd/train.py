@@ -233,6 +233,9 @@ class PCAATrainer:
         self.early_decoder_adam = os.environ.get("PCAA_EARLY_ADAM", "1") != "0"
         self._side_adam_blocks = int(os.environ.get("PCAA_SIDE_ADAM_BLOCKS", "256"))
         self._dp_chunks = max(1, int(os.environ.get("PCAA_DP_CHUNKS", "4")))
+        # data-parallel bucketing: one all-reduce per decoder layer, issued as soon as that layer's gradient is
+        # written (PCAA_DP_BUCKETS=chunks: the whole region in PCAA_DP_CHUNKS pieces after the decoder backward)
+        self._bucket_per_layer = os.environ.get("PCAA_DP_BUCKETS", "layers") == "layers"
         # measured (same box, ms/step): no side stream 8.08-8.26 | beside the temporal-conv/head backward
         # 7.90 (256 blocks), 7.99 (128) | beside the PointNet backward GEMMs 8.29 (256) .. 9.03 (32):
         # the GEMMs lose more to the extra HBM stream than the update costs on its own
@@ -357,22 +360,54 @@ class PCAATrainer:
             torch.cuda.current_stream().wait_event(joined)
             joined = None
         dh = None
+        collective = self.pg is not None and (self.world > 1 or self._force_collectives)
+        # Data-parallel: a decoder layer's gradient goes onto the wire as soon as it exists.  The backward
+        # produces the 118 M-parameter output layer FIRST (75 % of all gradient bytes), a quarter of a millisecond
+        # before the decoder backward is over: its all-reduce is issued from the wgrad stream right behind its
+        # weight / bias gradient kernels, the later (smaller) layers follow the same way, and the small rest
+        # (first layer, whose bias gradient is on the main stream) goes out after the decoder backward.
+        early_buckets = []                         # (lo, hi, work) in flat_g coordinates, in issue order
+        layer_hook = None
+        if collective and self.overlap_allreduce and self._wg is not None and self._bucket_per_layer:
+            fg = self.flat_g
+
+            def layer_hook(layer):
+                if layer < 2:
+                    return
+                lo = fg.offsets[fg.names.index(f"G.dense{layer}.weight")]
+                nxt = f"G.dense{layer + 1}.weight"
+                hi = fg.offsets[fg.names.index(nxt)] if nxt in fg.names else fg.total
+                # ordered behind this layer's dW / db kernels, whichever stream the layer's path put them on
+                self._wg.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._wg):
+                    early_buckets.append((lo, hi, self._allreduce(fg.g[lo:hi], async_op=True)))
+
         if self.decoder_projection_head is not None:
             # the head's own backward (dh -> dsup, dW, db) runs inside the heads' backward launch below
-            _, dh = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads, mode=mode)
+            _, dh = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads, mode=mode,
+                                           after_layer=layer_hook)
             if joined is not None:
                 torch.cuda.current_stream().wait_event(joined)
         else:
-            _, dsup = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads, dz_init=dsup, mode=mode)
+            _, dsup = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads, dz_init=dsup,
+                                             mode=mode, after_layer=layer_hook)
         # The decoder's gradients are final here (the projection head's follow with the encoder's: its backward
         # runs in the MLP heads' launch).  Data-parallel: their all-reduce goes out now, in a few chunks (the
         # collectives of one communicator run in order), so that the side-stream Adam of chunk i overlaps the
         # all-reduce of chunk i+1 instead of waiting for all 628 MB.
         F_hip.mark("dec_bwd")
         pending = []                               # (lo, hi, work) in flat_g coordinates
-        if self.overlap_allreduce:
+        if self.overlap_allreduce and early_buckets:
+            # per-layer buckets are on the wire already; what is left of the decoder region is its head
+            # (first layer): its weight gradient was written on the wgrad stream, its bias gradient on this one
+            rest_hi = min(lo for lo, _, _ in early_buckets)
+            if rest_hi > self._dec_start:
+                torch.cuda.current_stream().wait_stream(self._wg)
+                pending.append((self._dec_start, rest_hi,
+                                self._allreduce(self.flat_g.g[self._dec_start:rest_hi], async_op=True)))
+            pending = early_buckets + pending      # issue order = the order the collectives complete in
+        elif self.overlap_allreduce:
             bounds = [self._dec_start]
-            collective = self.pg is not None and (self.world > 1 or self._force_collectives)
             if collective and self._wg is not None:
                 torch.cuda.current_stream().wait_stream(self._wg)   # the decoder's dW/db were written on that stream
             nchunk = self._dp_chunks if collective else 1
