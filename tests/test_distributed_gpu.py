@@ -24,9 +24,10 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, precision):
+def _worker(rank, world, port, q, precision, zero=False):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        os.environ["PCAA_DP_ZERO"] = "1" if zero else "0"
         sys.path.insert(0, ROOT)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import torch.distributed as dist
@@ -82,8 +83,9 @@ def _worker(rank, world, port, q, precision):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("precision", ["fp32"])
-def test_two_rank_syncbn_step_equals_global_batch_golden(precision):
+@pytest.mark.parametrize("precision,zero", [("fp32", False), ("fp32", True)])
+def test_two_rank_syncbn_step_equals_global_batch_golden(precision, zero):
+    """zero=True: the sharded decoder optimizer (reduce-scatter, Adam on this rank's slice, all-gather)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import is_pre_bn_bias, load_golden
     g, m = load_golden("v4_B6_N32_C4_K4")
@@ -91,7 +93,7 @@ def test_two_rank_syncbn_step_equals_global_batch_golden(precision):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, precision)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, precision, zero)) for r in range(world)]
     for p in procs:
         p.start()
     results = {}
