@@ -253,7 +253,10 @@ class PCAATrainer:
         # measured (same box, ms/step): no side stream 8.08-8.26 | beside the temporal-conv/head backward
         # 7.90 (256 blocks), 7.99 (128) | beside the PointNet backward GEMMs 8.29 (256) .. 9.03 (32):
         # the GEMMs lose more to the extra HBM stream than the update costs on its own
-        self._side_adam_at = os.environ.get("PCAA_SIDE_ADAM_AT", "dtc")
+        # (current build, same-box A/B with tools/ab_env.py, median of 4: right after the decoder backward 6.576 |
+        # after the heads' launch ("dtc") 6.621 | before the PointNet backward 6.90; 256 blocks 6.63 | 128: 6.91 |
+        # 512: 6.72 | 1024: 6.76)
+        self._side_adam_at = os.environ.get("PCAA_SIDE_ADAM_AT", "decbwd")
         self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         # second stream for the critic branch of the step (see step()); PCAA_AUX_STREAM=0: everything inline
         self._aux = (torch.cuda.Stream(device=self.device)
