@@ -140,13 +140,18 @@ class DeviceBatcher:
     in HBM.  ``shuffle=True`` reproduces the batch composition of the reference's DataLoader under the
     same global torch seed; ``drop_last`` as there."""
 
-    def __init__(self, crops_dev, labels_dev, batch_size, shuffle=True, drop_last=True):
+    def __init__(self, crops_dev, labels_dev, batch_size, shuffle=True, drop_last=True, rank=0, world=1, group=None):
+        """``world`` > 1 (data parallel): ``batch_size`` is the GLOBAL batch; rank 0's epoch order is broadcast
+        over ``group`` and every rank assembles rows [rank*B/world, (rank+1)*B/world) of each global batch."""
         if not crops_dev.is_cuda or crops_dev.dim() != 4 or crops_dev.dtype != torch.float32:
             raise RuntimeError("DeviceBatcher: crops must be a [M,T,N,C] float32 tensor on the HIP device")
         if labels_dev.shape != (crops_dev.shape[0],) or labels_dev.dtype != torch.int64:
             raise ValueError("DeviceBatcher: labels must be [M] int64")
         self.crops, self.labels = crops_dev.contiguous(), labels_dev.contiguous()
         self.batch_size, self.shuffle, self.drop_last = int(batch_size), shuffle, drop_last
+        self.rank, self.world, self.group = int(rank), int(world), group
+        if self.batch_size % self.world:
+            raise ValueError(f"DeviceBatcher: global batch {batch_size} is not divisible by world size {world}")
         self.err = torch.zeros(1, dtype=torch.int32, device=crops_dev.device)
         # labels ride through the same row gather: pad each to one 16-byte row
         self._lab_rows = torch.zeros((labels_dev.numel(), 2), dtype=torch.int64, device=crops_dev.device)
@@ -159,9 +164,18 @@ class DeviceBatcher:
     def __iter__(self):
         n = self.crops.shape[0]
         order = dataloader_epoch_order(n, self.shuffle).to(self.crops.device, non_blocking=True)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.broadcast(order, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                           group=self.group)            # one order for all ranks (rank 0's RNG)
         nb = len(self)
+        per = self.batch_size // self.world
         for k in range(nb):
             idx = order[k * self.batch_size:(k + 1) * self.batch_size]
+            if self.world > 1:
+                if idx.numel() < self.batch_size:
+                    break                               # a ragged last global batch cannot be sharded evenly
+                idx = idx[self.rank * per:(self.rank + 1) * per]
             yield self.batch(idx)
 
     def batch(self, idx):
@@ -176,14 +190,14 @@ class DeviceBatcher:
             raise IndexError("DeviceBatcher: a batch index was outside the packed store")
 
 
-def batcher_for(dataset, batch_size, device, shuffle, drop_last=True, cache_dir=None):
+def batcher_for(dataset, batch_size, device, shuffle, drop_last=True, cache_dir=None, rank=0, world=1, group=None):
     """A :class:`DeviceBatcher` over ``dataset``: in-memory point-major datasets (``SyntheticGaitDataset``:
     ``.pcs [M,T,N,C]``, ``.labels``) go to the device as they are; file-backed ones (``MSRadarDataset``) are
     packed once into ``<dataset_dir>_packed`` (re-packed when the file list changed) and uploaded."""
     if hasattr(dataset, "pcs") and torch.is_tensor(dataset.pcs):
         crops = dataset.pcs.to(device).float().contiguous()
         labels = torch.as_tensor(dataset.labels).to(torch.int64).to(device)
-        return DeviceBatcher(crops, labels, batch_size, shuffle, drop_last)
+        return DeviceBatcher(crops, labels, batch_size, shuffle, drop_last, rank, world, group)
     cache_dir = cache_dir or str(dataset.dataset_dir).rstrip("/\\") + "_packed"
     fresh = False
     if os.path.exists(os.path.join(cache_dir, MANIFEST)):
@@ -191,8 +205,11 @@ def batcher_for(dataset, batch_size, device, shuffle, drop_last=True, cache_dir=
             man = json.load(f)
             fresh = (man.get("filenames") == list(dataset.filenames)
                      and man.get("source_signature") == source_signature(dataset))
-    if not fresh:
+    if not fresh and rank == 0:
         pack_split(dataset, cache_dir)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier(group=group)                        # the other ranks wait for rank 0's pack
     crops, labels = PackedCrops(cache_dir).to_device(device)
-    return DeviceBatcher(crops, labels, batch_size, shuffle, drop_last)
+    return DeviceBatcher(crops, labels, batch_size, shuffle, drop_last, rank, world, group)
 

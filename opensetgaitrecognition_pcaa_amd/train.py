@@ -595,12 +595,15 @@ class PCAATrainer:
         return rec_loss, ce, preds, sup_fv
 
     # ------------------------------------------------------------------ checkpoints (format of the reference)
-    def save_checkpoints(self, folder, model_name):
+    def save_checkpoints(self, folder, model_name, write=True):
         suffix = {"E": "_E", "G": "_G", "D": "_D", "GPH": "_GPH", "DPH": "_DPH", "ML": "_ML"}
-        for key, mod in self.modules().items():
-            save_model(mod, os.path.join(folder, f"{model_name}{suffix[key]}.pt"))
+        if write:
+            for key, mod in self.modules().items():
+                save_model(mod, os.path.join(folder, f"{model_name}{suffix[key]}.pt"))
         if self.mean_learner is not None:
-            torch.save(self.learned_centroids(), os.path.join(folder, "discriminator_means.pt"))
+            cent = self.learned_centroids()
+            if write:
+                torch.save(cent, os.path.join(folder, "discriminator_means.pt"))
 
     @torch.no_grad()
     def learned_centroids(self):
@@ -626,16 +629,29 @@ def _wandb():
         return None
 
 
-def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=None):
+def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=None, sync_bn=False, device="cuda"):
     from .datasets import MSRadarDataset
     from .constants import SPLIT
 
     nmax_points = config["NMAX"]
     os.makedirs(f"models/{config['MODEL_NAME']}", exist_ok=True)
-    with open(os.path.join("models", config["MODEL_NAME"], "config.pkl"), "wb") as f:
-        pickle.dump(config, f)
+    if process_group is None or torch.distributed.get_rank(process_group) == 0:
+        with open(os.path.join("models", config["MODEL_NAME"], "config.pkl"), "wb") as f:
+            pickle.dump(config, f)
 
-    trainer = PCAATrainer(config, variant=variant, process_group=process_group)
+    # Data parallel (process_group given, one process per GPU): config["BATCH_SIZE"] is the GLOBAL batch, as in the
+    # single-process reference; every rank steps on its slice of each global batch, and the host RNG draws of the
+    # loop (epoch order, z0, alphas) are rank 0's, broadcast -- so the N-rank loop IS the single-process loop on
+    # the global batch (exactly so with sync_bn=True; per-rank BatchNorm statistics otherwise).
+    rank, world = 0, 1
+    if process_group is not None:
+        import torch.distributed as dist
+        rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        if config["BATCH_SIZE"] % world:
+            raise ValueError(f"BATCH_SIZE {config['BATCH_SIZE']} is not divisible by the world size {world}")
+    local_cfg = dict(config)
+    local_cfg["BATCH_SIZE"] = config["BATCH_SIZE"] // world
+    trainer = PCAATrainer(local_cfg, variant=variant, process_group=process_group, sync_bn=sync_bn, device=device)
     dev = trainer.device
     make = dataset_factory or (lambda split: MSRadarDataset(split, subsample_factor=config["SUBSAMPLE_FACTOR"]))
     train_set, valid_set = make(SPLIT.TRAIN), make(SPLIT.VALID)
@@ -643,8 +659,12 @@ def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=
         # packed store in HBM + device-side batch assembly; same batches (and the same consumption of
         # torch's global RNG) as the DataLoaders of the reference (batcher.py)
         from .batcher import batcher_for
-        loader_train = batcher_for(train_set, config["BATCH_SIZE"], dev, shuffle=True)
-        loader_valid = batcher_for(valid_set, config["BATCH_SIZE"], dev, shuffle=False)
+        loader_train = batcher_for(train_set, config["BATCH_SIZE"], dev, shuffle=True, rank=rank, world=world,
+                                   group=process_group)
+        loader_valid = batcher_for(valid_set, config["BATCH_SIZE"], dev, shuffle=False, rank=rank, world=world,
+                                   group=process_group)
+    elif world > 1:
+        raise RuntimeError("the data-parallel loop needs the device batcher (PCAA_DEVICE_BATCHER=1)")
     else:
         loader_train = torch.utils.data.DataLoader(train_set, batch_size=config["BATCH_SIZE"], drop_last=True,
                                                    shuffle=True, num_workers=0)
@@ -661,7 +681,8 @@ def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=
 
     if variant != "v1":
         means = trainer.sample_prior_means()
-        torch.save(means, os.path.join("models", config["MODEL_NAME"], "discriminator_means.pt"))
+        if rank == 0:
+            torch.save(means, os.path.join("models", config["MODEL_NAME"], "discriminator_means.pt"))
     trainer.finalize()
 
     best_valid_accuracy = 0
@@ -674,9 +695,18 @@ def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=
         for i, (pcs, gt_labels) in enumerate(loader_train):
             pcs = pcs.to(dev, non_blocking=True)
             gt_labels = gt_labels.to(dev, non_blocking=True)
-            # the reference's two host RNG draws, same generators, same order (:915-925, :944-948)
-            z0 = torch.from_numpy(np.random.normal(0.0, 1.0, (pcs.shape[0], L))).to(dev).float()
-            alphas = torch.rand(size=(pcs.shape[0], 1)).to(dev)
+            # the reference's two host RNG draws, same generators, same order (:915-925, :944-948); data parallel:
+            # drawn for the global batch, rank 0's values broadcast, this rank's rows taken
+            gb = pcs.shape[0] * world
+            z0 = torch.from_numpy(np.random.normal(0.0, 1.0, (gb, L))).to(dev).float()
+            alphas = torch.rand(size=(gb, 1)).to(dev)
+            if world > 1:
+                import torch.distributed as dist
+                src = dist.get_global_rank(process_group, 0)
+                dist.broadcast(z0, src=src, group=process_group)
+                dist.broadcast(alphas, src=src, group=process_group)
+                z0 = z0[rank * pcs.shape[0]:(rank + 1) * pcs.shape[0]].contiguous()
+                alphas = alphas[rank * pcs.shape[0]:(rank + 1) * pcs.shape[0]].contiguous()
             out = trainer.step(pcs, gt_labels, z0, alphas,
                                supervise=(i % config["SUPERVISION_FREQUENCY"] == 0))
             steps.append(out)
@@ -706,16 +736,26 @@ def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=
             "Train Accuracy": float(np.mean(ys == y_hats)),
             "Valid Accuracy": float((torch.cat(v_y) == torch.cat(v_hat)).float().mean().item()) if v_y else 0.0,
         }
+        if world > 1:
+            # every entry is a mean over equally sized shards: the global value is the mean over the ranks
+            import torch.distributed as dist
+            vals = torch.tensor(list(record.values()), dtype=torch.float64, device=dev)
+            dist.all_reduce(vals, group=process_group)
+            record = {k: float(v) / world for k, v in zip(record, vals.tolist())}
         history.append(record)
-        if log_fn is not None:
-            log_fn(record)
-        elif wb is not None and hasattr(wb, "log"):
-            wb.log(record)
-        print(f"[Epoch {epoch}/{config['EPOCHS']}] " + " ".join(f"[{k}: {v:.4f}]" for k, v in record.items()))
+        if rank == 0:                    # logging is rank 0's
+            if log_fn is not None:
+                log_fn(record)
+            elif wb is not None and hasattr(wb, "log"):
+                wb.log(record)
+            print(f"[Epoch {epoch}/{config['EPOCHS']}] " + " ".join(f"[{k}: {v:.4f}]" for k, v in record.items()))
 
         if epoch % config["CHECKPOINT_FREQUENCY"] == 0 and record["Valid Accuracy"] > best_valid_accuracy:
             best_valid_accuracy = record["Valid Accuracy"]
-            trainer.save_checkpoints(os.path.join("models", config["MODEL_NAME"]), config["MODEL_NAME"])
+            # every rank takes part (variant 1 evaluates the mean learner: identical replicas, and with SyncBN a
+            # collective), rank 0 writes the files
+            trainer.save_checkpoints(os.path.join("models", config["MODEL_NAME"]), config["MODEL_NAME"],
+                                     write=rank == 0)
     run.finish()
     return trainer, history
 

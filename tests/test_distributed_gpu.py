@@ -127,3 +127,69 @@ def test_two_rank_syncbn_step_equals_global_batch_golden(precision, zero):
         assert err.mean() <= 2e-6 * max(scale, 1.0), (key, err.mean())
         checked += 1
     assert checked >= 20
+
+
+def _loop_worker(rank, world, port, q, workdir):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        sys.path.insert(0, ROOT)
+        os.chdir(workdir)
+        import torch.distributed as dist
+        from opensetgaitrecognition_pcaa_amd import constants, functional as F_hip
+        from opensetgaitrecognition_pcaa_amd.datasets import SyntheticGaitDataset
+        from opensetgaitrecognition_pcaa_amd.train import train_variant4
+        torch.cuda.set_device(0)
+        pg = None
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            pg = dist.group.WORLD
+        constants.NFEATURES = 4
+        F_hip.set_precision("fp32")
+        cfg = dict(constants.CONFIG)
+        cfg.update(MODEL_NAME=f"dp{world}", TRAIN_CLASSES=[0, 1, 2, 3], NMAX=16, BATCH_SIZE=8, EPOCHS=2,
+                   CHECKPOINT_FREQUENCY=1, NOTES="")
+        # the loop's host RNG: seeded identically everywhere -- rank 0's draws are the ones used
+        np.random.seed(5); torch.manual_seed(5)
+        make = lambda split: SyntheticGaitDataset(48 if split.value == "train" else 16, 4, N=16, C=4, seed=11)
+        trainer, hist = train_variant4(cfg, wandb_mode="disabled", dataset_factory=make, process_group=pg,
+                                       sync_bn=world > 1, device="cuda:0")
+        torch.cuda.synchronize()
+        q.put((rank, {"hist": hist, "p": trainer.flat_g.p.detach().cpu()[:4096].numpy(),
+                      "files": sorted(os.listdir(f"models/dp{world}"))}, None))
+        if world > 1:
+            dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, None, traceback.format_exc() + repr(e)))
+
+
+@pytest.mark.timeout(300)
+def test_data_parallel_loop_equals_single_process_loop(tmp_path):
+    """train_variant4 on 2 ranks (global BATCH_SIZE 8 = 4 per rank, SyncBN, rank 0's epoch order / z0 / alphas
+    broadcast) must log the same epoch records as the single-process loop at BATCH_SIZE 8 from the same seeds."""
+    ctx = mp.get_context("spawn")
+    out = {}
+    for world in (1, 2):
+        port = _free_port()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_loop_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = {}
+        for _ in range(world):
+            rank, rec, err = q.get(timeout=240)
+            assert err is None, f"world {world} rank {rank}: {err}"
+            res[rank] = rec
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        out[world] = res
+    h1, h2 = out[1][0]["hist"], out[2][0]["hist"]
+    assert out[2][0]["hist"] == out[2][1]["hist"], "both ranks log the same (global) records"
+    assert np.array_equal(out[2][0]["p"], out[2][1]["p"]), "replicas hold identical parameters"
+    assert len(h1) == len(h2) == 2
+    for e in range(2):
+        for k in h1[e]:
+            tol = 2e-3 if "Accuracy" not in k else 0.13          # one flipped argmax in 8/16 samples at most
+            assert abs(h1[e][k] - h2[e][k]) <= tol * max(abs(h1[e][k]), 1.0), (e, k, h1[e][k], h2[e][k])
+    assert "dp2_E.pt" in out[2][0]["files"] and "config.pkl" in out[2][0]["files"]
