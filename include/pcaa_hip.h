@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PCAA_ABI_VERSION 4 /* pcaa_abi_version() of a library built from this header */
+#define PCAA_ABI_VERSION 5 /* pcaa_abi_version() of a library built from this header */
 
 #define PCAA_OK 0
 #define PCAA_ERR_INVALID_ARG 1
@@ -246,10 +246,12 @@ int pcaa_chamfer_fwd_bwd(const float* preds, long p_sb, long p_sc, long p_st, lo
                          float* dpreds, long d_sb, long d_sc, long d_st, long d_sn,
                          float grad_scale, const float* grad_per_b, void* stream);
 /* CrossEntropyLoss(mean) (PCAA_ablation.py:1008) + argmax(softmax) (:891-893).
- * loss, dlogits, preds are each nullable. dlogits = grad_scale*(softmax - onehot)/B */
+ * loss, dlogits, preds are each nullable. dlogits = grad_scale*(softmax - onehot)/B.
+ * err_flag (nullable, device int32[1]): set to 1 if a target is outside [0,K) -- torch raises there; the
+ * row is then scored against class 0 so that nothing is read out of bounds. */
 int pcaa_cross_entropy(const float* logits, const long long* target, int B, int K,
                        float* loss, float* dlogits, float grad_scale, long long* preds,
-                       void* stream);
+                       int* err_flag, void* stream);
 
 /* ------------------------------------------------------------------ CGDiscriminator (models.py:405-421)
  * u = [x(32) ; label(K)] -> 64 ELU -> 32 ELU -> 1.  Parameters in PyTorch layout. */
@@ -282,11 +284,13 @@ int pcaa_disc_wgan_gp(const float* z, const float* fv, const float* label, const
  * joint_likelihood (inference_PCAA.py:129-136): lik[b] = (1/K) sum_k N(x_b; mu_k, I_D), float64,
  * evaluated as exp(log-pdf) like scipy.stats.multivariate_normal.pdf.
  * k-window vote (inference_PCAA.py:263-271): window w covers crops [w*k,(w+1)*k); known iff
- * #(lik > threshold) > k/2 -> most frequent predicted label (lowest on ties), else n_labels. */
+ * #(lik > threshold) > k/2 -> most frequent predicted label over the encoder's n_classes outputs
+ * (np.argmax(np.bincount(preds)): lowest label on ties), else n_labels (the "unknown" id = number of
+ * distinct labels of the known test split, which may be smaller than n_classes). */
 int pcaa_joint_likelihood(const float* x, const float* means, int B, int K, int D, double* lik,
                           void* stream);
 int pcaa_kvote(const double* lik, const long long* preds, double threshold, int k, int n_labels,
-               int n_windows, long long* out, void* stream);
+               int n_classes, int n_windows, long long* out, void* stream);
 
 /* ------------------------------------------------------------------ batch-skinny Linear layers
  * The CGDecoder's Linear stack (models.py CGDecoder: nn.Linear(32+K, S/16) ... nn.Linear(S/2, S),

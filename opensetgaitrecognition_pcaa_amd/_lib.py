@@ -84,6 +84,12 @@ def load():
             fn = getattr(lib, name)     # AttributeError if the .so does not export it
             fn.restype = ret
             fn.argtypes = args
+        # libpcaa_hip.so is git-ignored and travels prebuilt: a stale one would export the same names with other
+        # signatures and be called with mismatched arguments
+        built = lib.pcaa_abi_version()
+        if built != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} was built for ABI version {built}, include/pcaa_hip.h declares "
+                               f"{ABI_VERSION}: rebuild it (python -m opensetgaitrecognition_pcaa_amd.build)")
         _lib = lib
     return _lib
 

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(CH_THREADS) void chamfer_kernel(
 __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits,
                                                             const long long* __restrict__ target, int B,
                                                             int K, float* loss, float* dlogits,
-                                                            float grad_scale, long long* preds) {
+                                                            float grad_scale, long long* preds, int* err_flag) {
   __shared__ double red[4];
   double acc = 0.0;
   for (int r = threadIdx.x; r < B; r += 256) {
@@ -121,7 +121,11 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
     const float inv = 1.f / se;
     int am = 0;
     float pbest = -1.f;
-    const long long tg = target ? target[r] : 0;
+    long long tg = target ? target[r] : 0;
+    if (tg < 0 || tg >= K) {       // torch raises here; flag it and stay inside the row
+      if (err_flag) *err_flag = 1;
+      tg = 0;
+    }
     for (int k = 0; k < K; ++k) {
       const float pk = expf(x[k] - mx) / se;   // softmax exactly as exp / sum
       if (pk > pbest) { pbest = pk; am = k; }  // first index on ties
@@ -159,10 +163,11 @@ extern "C" int pcaa_chamfer_fwd_bwd(const float* preds, long p_sb, long p_sc, lo
 }
 
 extern "C" int pcaa_cross_entropy(const float* logits, const long long* target, int B, int K, float* loss,
-                                  float* dlogits, float grad_scale, long long* preds, void* stream) {
+                                  float* dlogits, float grad_scale, long long* preds, int* err_flag,
+                                  void* stream) {
   PCAA_CHECK_ARG(logits && B >= 1 && K >= 1, "pcaa_cross_entropy: bad args");
   PCAA_CHECK_ARG(target || (!loss && !dlogits), "pcaa_cross_entropy: loss/grad need targets");
   hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(256), 0, as_stream(stream), logits, target, B, K,
-                     loss, dlogits, grad_scale, preds);
+                     loss, dlogits, grad_scale, preds, err_flag);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_cross_entropy");
 }

@@ -25,9 +25,10 @@ __global__ void joint_likelihood_kernel(const float* __restrict__ x, const float
 }
 
 // window w = crops [w*k, (w+1)*k): known iff #(lik > thr) > k/2, then the most frequent
-// predicted label (lowest label on ties, like argmax(bincount)), else n_labels (= unknown)
+// predicted label over ALL n_classes encoder outputs (lowest label on ties, like argmax(bincount)), else
+// n_labels (= unknown; the number of labels present in the known test split)
 __global__ void kvote_kernel(const double* __restrict__ lik, const long long* __restrict__ preds, double thr,
-                             int k, int n_labels, int nwin, long long* __restrict__ out) {
+                             int k, int n_labels, int n_classes, int nwin, long long* __restrict__ out) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= nwin) return;
   int above = 0;
@@ -37,7 +38,7 @@ __global__ void kvote_kernel(const double* __restrict__ lik, const long long* __
     return;
   }
   int best = 0, best_count = -1;
-  for (int c = 0; c < n_labels; ++c) {
+  for (int c = 0; c < n_classes; ++c) {
     int cnt = 0;
     for (int i = 0; i < k; ++i) cnt += preds[(long)w * k + i] == c ? 1 : 0;
     if (cnt > best_count) { best_count = cnt; best = c; }
@@ -56,9 +57,10 @@ extern "C" int pcaa_joint_likelihood(const float* x, const float* means, int B, 
 }
 
 extern "C" int pcaa_kvote(const double* lik, const long long* preds, double threshold, int k, int n_labels,
-                          int n_windows, long long* out, void* stream) {
-  PCAA_CHECK_ARG(lik && preds && out && k >= 1 && n_labels >= 1 && n_windows >= 1, "pcaa_kvote: bad args");
+                          int n_classes, int n_windows, long long* out, void* stream) {
+  PCAA_CHECK_ARG(lik && preds && out && k >= 1 && n_labels >= 1 && n_classes >= 1 && n_windows >= 1,
+                 "pcaa_kvote: bad args");
   hipLaunchKernelGGL(kvote_kernel, dim3((unsigned)cdiv(n_windows, 128)), dim3(128), 0, as_stream(stream), lik, preds,
-                     threshold, k, n_labels, n_windows, out);
+                     threshold, k, n_labels, n_classes, n_windows, out);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_kvote");
 }

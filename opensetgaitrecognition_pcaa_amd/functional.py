@@ -62,6 +62,18 @@ def set_sync_bn_group(group):
     _SYNC_BN["group"] = group
 
 
+@contextlib.contextmanager
+def sync_bn_group(group):
+    """``with sync_bn_group(g):`` -- SyncBN over ``g`` inside the block, the previous setting restored after it
+    (how PCAATrainer scopes its group to its own train-mode work)."""
+    prev = _SYNC_BN["group"]
+    _SYNC_BN["group"] = group if group is not None else prev
+    try:
+        yield
+    finally:
+        _SYNC_BN["group"] = prev
+
+
 def _sync_stats(stats, count):
     g = _SYNC_BN["group"]
     if g is None:

@@ -37,16 +37,21 @@ def joint_likelihood(sup_fv: torch.Tensor, means: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def k_vote(lik: torch.Tensor, preds: torch.Tensor, threshold: float, k: int, n_labels: int) -> torch.Tensor:
+def k_vote(lik: torch.Tensor, preds: torch.Tensor, threshold: float, k: int, n_labels: int,
+           n_classes: int = None) -> torch.Tensor:
     """Windows of k consecutive crops (trailing partial window dropped, like DataLoader
-    drop_last=True) -> [n_windows] int64 open-set predictions (n_labels = unknown)."""
+    drop_last=True) -> [n_windows] int64 open-set predictions.  ``n_labels`` is the "unknown" id (the number
+    of distinct labels in the known test split); the majority is taken over the encoder's ``n_classes``
+    outputs (``np.argmax(np.bincount(preds))``, inference_PCAA.py:265-266) -- a test split that lacks a trained
+    class must not drop the votes for it.  Default ``n_classes = n_labels``."""
     ops._chk(lik, "k_vote.lik", torch.float64, 1)
     ops._chk(preds, "k_vote.preds", torch.int64, 1)
+    n_classes = int(n_labels if n_classes is None else n_classes)
     nwin = lik.numel() // k
     out = torch.empty(nwin, dtype=torch.int64, device=lik.device)
     if nwin:
         check(_lib.load().pcaa_kvote(ops._p(lik), ops._p(preds), ctypes.c_double(float(threshold)), int(k),
-                                     int(n_labels), nwin, ops._p(out), ops._s()), "pcaa_kvote")
+                                     int(n_labels), n_classes, nwin, ops._p(out), ops._s()), "pcaa_kvote")
     return out
 
 
@@ -103,7 +108,7 @@ class OpenSetScorer:
     def vote(self, lik: torch.Tensor, preds: torch.Tensor, k: int, n_labels: int) -> torch.Tensor:
         if self.threshold is None:
             raise RuntimeError("fit_threshold() first")
-        return k_vote(lik, preds, self.threshold, k, n_labels)
+        return k_vote(lik, preds, self.threshold, k, n_labels, n_classes=self.encoder.MLP_sup2[0].weight.shape[0])
 
 
 def _variation_uses_head(variation, model_name=""):

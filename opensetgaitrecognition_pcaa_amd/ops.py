@@ -791,16 +791,29 @@ def chamfer(preds, gts, want_grad, grad_scale=1.0, grad_per_b=None):
     return fl, dp
 
 
-def cross_entropy(logits, target=None, want_loss=True, want_grad=False, grad_scale=1.0, want_preds=False):
+def cross_entropy(logits, target=None, want_loss=True, want_grad=False, grad_scale=1.0, want_preds=False,
+                  err_flag=None):
+    """``err_flag`` (device int32[1]): the kernel raises it when a target is outside [0,K) and the caller checks
+    it when convenient (the trainer: once per epoch).  Without it the targets are range-checked here, on the
+    host (one synchronisation) -- torch's CrossEntropyLoss raises on such a label, so must this."""
     _chk(logits, "ce.logits", torch.float32, 2)
     B, K = logits.shape
     if target is not None:
         _chk(target, "ce.target", torch.int64, 1)
+        if target.shape[0] != B:
+            raise ValueError(f"cross_entropy: {target.shape[0]} targets for {B} rows of logits")
+        if err_flag is None:
+            lo, hi = int(target.min().item()), int(target.max().item())
+            if lo < 0 or hi >= K:
+                raise IndexError(f"cross_entropy: target {lo if lo < 0 else hi} is out of bounds for {K} classes")
+        else:
+            _chk(err_flag, "ce.err_flag", torch.int32)
     dev = logits.device
     loss = torch.empty((), dtype=torch.float32, device=dev) if (want_loss and target is not None) else None
     dl = torch.empty_like(logits) if want_grad else None
     pr = torch.empty(B, dtype=torch.int64, device=dev) if want_preds else None
-    check(_lib.load().pcaa_cross_entropy(_p(logits), _p(target), B, K, _p(loss), _p(dl), float(grad_scale), _p(pr), _s()),
+    check(_lib.load().pcaa_cross_entropy(_p(logits), _p(target), B, K, _p(loss), _p(dl), float(grad_scale), _p(pr),
+                                         _p(err_flag) if target is not None else None, _s()),
           "pcaa_cross_entropy")
     return loss, dl, pr
 

@@ -31,6 +31,24 @@ from .utils import sample_distant_points, save_model
 _ALIGN = 64  # floats; keeps every parameter view 256-B aligned inside the flat buffers
 
 
+class StepCount:
+    """An optimizer step count on the device (int32) with the two bias-correction scalars Adam derives from it
+    (``pcaa_adam_advance``), plus its host mirror."""
+
+    def __init__(self, device):
+        self.step = 0
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        self.coef_dev = torch.zeros(2, dtype=torch.float32, device=device)
+
+    def advance(self, lr, b1, b2):
+        self.step += 1
+        ops.adam_advance_(self.step_dev, self.coef_dev, lr, b1, b2)
+
+    def set(self, step):
+        self.step = int(step)
+        self.step_dev.fill_(self.step)
+
+
 class FlatBuffer:
     """Parameters re-pointed into one contiguous fp32 buffer (+ matching
     gradient and Adam moment buffers)."""
@@ -75,31 +93,49 @@ class FlatBuffer:
                 self.p[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = self.p[o:o + n].view(p.shape)
                 self.grad_views[name] = self.g[o:o + n].view(p.shape)
-        self.step = 0
         # The optimizer's step count also lives on the device (int32 + the two bias-correction scalars
         # derived from it by pcaa_adam_advance), so that a captured hipGraph of the train step replays
         # without per-step host arguments; ``step`` is the host mirror (replays bump it).
-        self.step_dev = torch.zeros(1, dtype=torch.int32, device=device)
-        self.coef_dev = torch.zeros(2, dtype=torch.float32, device=device)
+        self.count = StepCount(device)
+        # Parameters that only receive a gradient on SUPERVISED steps (MLP_head / MLP_sup2, see
+        # PCAATrainer._sup_range) keep their own count: torch.optim.Adam's ``step`` state is per parameter
+        # and is not advanced while the parameter's ``.grad`` is None.
+        self.sup_count = StepCount(device)
+
+    # the main counter under its historical names
+    @property
+    def step(self):
+        return self.count.step
+
+    @step.setter
+    def step(self, v):
+        self.count.step = int(v)
+
+    @property
+    def step_dev(self):
+        return self.count.step_dev
+
+    @property
+    def coef_dev(self):
+        return self.count.coef_dev
 
     def advance(self, lr, b1, b2):
         """Begin the next optimizer step (once per step, before any adam() range of it)."""
-        self.step += 1
-        ops.adam_advance_(self.step_dev, self.coef_dev, lr, b1, b2)
+        self.count.advance(lr, b1, b2)
 
     def set_step(self, step):
-        self.step = int(step)
-        self.step_dev.fill_(self.step)
+        self.count.set(step)
 
-    def adam(self, lr, b1, b2, eps=1e-8, grad_scale=1.0, lo=0, hi=None, advance=True, max_blocks=0):
+    def adam(self, lr, b1, b2, eps=1e-8, grad_scale=1.0, lo=0, hi=None, advance=True, max_blocks=0, count=None):
         """One Adam update of the elements [lo, hi) (default: everything).  ``advance=False``:
-        a further range of the SAME optimizer step (the step count is shared)."""
+        a further range of the SAME optimizer step (the step count is shared).  ``count``: the
+        :class:`StepCount` whose bias corrections apply (default: the buffer's main one)."""
         if advance:
             self.advance(lr, b1, b2)
         hi = self.total if hi is None else hi
         if hi > lo:
             ops.adam_step_dev_(self.p[lo:hi], self.g[lo:hi], self.m[lo:hi], self.v[lo:hi], b1, b2, eps,
-                               self.coef_dev, grad_scale, max_blocks)
+                               (count or self.count).coef_dev, grad_scale, max_blocks)
 
 
 class PCAATrainer:
@@ -126,18 +162,23 @@ class PCAATrainer:
         self.precision = precision
         self.pg = process_group
         self.world = 1
+        # SyncBN group: installed in functional for the duration of this trainer's train-mode work only
+        # (_sync_bn()), so a later trainer or module call in the same process never all-reduces over it
+        self._sync_bn_group = None
         if process_group is not None:
             import torch.distributed as dist
             self.world = dist.get_world_size(process_group)
             if sync_bn:
-                F_hip.set_sync_bn_group(process_group)
-        if variant not in ("v4", "base", "v1"):
+                self._sync_bn_group = process_group
+        if variant not in ("v4", "base", "v1", "v3"):
             raise ValueError(f"PCAATrainer: unknown variant {variant!r}")
         head = variant in ("v4", "v1")
         self.learn_centroids = bool(learn_centroids) and variant == "v1"
         # construction order = the reference's (PCAA_ablation.py:764-786): same draws from torch's RNG
         self.encoder = CGEncoder(n_out_labels=self.K, use_projection_head=head, nmax_points=self.N).to(self.device).float()
-        self.decoder = CGDecoder(input_dim=self.L * 2 if head else self.L, nmax_points=self.N).to(self.device).float()
+        # variant 3 has no decoder at all (PCAA_ablation.py:404-415)
+        self.decoder = None if variant == "v3" else \
+            CGDecoder(input_dim=self.L * 2 if head else self.L, nmax_points=self.N).to(self.device).float()
         if variant != "v1":
             self.discriminator = CGDiscriminator(self.K).to(self.device).float()
         self.decoder_projection_head = self.discriminator_projection_head = self.mean_learner = None
@@ -155,6 +196,9 @@ class PCAATrainer:
         self.discriminator_means = None
         self._flat_ready = False
         self._graphs = {}
+        # raised on the device by a label outside [0, K) (torch's CrossEntropyLoss raises there); read by check()
+        self._err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._sup_split = False        # an unsupervised step has happened: MLP_head / MLP_sup2 count separately
 
     # ------------------------------------------------------------------ setup
     def set_prior_means(self, means):
@@ -164,8 +208,20 @@ class PCAATrainer:
         self.set_prior_means(sample_distant_points(dimension=self.L, n=self.K, min_dist=10, sphere_radius=10))
         return self.discriminator_means
 
+    def _sync_bn(self):
+        """Context: BatchNorm statistics are all-reduced over this trainer's group inside (no-op without SyncBN)."""
+        return F_hip.sync_bn_group(self._sync_bn_group)
+
+    def betas_g(self):
+        """optimizer_G's betas: (B1, B2) -- except variant 3, whose G optimizer is built with (B1, B1)
+        (PCAA_ablation.py:455; a typo of the reference that its runs executed, so it is what is reproduced)."""
+        c = self.cfg
+        return (c["B1"], c["B1"]) if self.variant == "v3" else (c["B1"], c["B2"])
+
     def modules(self):
-        d = {"E": self.encoder, "G": self.decoder, "D": self.discriminator}
+        d = {"E": self.encoder, "D": self.discriminator}
+        if self.decoder is not None:
+            d = {"E": self.encoder, "G": self.decoder, "D": self.discriminator}
         if self.decoder_projection_head is not None:
             d["GPH"] = self.decoder_projection_head
         if self.discriminator_projection_head is not None:
@@ -180,7 +236,8 @@ class PCAATrainer:
         if self.decoder_projection_head is not None:
             g_named += [("GPH." + n, p) for n, p in self.decoder_projection_head.named_parameters()]
         # bn1..bn4 of the decoder never receive a gradient: torch.optim.Adam skips them
-        g_named += [("G." + n, p) for n, p in self.decoder.named_parameters() if n.startswith("dense")]
+        if self.decoder is not None:
+            g_named += [("G." + n, p) for n, p in self.decoder.named_parameters() if n.startswith("dense")]
         # Decoder widths that are not multiples of 64 (N=150, the reference's default: 1125 ... 18000) keep the
         # weight-streaming kernels away -- rows of 1125 floats are not even 16-B aligned.  The weights are then
         # STORED zero-padded to multiples of 64 in both dimensions and the decoder runs in the padded widths
@@ -188,7 +245,7 @@ class PCAATrainer:
         # gradients (their operands are zero), so Adam leaves the padding at zero and the [:N,:K] windows the
         # modules expose are bit-for-bit what an unpadded run of the same kernels would hold.
         pads = {}
-        if os.environ.get("PCAA_PAD_DECODER", "1") != "0":
+        if self.decoder is not None and os.environ.get("PCAA_PAD_DECODER", "1") != "0":
             r64 = lambda v: (v + 63) // 64 * 64
             lins = self.decoder.dense_layers()
             if any(l.weight.shape[0] % 64 for l in lins):
@@ -203,6 +260,8 @@ class PCAATrainer:
         self._zero = (os.environ.get("PCAA_DP_ZERO", "0") == "1" and self.pg is not None)
         self._zero_chunks = max(1, int(os.environ.get("PCAA_DP_CHUNKS", "4")))
         tail = None
+        if self.decoder is None:
+            self._zero = False
         if self._zero:
             first_dec = next(n for n, _ in g_named if n.startswith("G."))
             tail = (first_dec, self.world * self._zero_chunks * _ALIGN)
@@ -226,15 +285,22 @@ class PCAATrainer:
             self._ml_end = self.flat_d.offsets[len(ml)] if ml and len(ml) < len(self.flat_d.offsets) else 0
         self._d_params = ops._disc_params(self.discriminator)
         self._d_grads = [self.flat_d.grad_views["D." + n] for n, _ in self.discriminator.named_parameters()]
-        self._dec_grads = {n: (self.flat_g.padded["G." + n][1] if "G." + n in self.flat_g.padded
-                               else self.flat_g.grad_views["G." + n])
-                           for n, _ in self.decoder.named_parameters() if n.startswith("dense")}
+        self._dec_grads = {} if self.decoder is None else {
+            n: (self.flat_g.padded["G." + n][1] if "G." + n in self.flat_g.padded else self.flat_g.grad_views["G." + n])
+            for n, _ in self.decoder.named_parameters() if n.startswith("dense")}
         # encoder gradients are produced straight into the flat buffer; the split-K products
         # accumulate, so that (leading) region is cleared by one fill per step
         self._enc_grads = {n: self.flat_g.grad_views["E." + n] for n, _ in self.encoder.named_parameters()}
         n_enc = sum(1 for nm in self.flat_g.names if nm.startswith("E."))
         enc_end = self.flat_g.offsets[n_enc] if n_enc < len(self.flat_g.offsets) else self.flat_g.total
         self._enc_region = self.flat_g.g[:enc_end]
+        # MLP_head / MLP_sup2 only feed the logits: on an unsupervised step (i % SUPERVISION_FREQUENCY != 0) their
+        # ``.grad`` stays None in the reference and torch.optim.Adam skips them entirely -- no update, no moment
+        # decay, no advance of their per-parameter step.  They are the last encoder parameters: one contiguous range.
+        sup_idx = [i for i, nm in enumerate(self.flat_g.names)
+                   if nm.startswith("E.MLP_head.") or nm.startswith("E.MLP_sup2.")]
+        assert sup_idx == list(range(sup_idx[0], sup_idx[-1] + 1)) and sup_idx[-1] == n_enc - 1
+        self._sup_range = (self.flat_g.offsets[sup_idx[0]], enc_end)
         # projection-head + decoder gradients (>98 % of the bytes) are complete before the encoder
         # backward starts: their all-reduce is issued asynchronously and overlaps it
         self._tail_region = self.flat_g.g[enc_end:]
@@ -276,6 +342,43 @@ class PCAATrainer:
         self._force_collectives = os.environ.get("PCAA_DP_FORCE", "0") == "1"
         self._stats_pool = ops.StatsPool(self.device)
         self._flat_ready = True
+        if self.pg is not None and self.world > 1:
+            self.sync_replicas()
+
+    @torch.no_grad()
+    def sync_replicas(self, src_rank=0):
+        """Make every rank's replica rank ``src_rank``'s: parameters (the two flat buffers and every parameter
+        outside them: decoder bn1..4, the inert discriminator head, an untrained mean learner), all module
+        buffers (BatchNorm running statistics, ``num_batches_tracked``), the Adam moments and step counts, and
+        the prior centroids.  The reference never seeds, so under torchrun each rank draws its own initial
+        weights; without this the averaged gradients would be applied to diverging models."""
+        import torch.distributed as dist
+        if self.pg is None or self.world == 1:
+            return
+        src = dist.get_global_rank(self.pg, src_rank)
+        flat = []
+        for fb in (self.flat_g, self.flat_d):
+            flat += [fb.p, fb.m, fb.v, fb.count.step_dev, fb.count.coef_dev, fb.sup_count.step_dev,
+                     fb.sup_count.coef_dev]
+        lo_hi = [(fb.p.data_ptr(), fb.p.data_ptr() + fb.p.numel() * 4) for fb in (self.flat_g, self.flat_d)]
+        rest = []
+        for mod in self.modules().values():
+            for t in list(mod.parameters()) + list(mod.buffers()):
+                if not any(lo <= t.data_ptr() < hi for lo, hi in lo_hi):
+                    rest.append(t.data)
+        if self.discriminator_means is not None:
+            rest.append(self.discriminator_means)
+        for t in flat + rest:
+            dist.broadcast(t, src=src, group=self.pg)
+        for fb in (self.flat_g, self.flat_d):
+            for c in (fb.count, fb.sup_count):
+                c.step = int(c.step_dev.item())
+
+    def check(self):
+        """Raise if any step / validation batch so far carried a label outside [0, K) (one host sync; the loops
+        call it once per epoch)."""
+        if int(self._err.item()):
+            raise IndexError(f"PCAATrainer: a ground-truth label was outside [0, {self.K})")
 
     def train(self):
         for m in self.modules().values():
@@ -292,11 +395,41 @@ class PCAATrainer:
             return dist.all_reduce(t, group=self.pg, async_op=async_op)
         return None
 
+    def _advance_g(self, supervise):
+        """Begin optimizer_G's next step: the main count always, the supervised-only parameters' count on
+        supervised steps (see finalize: _sup_range)."""
+        b1, b2 = self.betas_g()
+        self.flat_g.advance(self.cfg["LR"], b1, b2)
+        if supervise:
+            self.flat_g.sup_count.advance(self.cfg["LR"], b1, b2)
+        else:
+            self._sup_split = True
+
+    def _adam_g(self, lo, hi, supervise, gs, max_blocks=0):
+        """Adam over [lo, hi) of optimizer_G's flat buffer for the step _advance_g began.  The MLP_head / MLP_sup2
+        range is skipped on unsupervised steps and uses its own step count once the two counts differ (one launch
+        as long as every step so far was supervised: the counts, hence the coefficients, are then identical)."""
+        b1, b2 = self.betas_g()
+        lr, fg = self.cfg["LR"], self.flat_g
+        a, b = max(lo, self._sup_range[0]), min(hi, self._sup_range[1])
+        if a >= b or (supervise and not self._sup_split):
+            fg.adam(lr, b1, b2, grad_scale=gs, lo=lo, hi=hi, advance=False, max_blocks=max_blocks)
+            return
+        fg.adam(lr, b1, b2, grad_scale=gs, lo=lo, hi=a, advance=False, max_blocks=max_blocks)
+        if supervise:
+            fg.adam(lr, b1, b2, grad_scale=gs, lo=a, hi=b, advance=False, count=fg.sup_count)
+        fg.adam(lr, b1, b2, grad_scale=gs, lo=b, hi=hi, advance=False, max_blocks=max_blocks)
+
     def step(self, pcs, gt, z0, alphas, supervise=True):
-        """One iteration of the reference's inner loop (PCAA_ablation.py:882-1021).
+        """One iteration of the reference's inner loop (PCAA_ablation.py:882-1021; variant 3: :514-655).
         pcs [B,C,T,N] fp32 (ideally a permuted view of point-major storage),
         gt [B] int64, z0 [B,L] fp32, alphas [B,1] fp32 -- all on the device.
-        Returns a dict of DEVICE tensors (no host sync)."""
+        ``supervise=False`` (``i % SUPERVISION_FREQUENCY != 0``): no cross-entropy term, and the parameters only it
+        reaches are left alone by Adam, as in the reference.  Returns a dict of DEVICE tensors (no host sync)."""
+        with self._sync_bn():
+            return self._step(pcs, gt, z0, alphas, supervise)
+
+    def _step(self, pcs, gt, z0, alphas, supervise):
         if not self._flat_ready:
             self.finalize()
         if self.discriminator_means is None and self.variant != "v1":
@@ -316,7 +449,7 @@ class PCAATrainer:
         F_hip.mark("heads_fwd")
         # (2) cross-entropy, its gradient and the predicted labels in one launch
         sup_loss, dlogits, preds = ops.cross_entropy(logits, gt, want_loss=True, want_grad=supervise,
-                                                     grad_scale=1.0, want_preds=True)
+                                                     grad_scale=1.0, want_preds=True, err_flag=self._err)
         # (3) D-step: prior sample, WGAN-GP loss + closed-form gradients, Adam; then the adversarial
         # term of the G-step with the UPDATED critic.  ~10 launches of one wave per batch row: they run
         # on a second stream beside the HBM-bound decoder forward / Chamfer / decoder backward, which do
@@ -367,6 +500,24 @@ class PCAATrainer:
                 t.record_stream(main)          # allocated on the aux stream, consumed on the main one
         else:
             d_losses, loss_g, dsup = critic_branch()
+
+        if self.variant == "v3":
+            # no decoder, no reconstruction term: tot = loss_g (+ sup_loss) (PCAA_ablation.py:621-645)
+            if joined is not None:
+                torch.cuda.current_stream().wait_event(joined)
+            F_hip.set_wgrad_stream(self._wg)
+            try:
+                F_hip.encoder_backward(enc, st, dlogits if supervise else None, dsup, gout=self._enc_grads)
+            finally:
+                F_hip.set_wgrad_stream(None)
+            if self._wg is not None:
+                torch.cuda.current_stream().wait_stream(self._wg)
+            self._allreduce(self.flat_g.g)
+            self._advance_g(supervise)
+            self._adam_g(0, self.flat_g.total, supervise, gs)
+            tot = loss_g + (sup_loss if supervise else 0.0)
+            return {"d_loss": d_losses[0], "gp": d_losses[1], "rec_loss": None, "loss_g": loss_g,
+                    "sup_loss": sup_loss, "tot_loss": tot, "preds": preds, "out_labels": logits, "sup_fvs": sup_fv}
 
         # (4) G-step forward: decoder + Chamfer (+ fused gradient)
         hproj = st.hproj if self.decoder_projection_head is not None else sup_fv
@@ -435,7 +586,7 @@ class PCAATrainer:
             for c in range(self._zero_chunks):
                 lo = self._dec_start + c * n
                 scatter.append(dist.reduce_scatter_tensor(self._zero_g[c], fg.g[lo:lo + n], group=self.pg, async_op=True))
-            fg.advance(cfg["LR"], cfg["B1"], cfg["B2"])
+            self._advance_g(supervise)
 
             def launch_zero_adam():
                 ready = torch.cuda.Event()
@@ -480,7 +631,7 @@ class PCAATrainer:
             early = False
             hook_heads = launch_zero_adam          # beside the temporal block's backward, like the replicated update
         if early:
-            self.flat_g.advance(cfg["LR"], cfg["B1"], cfg["B2"])
+            self._advance_g(supervise)
 
             def launch_side_adam():
                 ready = torch.cuda.Event()
@@ -524,14 +675,15 @@ class PCAATrainer:
         else:
             self._allreduce(self.flat_g.g)
         if zero:
-            self.flat_g.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs, hi=self._dec_start, advance=False)
+            self._adam_g(0, self._dec_start, supervise, gs)
             for work in zero_gather:
                 work.wait()                                      # next forward reads the gathered decoder
         elif early:
-            self.flat_g.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs, hi=self._dec_start, advance=False)
+            self._adam_g(0, self._dec_start, supervise, gs)
             torch.cuda.current_stream().wait_event(done[0])      # next forward reads the updated decoder
         else:
-            self.flat_g.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs)
+            self._advance_g(supervise)
+            self._adam_g(0, self.flat_g.total, supervise, gs)
 
         F_hip.mark("adam+join")
         tot = rec_loss + loss_g + (sup_loss if supervise else 0.0)
@@ -548,6 +700,10 @@ class PCAATrainer:
         initialisation, allocator warm-up), the next one captures; every call performs exactly one real
         train step.  The returned tensors are the graph's static outputs: they are overwritten by the
         next replay (clone what must survive)."""
+        if not supervise and not self._sup_split:
+            # the first unsupervised step changes the launch sequence of the supervised one as well
+            self._sup_split = True
+            self._graphs.clear()
         key = (tuple(pcs.shape), tuple(pcs.stride()), bool(supervise))
         ent = self._graphs.setdefault(key, {"eager": 0, "graph": None})
         if ent["graph"] is None:
@@ -575,6 +731,8 @@ class PCAATrainer:
                 dst.copy_(src, non_blocking=True)
         self.flat_g.step += 1
         self.flat_d.step += 1
+        if supervise:
+            self.flat_g.sup_count.step += 1
         ent["graph"].replay()
         return ent["out"]
 
@@ -584,6 +742,9 @@ class PCAATrainer:
         projection head -> decoder -> Chamfer, CE, argmax."""
         mode = self.precision or F_hip.get_precision()
         logits, sup_fv, _ = F_hip.encoder_forward(self.encoder, pcs, False, mode)
+        if self.decoder is None:         # variant 3 validates cross-entropy and accuracy only (:672-692)
+            ce, _, preds = ops.cross_entropy(logits, gt, want_loss=True, want_preds=True, err_flag=self._err)
+            return None, ce, preds, sup_fv
         hproj = sup_fv
         if self.decoder_projection_head is not None:
             hproj = F_hip.linear_act_forward(sup_fv, self.decoder_projection_head[0], ACT_ELU)
@@ -591,7 +752,7 @@ class PCAATrainer:
         B = pcs.shape[0]
         fl, _ = ops.chamfer(rec.view(B, self.C, self.T, self.N), pcs, want_grad=False)
         rec_loss = ops.total(fl, 1.0 / (B * self.T))
-        ce, _, preds = ops.cross_entropy(logits, gt, want_loss=True, want_preds=True)
+        ce, _, preds = ops.cross_entropy(logits, gt, want_loss=True, want_preds=True, err_flag=self._err)
         return rec_loss, ce, preds, sup_fv
 
     # ------------------------------------------------------------------ checkpoints (format of the reference)
@@ -601,9 +762,13 @@ class PCAATrainer:
             for key, mod in self.modules().items():
                 save_model(mod, os.path.join(folder, f"{model_name}{suffix[key]}.pt"))
         if self.mean_learner is not None:
-            cent = self.learned_centroids()
+            with self._sync_bn():
+                cent = self.learned_centroids()
             if write:
                 torch.save(cent, os.path.join(folder, "discriminator_means.pt"))
+        elif self.variant == "v3" and write:
+            # variant 3 re-saves the (fixed) centroids with every checkpoint (PCAA_ablation.py:738-739)
+            torch.save(self.discriminator_means, os.path.join(folder, "discriminator_means.pt"))
 
     @torch.no_grad()
     def learned_centroids(self):
@@ -672,7 +837,7 @@ def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=
                                                    shuffle=False, num_workers=0)
     _ = make(SPLIT.UNSEEN) if dataset_factory is None else None
 
-    wb = _wandb()
+    wb = _wandb() if rank == 0 else None          # logging is rank 0's: one wandb run per job, not per rank
     run = _NullRun()
     if wb is not None and hasattr(wb, "init"):
         wb.login()
@@ -707,15 +872,22 @@ def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=
                 dist.broadcast(alphas, src=src, group=process_group)
                 z0 = z0[rank * pcs.shape[0]:(rank + 1) * pcs.shape[0]].contiguous()
                 alphas = alphas[rank * pcs.shape[0]:(rank + 1) * pcs.shape[0]].contiguous()
-            out = trainer.step(pcs, gt_labels, z0, alphas,
-                               supervise=(i % config["SUPERVISION_FREQUENCY"] == 0))
+            supervise = i % config["SUPERVISION_FREQUENCY"] == 0
+            out = trainer.step(pcs, gt_labels, z0, alphas, supervise=supervise)
+            out["supervised"] = supervise
             steps.append(out)
             ys.append(gt_labels)
-        # one device->host transfer per epoch instead of four blocking .item() per step
-        rec_losses = torch.stack([o["rec_loss"] for o in steps]).cpu().numpy()
-        d_losses = torch.stack([o["d_loss"] for o in steps]).cpu().numpy()
-        sup_losses = torch.stack([o["sup_loss"] for o in steps]).cpu().numpy()
-        tot_losses = torch.stack([o["tot_loss"] for o in steps]).cpu().numpy()
+        for ld in (loader_train, loader_valid):
+            if hasattr(ld, "check"):
+                ld.check()               # a batch index outside the packed store (one host sync per epoch)
+        trainer.check()
+
+        def _mean(key, only_supervised=False):
+            # one device->host transfer per logged quantity and epoch instead of blocking .item()s per step;
+            # an empty list averages to nan, like the reference's np.mean([]) (variant 3's reconstruction loss)
+            vals = [o[key] for o in steps if o[key] is not None and (o["supervised"] or not only_supervised)]
+            return float(torch.stack(vals).double().mean().item()) if vals else float("nan")
+
         y_hats = torch.cat([o["preds"] for o in steps]).cpu().numpy()
         ys = torch.cat(ys).cpu().numpy()
 
@@ -725,14 +897,17 @@ def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=
             valid_pc = valid_pc.to(dev, non_blocking=True)
             valid_gt = valid_gt.to(dev, non_blocking=True)
             r, c, p, _ = trainer.evaluate_batch(valid_pc, valid_gt)
-            v_rec.append(r); v_ce.append(c); v_hat.append(p); v_y.append(valid_gt)
+            if r is not None:
+                v_rec.append(r)
+            v_ce.append(c); v_hat.append(p); v_y.append(valid_gt)
+        # the cross-entropy and the total loss are logged over the SUPERVISED steps only (:1005-1012)
         record = {
-            "Reconstruction Loss Train": float(np.mean(rec_losses)),
+            "Reconstruction Loss Train": _mean("rec_loss"),
             "Reconstruction Loss Valid": float(torch.stack(v_rec).mean().item()) if v_rec else float("nan"),
-            "Cross Entropy Loss Train": float(np.mean(sup_losses)),
+            "Cross Entropy Loss Train": _mean("sup_loss", only_supervised=True),
             "Cross Entropy Loss Valid": float(torch.stack(v_ce).mean().item()) if v_ce else float("nan"),
-            "Discriminator Loss": float(np.mean(d_losses)),
-            "Total Loss Train": float(np.mean(tot_losses)),
+            "Discriminator Loss": _mean("d_loss"),
+            "Total Loss Train": _mean("tot_loss", only_supervised=True),
             "Train Accuracy": float(np.mean(ys == y_hats)),
             "Valid Accuracy": float((torch.cat(v_y) == torch.cat(v_hat)).float().mean().item()) if v_y else 0.0,
         }
@@ -781,8 +956,19 @@ def train_CGAAE(config=None, **kw):
 
 
 def train_variant2(config, wandb_mode="online", **kw):
-    """Variant 2 == train_CGAAE (PCAA_ablation.py:381-389)."""
+    """Variant 2 == train_CGAAE with the supervision frequency forced to 1 -- in the caller's dict, as the
+    reference does (PCAA_ablation.py:381-389)."""
+    config["SUPERVISION_FREQUENCY"] = 1
     return train_CGAAE(config, **kw)
+
+
+def train_variant3(config, wandb_mode="online", **kw):
+    """Variant 3: the conditional-Gaussian AAE without the decoder (PCAA_ablation.py:392-743): encoder without
+    projection head + critic only, ``tot = loss_g (+ sup_loss)``, optimizer_G's betas are ``(B1, B1)`` (:455),
+    the reconstruction losses are logged as nan (``np.mean([])``), checkpoints are ``_E.pt``, ``_D.pt`` and
+    ``discriminator_means.pt``.  (The reference builds the encoder with the DEFAULT ``nmax_points`` (:404-409),
+    i.e. it only works when ``config["NMAX"] == constants.NMAX``; here the encoder follows ``config["NMAX"]``.)"""
+    return _run_loop(config, "v3", **kw)
 
 
 def train_pointsubsampling(n_training_classes=(2, 4, 6, 8), n_points_subs=(50, 70, 90, 110, 130, 150), n_tests=5,

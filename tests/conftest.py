@@ -21,3 +21,16 @@ def _restore_constants():
     yield
     for k, v in saved.items():
         setattr(constants, k, v)
+
+
+@pytest.fixture(autouse=True)
+def _pin_global_numerics_state():
+    """Every test starts (and leaves the process) in the documented defaults: fp32 parity mode, no SyncBN group.
+    A test that wants bf16 says so itself (``set_precision`` or the trainer's ``precision=``), so no result depends
+    on which test ran before it."""
+    from opensetgaitrecognition_pcaa_amd import functional as F_hip
+    F_hip.set_precision("fp32")
+    F_hip.set_sync_bn_group(None)
+    yield
+    F_hip.set_precision("fp32")
+    F_hip.set_sync_bn_group(None)

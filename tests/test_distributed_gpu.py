@@ -148,13 +148,18 @@ def _loop_worker(rank, world, port, q, workdir):
         cfg = dict(constants.CONFIG)
         cfg.update(MODEL_NAME=f"dp{world}", TRAIN_CLASSES=[0, 1, 2, 3], NMAX=16, BATCH_SIZE=8, EPOCHS=2,
                    CHECKPOINT_FREQUENCY=1, NOTES="")
-        # the loop's host RNG: seeded identically everywhere -- rank 0's draws are the ones used
-        np.random.seed(5); torch.manual_seed(5)
+        # the loop's host RNG: every rank seeds DIFFERENTLY, as under a plain torchrun launch of the unseeded
+        # reference loop -- rank 0's initial weights, epoch order and z0 / alphas draws are the ones used
+        # (PCAATrainer.sync_replicas, the batcher's and the loop's broadcasts)
+        np.random.seed(5 + 1000 * rank); torch.manual_seed(5 + 1000 * rank)
         make = lambda split: SyntheticGaitDataset(48 if split.value == "train" else 16, 4, N=16, C=4, seed=11)
         trainer, hist = train_variant4(cfg, wandb_mode="disabled", dataset_factory=make, process_group=pg,
                                        sync_bn=world > 1, device="cuda:0")
         torch.cuda.synchronize()
+        state = torch.cat([t.detach().double().reshape(-1).cpu() for m in trainer.modules().values()
+                           for t in list(m.parameters()) + list(m.buffers())])
         q.put((rank, {"hist": hist, "p": trainer.flat_g.p.detach().cpu()[:4096].numpy(),
+                      "state_sum": float(state.sum()), "state_l2": float(state.norm()),
                       "files": sorted(os.listdir(f"models/dp{world}"))}, None))
         if world > 1:
             dist.destroy_process_group()
@@ -187,6 +192,9 @@ def test_data_parallel_loop_equals_single_process_loop(tmp_path):
     h1, h2 = out[1][0]["hist"], out[2][0]["hist"]
     assert out[2][0]["hist"] == out[2][1]["hist"], "both ranks log the same (global) records"
     assert np.array_equal(out[2][0]["p"], out[2][1]["p"]), "replicas hold identical parameters"
+    # ... every parameter AND buffer of every module (BatchNorm running statistics, the inert heads), although the
+    # two ranks drew different initial weights
+    assert out[2][0]["state_sum"] == out[2][1]["state_sum"] and out[2][0]["state_l2"] == out[2][1]["state_l2"]
     assert len(h1) == len(h2) == 2
     for e in range(2):
         for k in h1[e]:

@@ -172,6 +172,82 @@ def test_v4_train_steps():
                     check_against_record(g, f"s{s}.param.{nm}.", name, v, 2e-5)
 
 
+def test_v4_unsupervised_steps_leave_the_label_heads_alone():
+    """SUPERVISION_FREQUENCY = 2 (reference loop body, tests/golden/make_golden_r2.py): on the odd steps the
+    gradients of MLP_head / MLP_sup2 are None, Adam skips them and their step count stays behind."""
+    g, m = load_golden("v4_supfreq2_B6_N32_C4_K4")
+    B, N, C, K, steps = m["B"], m["N"], m["C"], m["K"], m["steps"]
+    enc, dec, disc, gph, dph = _v4_state(m)
+    means = torch.from_numpy(g["means"])
+    st = O.V4State(sd_clone(enc), sd_clone(dec), sd_clone(disc), sd_clone(gph), sd_clone(dph), means, C, T, N, K)
+    cfg = dict(LR=1e-4, B1=0.9, B2=0.99, GP_WEIGHT=15, ADV_WEIGHT=1)
+    heads = ("MLP_head.0.weight", "MLP_head.0.bias", "MLP_sup2.0.weight", "MLP_sup2.0.bias")
+    for s in range(steps):
+        pcs = syn.synthetic_pcs(B, T, N, C, seed=m["pcs_seed0"] + s).permute(0, 3, 1, 2)
+        gt = syn.synthetic_labels(B, K, seed=m["gt_seed0"] + s)
+        z0 = syn.synthetic_z0(B, 32, seed=m["z0_seed0"] + s)
+        al = syn.synthetic_alphas(B, seed=m["alpha_seed0"] + s)
+        sup = bool(g[f"s{s}.supervised"])
+        assert sup == (s % m["freq"] == 0)
+        before = {nm: st.enc[nm].clone() for nm in heads}
+        out = O.v4_train_step(st, pcs, gt, z0, al, cfg, supervise=sup)
+        ref = g[f"s{s}.losses"]
+        got = np.array([out[k].item() for k in ("d_loss", "gp", "rec_loss", "loss_g", "sup_loss", "tot_loss")])
+        idx = [0, 1, 2, 3, 4, 5] if sup else [0, 1, 2, 3, 5]      # the golden's sup_loss is the last SUPERVISED one
+        assert np.allclose(got[idx], ref[idx], rtol=5e-5 * (s + 1), atol=1e-6), (s, got, ref)
+        assert np.array_equal(out["preds"].numpy(), g[f"s{s}.preds"])
+        for nm in heads:
+            if not sup:
+                assert out["g_grads"]["E." + nm] is None
+                assert torch.equal(st.enc[nm], before[nm]), f"{nm} moved on an unsupervised step"
+            check_against_record(g, f"s{s}.param.E.", nm, st.enc[nm], 2e-5)
+    adam_steps = json.loads(str(g["adam_steps"]))
+    assert adam_steps["MLP_sup2.0.weight"] == 2 and adam_steps["MLP_sup1.0.weight"] == 4
+    assert st.adam_g["E.MLP_sup2.0.weight"]["step"] == 2 and st.adam_g["E.MLP_sup1.0.weight"]["step"] == 4
+
+
+def test_v3_train_steps():
+    """Variant 3 (no decoder, G betas (B1,B1)): oracle against the reference-generated trajectory."""
+    g, m = load_golden("v3_B6_N32_C4_K4")
+    B, N, C, K, steps = m["B"], m["N"], m["C"], m["K"], m["steps"]
+    enc, disc = make_encoder(K, N, C, False, m["fill_seeds"][0]), make_disc(K, m["fill_seeds"][1])
+    st = O.V3State(sd_clone(enc), sd_clone(disc), torch.from_numpy(g["means"]), C, T, N, K)
+    cfg = dict(LR=1e-4, B1=0.9, B2=0.99, GP_WEIGHT=15, ADV_WEIGHT=1)
+    for s in range(steps):
+        pcs = syn.synthetic_pcs(B, T, N, C, seed=m["pcs_seed0"] + s).permute(0, 3, 1, 2)
+        gt = syn.synthetic_labels(B, K, seed=m["gt_seed0"] + s)
+        z0 = syn.synthetic_z0(B, 32, seed=m["z0_seed0"] + s)
+        al = syn.synthetic_alphas(B, seed=m["alpha_seed0"] + s)
+        out = O.v3_train_step(st, pcs, gt, z0, al, cfg)
+        got = np.array([out[k].item() for k in ("d_loss", "gp", "loss_g", "sup_loss", "tot_loss")])
+        assert np.allclose(got, g[f"s{s}.losses"], rtol=5e-5 * (s + 1), atol=1e-6), (s, got, g[f"s{s}.losses"])
+        assert np.array_equal(out["preds"].numpy(), g[f"s{s}.preds"])
+        assert torch.allclose(out["sup_fvs"], torch.from_numpy(g[f"s{s}.sup_fvs"]), rtol=1e-4, atol=1e-5 * (s + 1))
+        if s == 0:
+            wscale = max(float(np.abs(g[k]).max()) for k in g.files
+                         if k.startswith("s0.ggrad.E.") and k.endswith("weight::full"))
+            for name, gr in out["g_grads"].items():
+                if is_pre_bn_bias(name):
+                    assert float(gr.abs().max()) <= 1e-4 * wscale + 1e-4
+                    continue
+                check_against_record(g, "s0.ggrad.", name, gr, 3e-4)
+        if s in (0, steps - 1):
+            # post-Adam parameters: with tot = loss_g + sup_loss only, many gradient elements are within ~10x of
+            # Adam's eps, where the +-lr first steps depend on the gradient's last bits (DESIGN.md section 2):
+            # worst element within 0.5*lr per step, mean error at rounding level
+            for nm, sd in (("E", st.enc), ("D", st.disc)):
+                for name, v in sd.items():
+                    key = f"s{s}.param.{nm}.{name}::full"
+                    if is_pre_bn_bias(name) or key not in g.files or not v.dtype.is_floating_point:
+                        continue
+                    ref = g[key].astype(np.float64)
+                    err = np.abs(v.numpy().astype(np.float64) - ref)
+                    scale = max(float(np.abs(ref).max()), 5.0 if name.endswith("running_mean") else 0.0)
+                    assert err.max() <= 2e-5 * scale + 0.5e-4 * (s + 1), (name, err.max())
+                    if not name.endswith("running_mean"):      # inherits the pre-BN bias's +-lr walk (DESIGN.md section 2)
+                        assert err.mean() <= 2e-6 * max(scale, 1.0), (name, err.mean())
+
+
 def test_prior_means_and_manifest():
     g, _ = load_golden("misc")
     for K in (2, 4, 6, 8):
