@@ -13,6 +13,7 @@ region; data parallel over N GPUs (weak scaling: global batch 64*N, RCCL
 all-reduce of the flat gradient buffers).  One JSON line on rank 0.
 """
 import argparse
+import itertools
 import json
 import os
 import sys
@@ -41,6 +42,10 @@ def parse():
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-parity-mode", action="store_true",
+                    help="skip the fp32 parity-mode leg (same workload in the mode the 1e-4 parity tests run in)")
+    ap.add_argument("--no-batcher-leg", action="store_true",
+                    help="skip the leg that assembles every step's batch from the HBM-resident packed store")
     ap.add_argument("--backend", default=os.environ.get("PCAA_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on a one-GPU box "
                          "together with PCAA_BENCH_DEVICE=0, which puts every rank on that GPU)")
@@ -178,6 +183,69 @@ def main():
         dt = float(t.item())
     loss_ok = bool(torch.isfinite(out["tot_loss"]).item())
 
+    def timed_leg(trainer, batches, steps, warmup):
+        """warmup untimed + steps timed trainer steps; ``batches`` yields (pcs, gt).  Same bracket as the main
+        region (barrier + synchronize on both sides); max over ranks.  -> seconds."""
+        it = iter(batches)
+        for _ in range(warmup):
+            trainer.step(*next(it), z0, al)
+        barrier()
+        t_0 = time.perf_counter()
+        for _ in range(steps):
+            trainer.step(*next(it), z0, al)
+        barrier()
+        d = time.perf_counter() - t_0
+        if world > 1:
+            tt = torch.tensor([d], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d = float(tt.item())
+        return d
+
+    batcher_leg = None
+    if not a.no_batcher_leg and not use_graph:
+        # datasets.py batch collation inside the timed loop: a packed point-major store of `pool` synthetic crops
+        # resident in HBM, every step's batch gathered from it in the DataLoader's shuffled order
+        # (DeviceBatcher = pcaa_gather_rows), then the same train step
+        from opensetgaitrecognition_pcaa_amd.batcher import DeviceBatcher
+        pool = 64 * B
+        store = syn.synthetic_pcs(pool, T, N, C, seed=4321 + rank).to(dev)
+        labels = syn.synthetic_labels(pool, K, seed=4322 + rank).to(dev)
+        loader = DeviceBatcher(store, labels, B, shuffle=True)
+
+        def epochs():
+            while True:
+                yield from loader
+        d = timed_leg(tr, epochs(), a.steps, 2)
+        loader.check()
+        batcher_leg = {"ms_per_step": d / a.steps * 1e3, "value": world * B * a.steps / d,
+                       "store": f"{pool} crops [{pool},{T},{N},{C}] fp32 resident in HBM, shuffled epoch order, "
+                                "pcaa_gather_rows per batch"}
+        del store, loader
+
+    parity_leg = None
+    if a.precision == "bf16" and not a.no_parity_mode and not use_graph:
+        # the SAME workload in fp32 parity mode (exact-fp32 MFMA, fp32 activations): the mode the 1e-4 / bit-exact
+        # label tests run in (tests/test_round2_parity.py::test_config1_full_size_fp32_step_vs_oracle)
+        del tr
+        torch.cuda.empty_cache()
+        F_hip.set_precision("fp32")
+        tr32 = PCAATrainer(cfg, device=dev, precision="fp32", process_group=pg, sync_bn=a.sync_bn)
+        for i, m in enumerate((tr32.encoder, tr32.decoder, tr32.discriminator, tr32.decoder_projection_head,
+                               tr32.discriminator_projection_head)):
+            syn.deterministic_fill_(m, i)
+        tr32.set_prior_means(sample_distant_points(32, K, 10, 10))
+        tr32.finalize()
+        tr32.train()
+        psteps = max(1, min(a.steps, 10))
+        d = timed_leg(tr32, itertools.repeat((pcs, gt)), psteps, 2)
+        parity_leg = {"precision": "fp32", "dtype": "f32", "steps": psteps, "warmup": 2,
+                      "ms_per_step": d / psteps * 1e3, "value": world * B * psteps / d, "unit": "sequences/s",
+                      "tolerance": "1e-4 rel on losses/embeddings/logits, argmax labels bit-exact vs the CPU oracle "
+                                   "at this size (tests/test_round2_parity.py)"}
+        del tr32
+        torch.cuda.empty_cache()
+        F_hip.set_precision(a.precision)
+
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = world * B * a.steps / dt
@@ -194,6 +262,10 @@ def main():
                        # time the host spends enqueueing one step (no synchronisation inside step())
                        "host_enqueue_ms_per_step": host_s / a.steps * 1e3},
         }
+        if parity_leg is not None:
+            line["parity_mode"] = parity_leg
+        if batcher_leg is not None:
+            line["with_batcher"] = batcher_leg
         if timer is not None:
             agg = timer.summary()
             dom = max(agg.items(), key=lambda kv: kv[1]["ms"])

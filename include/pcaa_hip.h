@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PCAA_ABI_VERSION 5 /* pcaa_abi_version() of a library built from this header */
+#define PCAA_ABI_VERSION 6 /* pcaa_abi_version() of a library built from this header */
 
 #define PCAA_OK 0
 #define PCAA_ERR_INVALID_ARG 1
@@ -74,10 +74,6 @@ int pcaa_gemm(int math,
  * out (=|+=).  pcaa_gemm_num_splits tells how many splits pcaa_gemm / pcaa_gemm_slabs will
  * actually run for a requested split_k (K is cut into multiples of the kernel's K step). */
 int pcaa_gemm_num_splits(int math, int K, int split_k);
-/* Diagnostics (PCAA_GEMM_DIAG=20 build of the bf16 LDS-DMA kernel): per-workgroup s_memtime stamps of
- * its phases, host_out[workgroup*8 + slot], slots 0 start, 1 first stage issued, 4 first stage landed,
- * 2 K loop done, 3 C stores issued, 5 statistics issued, 6 stores retired, 7 s_memrealtime at start. */
-int pcaa_debug_gemm_stamps(unsigned long long* host_out, int n);
 int pcaa_gemm_slabs(int math,
                     const void* A, int a_dtype, int a_layout, long lda,
                     const void* B, int b_dtype, int b_layout, long ldb,
@@ -266,6 +262,17 @@ int pcaa_disc_backward(const float* x, const float* label, int B, int K,
                        float* dx, float* dlabel,
                        float* dW1, float* db1, float* dW2, float* db2, float* dW3, float* db3,
                        float* workspace, size_t workspace_bytes, void* stream);
+/* backward OF that input gradient (what torch.autograd.grad(D(interp), interp, create_graph=True) followed by
+ * .backward() needs, PCAA_ablation.py:955-976): with g[B,32] = the dx of pcaa_disc_backward for the same
+ * (x, label, gout) and gbar[B,32] the incoming gradient w.r.t. g, the gradients of sum_b <gbar_b, g_b> w.r.t.
+ * x (dx2), label (dlabel2), gout (dgout [B]) and the parameters (db3 = 0).  Outputs nullable, OVERWRITTEN;
+ * workspace as pcaa_disc_workspace_bytes. */
+int pcaa_disc_backward_backward(const float* x, const float* label, int B, int K,
+                                const float* W1, const float* b1, const float* W2, const float* b2,
+                                const float* W3, const float* b3, const float* gout, const float* gbar,
+                                float* dx2, float* dlabel2, float* dgout,
+                                float* dW1, float* db1, float* dW2, float* db2, float* dW3, float* db3,
+                                float* workspace, size_t workspace_bytes, void* stream);
 /* WGAN-GP critic step (PCAA_ablation.py:939-976): d_loss = mean D(fv) - mean D(z)
  * + gp_weight * mean (|dD/dx(z + alpha (fv - z))| - 1)^2 with the closed-form
  * second-order gradient.  losses[0]=d_loss, losses[1]=gp.

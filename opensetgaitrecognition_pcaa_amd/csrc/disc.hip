@@ -100,7 +100,11 @@ __device__ __forceinline__ float first_order(DiscLds& s, const Fwd& f, float c, 
   return du;
 }
 
-// MODE 0: forward, 1: first-order backward with gout, 2: WGAN-GP critic step
+// MODE 0: forward, 1: first-order backward with gout, 2: WGAN-GP critic step,
+// 3: backward OF the first-order input gradient (double backward): with g = d(sum_b c_b D_b)/dx the input
+//    gradient MODE 1 returns and gbar the incoming gradient w.r.t. g, the gradients of <gbar, g> w.r.t. the
+//    parameters, x, label and c (SURVEY.md Appendix A with c general) -- what autograd needs to differentiate
+//    through torch.autograd.grad(D(interp), interp, create_graph=True) (PCAA_ablation.py:955-963)
 template <int MODE>
 __global__ __launch_bounds__(64) void disc_rows_kernel(const float* __restrict__ xa,   // x (MODE 0/1) or z (MODE 2)
                                                        const float* __restrict__ xb,   // fv (MODE 2)
@@ -129,6 +133,71 @@ __global__ __launch_bounds__(64) void disc_rows_kernel(const float* __restrict__
     const float du = first_order(s, f, c, IN, P1, t, recs ? recs + (long)row * REC : nullptr);
     if (dx && t < XD) dx[(long)row * XD + t] = du;
     if (dlabel && t >= XD && t < IN) dlabel[(long)row * K + (t - XD)] = du;
+    return;
+  }
+
+  if (MODE == 3) {
+    s.u[t] = (t < XD) ? xa[(long)row * XD + t] : lab;
+    __syncthreads();
+    Fwd fi = forward_pass(s, IN, P1, t);
+    const float c = aux[row];
+    float* rec = recs + (long)row * REC;
+    float* gx = gpx + (long)row * GPX;
+    if (t < H2) {
+      const float s2 = c * fi.e2 * s.w3[t];
+      s.d2[t] = s2;
+      gx[G_S2 + t] = s2;
+    }
+    __syncthreads();
+    float r1 = 0.f;
+#pragma unroll 8
+    for (int p = 0; p < H2; ++p) r1 = fmaf(s.W2[p * 65 + t], s.d2[p], r1);
+    gx[G_S1 + t] = fi.e1 * r1;
+    const float gbar = (t < XD) ? xb[(long)row * XD + t] : 0.f;
+    s.va[t] = gbar;
+    if (t < XD) gx[G_GB + t] = gbar;
+    __syncthreads();
+    float sb1 = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < XD; ++i) sb1 = fmaf(s.W1[t * P1 + i], s.va[i], sb1);
+    const float rb1 = fi.e1 * sb1;
+    float ab1 = fi.e1pp * r1 * sb1;
+    s.vb[t] = rb1;
+    gx[G_RB1 + t] = rb1;
+    __syncthreads();
+    float dc_part = 0.f;
+    if (t < H2) {
+      float sb2 = 0.f;
+#pragma unroll 8
+      for (int o = 0; o < H1; ++o) sb2 = fmaf(s.W2[t * 65 + o], s.vb[o], sb2);
+      const float ab2 = fi.e2pp * c * s.w3[t] * sb2;
+      s.d2[t] = ab2;
+      rec[R_D2 + t] = ab2;
+      rec[R_H2C + t] = c * fi.e2 * sb2;
+      dc_part = fi.e2 * s.w3[t] * sb2;
+    }
+    const float dc = wave_sum(dc_part);
+    __syncthreads();
+    float hb1 = 0.f;
+#pragma unroll 8
+    for (int p = 0; p < H2; ++p) hb1 = fmaf(s.W2[p * 65 + t], s.d2[p], hb1);
+    ab1 = fmaf(fi.e1, hb1, ab1);
+    rec[R_D1 + t] = ab1;
+    rec[R_H1 + t] = fi.h1;
+    rec[R_U + t] = (t < IN) ? s.u[t] : 0.f;
+    s.d1[t] = ab1;
+    __syncthreads();
+    if (t < IN && (dx || dlabel)) {
+      float du = 0.f;
+#pragma unroll 8
+      for (int o = 0; o < H1; ++o) du = fmaf(s.W1[o * P1 + t], s.d1[o], du);
+      if (dx && t < XD) dx[(long)row * XD + t] = du;
+      if (dlabel && t >= XD) dlabel[(long)row * K + (t - XD)] = du;
+    }
+    if (t == 0) {
+      rec[R_C] = 0.f;                       // b3 is not reached by the input gradient
+      if (out) out[row] = dc;
+    }
     return;
   }
 
@@ -348,6 +417,33 @@ extern "C" int pcaa_disc_backward(const float* x, const float* label, int B, int
                        (const float*)nullptr, 1, B, K, dW1, db1, dW2, db2, dW3, db3);
   }
   PCAA_RETURN_LAUNCH_STATUS("pcaa_disc_backward");
+}
+
+// double backward: gradients of <gbar, g> with g = d(sum_b gout_b D(x_b, label_b)) / dx (the dx of
+// pcaa_disc_backward).  d_b3 is identically zero and is written as such.  dx2 / dlabel2 / dgout nullable.
+extern "C" int pcaa_disc_backward_backward(const float* x, const float* label, int B, int K, const float* W1,
+                                           const float* b1, const float* W2, const float* b2, const float* W3,
+                                           const float* b3, const float* gout, const float* gbar, float* dx2,
+                                           float* dlabel2, float* dgout, float* dW1, float* db1, float* dW2,
+                                           float* db2, float* dW3, float* db3, float* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  PCAA_CHECK_ARG(disc_args_ok(B, K), "pcaa_disc_backward_backward: bad B=%d K=%d", B, K);
+  PCAA_CHECK_ARG(x && (label || K == 0) && W1 && b1 && W2 && b2 && W3 && b3 && gout && gbar,
+                 "pcaa_disc_backward_backward: null pointer");
+  PCAA_CHECK_ARG(workspace && workspace_bytes >= pcaa_disc_workspace_bytes(B, K),
+                 "pcaa_disc_backward_backward: workspace too small");
+  DiscParams p{W1, b1, W2, b2, W3, b3};
+  hipStream_t s = as_stream(stream);
+  float* recs = workspace;
+  float* gpx = recs + (size_t)3 * B * REC;
+  hipLaunchKernelGGL(disc_rows_kernel<3>, dim3(B), dim3(64), 0, s, x, gbar, label, gout, B, K, p, 0.f, dgout, dx2,
+                     dlabel2, recs, gpx);
+  if (dW1 || db1 || dW2 || db2 || dW3 || db3) {
+    const int total = H1 * (XD + K) + H1 + H2 * H1 + H2 + H2 + 1;
+    hipLaunchKernelGGL(disc_param_grad_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, recs, gpx, 1, B,
+                       K, dW1, db1, dW2, db2, dW3, db3);
+  }
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_disc_backward_backward");
 }
 
 extern "C" int pcaa_disc_wgan_gp(const float* z, const float* fv, const float* label, const float* alphas,

@@ -402,7 +402,7 @@ static int gemm_impl(int math,
   p.atomic = atomic;
   p.nsplit = 1;
   p.split_fast = 0;
-  p.diag = 0;
+
   p.c_split_stride = c_split_stride;
   int kps = 0;
   const int nsplit = gemm_num_splits(math, K, split_k, &kps);

@@ -18,7 +18,7 @@ struct GemmParams {
   // dgrad fused with the BatchNorm+ELU backward of the layer below (pcaa_gemm_dgrad_bn)
   const void* ep_y; const float* ep_scale; const float* ep_shift; const float* ep_mean; const float* ep_rstd;
   const float* ep_x; const float* ep_w1; int ep_xc;   // ep_y == NULL: y = x[M,xc] . W1[N,xc]^T is recomputed
-  int diag;       // timing-only diagnostics of the 2-stage DMA kernel (WRONG results): 1 no DMA in the loop, 2 no MFMA, 3 no epilogue
+
 };
 
 // XCD-aware, bijective block -> (tile_m, tile_n) map: the 8 XCDs (blocks b, b+8,

@@ -930,30 +930,67 @@ def cg_decoder(dec, z):
 
 
 # ======================================================================
-# CGDiscriminator (models.py:405-421) -- first-order autograd only; the
-# WGAN-GP double backward lives in ops.disc_wgan_gp (closed form).
+# CGDiscriminator (models.py:405-421).  Twice differentiable: the reference's D-step differentiates THROUGH
+# torch.autograd.grad(D(interp), interp, create_graph=True) (PCAA_ablation.py:955-976), so the backward of this
+# Function is itself a Function (_DiscBwdFn) whose backward is the closed-form second-order kernel
+# (pcaa_disc_backward_backward).  The fused trainer does not go through autograd at all
+# (ops.disc_wgan_gp); this is what lets the reference's own loop body drive the drop-in module unchanged.
 # ======================================================================
+class _DiscBwdFn(torch.autograd.Function):
+    """(x, label, gout, params) -> (dx, dlabel, dparams...) = the first-order backward, as a differentiable op.
+    Its own backward supports an incoming gradient w.r.t. ``dx`` (the gradient-penalty use)."""
+
+    @staticmethod
+    def forward(ctx, disc, want, x, label, gout, *params):
+        ctx.set_materialize_grads(False)
+        dx, dl, grads = ops.disc_backward(x, label, list(params), gout, want_dx=want[0], want_dlabel=want[1],
+                                          want_params=want[2])
+        ctx.save_for_backward(x, label, gout, *params)
+        outs = (dx, dl) + (tuple(grads) if grads is not None else (None,) * 6)
+        ctx.mark_non_differentiable(*[o for o in outs[1:] if o is not None])
+        return outs
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_dx, *g_rest):
+        if any(g is not None for g in g_rest):
+            raise NotImplementedError("CGDiscriminator: only the input gradient dD/dx can be differentiated again "
+                                      "(the WGAN-GP penalty); gradients of parameter gradients are not implemented")
+        if g_dx is None:
+            return (None,) * (5 + 6)
+        x, label, gout, *params = ctx.saved_tensors
+        need = ctx.needs_input_grad        # (disc, want, x, label, gout, *params)
+        dx2, dl2, dgo, grads = ops.disc_backward_backward(
+            x, label, params, gout, g_dx.contiguous().float(), want_dx=need[2], want_dlabel=need[3],
+            want_dgout=need[4], want_params=any(need[5:]))
+        return (None, None, dx2, dl2, dgo) + (tuple(grads) if grads is not None else (None,) * 6)
+
+
 class _DiscFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, disc, x, label, *params):
-        x = x.contiguous().float()
-        label = label.contiguous().float()
-        ctx.disc, ctx.x, ctx.label = disc, x, label
+        ctx.disc = disc
+        ctx.save_for_backward(x, label, *params)       # the inputs themselves: they keep their place in the graph
         ctx.need = (ctx.needs_input_grad[1], ctx.needs_input_grad[2], any(ctx.needs_input_grad[3:]))
         return ops.disc_forward(x, label, list(params))
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, gout):
-        params = ops._disc_params(ctx.disc)
-        dx, dl, grads = ops.disc_backward(ctx.x, ctx.label, params, gout.contiguous().view(-1),
-                                          want_dx=ctx.need[0], want_dlabel=ctx.need[1], want_params=ctx.need[2])
+        x, label, *params = ctx.saved_tensors
+        gout = gout.contiguous().view(-1)
+        if torch.is_grad_enabled():
+            # create_graph=True: the input gradient stays attached to (x, gout, parameters)
+            outs = _DiscBwdFn.apply(ctx.disc, ctx.need, x, label, gout, *params)
+            return (None,) + tuple(outs)
+        dx, dl, grads = ops.disc_backward(x, label, params, gout, want_dx=ctx.need[0], want_dlabel=ctx.need[1],
+                                          want_params=ctx.need[2])
         return (None, dx, dl) + (tuple(grads) if grads is not None else (None,) * 6)
 
 
 def cg_discriminator(disc, x, label):
     _require_gpu(x, "CGDiscriminator")
-    return _DiscFn.apply(disc, x, label, *ops._disc_params(disc))
+    # (conversions happen out here, under autograd, so that what the Function saves are its own inputs)
+    return _DiscFn.apply(disc, x.contiguous().float(), label.contiguous().float(), *ops._disc_params(disc))
 
 
 # ======================================================================

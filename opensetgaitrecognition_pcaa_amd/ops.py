@@ -861,6 +861,26 @@ def disc_backward(x, label, params, gout, want_dx=True, want_dlabel=False, want_
     return dx, dl, (grads if want_params else None)
 
 
+def disc_backward_backward(x, label, params, gout, gbar, want_dx=True, want_dlabel=False, want_dgout=True,
+                           want_params=True):
+    """Backward of disc_backward's ``dx`` output: gradients of sum <gbar, dx> w.r.t. (x, label, gout, params)."""
+    for t, nm in ((x, "x"), (label, "label"), (gout, "gout"), (gbar, "gbar")):
+        _chk(t, f"disc_bb.{nm}", torch.float32)
+    B, K = label.shape
+    if x.shape != (B, 32) or gbar.shape != (B, 32) or gout.numel() != B:
+        raise ValueError("disc_backward_backward: shapes")
+    dev = x.device
+    dx2 = torch.empty_like(x) if want_dx else None
+    dl2 = torch.empty_like(label) if want_dlabel else None
+    dgo = torch.empty(B, dtype=torch.float32, device=dev) if want_dgout else None
+    grads = [torch.empty_like(p) for p in params] if want_params else [None] * 6
+    ws = disc_workspace(B, K, dev)
+    check(_lib.load().pcaa_disc_backward_backward(_p(x), _p(label), B, K, *[_p(p) for p in params], _p(gout), _p(gbar),
+                                                  _p(dx2), _p(dl2), _p(dgo), *[_p(g) for g in grads], _p(ws),
+                                                  ws.numel() * 4, _s()), "pcaa_disc_backward_backward")
+    return dx2, dl2, dgo, (grads if want_params else None)
+
+
 def disc_wgan_gp(z, fv, label, alphas, params, gp_weight, grads_out=None, want_dz=False):
     for t, nm in ((z, "z"), (fv, "fv"), (label, "label"), (alphas, "alphas")):
         _chk(t, f"wgan.{nm}", torch.float32)

@@ -123,7 +123,12 @@ def test_config1_full_size_fp32_step_vs_oracle(full_size_oracle):
                 continue
             err = (v.detach().cpu().double() - sd[name].double()).abs()
             scale = max(float(sd[name].abs().max()), 5.0 if name.endswith("running_mean") else 0.0)
-            assert err.max().item() <= 5e-5 * scale + 0.5e-4, (nm, name, err.max().item())
+            # Adam's first step is -lr * g / (|g| + eps): an element whose gradient is rounding noise on both sides
+            # can go opposite ways (2 lr apart at worst); those must be rare, everything else agrees to round-off
+            assert err.max().item() <= 5e-5 * scale + 2.0e-4 * 1.001, (nm, name, err.max().item())
+            if v.numel() >= 1024:
+                assert (err > 5e-5 * scale + 0.5e-4).double().mean().item() <= 1e-3, (nm, name)
+                assert err.mean().item() <= 2e-6 * max(scale, 1.0), (nm, name, err.mean().item())
     w5 = tr.decoder.dense5.weight.detach().cpu()
     assert float((w5.double() - st.dec["dense5.weight"].double()).abs().mean()) <= 2e-6
     print("config[1] fp32 worst gradient rel-l2:", max(worst.items(), key=lambda kv: kv[1]))
@@ -307,3 +312,58 @@ def test_cross_entropy_rejects_out_of_range_labels():
     flag.zero_()
     ops.cross_entropy(x, torch.tensor([0, 1, 2, 2], device=DEV), err_flag=flag)
     assert int(flag.item()) == 0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the reference's D-step body, unmodified, on the drop-in critic (double backward through autograd)
+# ---------------------------------------------------------------------------------------------------------
+def _reference_d_step_body(discriminator, optimizer_D, sup_fvs, z, oh_labels, alphas, GP_WEIGHT, latent):
+    """The caller's side of PCAA_ablation.py:939-976 (what a user of the reference has in their loop), written
+    against ``discriminator`` as a black-box nn.Module: torch.autograd.grad(..., create_graph=True) + backward."""
+    optimizer_D.zero_grad()
+    discriminator.zero_grad()
+    real_logits = discriminator(z, oh_labels)
+    fake_logits = discriminator(sup_fvs.detach(), oh_labels)
+    differences = sup_fvs.detach() - z
+    interpolates = z + alphas.repeat(1, latent) * differences
+    disc_interpolates = discriminator(interpolates, oh_labels)
+    gradients = torch.autograd.grad(outputs=disc_interpolates, inputs=interpolates,
+                                    grad_outputs=torch.ones_like(disc_interpolates), create_graph=True,
+                                    retain_graph=True, only_inputs=True)[0]
+    slopes = torch.sqrt(torch.sum(gradients ** 2, dim=1) + 1e-12)
+    gradient_penalty = ((slopes - 1) ** 2).mean()
+    d_loss = torch.mean(fake_logits) - torch.mean(real_logits) + GP_WEIGHT * gradient_penalty
+    d_loss.backward()
+    return real_logits, fake_logits, gradients, gradient_penalty, d_loss
+
+
+@pytest.mark.parametrize("tag", ["disc_B6_K4", "disc_B16_K8"])
+def test_reference_d_step_body_runs_unmodified_on_the_drop_in_critic(tag):
+    from helpers import make_disc
+    g, m = load_golden(tag)
+    K = m["K"]
+    disc = make_disc(K, seed=m["fill_seed"]).to(DEV)
+    opt = torch.optim.Adam(disc.parameters(), lr=1e-4, betas=(0.9, 0.99))
+    fv, alphas = torch.from_numpy(g["fv"]).to(DEV), torch.from_numpy(g["alphas"]).to(DEV)
+    z = torch.from_numpy(g["z"]).to(DEV).requires_grad_(True)
+    oh = torch.nn.functional.one_hot(torch.from_numpy(g["gt"]).to(DEV), K).float()
+    real, fake, grads, gp, d_loss = _reference_d_step_body(disc, opt, fv, z, oh, alphas, 15, 32)
+    assert grads.requires_grad, "create_graph=True must keep the input gradient attached"
+    for got, key in ((real, "real"), (fake, "fake"), (grads, "interp_grad")):
+        ref = g[key]
+        assert np.abs(got.detach().cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max(), key
+    assert abs(gp.item() - float(g["gp"])) <= 1e-4 * abs(float(g["gp"]))
+    assert abs(d_loss.item() - float(g["d_loss"])) <= 1e-4 * abs(float(g["d_loss"]))
+    for name, p in disc.named_parameters():
+        if name == "model.4.bias":
+            assert abs(float(p.grad)) <= 1e-6         # +1/B and -1/B sums: zero up to fp32 summation order here
+            continue
+        check_against_record(g, "grad.", name, p.grad, 2e-4, scale_floor=1e-3)
+    # z is a leaf that requires grad in the reference (:930-933): its gradient through the real pass and the
+    # penalty must exist and match the oracle's autograd
+    sd = {k: v.detach().cpu().clone() for k, v in disc.state_dict().items()}
+    zc = torch.from_numpy(g["z"]).clone().requires_grad_(True)
+    dl, _ = O.wgan_gp_d_loss(sd, fv.cpu(), oh.cpu(), zc, alphas.cpu(), 15)
+    dl.backward()
+    assert (z.grad.cpu() - zc.grad).abs().max().item() <= 2e-4 * zc.grad.abs().max().item()
+    opt.step()          # and the optimizer of the caller steps on those gradients
