@@ -41,6 +41,14 @@ def parse():
     ap.add_argument("--classes", type=int, default=8)
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="train", choices=["train", "sweep", "infer"],
+                    help="train: BASELINE config[1] (default, the driver's line); sweep: config[3], the point-subsampling "
+                         "sweep N in {32,64,128,256} of the train step; infer: config[4], open-set inference at B=1024")
+    ap.add_argument("--dp-mode", default="allreduce", choices=["allreduce", "zero"],
+                    help="data-parallel exchange of the decoder gradients: per-layer all-reduce buckets (default) or "
+                         "reduce-scatter + sharded Adam + all-gather (ZeRO-1)")
+    ap.add_argument("--grad-compress", default="none", choices=["none", "bf16"],
+                    help="decoder gradient buckets cross the wire as bf16 (fp32 master gradients)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true",
                     help="skip the fp32 parity-mode leg (same workload in the mode the 1e-4 parity tests run in)")
@@ -49,7 +57,7 @@ def parse():
     ap.add_argument("--backend", default=os.environ.get("PCAA_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on a one-GPU box "
                          "together with PCAA_BENCH_DEVICE=0, which puts every rank on that GPU)")
-    ap.add_argument("--graph", default=os.environ.get("PCAA_GRAPH", "off"), choices=["on", "off"],
+    ap.add_argument("--graph", default=os.environ.get("PCAA_GRAPH", "auto"), choices=["on", "off", "auto"],
                     help="replay the step as a captured hipGraph (PCAATrainer.step_graphed).  Measured SLOWER than "
                          "eager enqueue on this stack (7.48 vs 6.99 ms/step: the 4-stream step is GPU-bound, and "
                          "graph replay loses some of the cross-stream overlap), so it is opt-in")
@@ -100,8 +108,163 @@ def cpu_baseline(B, N, C, K, T):
                       f"calibration step) on a {ncpu}-CPU host, torch {torch.__version__}"}
 
 
+def pointnet_train_flops(P):
+    """2 FLOP/MAC x 1.837 M MAC per point forward, x3 for forward + dgrad + wgrad."""
+    return 3 * 2 * 1.837e6 * P
+
+
+def step_algorithmic(tr, B, T, N):
+    """(FLOPs, HBM bytes) of one train step, SURVEY section 8(d): GEMM layers 3x forward; decoder/optimizer
+    parameters 40 B each (fwd read, bwd read, dW write, Adam 28), encoder activations 18.4 KB per point."""
+    P = B * T * N
+    n_dec = sum(p.numel() for p in tr.decoder.parameters() if p.dim() == 2)
+    flops = pointnet_train_flops(P) + 3 * 2 * n_dec * B + 3 * 2 * 572928 * B * T
+    nbytes = 40.0 * tr.flat_g.total + 3 * 2 * 3072 * P
+    return flops, nbytes
+
+
+def build_trainer(a, N, dev, pg, precision):
+    from opensetgaitrecognition_pcaa_amd import constants, synthetic as syn
+    from opensetgaitrecognition_pcaa_amd.train import PCAATrainer
+    from opensetgaitrecognition_pcaa_amd.utils import sample_distant_points
+    cfg = dict(constants.CONFIG)
+    cfg.update(NMAX=N, TRAIN_CLASSES=list(range(a.classes)), BATCH_SIZE=a.batch)
+    tr = PCAATrainer(cfg, device=dev, precision=precision, process_group=pg, sync_bn=a.sync_bn,
+                     dp_zero=(a.dp_mode == "zero") if pg is not None else None,
+                     grad_compress=None if a.grad_compress == "none" else a.grad_compress)
+    for i, m in enumerate((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head,
+                           tr.discriminator_projection_head)):
+        syn.deterministic_fill_(m, i)
+    tr.set_prior_means(sample_distant_points(32, a.classes, 10, 10))
+    tr.finalize()
+    tr.train()
+    return tr, cfg
+
+
+def workload_sweep(a, dev):
+    """BASELINE config[3]: the train step at N in {32,64,128,256} (train_pointsubsampling.py path), B=64, one GPU.
+    Small N replays the step as a hipGraph (the eager step is bound by the host's ~120 enqueues there)."""
+    from opensetgaitrecognition_pcaa_amd import constants, functional as F_hip, synthetic as syn
+    B, C, K, T = a.batch, a.features, a.classes, constants.NSTEPS
+    constants.NFEATURES = C
+    F_hip.set_precision(a.precision)
+    entries, tot_seq, tot_s = [], 0, 0.0
+    for N in (32, 64, 128, 256):
+        tr, _ = build_trainer(a, N, dev, None, a.precision)
+        pcs = syn.synthetic_pcs(B, T, N, C, seed=1234).to(dev).permute(0, 3, 1, 2)
+        gt = syn.synthetic_labels(B, K, seed=1235).to(dev)
+        z0, al = syn.synthetic_z0(B, 32, seed=1236).to(dev), syn.synthetic_alphas(B, seed=1237).to(dev)
+        graph = a.graph == "on" or (a.graph == "auto" and tr.prefers_graph(B, N))
+        run = (lambda: tr.step_graphed(pcs, gt, z0, al, warmup=0)) if graph else (lambda: tr.step(pcs, gt, z0, al))
+        for _ in range(max(a.warmup, 3)):
+            tr.step(pcs, gt, z0, al)
+        run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        flops, nbytes = step_algorithmic(tr, B, T, N)
+        ms = dt / a.steps * 1e3
+        entries.append({"N": N, "ms_per_step": ms, "value": B * a.steps / dt, "hip_graph": bool(graph),
+                        "finite_loss": bool(torch.isfinite(out["tot_loss"]).item()),
+                        "step_flops": flops, "step_hbm_bytes": nbytes,
+                        "mfma_frac": flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                        "hbm_frac": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                        "bound": "hbm" if nbytes / PEAK_HBM_GBS / 1e9 > flops / PEAK_BF16_TFLOPS / 1e12 else "mfma"})
+        tot_seq += B * a.steps
+        tot_s += dt
+        del tr
+        torch.cuda.empty_cache()
+    worst = min(entries, key=lambda e: max(e["mfma_frac"], e["hbm_frac"]))
+    line = {"metric": "gait sequences/sec (train step), point-subsampling sweep", "value": tot_seq / tot_s,
+            "unit": "sequences/s", "n_gpus": 1, "steps": a.steps, "warmup": max(a.warmup, 3),
+            "ms_per_step": tot_s / (4 * a.steps) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if a.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"PCAA V4 train step at N in (32,64,128,256), B={B} T={T} C={C} K={K}, BASELINE config[3]; "
+                                   "value = all sequences / all time", "sweep": entries},
+            "roofline": {"bound": worst["bound"], "achieved": worst["step_flops"] / (worst["ms_per_step"] * 1e-3) / 1e12
+                         if worst["bound"] == "mfma" else worst["step_hbm_bytes"] / (worst["ms_per_step"] * 1e-3) / 1e9,
+                         "peak": PEAK_BF16_TFLOPS if worst["bound"] == "mfma" else PEAK_HBM_GBS,
+                         "unit": "TFLOP/s" if worst["bound"] == "mfma" else "GB/s",
+                         "frac": max(worst["mfma_frac"], worst["hbm_frac"]), "traffic": None,
+                         "note": f"whole-step algorithmic work / step time at the sweep's worst point (N={worst['N']}); "
+                                 "per-N figures in config.sweep"}}
+    print(json.dumps(line), flush=True)
+
+
+def workload_infer(a, dev):
+    """BASELINE config[4]: eval-mode CGEncoder (BatchNorm + ELU [+ mean-pool] in the GEMM epilogues) -> fp64 mixture
+    likelihood -> k=6 window vote on B=1024 sequences resident in HBM; one step = one batch."""
+    from opensetgaitrecognition_pcaa_amd import constants, functional as F_hip, inference, models, ops, synthetic as syn
+    from opensetgaitrecognition_pcaa_amd.utils import sample_distant_points
+    B, N, C, K, T = 1024, a.points, a.features, a.classes, constants.NSTEPS
+    constants.NFEATURES = C
+    F_hip.set_precision(a.precision)
+    enc = models.CGEncoder(K, nmax_points=N, use_projection_head=True).float()
+    syn.deterministic_fill_(enc, 0)
+    enc = enc.to(dev).eval()
+    scorer = inference.OpenSetScorer(enc, sample_distant_points(32, K, 10, 10), batch_size=B)
+    pcs = syn.synthetic_pcs(B, T, N, C, seed=5).to(dev).permute(0, 3, 1, 2)
+
+    def step():
+        preds, fv, lik = scorer.embed(pcs)
+        scorer.threshold = 1e-30
+        return scorer.vote(lik, preds, 6, K), lik
+
+    for _ in range(max(a.warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    timer = ops.LaunchTimer(only_prefix="gemm_bf16_dma_kernel" if a.precision == "bf16" else "gemm_f32_kernel")
+    ops.set_timer(timer)
+    step()
+    ops.set_timer(None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        votes, lik = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    agg = timer.summary()
+    name, r = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    peak = PEAK_BF16_TFLOPS if name.startswith("gemm_bf16") else PEAK_F32_TFLOPS
+    achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+    flops_seq = 2 * 1.837e6 * T * N + 2 * 572928 * T
+    line = {"metric": "gait sequences/sec (open-set inference)", "value": B * a.steps / dt, "unit": "sequences/s",
+            "n_gpus": 1, "steps": a.steps, "warmup": max(a.warmup, 2), "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if a.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"open-set inference: eval CGEncoder + joint likelihood + k=6 vote, B={B} T={T} N={N} C={C} "
+                                   f"K={K}, BASELINE config[4]", "finite": bool(torch.isfinite(lik).all().item()),
+                       "windows": int(votes.numel()), "algorithmic_gflop_per_sequence": flops_seq / 1e9,
+                       "whole_path_mfma_frac": flops_seq * B / (dt / a.steps) / 1e12 / PEAK_BF16_TFLOPS},
+            "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None, "launches_per_step": r["launches"],
+                         "avg_launch_ms": r["ms"] / r["launches"],
+                         "algorithmic_flop_per_launch": r["flops"] / r["launches"]}}
+    if not a.no_cpu_baseline:
+        from oracle import pcaa_oracle as O
+        sd = {k: v.detach().cpu().clone() for k, v in enc.state_dict().items()}
+        xb = pcs[:64].cpu().contiguous()
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            O.cg_encoder_forward(xb, sd, True, training=False)
+        d = time.perf_counter() - t1
+        line["cpu_baseline"] = {"value": 64 / d, "unit": "sequences/s", "cores": torch.get_num_threads(), "kind": "port",
+                                "sample": f"oracle eval-mode encoder forward on 64 of the 1024 sequences: {d:.1f} s"}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     a = parse()
+    if a.workload != "train":
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise SystemExit("bench.py: --workload sweep / infer are single-GPU workloads")
+        dev = torch.device("cuda", int(os.environ.get("PCAA_BENCH_DEVICE", "0")))
+        torch.cuda.set_device(dev)
+        return workload_sweep(a, dev) if a.workload == "sweep" else workload_infer(a, dev)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,16 +288,8 @@ def main():
 
     B, N, C, K, T = a.batch, a.points, a.features, a.classes, constants.NSTEPS
     constants.NFEATURES = C
-    cfg = dict(constants.CONFIG)
-    cfg.update(NMAX=N, TRAIN_CLASSES=list(range(K)), BATCH_SIZE=B)
     F_hip.set_precision(a.precision)
-    tr = PCAATrainer(cfg, device=dev, precision=a.precision, process_group=pg, sync_bn=a.sync_bn)
-    for i, m in enumerate((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head,
-                           tr.discriminator_projection_head)):
-        syn.deterministic_fill_(m, i)
-    tr.set_prior_means(sample_distant_points(32, K, 10, 10))
-    tr.finalize()
-    tr.train()
+    tr, cfg = build_trainer(a, N, dev, pg, a.precision)
     # inputs resident in HBM (point-major storage, [B,C,T,N] view), different data per rank
     pcs = syn.synthetic_pcs(B, T, N, C, seed=1234 + rank).to(dev).permute(0, 3, 1, 2)
     gt = syn.synthetic_labels(B, K, seed=1235 + rank).to(dev)
@@ -146,7 +301,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = a.graph == "on"
+    use_graph = a.graph == "on" or (a.graph == "auto" and world == 1 and tr.prefers_graph(B, N))
     run_step = tr.step
     for _ in range(a.warmup):
         out = tr.step(pcs, gt, z0, al)
@@ -182,6 +337,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_ok = bool(torch.isfinite(out["tot_loss"]).item())
+    comm = dict(tr.comm)
 
     def timed_leg(trainer, batches, steps, warmup):
         """warmup untimed + steps timed trainer steps; ``batches`` yields (pcs, gt).  Same bracket as the main
@@ -229,13 +385,7 @@ def main():
         del tr
         torch.cuda.empty_cache()
         F_hip.set_precision("fp32")
-        tr32 = PCAATrainer(cfg, device=dev, precision="fp32", process_group=pg, sync_bn=a.sync_bn)
-        for i, m in enumerate((tr32.encoder, tr32.decoder, tr32.discriminator, tr32.decoder_projection_head,
-                               tr32.discriminator_projection_head)):
-            syn.deterministic_fill_(m, i)
-        tr32.set_prior_means(sample_distant_points(32, K, 10, 10))
-        tr32.finalize()
-        tr32.train()
+        tr32, _ = build_trainer(a, N, dev, pg, "fp32")
         psteps = max(1, min(a.steps, 10))
         d = timed_leg(tr32, itertools.repeat((pcs, gt)), psteps, 2)
         parity_leg = {"precision": "fp32", "dtype": "f32", "steps": psteps, "warmup": 2,
@@ -259,6 +409,14 @@ def main():
                        "global_batch": B * world, "precision": a.precision,
                        "parallelism": f"dp{world}", "sync_bn": bool(a.sync_bn), "finite_loss": loss_ok,
                        "hip_graph": bool(use_graph),
+                       # gradient / parameter exchanges of one step: number of collectives, payload bytes, and what a
+                       # ring moves per rank and direction for them (2 (w-1)/w x payload for an all-reduce; the
+                       # reduce-scatter + all-gather pair of --dp-mode zero moves the same)
+                       "dp": {"mode": a.dp_mode if world > 1 else "none", "grad_compress": a.grad_compress,
+                              "collectives_per_step": comm["collectives"], "payload_bytes_per_step": comm["payload_bytes"],
+                              "ring_wire_bytes_per_rank": (2.0 * (world - 1) / world * comm["payload_bytes"]
+                                                           if a.dp_mode == "allreduce" else
+                                                           1.0 * (world - 1) / world * comm["payload_bytes"])},
                        # time the host spends enqueueing one step (no synchronisation inside step())
                        "host_enqueue_ms_per_step": host_s / a.steps * 1e3},
         }

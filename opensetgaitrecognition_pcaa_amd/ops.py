@@ -301,8 +301,17 @@ def gemm_affine_elu(a, W16, scale, shift, pool_rows=0):
         out = torch.empty((M // pool_rows, N), dtype=torch.float32, device=a.device)
     else:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    timer = TIMER
+    key = "gemm_bf16_dma_kernel<bf16,KC,KC,affine_elu>"     # eval-mode epilogues (BatchNorm affine + ELU [+ mean-pool])
+    timer = timer if (timer is not None and timer.wants(key)) else None
+    if timer is not None:
+        ev = _begin_timing(key)
     check(_lib.load().pcaa_gemm_affine_elu(_p(a), a.stride(0), _p(W16), W16.stride(0), _p(out), N, _p(scale),
                                            _p(shift), M, N, K, int(pool_rows), _s()), "pcaa_gemm_affine_elu")
+    if timer is not None:
+        ev.end()
+        nbytes = 2 * (M * K + N * K) + out.numel() * out.element_size()
+        timer.records.append((key, 2.0 * M * N * K, float(nbytes), ev))
     return out
 
 

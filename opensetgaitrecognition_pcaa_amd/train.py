@@ -49,6 +49,20 @@ class StepCount:
         self.step_dev.fill_(self.step)
 
 
+class _CompressedWork:
+    """An async all-reduce of the bf16 image of a gradient bucket: ``wait()`` (stream-side, like the work's own)
+    is followed by widening the sum back into the fp32 bucket, once, on the stream of the first waiter."""
+
+    def __init__(self, work, dst32, src16):
+        self.work, self.dst32, self.src16, self.done = work, dst32, src16, False
+
+    def wait(self):
+        self.work.wait()
+        if not self.done:
+            self.dst32.copy_(self.src16)
+            self.done = True
+
+
 class FlatBuffer:
     """Parameters re-pointed into one contiguous fp32 buffer (+ matching
     gradient and Adam moment buffers)."""
@@ -150,7 +164,12 @@ class PCAATrainer:
     attached, ``pcaa_disc_wgan_gp`` returns d(d_loss)/dz and the learner is trained by optimizer_D."""
 
     def __init__(self, config, n_classes=None, device="cuda", variant="v4", precision=None,
-                 process_group=None, sync_bn=False, learn_centroids=False):
+                 process_group=None, sync_bn=False, learn_centroids=False, dp_zero=None, grad_compress=None):
+        """Data-parallel options (``process_group`` given): ``dp_zero`` True = sharded decoder optimizer
+        (reduce-scatter, Adam on 1/world of the decoder, all-gather; default: the ``PCAA_DP_ZERO`` environment
+        switch, off); ``grad_compress="bf16"`` = the decoder's gradient buckets cross the wire as bf16 (half the
+        bytes; fp32 master gradients, moments and weights; each bucket is rounded once before the sum and the sum
+        is accumulated in bf16 by the collective: relative error of a reduced element ~2^-8)."""
         self.cfg = dict(config)
         self.K = n_classes if n_classes is not None else len(config["TRAIN_CLASSES"])
         self.N = config["NMAX"]
@@ -170,6 +189,11 @@ class PCAATrainer:
             self.world = dist.get_world_size(process_group)
             if sync_bn:
                 self._sync_bn_group = process_group
+        self._dp_zero_arg = dp_zero
+        if grad_compress not in (None, "bf16"):
+            raise ValueError("grad_compress must be None or 'bf16'")
+        self.grad_compress = grad_compress
+        self.comm = {"collectives": 0, "payload_bytes": 0}     # of the LAST step (gradient / parameter exchanges)
         if variant not in ("v4", "base", "v1", "v3"):
             raise ValueError(f"PCAATrainer: unknown variant {variant!r}")
         head = variant in ("v4", "v1")
@@ -257,7 +281,8 @@ class PCAATrainer:
         # Data-parallel with a sharded decoder optimizer (PCAA_DP_ZERO=1, ZeRO-1 style): the decoder gradients are
         # reduce-SCATTERED, every rank runs Adam on its 1/world slice only (the 0.78 ms, 4.4 GB update shrinks by the
         # world size) and the updated parameters are all-gathered -- the same bytes on the wire as the all-reduce.
-        self._zero = (os.environ.get("PCAA_DP_ZERO", "0") == "1" and self.pg is not None)
+        want_zero = (os.environ.get("PCAA_DP_ZERO", "0") == "1") if self._dp_zero_arg is None else bool(self._dp_zero_arg)
+        self._zero = want_zero and self.pg is not None
         self._zero_chunks = max(1, int(os.environ.get("PCAA_DP_CHUNKS", "4")))
         tail = None
         if self.decoder is None:
@@ -340,6 +365,8 @@ class PCAATrainer:
                             for _ in range(self._zero_chunks)]            # staging of the updated slice for the gather
         # PCAA_DP_FORCE=1 issues the collectives even on a 1-rank group (exercises the RCCL path on one GPU)
         self._force_collectives = os.environ.get("PCAA_DP_FORCE", "0") == "1"
+        if self.grad_compress == "bf16" and self.pg is not None:
+            self._g16 = torch.empty(self.flat_g.total, dtype=torch.bfloat16, device=self.device)
         self._stats_pool = ops.StatsPool(self.device)
         self._flat_ready = True
         if self.pg is not None and self.world > 1:
@@ -389,9 +416,28 @@ class PCAATrainer:
             m.eval()
 
     # ------------------------------------------------------------------ one step
+    def _count(self, nbytes):
+        self.comm["collectives"] += 1
+        self.comm["payload_bytes"] += int(nbytes)
+
     def _allreduce(self, t, async_op=False):
         if self.pg is not None and (self.world > 1 or self._force_collectives) and t.numel():
             import torch.distributed as dist
+            if (self.grad_compress == "bf16" and t.numel() >= (1 << 16)
+                    and t.data_ptr() >= self.flat_g.g.data_ptr() + 4 * self._dec_start
+                    and t.data_ptr() < self.flat_g.g.data_ptr() + 4 * self.flat_g.total):
+                # decoder gradient bucket: round to bf16 once, sum on the wire in bf16, widen back into the fp32
+                # gradient buffer when the consumer waits for it
+                off = (t.data_ptr() - self.flat_g.g.data_ptr()) // 4
+                g16 = self._g16[off:off + t.numel()]
+                g16.copy_(t)
+                self._count(2 * t.numel())
+                work = dist.all_reduce(g16, group=self.pg, async_op=async_op)
+                if not async_op:
+                    t.copy_(g16)
+                    return None
+                return _CompressedWork(work, t, g16)
+            self._count(t.numel() * t.element_size())
             return dist.all_reduce(t, group=self.pg, async_op=async_op)
         return None
 
@@ -442,6 +488,7 @@ class PCAATrainer:
         ops.set_stats_pool(self._stats_pool)
         self._stats_pool.begin()
         self._enc_region.zero_()
+        self.comm = {"collectives": 0, "payload_bytes": 0}
 
         # (1) encoder forward (train-mode BatchNorm)
         # (the decoder projection head rides in the launch of the MLP heads)
@@ -585,6 +632,7 @@ class PCAATrainer:
             scatter = []
             for c in range(self._zero_chunks):
                 lo = self._dec_start + c * n
+                self._count(4 * n)
                 scatter.append(dist.reduce_scatter_tensor(self._zero_g[c], fg.g[lo:lo + n], group=self.pg, async_op=True))
             self._advance_g(supervise)
 
@@ -600,6 +648,7 @@ class PCAATrainer:
                         ops.adam_step_dev_(fg.p[lo:hi], self._zero_g[c], fg.m[lo:hi], fg.v[lo:hi], cfg["B1"], cfg["B2"],
                                            1e-8, fg.coef_dev, gs, self._side_adam_blocks)
                         self._zero_p[c].copy_(fg.p[lo:hi])
+                        self._count(4 * n)
                         zero_gather.append(dist.all_gather_into_tensor(
                             fg.p[self._dec_start + c * n:self._dec_start + (c + 1) * n], self._zero_p[c],
                             group=self.pg, async_op=True))
@@ -691,6 +740,15 @@ class PCAATrainer:
                 "sup_loss": sup_loss, "tot_loss": tot, "preds": preds, "out_labels": logits, "sup_fvs": sup_fv}
 
     # ------------------------------------------------------------------ hipGraph replay of the step
+    def prefers_graph(self, B, N):
+        """Whether step_graphed beats step for this shape on one GPU.  The eager step costs the host ~2.5 ms of
+        enqueues (~120 launches); that only binds when the GPU needs less: measured (B=64, bf16, ms/step eager |
+        graph) N=32: 2.56 | 2.34, N=64: 3.56 | 3.71, N=128: 6.51 | 6.66 -- replay wins below ~80 K points per step
+        and loses 2-4 % above (profiles/r02_graph_vs_eager.txt).  Single process, variants without autograd inside
+        the step only."""
+        return (self.world == 1 and self.variant in ("v4", "base", "v3") and self.device.type == "cuda"
+                and B * self.T * N <= 80_000 and os.environ.get("PCAA_GRAPH", "auto") != "off")
+
     def step_graphed(self, pcs, gt, z0, alphas, supervise=True, warmup=2):
         """step() through a captured hipGraph.  The step is a fixed sequence of ~200 launches on four
         streams with no host synchronisation and no per-step host scalar (the Adam step count lives on
@@ -853,6 +911,7 @@ def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=
     best_valid_accuracy = 0
     history = []
     L = config["SUP_LATENT_DIM"]
+    use_graph = world == 1 and trainer.prefers_graph(local_cfg["BATCH_SIZE"], nmax_points)
     for epoch in range(config["EPOCHS"]):
         trainer.train()
         steps = []
@@ -873,7 +932,14 @@ def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=
                 z0 = z0[rank * pcs.shape[0]:(rank + 1) * pcs.shape[0]].contiguous()
                 alphas = alphas[rank * pcs.shape[0]:(rank + 1) * pcs.shape[0]].contiguous()
             supervise = i % config["SUPERVISION_FREQUENCY"] == 0
-            out = trainer.step(pcs, gt_labels, z0, alphas, supervise=supervise)
+            if use_graph:
+                # replayed hipGraph (small shapes, where the host's enqueues bound the eager step): the outputs are
+                # the graph's static tensors, so what the epoch statistics keep is copied out
+                out = trainer.step_graphed(pcs, gt_labels, z0, alphas, supervise=supervise)
+                out = {k: (v.clone() if torch.is_tensor(v) and k in ("rec_loss", "d_loss", "sup_loss", "tot_loss", "preds")
+                           else v) for k, v in out.items()}
+            else:
+                out = trainer.step(pcs, gt_labels, z0, alphas, supervise=supervise)
             out["supervised"] = supervise
             steps.append(out)
             ys.append(gt_labels)
