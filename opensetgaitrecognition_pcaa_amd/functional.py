@@ -13,6 +13,7 @@ Numerics modes (``set_precision``):
     bf16 MFMA pipe with fp32 accumulation; everything else fp32.
 """
 import contextlib
+import itertools
 import os
 
 import torch
@@ -784,6 +785,50 @@ def cg_encoder(enc, x):
         return _EncoderFn.apply(enc, x, *enc.parameters())
     logits, sup_fv, _ = encoder_forward(enc, x, enc.training)
     return logits, sup_fv
+
+
+# ---------------------------------------------------------------- encoder trunk (OR-CED baseline, models.py:446-505)
+class _TrunkFn(torch.autograd.Function):
+    """PointNetBlock -> mean over the points -> TemporalConvolutionBlock -> mean over time: x [B,C,T,N] -> x4 [B,512],
+    the part ORCEDEncoder shares with CGEncoder, on the same kernels (its three Linear heads follow in torch)."""
+
+    @staticmethod
+    def forward(ctx, enc, x, *params):
+        B, C, T, N = x.shape
+        mode = get_precision()
+        xp = _point_major(x).view(B * T * N, C)
+        x2, pn = pointnet_forward(xp, enc.pc_block.layers(), enc.training, mode, pool_rows=N)
+        x4, dtc = dtc_forward(x2, B, T, enc.tc_block.layers(), enc.training, pool_time=True)
+        ctx.enc, ctx.pn, ctx.dtc, ctx.shape, ctx.mode, ctx.training = enc, pn, dtc, (B, C, T, N), mode, enc.training
+        ctx.names = [n for n, _ in itertools.chain(enc.pc_block.named_parameters(prefix="pc_block"),
+                                                   enc.tc_block.named_parameters(prefix="tc_block"))]
+        return x4
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dx4):
+        if not ctx.training:
+            raise RuntimeError("ORCEDEncoder backward in eval mode is not implemented on the HIP path")
+        B, C, T, N = ctx.shape
+        enc = ctx.enc
+        g = {}
+        dg, dx2 = dtc_backward(ctx.dtc, enc.tc_block.layers(), B, T, dpool=dx4.contiguous().float(), need_dx=True)
+        for i, d in enumerate(dg, start=1):
+            for k, v in d.items():
+                g[f"tc_block.dtc{i}.{k}"] = v
+        pg, _ = pointnet_backward(ctx.pn, enc.pc_block.layers(), ctx.mode, dpool=dx2, pool_rows=N, need_dx=False)
+        for i, d in enumerate(pg, start=1):
+            for k, v in d.items():
+                g[f"pc_block.pointnet{i}.{k}"] = v
+        return (None, None) + tuple(g.get(n) for n in ctx.names)
+
+
+def encoder_trunk(enc, x):
+    _require_gpu(x, "ORCEDEncoder")
+    if x.dim() != 4 or x.shape[3] != enc.nmax_points:
+        raise RuntimeError(f"ORCEDEncoder expects [B,C,T,{enc.nmax_points}], got {tuple(x.shape)}")
+    params = list(enc.pc_block.parameters()) + list(enc.tc_block.parameters())
+    return _TrunkFn.apply(enc, x, *params)
 
 
 # ---------------------------------------------------------------- standalone blocks

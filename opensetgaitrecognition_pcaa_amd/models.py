@@ -184,3 +184,40 @@ class GaussianMeanLearner(torch.nn.Module):
 
     def forward(self, x):
         return F_hip.gaussian_mean_learner(self, x)
+
+
+class ORCEDEncoder(torch.nn.Module):
+    """OR-CED baseline encoder (reference models.py:446-505): the CGEncoder trunk, then ``MLP_mu`` / ``MLP_logvar``
+    (Linear 512 -> 32, no activation), the reparametrisation ``sup_fv = mu + eps * exp(0.5 logvar)`` with
+    ``eps = torch.randn_like(logvar)`` drawn in BOTH train and eval mode, and ``MLP_classification`` (Linear 32 -> K,
+    no activation).  forward(x[B,C,T,N]) -> (out_classes, sup_fv, vae_mu, vae_logvar).  The trunk runs on the HIP
+    kernels (functional.encoder_trunk); the three tiny heads and the sampling are plain torch device ops."""
+
+    def __init__(self, n_out_labels, nmax_points=None):
+        super().__init__()
+        self.nmax_points = constants.NMAX if nmax_points is None else nmax_points   # the reference hard-wires constants.NMAX
+        self.pc_block = PointNetBlock()
+        self.glob_avg_pool1 = torch.nn.AvgPool2d(kernel_size=(1, self.nmax_points))
+        self.tc_block = TemporalConvolutionBlock()
+        self.glob_avg_pool2 = torch.nn.AvgPool1d(kernel_size=constants.NSTEPS)
+        lat = constants.SUP_LATENT_DIM
+        self.MLP_mu = torch.nn.Sequential(torch.nn.Linear(constants.DTC_FILTERS[-1], lat))
+        self.MLP_logvar = torch.nn.Sequential(torch.nn.Linear(constants.DTC_FILTERS[-1], lat))
+        self.MLP_classification = torch.nn.Sequential(torch.nn.Linear(lat, n_out_labels))
+
+    def forward(self, x):
+        x4 = F_hip.encoder_trunk(self, x)
+        vae_mu = self.MLP_mu(x4)
+        vae_logvar = self.MLP_logvar(x4)
+        eps = torch.randn_like(vae_logvar)
+        sup_fv = vae_mu + eps * torch.exp(0.5 * vae_logvar)
+        return self.MLP_classification(sup_fv), sup_fv, vae_mu, vae_logvar
+
+
+class ORCEDDecoder(CGDecoder):
+    """OR-CED decoder (reference models.py:508-545): the same five-Linear stack as CGDecoder fed by the 32-wide latent,
+    bn1..bn4 registered and unused, widths from ``DEC_MLP_SIZE`` (= NSTEPS * NMAX * NFEATURES)."""
+
+    def __init__(self, nmax_points=None):
+        super().__init__(input_dim=constants.SUP_LATENT_DIM,
+                         nmax_points=constants.NMAX if nmax_points is None else nmax_points)

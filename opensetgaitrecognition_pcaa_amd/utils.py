@@ -63,3 +63,10 @@ def sample_distant_points(dimension, n, min_dist, sphere_radius, seed=42, verbos
 
 def openness(n_train_classes, n_test_classes):
     return 1 - math.sqrt(2 * n_train_classes / (n_train_classes + n_test_classes))
+
+
+def CG_kl_divergence(mu, logvar, mu_k):
+    """KL( N(mu, exp(logvar)) || N(mu_k, I) ) averaged over the batch (reference utils.py:72-85, equation (6) of
+    "Conditional Gaussian Distribution Learning for Open Set Recognition"): [B,32] device tensors -> scalar."""
+    batch_kl_div = -0.5 * torch.sum(1 + logvar - (mu - mu_k) ** 2 - torch.exp(logvar), axis=1)
+    return torch.mean(batch_kl_div)
