@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--dp-mode", default="allreduce", choices=["allreduce", "zero"],
                     help="data-parallel exchange of the decoder gradients: per-layer all-reduce buckets (default) or "
                          "reduce-scatter + sharded Adam + all-gather (ZeRO-1)")
+    ap.add_argument("--dp-force", action="store_true",
+                    help="N=1 only: create a 1-rank RCCL group and issue the step's collectives on it (exercises the RCCL "
+                         "calls and measures their fixed cost on one GPU)")
     ap.add_argument("--grad-compress", default="none", choices=["none", "bf16"],
                     help="decoder gradient buckets cross the wire as bf16 (fp32 master gradients)")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -58,9 +61,9 @@ def parse():
                     help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on a one-GPU box "
                          "together with PCAA_BENCH_DEVICE=0, which puts every rank on that GPU)")
     ap.add_argument("--graph", default=os.environ.get("PCAA_GRAPH", "auto"), choices=["on", "off", "auto"],
-                    help="replay the step as a captured hipGraph (PCAATrainer.step_graphed).  Measured SLOWER than "
-                         "eager enqueue on this stack (7.48 vs 6.99 ms/step: the 4-stream step is GPU-bound, and "
-                         "graph replay loses some of the cross-stream overlap), so it is opt-in")
+                    help="replay the step as a captured hipGraph (PCAATrainer.step_graphed): auto = where the eager step is "
+                         "bound by the host's enqueues (PCAATrainer.prefers_graph: below ~80 K points per step; "
+                         "profiles/r02_graph_vs_eager.txt); at the default workload eager is 2-3 % faster")
     return ap.parse_args()
 
 
@@ -130,8 +133,9 @@ def build_trainer(a, N, dev, pg, precision):
     cfg = dict(constants.CONFIG)
     cfg.update(NMAX=N, TRAIN_CLASSES=list(range(a.classes)), BATCH_SIZE=a.batch)
     tr = PCAATrainer(cfg, device=dev, precision=precision, process_group=pg, sync_bn=a.sync_bn,
-                     dp_zero=(a.dp_mode == "zero") if pg is not None else None,
-                     grad_compress=None if a.grad_compress == "none" else a.grad_compress)
+                     dp_zero=(a.dp_mode == "zero") and pg is not None,
+                     grad_compress=None if a.grad_compress == "none" else a.grad_compress,
+                     force_collectives=a.dp_force)
     for i, m in enumerate((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head,
                            tr.discriminator_projection_head)):
         syn.deterministic_fill_(m, i)
@@ -277,7 +281,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     pg = None
-    if world > 1 or os.environ.get("PCAA_DP_FORCE", "0") == "1":
+    if world > 1 or a.dp_force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if a.backend == "nccl":
@@ -358,7 +362,7 @@ def main():
         return d
 
     batcher_leg = None
-    if not a.no_batcher_leg and not use_graph:
+    if not a.no_batcher_leg and not use_graph and world == 1:
         # datasets.py batch collation inside the timed loop: a packed point-major store of `pool` synthetic crops
         # resident in HBM, every step's batch gathered from it in the DataLoader's shuffled order
         # (DeviceBatcher = pcaa_gather_rows), then the same train step
@@ -379,7 +383,7 @@ def main():
         del store, loader
 
     parity_leg = None
-    if a.precision == "bf16" and not a.no_parity_mode and not use_graph:
+    if a.precision == "bf16" and not a.no_parity_mode and not use_graph and world == 1:
         # the SAME workload in fp32 parity mode (exact-fp32 MFMA, fp32 activations): the mode the 1e-4 / bit-exact
         # label tests run in (tests/test_round2_parity.py::test_config1_full_size_fp32_step_vs_oracle)
         del tr

@@ -895,8 +895,7 @@ static int launch_adam(float* param, const float* grad, float* exp_avg, float* e
                        float grad_scale, int max_blocks, void* stream, const char* what) {
   PCAA_CHECK_ARG(((uintptr_t)param % 16) == 0 && ((uintptr_t)grad % 16) == 0 && ((uintptr_t)exp_avg % 16) == 0 &&
                  ((uintptr_t)exp_avg_sq % 16) == 0, "pcaa_adam_step: buffers must be 16-B aligned");
-  static const int env_cap = getenv("PCAA_ADAM_BLOCKS") ? atoi(getenv("PCAA_ADAM_BLOCKS")) : 0;
-  const int cap = env_cap > 0 ? env_cap : (max_blocks > 0 ? max_blocks : 256 * 16);
+  const int cap = max_blocks > 0 ? max_blocks : 256 * 16;
   if (cap <= 1024)
     hipLaunchKernelGGL(adam_kernel<4>, dim3(grid_for(n >> 4, 256, cap)), dim3(256), 0, as_stream(stream), param, grad,
                        exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size, inv_bc2_sqrt, grad_scale, coef);

@@ -381,15 +381,8 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* __restr
   }
 }
 
-int target_blocks() {
-  static int t = -1;
-  if (t < 0) {
-    const char* e = getenv("PCAA_SKINNY_TARGET");
-    t = e ? atoi(e) : 768;
-    if (t < 1) t = 1;
-  }
-  return t;
-}
+// workgroups a forward / dgrad launch aims for (3 per CU: the split-K depth follows from it)
+int target_blocks() { return 768; }
 
 bool aligned16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
@@ -458,8 +451,8 @@ extern "C" int pcaa_skinny_linear_dgrad(const float* dz, long lddz, const float*
   const long stride = (long)M * K;
   PCAA_CHECK_ARG(ws_floats >= stride * nsplit, "pcaa_skinny_linear_dgrad: workspace too small");
   hipStream_t s = as_stream(stream);
-  static const bool narrow = getenv("PCAA_SKINNY_DGRAD_NARROW") != nullptr;      // the one-column-per-lane kernel
-  if (!narrow && (ldw % 2) == 0 && ((uintptr_t)W % 8) == 0)
+  // two columns per lane where the 8-B loads are aligned, else the one-column-per-lane kernel
+  if ((ldw % 2) == 0 && ((uintptr_t)W % 8) == 0)
     hipLaunchKernelGGL(skinny_dgrad2_kernel, dim3((unsigned)cdiv(K, 256), nsplit), dim3(256), 0, s, dz, lddz, W, ldw,
                        ws, stride, M, N, K, cps);
   else

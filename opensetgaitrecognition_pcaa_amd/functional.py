@@ -14,7 +14,6 @@ Numerics modes (``set_precision``):
 """
 import contextlib
 import itertools
-import os
 
 import torch
 from torch.autograd.function import once_differentiable
@@ -260,12 +259,15 @@ class _on_wgrad_stream:
         return False
 
 
-_BIG_WGRAD_ASIDE = os.environ.get("PCAA_BIG_WGRAD_ASIDE", "0") == "1"    # experiment: PointNet wgrads on that stream too
-_FUSE_DGRAD_BN = os.environ.get("PCAA_FUSE_DGRAD_BN", "1") != "0"
-# the same fusion into the dgrad above the FIRST layer (y rebuilt from the points in the epilogue) is correct
-# but measured slower: the layer-2 dgrad went 0.195 -> 0.361 ms (64 FMAs + 192 live registers per lane in the
-# epilogue) to save a 0.10 ms statistics pass.  Opt-in.
-_FUSE_DGRAD_POINTS = os.environ.get("PCAA_FUSE_DGRAD_POINTS", "0") == "1"
+# Fusions that have an unfused fallback for the shapes their kernels do not take.  They were A/B-ed through
+# environment switches in round 1 and are plain constants now: the product has one path per shape.
+# PointNet weight gradients on the wgrad side stream: measured no change (they fill the chip either way) -> off.
+_BIG_WGRAD_ASIDE = False
+_FUSE_DGRAD_BN = True
+# the same fusion into the dgrad above the FIRST layer (y rebuilt from the points in the epilogue; the kernel and
+# ops.gemm_dgrad_bn(points=...) exist and are tested) measured slower: the layer-2 dgrad went 0.195 -> 0.361 ms
+# (64 FMAs + 192 live registers per lane in the epilogue) to save a 0.10 ms statistics pass -> off.
+_FUSE_DGRAD_POINTS = False
 
 
 def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool_scale=1.0,
@@ -418,8 +420,8 @@ def pointnet_backward(saves, layers, mode, d_last=None, dpool=None, pool_rows=0,
     return grads, da
 
 
-_FUSE_DTC = os.environ.get("PCAA_FUSE_DTC", "1") != "0"
-_FUSE_DTC_BWD = os.environ.get("PCAA_FUSE_DTC_BWD", "1") != "0"
+_FUSE_DTC = True
+_FUSE_DTC_BWD = True
 
 
 def dtc_forward(a2d, B, T, layers, training, pool_time):
@@ -603,8 +605,8 @@ class EncoderState:
     pass
 
 
-_FUSE_HEADS = os.environ.get("PCAA_FUSE_HEADS", "1") != "0"
-_FUSE_EVAL_EPILOGUE = os.environ.get("PCAA_FUSE_EVAL_EPILOGUE", "1") != "0"
+_FUSE_HEADS = True
+_FUSE_EVAL_EPILOGUE = True
 
 
 def _heads_mods(enc, gph):

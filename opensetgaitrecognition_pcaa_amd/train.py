@@ -164,12 +164,13 @@ class PCAATrainer:
     attached, ``pcaa_disc_wgan_gp`` returns d(d_loss)/dz and the learner is trained by optimizer_D."""
 
     def __init__(self, config, n_classes=None, device="cuda", variant="v4", precision=None,
-                 process_group=None, sync_bn=False, learn_centroids=False, dp_zero=None, grad_compress=None):
+                 process_group=None, sync_bn=False, learn_centroids=False, dp_zero=False, grad_compress=None,
+                 force_collectives=False):
         """Data-parallel options (``process_group`` given): ``dp_zero`` True = sharded decoder optimizer
-        (reduce-scatter, Adam on 1/world of the decoder, all-gather; default: the ``PCAA_DP_ZERO`` environment
-        switch, off); ``grad_compress="bf16"`` = the decoder's gradient buckets cross the wire as bf16 (half the
+        (reduce-scatter, Adam on 1/world of the decoder, all-gather; default off); ``grad_compress="bf16"`` = the decoder's gradient buckets cross the wire as bf16 (half the
         bytes; fp32 master gradients, moments and weights; each bucket is rounded once before the sum and the sum
-        is accumulated in bf16 by the collective: relative error of a reduced element ~2^-8)."""
+        is accumulated in bf16 by the collective: relative error of a reduced element ~2^-8).
+        ``force_collectives`` issues the collectives on a 1-rank group too (exercises the RCCL calls on one GPU)."""
         self.cfg = dict(config)
         self.K = n_classes if n_classes is not None else len(config["TRAIN_CLASSES"])
         self.N = config["NMAX"]
@@ -189,7 +190,8 @@ class PCAATrainer:
             self.world = dist.get_world_size(process_group)
             if sync_bn:
                 self._sync_bn_group = process_group
-        self._dp_zero_arg = dp_zero
+        self._dp_zero_arg = bool(dp_zero)
+        self._force_collectives = bool(force_collectives)
         if grad_compress not in (None, "bf16"):
             raise ValueError("grad_compress must be None or 'bf16'")
         self.grad_compress = grad_compress
@@ -269,7 +271,7 @@ class PCAATrainer:
         # gradients (their operands are zero), so Adam leaves the padding at zero and the [:N,:K] windows the
         # modules expose are bit-for-bit what an unpadded run of the same kernels would hold.
         pads = {}
-        if self.decoder is not None and os.environ.get("PCAA_PAD_DECODER", "1") != "0":
+        if self.decoder is not None:
             r64 = lambda v: (v + 63) // 64 * 64
             lins = self.decoder.dense_layers()
             if any(l.weight.shape[0] % 64 for l in lins):
@@ -281,9 +283,8 @@ class PCAATrainer:
         # Data-parallel with a sharded decoder optimizer (PCAA_DP_ZERO=1, ZeRO-1 style): the decoder gradients are
         # reduce-SCATTERED, every rank runs Adam on its 1/world slice only (the 0.78 ms, 4.4 GB update shrinks by the
         # world size) and the updated parameters are all-gathered -- the same bytes on the wire as the all-reduce.
-        want_zero = (os.environ.get("PCAA_DP_ZERO", "0") == "1") if self._dp_zero_arg is None else bool(self._dp_zero_arg)
-        self._zero = want_zero and self.pg is not None
-        self._zero_chunks = max(1, int(os.environ.get("PCAA_DP_CHUNKS", "4")))
+        self._zero = self._dp_zero_arg and self.pg is not None
+        self._zero_chunks = 4
         tail = None
         if self.decoder is None:
             self._zero = False
@@ -335,27 +336,18 @@ class PCAATrainer:
         # latency-bound temporal-conv / MLP-head backward kernels instead of after everything.
         dec_names = [i for i, nm in enumerate(self.flat_g.names) if nm.startswith("G.")]
         self._dec_start = self.flat_g.offsets[dec_names[0]] if dec_names else self.flat_g.total
-        self.early_decoder_adam = os.environ.get("PCAA_EARLY_ADAM", "1") != "0"
-        self._side_adam_blocks = int(os.environ.get("PCAA_SIDE_ADAM_BLOCKS", "256"))
-        self._dp_chunks = max(1, int(os.environ.get("PCAA_DP_CHUNKS", "4")))
+        self._side_adam_blocks = 256
+        self._dp_chunks = 4
         # data-parallel bucketing: one all-reduce per decoder layer, issued as soon as that layer's gradient is
-        # written (PCAA_DP_BUCKETS=chunks: the whole region in PCAA_DP_CHUNKS pieces after the decoder backward)
-        self._bucket_per_layer = os.environ.get("PCAA_DP_BUCKETS", "layers") == "layers"
-        # measured (same box, ms/step): no side stream 8.08-8.26 | beside the temporal-conv/head backward
-        # 7.90 (256 blocks), 7.99 (128) | beside the PointNet backward GEMMs 8.29 (256) .. 9.03 (32):
-        # the GEMMs lose more to the extra HBM stream than the update costs on its own
-        # (current build, same-box A/B with tools/ab_env.py, median of 4: right after the decoder backward 6.576 |
-        # after the heads' launch ("dtc") 6.621 | before the PointNet backward 6.90; 256 blocks 6.63 | 128: 6.91 |
-        # 512: 6.72 | 1024: 6.76)
-        self._side_adam_at = os.environ.get("PCAA_SIDE_ADAM_AT", "decbwd")
+        # written (fallback without the wgrad stream: the whole region in 4 pieces after the decoder backward)
+        # measured (round 1, same box, ms/step): no side stream 8.08-8.26 | beside the temporal-conv/head backward
+        # 7.90 (256 blocks), 7.99 (128) | beside the PointNet backward GEMMs 8.29 (256) .. 9.03 (32): the GEMMs lose
+        # more to the extra HBM stream than the update costs on its own; 256 blocks 6.63 | 128: 6.91 | 512: 6.72 | 1024: 6.76
         self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        # second stream for the critic branch of the step (see step()); PCAA_AUX_STREAM=0: everything inline
-        self._aux = (torch.cuda.Stream(device=self.device)
-                     if self.device.type == "cuda" and os.environ.get("PCAA_AUX_STREAM", "1") != "0" else None)
+        # second stream for the critic branch of the step (see step())
+        self._aux = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         # third stream: the small weight-gradient products of the temporal block / heads (functional._WGRAD_STREAM)
-        self._wg = (torch.cuda.Stream(device=self.device)
-                    if self.device.type == "cuda" and os.environ.get("PCAA_WGRAD_STREAM", "1") != "0" else None)
-        self.overlap_allreduce = os.environ.get("PCAA_DP_OVERLAP", "1") != "0"
+        self._wg = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         if self._zero:
             n = (self.flat_g.total - self._dec_start) // self._zero_chunks
             self._zero_len = n                                            # floats per chunk (divisible by world * 64)
@@ -363,8 +355,6 @@ class PCAATrainer:
                             for _ in range(self._zero_chunks)]            # this rank's reduced gradient slice
             self._zero_p = [torch.empty(n // self.world, dtype=torch.float32, device=self.device)
                             for _ in range(self._zero_chunks)]            # staging of the updated slice for the gather
-        # PCAA_DP_FORCE=1 issues the collectives even on a 1-rank group (exercises the RCCL path on one GPU)
-        self._force_collectives = os.environ.get("PCAA_DP_FORCE", "0") == "1"
         if self.grad_compress == "bf16" and self.pg is not None:
             self._g16 = torch.empty(self.flat_g.total, dtype=torch.bfloat16, device=self.device)
         self._stats_pool = ops.StatsPool(self.device)
@@ -590,10 +580,10 @@ class PCAATrainer:
         # (first layer, whose bias gradient is on the main stream) goes out after the decoder backward.
         early_buckets = []                         # (lo, hi, work) in flat_g coordinates, in issue order
         layer_hook = None
-        zero = self._zero and collective and self.overlap_allreduce and self._side is not None
+        zero = self._zero and collective and self._side is not None
         if zero:
             pass
-        elif collective and self.overlap_allreduce and self._wg is not None and self._bucket_per_layer:
+        elif collective and self._wg is not None:
             fg = self.flat_g
 
             def layer_hook(layer):
@@ -652,7 +642,7 @@ class PCAATrainer:
                         zero_gather.append(dist.all_gather_into_tensor(
                             fg.p[self._dec_start + c * n:self._dec_start + (c + 1) * n], self._zero_p[c],
                             group=self.pg, async_op=True))
-        elif self.overlap_allreduce and early_buckets:
+        elif early_buckets:
             # per-layer buckets are on the wire already; what is left of the decoder region is its head
             # (first layer): its weight gradient was written on the wgrad stream, its bias gradient on this one
             rest_hi = min(lo for lo, _, _ in early_buckets)
@@ -661,7 +651,7 @@ class PCAATrainer:
                 pending.append((self._dec_start, rest_hi,
                                 self._allreduce(self.flat_g.g[self._dec_start:rest_hi], async_op=True)))
             pending = early_buckets + pending      # issue order = the order the collectives complete in
-        elif self.overlap_allreduce:
+        else:
             bounds = [self._dec_start]
             if collective and self._wg is not None:
                 torch.cuda.current_stream().wait_stream(self._wg)   # the decoder's dW/db were written on that stream
@@ -673,7 +663,7 @@ class PCAATrainer:
                     bounds.append(b)
             for lo, hi in zip(bounds[:-1], bounds[1:]):
                 pending.append((lo, hi, self._allreduce(self.flat_g.g[lo:hi], async_op=True)))
-        early = self.early_decoder_adam and self.overlap_allreduce and self._side is not None
+        early = self._side is not None
         hook = hook_heads = None
         done = []
         if zero:
@@ -700,12 +690,9 @@ class PCAATrainer:
                     ev.record(self._side)
                     done.append(ev)
 
-            if self._side_adam_at == "pointnet":
-                hook = launch_side_adam                 # beside the MFMA-bound PointNet backward
-            elif self._side_adam_at == "dtc":
-                hook_heads = launch_side_adam           # beside the temporal-conv backward, after the heads' launch
-            else:
-                launch_side_adam()                      # right after the decoder backward
+            # right after the decoder backward, i.e. beside the heads' and the temporal block's backward (measured
+            # against "after the heads' launch" 6.576 | 6.621 and "beside the PointNet backward GEMMs" 6.90 ms/step)
+            launch_side_adam()
         try:
             gv = self.flat_g.grad_views
             F_hip.encoder_backward(enc, st, dlogits if supervise else None, dsup, gout=self._enc_grads,
@@ -716,13 +703,10 @@ class PCAATrainer:
             F_hip.set_wgrad_stream(None)
         if self._wg is not None:
             torch.cuda.current_stream().wait_stream(self._wg)       # its products feed the all-reduce / Adam below
-        if self.overlap_allreduce:
-            self._allreduce(self.flat_g.g[:self._dec_start])      # encoder + projection head
-            for _, _, work in pending:
-                if work is not None:
-                    work.wait()         # stream-side wait, no host block
-        else:
-            self._allreduce(self.flat_g.g)
+        self._allreduce(self.flat_g.g[:self._dec_start])      # encoder + projection head
+        for _, _, work in pending:
+            if work is not None:
+                work.wait()         # stream-side wait, no host block
         if zero:
             self._adam_g(0, self._dec_start, supervise, gs)
             for work in zero_gather:
@@ -878,7 +862,7 @@ def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=
     dev = trainer.device
     make = dataset_factory or (lambda split: MSRadarDataset(split, subsample_factor=config["SUBSAMPLE_FACTOR"]))
     train_set, valid_set = make(SPLIT.TRAIN), make(SPLIT.VALID)
-    if os.environ.get("PCAA_DEVICE_BATCHER", "1") != "0" and len(train_set) and len(valid_set):
+    if len(train_set) and len(valid_set):
         # packed store in HBM + device-side batch assembly; same batches (and the same consumption of
         # torch's global RNG) as the DataLoaders of the reference (batcher.py)
         from .batcher import batcher_for
