@@ -1,12 +1,12 @@
 #!/bin/bash
 # usage (on the GPU box, via gpurun): bash tools/pmc_mfma.sh <tag>
 # MFMA-pipe utilisation of the GEMM kernels from hardware counters: SQ_VALU_MFMA_BUSY_CYCLES (cycles the MFMA
-# pipe of a SIMD is busy, summed over the chip's 1024 SIMDs; = 32 x the number of v_mfma_f32_32x32x16_bf16) and
+# pipe of a SIMD is busy, summed over the chip's 1024 SIMDs; = 32 cycles per v_mfma_f32_32x32x16_bf16, 16 per v_mfma_f32_16x16x32_bf16) and
 # GRBM_GUI_ACTIVE (active cycles summed over the 8 XCDs).  Counters only with --kernel-trace.
 tag=$1
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_${tag}_mfma -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/pmc_${tag}_mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_${tag}_mfma -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-parity-mode --no-batcher-leg > $R/gpurun_out/pmc_${tag}_mfma.log 2>&1
 echo mfma_exit=$?
 python - <<PY
 import collections, csv, glob, json, sys

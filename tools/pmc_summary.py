@@ -11,23 +11,28 @@ import re
 import sys
 
 
+_EPI_TAIL = {"1": ",dgrad_bn", "2": ",dgrad_bn", "3": ",affine_elu", "4": ",affine_elu", "5": ",affine_elu",
+             "6": ",affine_elu"}
+
+
 def key_of(name):
     m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
     if m:                                   # rocprofv3 leaves some template instantiations mangled
         ln = int(m.group(1))
         base, rest = name[m.end():m.end() + ln], name[m.end() + ln:]
         if base == "gemm_bf16_dma_kernel":
+            # template <TC, ALAY, BLAY, EPI, MF>; EPI 1/2 = dgrad fused with the BatchNorm backward, 3..6 = eval epilogues
             t = re.match(r"I(DF16b|f)Li(\d)ELi(\d)ELi(\d+)E", rest)
             lay = "KC" if t.group(2) == "0" else "RC"
-            tail = ",dgrad_bn" if t.group(4) in ("30", "31") else ""
-            return f"gemm_bf16_dma_kernel<{'bf16' if t.group(1) == 'DF16b' else 'f32'},{lay},{lay}{tail}>"
+            tail = _EPI_TAIL.get(t.group(4), "")
+            return f"gemm_bf16_dma_kernel<{'bf16' if (t.group(1) == 'DF16b' or tail == ',affine_elu') else 'f32'},{lay},{lay}{tail}>"
         return base + ("<bf16>" if rest.startswith("IDF16b") else "")
     n = name.replace("(anonymous namespace)::", "").replace("void ", "")
     m = re.match(r"gemm_bf16_dma_kernel<(__bf16|float), (\d), (\d), (\d+)", n)
     if m:
         lay = "KC" if m.group(2) == "0" else "RC"
-        tail = ",dgrad_bn" if m.group(4) in ("30", "31") else ""
-        return f"gemm_bf16_dma_kernel<{'bf16' if m.group(1) == '__bf16' else 'f32'},{lay},{lay}{tail}>"
+        tail = _EPI_TAIL.get(m.group(4), "")
+        return f"gemm_bf16_dma_kernel<{'bf16' if (m.group(1) == '__bf16' or tail == ',affine_elu') else 'f32'},{lay},{lay}{tail}>"
     n = re.sub(r"\(.*", "", n)
     n = re.sub(r"<.*", "", n)
     return n
