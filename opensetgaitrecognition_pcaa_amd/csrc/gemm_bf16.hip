@@ -332,7 +332,8 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ base, long l
 template <int MF> struct AccLayout;
 template <> struct AccLayout<32> {
   typedef f32x16 vec;
-  static constexpr int MB = 4, NB = 2, NR = 16, BR = 32;
+  static constexpr int MB = 4, NB = 2, NR = 16;
+  [[maybe_unused]] static constexpr int BR = 32;
   static __device__ __forceinline__ int row(int i, int r, int lane) { return i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
   static __device__ __forceinline__ int col(int j, int lane) { return j * 32 + (lane & 31); }
   static __device__ __forceinline__ float colreduce(float v) { return v + __shfl_xor(v, 32, 64); }

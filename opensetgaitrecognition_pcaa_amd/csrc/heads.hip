@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int HB_MAX_ROWS = 64;    // backward: all batch rows of the chain live in LDS (40 KB)
+constexpr int HB_MAX_ROWS = 64;    // backward: all batch rows of the chain live in LDS (74 KB)
 constexpr int D_IN = 512, D_SUP = 32, D_HEAD = 16, D_PROJ = 64;
 
 struct HeadsParams {
@@ -110,76 +110,119 @@ struct HeadsBwdParams {
 
 constexpr int HB_SLICE = 32;      // input columns per workgroup -> 16 workgroups
 
+// LDS plan of the backward kernel (floats): everything the chain reads from global memory is staged in ONE burst
+// at the top of the kernel.  The kernel runs beside the decoder's side-stream Adam (4.4 GB at ~5.5 TB/s): with its
+// weights and activations read from global memory inside each of its five barrier-separated phases, every phase
+// paid a loaded-memory round trip of tens of microseconds (233 us on the step's critical path, 45 us alone); staged
+// up front it pays one.
+struct HbLds {
+  static constexpr int R = HB_MAX_ROWS;
+  static constexpr int DL = 0;                         // [R][9]   d(pre-activation of the logits)
+  static constexpr int DH = DL + R * 9;                // [R][17]  d(pre-activation of h)
+  static constexpr int DG = DH + R * 17;               // [R][65]  d(pre-activation of hproj)
+  static constexpr int DS = DG + R * 65;               // [R][33]  d(pre-activation of sup_fv)
+  static constexpr int XS = DS + R * 33;               // [R][33]  this workgroup's slice of x4
+  static constexpr int SUP = XS + R * 33;              // [R][33]  sup_fv
+  static constexpr int HH = SUP + R * 33;              // [R][17]  h
+  static constexpr int DSI = HH + R * 17;              // [R][33]  d_sup (incoming)
+  static constexpr int W2 = DSI + R * 33;              // [8][33]
+  static constexpr int WH = W2 + 8 * 33;               // [16][33]
+  static constexpr int WG = WH + 16 * 33;              // [64][33]
+  static constexpr int W1 = WG + 64 * 33;              // [32][33] rows of W1, this workgroup's columns
+  static constexpr int TOTAL = W1 + 32 * 33;
+};
+constexpr int HB_LDS_BYTES = HbLds::TOTAL * 4;
+
 __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsBwdParams p) {
-  __shared__ float dl[HB_MAX_ROWS][8 + 1];          // d(pre-activation of the logits), K <= 8 ... see launcher
-  __shared__ float dh[HB_MAX_ROWS][D_HEAD + 1];     // d(pre-activation of h)
-  __shared__ float dg[HB_MAX_ROWS][D_PROJ + 1];     // d(pre-activation of hproj)
-  __shared__ float ds[HB_MAX_ROWS][D_SUP + 1];      // d(pre-activation of sup_fv)
-  __shared__ float xs[HB_MAX_ROWS][HB_SLICE + 1];   // this workgroup's slice of x4
+  extern __shared__ __attribute__((aligned(16))) float hb[];
+  float* dl = hb + HbLds::DL;
+  float* dh = hb + HbLds::DH;
+  float* dg = hb + HbLds::DG;
+  float* ds = hb + HbLds::DS;
+  float* xs = hb + HbLds::XS;
+  float* sups = hb + HbLds::SUP;
+  float* hs = hb + HbLds::HH;
+  float* dsi = hb + HbLds::DSI;
+  float* W2s = hb + HbLds::W2;
+  float* Whs = hb + HbLds::WH;
+  float* Wgs = hb + HbLds::WG;
+  float* W1s = hb + HbLds::W1;
   const int tid = threadIdx.x, B = p.B, K = p.K;
   const bool head = p.Wh != nullptr, proj = p.Wg != nullptr && p.d_hproj != nullptr;
   const int din2 = head ? D_HEAD : D_SUP;
   const int c0 = blockIdx.x * HB_SLICE;
 
-  // slice of x4 (for dW1) -- issued first, consumed last
+  // ---- (0) one burst of global reads: activations, incoming gradients, weights
   for (int q = tid; q < B * (HB_SLICE / 4); q += 256) {
     const int r = q / (HB_SLICE / 4), c4 = (q - r * (HB_SLICE / 4)) << 2;
     const f32x4 v = load4(p.x4 + (long)r * D_IN + c0 + c4);
-    xs[r][c4 + 0] = v.x; xs[r][c4 + 1] = v.y; xs[r][c4 + 2] = v.z; xs[r][c4 + 3] = v.w;
+    xs[r * 33 + c4 + 0] = v.x; xs[r * 33 + c4 + 1] = v.y; xs[r * 33 + c4 + 2] = v.z; xs[r * 33 + c4 + 3] = v.w;
   }
-  // (1) through the ELUs of the outputs
   for (int q = tid; q < B * K; q += 256) {
     const int r = q / K, o = q - r * K;
-    dl[r][o] = p.d_logits != nullptr ? p.d_logits[q] * elu_grad_from_out(p.logits[q]) : 0.f;
+    dl[r * 9 + o] = p.d_logits != nullptr ? p.d_logits[q] * elu_grad_from_out(p.logits[q]) : 0.f;
   }
   if (proj)
     for (int q = tid; q < B * D_PROJ; q += 256)
-      dg[q >> 6][q & 63] = p.d_hproj[q] * elu_grad_from_out(p.hproj[q]);
+      dg[(q >> 6) * 65 + (q & 63)] = p.d_hproj[q] * elu_grad_from_out(p.hproj[q]);
+  for (int q = tid; q < B * D_SUP; q += 256) {
+    sups[(q >> 5) * 33 + (q & 31)] = p.sup_fv[q];
+    dsi[(q >> 5) * 33 + (q & 31)] = p.d_sup != nullptr ? p.d_sup[q] : 0.f;
+  }
+  if (head) {
+    for (int q = tid; q < B * D_HEAD; q += 256) hs[(q >> 4) * 17 + (q & 15)] = p.h[q];
+    for (int q = tid; q < D_HEAD * D_SUP; q += 256) Whs[(q >> 5) * 33 + (q & 31)] = p.Wh[q];
+  }
+  for (int q = tid; q < K * din2; q += 256) W2s[(q / din2) * 33 + (q % din2)] = p.W2[q];
+  if (proj)
+    for (int q = tid; q < D_PROJ * D_SUP; q += 256) Wgs[(q >> 5) * 33 + (q & 31)] = p.Wg[q];
+  for (int q = tid; q < D_SUP * HB_SLICE; q += 256) W1s[(q >> 5) * 33 + (q & 31)] = p.W1[(long)(q >> 5) * D_IN + c0 + (q & 31)];
   __syncthreads();
-  // (2) projection head
+
+  // ---- (2) projection head
   if (head) {
     for (int q = tid; q < B * D_HEAD; q += 256) {
       const int r = q >> 4, j = q & 15;
       float acc = 0.f;
-      for (int o = 0; o < K; ++o) acc = fmaf(dl[r][o], p.W2[o * D_HEAD + j], acc);
-      dh[r][j] = acc * elu_grad_from_out(p.h[q]);
+      for (int o = 0; o < K; ++o) acc = fmaf(dl[r * 9 + o], W2s[o * 33 + j], acc);
+      dh[r * 17 + j] = acc * elu_grad_from_out(hs[r * 17 + j]);
     }
     __syncthreads();
   }
-  // (3) sup_fv: everything that arrives there, then through its ELU
+  // ---- (3) sup_fv: everything that arrives there, then through its ELU
   for (int q = tid; q < B * D_SUP; q += 256) {
     const int r = q >> 5, i = q & 31;
-    float acc = p.d_sup != nullptr ? p.d_sup[q] : 0.f;
+    float acc = dsi[r * 33 + i];
     if (head) {
 #pragma unroll
-      for (int j = 0; j < D_HEAD; ++j) acc = fmaf(dh[r][j], p.Wh[j * D_SUP + i], acc);
+      for (int j = 0; j < D_HEAD; ++j) acc = fmaf(dh[r * 17 + j], Whs[j * 33 + i], acc);
     } else {
-      for (int o = 0; o < K; ++o) acc = fmaf(dl[r][o], p.W2[o * D_SUP + i], acc);
+      for (int o = 0; o < K; ++o) acc = fmaf(dl[r * 9 + o], W2s[o * 33 + i], acc);
     }
     if (proj) {
 #pragma unroll 8
-      for (int g = 0; g < D_PROJ; ++g) acc = fmaf(dg[r][g], p.Wg[g * D_SUP + i], acc);
+      for (int g = 0; g < D_PROJ; ++g) acc = fmaf(dg[r * 65 + g], Wgs[g * 33 + i], acc);
     }
-    ds[r][i] = acc * elu_grad_from_out(p.sup_fv[q]);
+    ds[r * 33 + i] = acc * elu_grad_from_out(sups[r * 33 + i]);
   }
   __syncthreads();
 
-  // (4) this workgroup's slice of the wide layer: dx4[:, c0:c0+32] and dW1[:, c0:c0+32]
+  // ---- (4) this workgroup's slice of the wide layer: dx4[:, c0:c0+32] and dW1[:, c0:c0+32]
   for (int q = tid; q < B * HB_SLICE; q += 256) {
     const int r = q >> 5, c = q & 31;
     float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < D_SUP; ++i) acc = fmaf(ds[r][i], p.W1[(long)i * D_IN + c0 + c], acc);
+    for (int i = 0; i < D_SUP; ++i) acc = fmaf(ds[r * 33 + i], W1s[i * 33 + c], acc);
     p.dx4[(long)r * D_IN + c0 + c] = acc;
   }
   for (int q = tid; q < D_SUP * HB_SLICE; q += 256) {
     const int i = q >> 5, c = q & 31;
     float acc = 0.f;
-    for (int r = 0; r < B; ++r) acc = fmaf(ds[r][i], xs[r][c], acc);
+    for (int r = 0; r < B; ++r) acc = fmaf(ds[r * 33 + i], xs[r * 33 + c], acc);
     p.dW1[(long)i * D_IN + c0 + c] = acc;
   }
 
-  // (5) the small gradients, spread over the workgroups by a running job index
+  // ---- (5) the small gradients, spread over the workgroups by a running job index
   const int nwg = gridDim.x;
   int job = 0;
   auto mine = [&](int j) { return (j % nwg) == (int)blockIdx.x; };
@@ -187,29 +230,28 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsBwdParams p) {
     for (int q = tid; q < D_SUP + K + (head ? D_HEAD : 0) + (proj ? D_PROJ : 0); q += 256) {
       float acc = 0.f;
       if (q < D_SUP) {
-        for (int r = 0; r < B; ++r) acc += ds[r][q];
+        for (int r = 0; r < B; ++r) acc += ds[r * 33 + q];
         p.db1[q] = acc;
       } else if (q < D_SUP + K) {
         const int o = q - D_SUP;
-        for (int r = 0; r < B; ++r) acc += dl[r][o];
+        for (int r = 0; r < B; ++r) acc += dl[r * 9 + o];
         p.db2[o] = acc;
       } else if (head && q < D_SUP + K + D_HEAD) {
         const int j = q - D_SUP - K;
-        for (int r = 0; r < B; ++r) acc += dh[r][j];
+        for (int r = 0; r < B; ++r) acc += dh[r * 17 + j];
         p.dbh[j] = acc;
       } else {
         const int g = q - D_SUP - K - (head ? D_HEAD : 0);
-        for (int r = 0; r < B; ++r) acc += dg[r][g];
+        for (int r = 0; r < B; ++r) acc += dg[r * 65 + g];
         p.dbg[g] = acc;
       }
     }
   }
   if (mine(job++)) {            // dW2 [K, din2] = dl^T . (h | sup_fv)
-    const float* a = head ? p.h : p.sup_fv;
     for (int q = tid; q < K * din2; q += 256) {
       const int o = q / din2, j = q - o * din2;
       float acc = 0.f;
-      for (int r = 0; r < B; ++r) acc = fmaf(dl[r][o], a[r * din2 + j], acc);
+      for (int r = 0; r < B; ++r) acc = fmaf(dl[r * 9 + o], head ? hs[r * 17 + j] : sups[r * 33 + j], acc);
       p.dW2[q] = acc;
     }
   }
@@ -217,7 +259,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsBwdParams p) {
     for (int q = tid; q < D_HEAD * D_SUP; q += 256) {
       const int j = q >> 5, i = q & 31;
       float acc = 0.f;
-      for (int r = 0; r < B; ++r) acc = fmaf(dh[r][j], p.sup_fv[r * D_SUP + i], acc);
+      for (int r = 0; r < B; ++r) acc = fmaf(dh[r * 17 + j], sups[r * 33 + i], acc);
       p.dWh[q] = acc;
     }
   }
@@ -227,7 +269,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsBwdParams p) {
       for (int q = tid; q < 16 * D_SUP; q += 256) {
         const int g = part * 16 + (q >> 5), i = q & 31;
         float acc = 0.f;
-        for (int r = 0; r < B; ++r) acc = fmaf(dg[r][g], p.sup_fv[r * D_SUP + i], acc);
+        for (int r = 0; r < B; ++r) acc = fmaf(dg[r * 65 + g], sups[r * 33 + i], acc);
         p.dWg[g * D_SUP + i] = acc;
       }
     }
@@ -271,6 +313,15 @@ extern "C" int pcaa_heads_bwd(const float* x4, const float* sup_fv, const float*
   PCAA_CHECK_ARG(((uintptr_t)x4 % 16) == 0, "pcaa_heads_bwd: x4 must be 16-B aligned");
   HeadsBwdParams p{x4, sup_fv, h, logits, hproj, W1, Wh, W2, Wg, d_logits, d_sup, d_hproj,
                    dW1, db1, dWh, dbh, dW2, db2, dWg, dbg, dx4, B, K};
-  hipLaunchKernelGGL(heads_bwd_kernel, dim3(D_IN / HB_SLICE), dim3(256), 0, as_stream(stream), p);
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(heads_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            HB_LDS_BYTES) != hipSuccess) {
+      pcaa_set_error("pcaa_heads_bwd: cannot raise the LDS limit to %d bytes", HB_LDS_BYTES);
+      return PCAA_ERR_LAUNCH;
+    }
+    configured = true;
+  }
+  hipLaunchKernelGGL(heads_bwd_kernel, dim3(D_IN / HB_SLICE), dim3(256), HB_LDS_BYTES, as_stream(stream), p);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_heads_bwd");
 }
