@@ -325,6 +325,40 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ base, long l
   for (int j = 0; j < 4; ++j) dma_piece<LAY>(base, ld, row0, R, k0, s_tile, wave, lane, j);
 }
 
+// The same piece through a buffer resource (buffer_load_dwordx4 ... offen lds): the per-lane part of the source address
+// is a 32-bit offset that never changes (row-in-piece, swizzled granule; it depends on the piece only through its
+// parity), everything else -- tile origin, piece, K step -- is wave-uniform and rides in the scalar offset.  A piece
+// then costs the vector ALU nothing (the flat form spent ~7 VALU instructions per piece on 64-bit address arithmetic,
+// on the issue port the MFMAs share).  Whole-tile shapes only: no row clamp; operands below 4 GiB.
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_rsrc(const void* base, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(unsigned)bytes, 0x00020000);
+}
+// per-lane byte offsets for pieces of even / odd index
+template <int LAY>
+__device__ __forceinline__ void piece_lane_offsets(long ld, int lane, unsigned (&voff)[2]) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    if (LAY == KC) {
+      const int g = (lane & 7) ^ ((4 * e + (lane >> 4)) & 7);            // r >> 1 = 4 p + (lane >> 4)
+      voff[e] = (unsigned)((lane >> 3) * ld * 2 + 16 * g);
+    } else {
+      const int c = (lane & 31) ^ (4 * ((2 * e + (lane >> 5)) & 3));     // k & 3 = (2 p + (lane >> 5)) & 3
+      voff[e] = (unsigned)((lane >> 5) * ld * 2 + 16 * c);
+    }
+  }
+}
+// wave (scalar) and j select the piece p = 4 wave + j; row0 / k0 as in dma_piece
+template <int LAY>
+__device__ __forceinline__ void dma_piece_buf(buf_rsrc_t rsrc, long ld, int row0, int k0, bf16_t* s_tile, int wave,
+                                              const unsigned (&voff)[2], int j) {
+  const int p = wave * 4 + j;
+  const unsigned soff = LAY == KC ? (unsigned)(((long)(row0 + 8 * p) * ld + k0) * 2)
+                                  : (unsigned)(((long)(k0 + 2 * p) * ld + row0) * 2);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(s_tile + p * 512), 16,
+                                           voff[j & 1], soff, 0, 0);
+}
+
 // Accumulator layouts of the two bf16 MFMA shapes (a wave owns 128 rows x 64 columns of the tile):
 //   MF = 32: v_mfma_f32_32x32x16_bf16, 4 x 2 blocks of f32x16; MF = 16: v_mfma_f32_16x16x32_bf16, 8 x 4 blocks of f32x4.
 // In both, registers r (even) and r+1 of a block are two consecutive rows of one column, neighbouring lanes
@@ -366,6 +400,11 @@ __device__ __forceinline__ void park_bf16(typename AccLayout<MF>::vec (&acc)[Acc
   typedef AccLayout<MF> L;
   uint32_t* w32 = reinterpret_cast<uint32_t*>(wave_img);
   const bool odd = lane & 1;
+  // mine = {row R, row R+1} of my column as two bf16; theirs = the same of the neighbouring column (one DPP move).
+  // even lane stores row R: (mine.lo, theirs.lo); odd lane stores row R+1: (theirs.hi, mine.hi) -- one v_perm_b32 with
+  // a per-lane byte selector instead of three selects per pair (the epilogue is VALU-issue bound: ~1000 vector
+  // instructions per wave and tile at 2 cycles each with both waves of a SIMD in it)
+  const uint32_t sel = odd ? 0x03020706u : 0x05040100u;       // bytes 0-3 = mine (S1), 4-7 = theirs (S0)
 #pragma unroll
   for (int j = 0; j < L::NB; ++j) {
     const int colw = (L::col(j, lane) & ~1) >> 1;            // 32-bit word index of the column pair
@@ -373,10 +412,9 @@ __device__ __forceinline__ void park_bf16(typename AccLayout<MF>::vec (&acc)[Acc
     for (int i = 0; i < L::MB; ++i)
 #pragma unroll
       for (int r = 0; r < L::NR; r += 2) {
-        const float va = f(acc[i][j][r], j), vb = f(acc[i][j][r + 1], j);   // rows R and R+1, my column
-        const float got = dpp_swap_neighbour(odd ? va : vb);
-        // even lane: row R, (mine, right neighbour's) ; odd lane: row R+1, (left neighbour's, mine)
-        const uint32_t packed = odd ? pack2(got, vb) : pack2(va, got);
+        const uint32_t mine = pack2(f(acc[i][j][r], j), f(acc[i][j][r + 1], j));
+        const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, true);
+        const uint32_t packed = __builtin_amdgcn_perm(theirs, mine, sel);
         const int row = L::row(i, r, lane) + (odd ? 1 : 0);
         w32[row * (EP_PITCH / 2) + colw] = packed;
       }
@@ -407,14 +445,16 @@ __device__ __forceinline__ void epilogue_full_tile(const GemmParams& p,
       esc[j] = AFFINE ? p.ep_scale[gc] : 1.f;
       esh[j] = AFFINE ? p.ep_shift[gc] : 0.f;
     }
-    park_bf16<MF>(acc, w, lane, [&](float v, int j) {
-      v += bv[j];
-      if constexpr (AFFINE) {
-        v = fmaf(v, esc[j], esh[j]);
-        v = v > 0.f ? v : __expf(v) - 1.f;
-      }
-      return v;
-    });
+    if constexpr (AFFINE) {
+      park_bf16<MF>(acc, w, lane, [&](float v, int j) {
+        v = fmaf(v + bv[j], esc[j], esh[j]);
+        return v > 0.f ? v : __expf(v) - 1.f;
+      });
+    } else if (add_bias) {                   // (uniform) the BatchNorm layers pass no bias: keep 128 adds out of their way
+      park_bf16<MF>(acc, w, lane, [&](float v, int j) { return v + bv[j]; });
+    } else {
+      park_bf16<MF>(acc, w, lane, [](float v, int) { return v; });
+    }
     __syncthreads();
     bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + (long)(tm * BM + wm * 128) * p.ldc + tn * BN + wn * 64;
     const int cg = (lane & 7) * 8, r0 = lane >> 3;
@@ -454,19 +494,20 @@ __device__ __forceinline__ void epilogue_colstats(const GemmParams& p,
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   float* red = reinterpret_cast<float*>(smem_raw);   // [2 stats][2 wm][256 cols]
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int j = 0; j < L::NB; ++j) {
-    float s1 = 0.f, s2 = 0.f;
+    f32x2 a1 = {0.f, 0.f}, a2 = {0.f, 0.f};      // two partial sums each: v_pk_add_f32 / v_pk_fma_f32
 #pragma unroll
     for (int i = 0; i < L::MB; ++i)
 #pragma unroll
-      for (int r = 0; r < L::NR; ++r) {
-        const float v = acc[i][j][r];
-        s1 += v;
-        s2 += v * v;
+      for (int r = 0; r < L::NR; r += 2) {
+        const f32x2 v = {acc[i][j][r], acc[i][j][r + 1]};
+        a1 += v;
+        a2 = __builtin_elementwise_fma(v, v, a2);
       }
-    s1 = L::colreduce(s1);
-    s2 = L::colreduce(s2);
+    float s1 = L::colreduce(a1.x + a1.y);
+    float s2 = L::colreduce(a2.x + a2.y);
     if (L::col_leader(lane)) {
       const int col = wn * 64 + L::col(j, lane);
       red[(0 * 2 + wm) * 256 + col] = s1;
@@ -660,14 +701,15 @@ __device__ __forceinline__ void step_barrier() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <typename TC, int ALAY, int BLAY, int EPI, int MF>
+template <typename TC, int ALAY, int BLAY, int EPI, int MF, bool BUF>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   typedef AccLayout<MF> L;
   static_assert(MF == 32 || (ALAY == KC && BLAY == KC), "the 16x16x32 fragments are built for KC operands");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: piece indices and LDS bases are SGPR math
   const int wm = wave >> 2, wn = wave & 3;
   int tm, tn;
   const int split = block_coords(p, p.M / BM, p.N / BN, tm, tn);
@@ -677,6 +719,31 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   const int nt = (kend - kbeg) / BK;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
   const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+  // buffer resources over the whole operands (A: M x lda or K x lda elements, B likewise)
+  buf_rsrc_t rA = make_rsrc(A, 0), rB = make_rsrc(B, 0);
+  unsigned voA[2] = {0, 0}, voB[2] = {0, 0};
+  if (BUF) {
+    rA = make_rsrc(A, (long)(ALAY == KC ? p.M : p.K) * p.lda * 2);
+    rB = make_rsrc(B, (long)(BLAY == KC ? p.N : p.K) * p.ldb * 2);
+    piece_lane_offsets<ALAY>(p.lda, lane, voA);
+    piece_lane_offsets<BLAY>(p.ldb, lane, voB);
+  }
+  // one 1-KB piece of the A (which = 0) or B (1) tile of the K step starting at k0 into stage image s_tile
+  auto piece = [&](int which, int k0, bf16_t* s_tile, int j) {
+    if (BUF) {
+      if (which == 0) dma_piece_buf<ALAY>(rA, p.lda, tm * BM, k0, s_tile, wave, voA, j);
+      else dma_piece_buf<BLAY>(rB, p.ldb, tn * BN, k0, s_tile, wave, voB, j);
+    } else {
+      if (which == 0) dma_piece<ALAY>(A, p.lda, tm * BM, p.M, k0, s_tile, wave, lane, j);
+      else dma_piece<BLAY>(B, p.ldb, tn * BN, p.N, k0, s_tile, wave, lane, j);
+    }
+  };
+  auto tile = [&](int k0, bf16_t* sA_) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) piece(0, k0, sA_, j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) piece(1, k0, sA_ + D_TILE, j);
+  };
 
   typename L::vec acc[L::MB][L::NB];
 #pragma unroll
@@ -686,10 +753,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < L::NR; ++r) acc[i][j][r] = 0.f;
 
-  if (nt > 0) {
-    dma_tile<ALAY>(A, p.lda, tm * BM, p.M, kbeg, smem, wave, lane);
-    dma_tile<BLAY>(B, p.ldb, tn * BN, p.N, kbeg, smem + D_TILE, wave, lane);
-  }
+  if (nt > 0) tile(kbeg, smem);
   step_barrier();
 
   if constexpr (MF == 32) {
@@ -714,10 +778,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
       bf16_t* nA = smem + ((t + 1) & 1) * 2 * D_TILE;
       const int k0 = kbeg + (t + 1) * BK;
       const bool more = t + 1 < nt;
-      if (more && !kFine) {
-        dma_tile<ALAY>(A, p.lda, tm * BM, p.M, k0, nA, wave, lane);
-        dma_tile<BLAY>(B, p.ldb, tn * BN, p.N, k0, nA + D_TILE, wave, lane);
-      }
+      if (more && !kFine) tile(k0, nA);
       // software-pipelined fragment reads: the 6 ds_reads of k-step ks+1 are issued before the 8
       // MFMAs of k-step ks, so only the first read group of a stage exposes LDS latency
       bf16x8 af[2][4], bfr[2][2];
@@ -740,8 +801,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
         for (int g = 0; g < 2; ++g) {
           if (kFine && more) {
             const int pc = 2 * ks + g;
-            if (pc < 4) dma_piece<ALAY>(A, p.lda, tm * BM, p.M, k0, nA, wave, lane, pc);
-            else dma_piece<BLAY>(B, p.ldb, tn * BN, p.N, k0, nA + D_TILE, wave, lane, pc - 4);
+            if (pc < 4) piece(0, k0, nA, pc);
+            else piece(1, k0, nA + D_TILE, pc - 4);
           }
 #pragma unroll
           for (int i = 2 * g; i < 2 * g + 2; ++i)
@@ -793,8 +854,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
         for (int g = 0; g < 2; ++g) {
           if (more) {
             const int pc = 2 * blk + g;
-            if (pc < 4) dma_piece<KC>(A, p.lda, tm * BM, p.M, k0, nA, wave, lane, pc);
-            else dma_piece<KC>(B, p.ldb, tn * BN, p.N, k0, nA + D_TILE, wave, lane, pc - 4);
+            if (pc < 4) piece(0, k0, nA, pc);
+            else piece(1, k0, nA + D_TILE, pc - 4);
           }
 #pragma unroll
           for (int i = 2 * g; i < 2 * g + 2; ++i)
@@ -823,11 +884,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
 // 32x32x16, but the chip holds a higher clock on it (MI355X_MICROARCH.md, DVFS item 7); same-box A/B on the three
 // PointNet shapes (median of 5 interleaved rounds): forward +9.2 / -0.7 / +2.6 %, fused dgrad +4.4 / +4.0 / +1.9 %.
 // RC x RC (wgrad) keeps 32x32x16: its fragments come from ds_read_b64_tr_b16 pairs laid out for that shape.
-template <typename TC, int ALAY, int BLAY, int EPI>
-bool launch_dma(const GemmParams& p, dim3 grid, hipStream_t s) {
+template <typename TC, int ALAY, int BLAY, int EPI, bool BUF>
+bool launch_dma_inst(const GemmParams& p, dim3 grid, hipStream_t s) {
   constexpr int MF = ALAY == KC ? 16 : 32;
   static bool configured = false;
-  auto kern = gemm_bf16_dma_kernel<TC, ALAY, BLAY, EPI, MF>;
+  auto kern = gemm_bf16_dma_kernel<TC, ALAY, BLAY, EPI, MF, BUF>;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             D_LDS_BYTES) != hipSuccess)
@@ -840,6 +901,16 @@ bool launch_dma(const GemmParams& p, dim3 grid, hipStream_t s) {
   else
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), D_LDS_BYTES, s, p);
   return true;
+}
+
+template <typename TC, int ALAY, int BLAY, int EPI>
+bool launch_dma(const GemmParams& p, dim3 grid, hipStream_t s) {
+  // buffer addressing needs each operand below 4 GiB (32-bit offsets); the flat form serves anything larger.  Same-box
+  // A/B (profiles/r02_gemm_lab2.txt): forward / fused dgrad +1..3 %, wgrad (whole stage issued at the top of the step:
+  // 8 pieces x ~7 VALU each in front of the first MFMA) +2.6 / +7.3 / +10.1 % on the three PointNet shapes.
+  const long a_bytes = (long)(ALAY == KC ? p.M : p.K) * p.lda * 2, b_bytes = (long)(BLAY == KC ? p.N : p.K) * p.ldb * 2;
+  if (a_bytes < (1L << 32) && b_bytes < (1L << 32)) return launch_dma_inst<TC, ALAY, BLAY, EPI, true>(p, grid, s);
+  return launch_dma_inst<TC, ALAY, BLAY, EPI, false>(p, grid, s);
 }
 
 template <typename TA, typename TB, typename TC, int ALAY, int BLAY>

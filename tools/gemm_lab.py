@@ -4,8 +4,9 @@ layer below, slab split-K wgrad) on the PointNet shapes of BASELINE config[1] (P
 each is checked against an fp32 product of the same bf16 operands, then timed in interleaved rounds in ONE process
 (cdna_hip_programming.md rule 24) next to rocBLAS/hipBLASLt through torch.matmul on the same operands.
 
-History (round 2, profiles/r02_gemm_lab.txt): this harness A/B-ed the MFMA shape (16x16x32 adopted for the
-KC x KC instantiations) and a software L2 prefetch of the streamed operand (rejected: 3-10 % slower).
+History (round 2): this harness A/B-ed the MFMA shape (16x16x32 adopted for the KC x KC instantiations), a software L2
+prefetch of the streamed operand (rejected: 3-10 % slower; profiles/r02_gemm_lab.txt) and buffer-resource addressing of
+the LDS-DMA pieces (adopted: +1..10 %; profiles/r02_gemm_lab2.txt, rows "mf= 0" flat / "mf= 1" buffer).
 
     python tools/gemm_lab.py [--rounds 5] [--iters 10]
 """
@@ -127,7 +128,7 @@ def main():
                 med = t[len(t) // 2]
                 print(f"[{cin}->{cout}] {c:10s} mf={v[0]:2d} pf={v[1]}  median {med:.3f} ms  {fl / med / 1e9:7.1f} TF   "
                       f"min {t[0]:.3f}", flush=True)
-    lab_set(32, 0)
+    lab_set(1, 0)
 
 
 if __name__ == "__main__":
