@@ -6,4 +6,4 @@ grep -E "passed|failed|rc=|agreement|rel-l2" $R/gpurun_out/r2_suite.log | tail -
 python bench.py --steps 20 --warmup 5 > $R/gpurun_out/r2_bench_train.json 2> $R/gpurun_out/r2_bench_train.err; tail -c 1500 $R/gpurun_out/r2_bench_train.json
 python bench.py --workload sweep --steps 20 --warmup 5 > $R/gpurun_out/r2_bench_sweep.json 2> $R/gpurun_out/r2_bench_sweep.err; tail -c 2500 $R/gpurun_out/r2_bench_sweep.json
 python bench.py --workload infer --steps 10 --warmup 3 > $R/gpurun_out/r2_bench_infer.json 2> $R/gpurun_out/r2_bench_infer.err; tail -c 1500 $R/gpurun_out/r2_bench_infer.json
-tail -3 $R/gpurun_out/r2_bench_*.err
+for f in $R/gpurun_out/r2_bench_*.err; do tail -n 3 "$f"; done
