@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PCAA_ABI_VERSION 6 /* pcaa_abi_version() of a library built from this header */
+#define PCAA_ABI_VERSION 7 /* pcaa_abi_version() of a library built from this header */
 
 #define PCAA_OK 0
 #define PCAA_ERR_INVALID_ARG 1
@@ -321,6 +321,15 @@ int pcaa_skinny_linear_dgrad(const float* dz, long lddz, const float* W, long ld
                              int K, int nsplit, void* stream);
 int pcaa_skinny_linear_wgrad(const float* dz, long lddz, const float* x, long ldx, float* dW, long lddw,
                              int M, int N, int K, void* stream);
+/* The same product fused with optimizer_G's Adam update of that weight (PCAA_ablation.py:1018-1021: backward,
+ * then optimizer_G.step()): dW[N,K] = dz^T x stays in registers, W / exp_avg / exp_avg_sq [N,ldw] are read and
+ * written in place -- torch.optim.Adam's update with the step-dependent scalars from coef_dev (pcaa_adam_advance),
+ * bit-identical to pcaa_skinny_linear_wgrad followed by pcaa_adam_step_dev on the same buffers.  W must not be
+ * read by anything still in flight (the layer's dgrad).  Single-process training only. */
+int pcaa_skinny_linear_wgrad_adam(const float* dz, long lddz, const float* x, long ldx, float* W,
+                                  float* exp_avg, float* exp_avg_sq, long ldw, int M, int N, int K,
+                                  float beta1, float beta2, float eps, float grad_scale,
+                                  const float* coef_dev, void* stream);
 
 /* ------------------------------------------------------------------ temporal block, fused forward
  * One DilTempConv1d layer (models.py:37-79) in one launch: implicit im2col of the causal dilated

@@ -77,6 +77,19 @@ __device__ __forceinline__ float load1(const bf16_t* p) { return (float)*p; }
 __device__ __forceinline__ void store1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void store1(bf16_t* p, float v) { *p = (bf16_t)v; }
 
+// One element of torch.optim.Adam (amsgrad off, no weight decay; step_size = lr / (1 - b1^t), inv_bc2_sqrt =
+// 1 / sqrt(1 - b2^t)) with its rounding points FIXED (explicit fused multiply-adds, no contraction elsewhere):
+// every kernel that applies the update -- the flat-buffer pass and the decoder's weight-gradient kernel --
+// produces the same bits from the same operands.
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, float b1, float b2, float eps,
+                                            float step_size, float inv_bc2_sqrt) {
+#pragma clang fp contract(off)
+  m = __builtin_fmaf(b1, m, (1.f - b1) * g);
+  v = __builtin_fmaf(b2, v, ((1.f - b2) * g) * g);
+  const float denom = __builtin_fmaf(sqrtf(v), inv_bc2_sqrt, eps);
+  p = __builtin_fmaf(-step_size, m / denom, p);
+}
+
 // block-wide sum of one float (blockDim.x multiple of 64, <= 1024); result valid in thread 0
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

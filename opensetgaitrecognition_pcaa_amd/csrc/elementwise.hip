@@ -463,11 +463,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
       if (q >= nq) break;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float gg = gv[u][e] * grad_scale;
-        mv[u][e] = b1 * mv[u][e] + (1.f - b1) * gg;
-        vv[u][e] = b2 * vv[u][e] + (1.f - b2) * gg * gg;
-        const float denom = sqrtf(vv[u][e]) * inv_bc2_sqrt + eps;
-        pv[u][e] -= step_size * (mv[u][e] / denom);
+        float pe = pv[u][e], me = mv[u][e], ve = vv[u][e];
+        adam_update(pe, me, ve, gv[u][e] * grad_scale, b1, b2, eps, step_size, inv_bc2_sqrt);
+        pv[u][e] = pe; mv[u][e] = me; vv[u][e] = ve;
       }
       store4(p + q * 4, pv[u]);
       store4(m + q * 4, mv[u]);
@@ -477,12 +475,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   // tail (n % 4)
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const long i = (nq << 2) + threadIdx.x;
-    const float gg = g[i] * grad_scale;
-    const float mm = b1 * m[i] + (1.f - b1) * gg;
-    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    float pp = p[i], mm = m[i], vv = v[i];
+    adam_update(pp, mm, vv, g[i] * grad_scale, b1, b2, eps, step_size, inv_bc2_sqrt);
     m[i] = mm;
     v[i] = vv;
-    p[i] -= step_size * (mm / (sqrtf(vv) * inv_bc2_sqrt + eps));
+    p[i] = pp;
   }
 }
 

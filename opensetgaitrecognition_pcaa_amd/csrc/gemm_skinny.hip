@@ -361,6 +361,113 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------ wgrad + Adam: W -= step(dz^T . x)
+// Same contraction as skinny_wgrad_kernel, but the 128 x 32 tile of dW a wave has just formed never leaves its
+// registers: the wave reads W, exp_avg, exp_avg_sq at the addresses it would have stored dW to, applies Adam (the
+// arithmetic of elementwise.hip's adam_kernel, expression for expression: fused and unfused updates are bit-identical)
+// (common.h adam_update) and writes the three back -- 24 B per parameter instead of 4 (dW store) + 28 (Adam pass).  One 32 x 32 fragment's
+// operands (48 dwords per lane) are in flight while the previous fragment is updated.  Single-process training only:
+// a data-parallel step needs the reduced gradient before the update.
+template <int JL, bool FULLN>
+__global__ __launch_bounds__(256) void skinny_wgrad_adam_kernel(const float* __restrict__ dz, long lddz,
+                                                                const float* __restrict__ x, long ldx,
+                                                                float* __restrict__ W, float* __restrict__ mo,
+                                                                float* __restrict__ vo, long ldw, int M, int N, int K,
+                                                                float b1, float b2, float eps, float grad_scale,
+                                                                const float* __restrict__ coef) {
+  __shared__ __attribute__((aligned(16))) bf16x8 apan[4][4][64];      // [row fragment i][k-step s][lane]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.y * 128;
+  const int kb = (blockIdx.x * 4 + wave) * (32 * JL);
+  const int jn = kb < K ? min(JL, (K - kb) / 32) : 0;
+  const float step_size = coef[0], inv_bc2_sqrt = coef[1];
+  {
+    const int s = wave;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned ncol = (unsigned)min(n0 + 32 * i + l31, N - 1);
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int m = 16 * s + 8 * h + e;
+        const float v = dz[(unsigned)min(m, M - 1) * (unsigned)lddz + ncol];
+        t[e] = m < M ? v : 0.f;
+      }
+      apan[i][s][lane] = pack8(t);
+    }
+  }
+  unsigned xoff[4][8];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      xoff[s][e] = (unsigned)min(16 * s + 8 * h + e, M - 1) * (unsigned)ldx + min(kb, K - 32) + l31;
+  float br[4][8];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) br[s][e] = x[xoff[s][e]];
+  __syncthreads();
+
+  const unsigned row0 = (unsigned)(n0 + 4 * h);
+  for (int j = 0; j < jn; ++j) {
+    bf16x8 bf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bf[s] = pack8(br[s]);
+    {
+      const float* xn = x + 32 * min(j + 1, jn - 1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) br[s][e] = xn[xoff[s][e]];
+    }
+    const long tile = kb + 32 * j;                         // uniform
+    float* Wj = W + tile;
+    float* mj = mo + tile;
+    float* vj = vo + tile;
+    unsigned o0 = row0 * (unsigned)ldw + l31;
+    asm volatile("" : "+v"(o0) : : "memory");
+    float pw[2][16], pm[2][16], pv[2][16];
+    auto fetch = [&](int i, int b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned rr = 32 * i + (r & 3) + 8 * (r >> 2);
+        if (FULLN || row0 + rr < (unsigned)N) {
+          const unsigned o = o0 + rr * (unsigned)ldw;
+          pw[b][r] = Wj[o]; pm[b][r] = mj[o]; pv[b][r] = vj[o];
+        }
+      }
+    };
+    fetch(0, 0);
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apan[i][s][lane], bf[s], acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = i & 1;
+      if (i + 1 < 4) fetch(i + 1, b ^ 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned rr = 32 * i + (r & 3) + 8 * (r >> 2);
+        if (FULLN || row0 + rr < (unsigned)N) {
+          const unsigned o = o0 + rr * (unsigned)ldw;
+          adam_update(pw[b][r], pm[b][r], pv[b][r], acc[i][r] * grad_scale, b1, b2, eps, step_size, inv_bc2_sqrt);
+          Wj[o] = pw[b][r];
+          mj[o] = pm[b][r];
+          vj[o] = pv[b][r];
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ slab reduction (+ bias/ELU, or * ELU'(a_prev))
 __global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* __restrict__ slabs, int ns, long stride,
                                                             float* __restrict__ out, const float* __restrict__ bias,
@@ -479,4 +586,25 @@ extern "C" int pcaa_skinny_linear_wgrad(const float* dz, long lddz, const float*
     hipLaunchKernelGGL((skinny_wgrad_kernel<JL, false>), grid, dim3(256), 0, as_stream(stream), dz, lddz, x, ldx, dW,
                        lddw, M, N, K);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_wgrad");
+}
+
+extern "C" int pcaa_skinny_linear_wgrad_adam(const float* dz, long lddz, const float* x, long ldx, float* W,
+                                             float* exp_avg, float* exp_avg_sq, long ldw, int M, int N, int K,
+                                             float beta1, float beta2, float eps, float grad_scale,
+                                             const float* coef_dev, void* stream) {
+  PCAA_CHECK_ARG(dz && x && W && exp_avg && exp_avg_sq && coef_dev, "pcaa_skinny_linear_wgrad_adam: null pointer");
+  PCAA_CHECK_ARG(M >= 1 && M <= 64 && N >= 1 && K >= 32 && K % 32 == 0,
+                 "pcaa_skinny_linear_wgrad_adam: unsupported shape M=%d N=%d K=%d", M, N, K);
+  PCAA_CHECK_ARG(lddz >= N && ldx >= K && ldw >= K, "pcaa_skinny_linear_wgrad_adam: bad leading dimensions");
+  PCAA_CHECK_ARG((long)M * lddz < (1L << 31) && (long)M * ldx < (1L << 31) && (long)N * ldw < (1L << 30),
+                 "pcaa_skinny_linear_wgrad_adam: operands beyond 32-bit offsets");
+  constexpr int JL = 4;
+  const dim3 grid((unsigned)cdiv(K, 4 * 32 * JL), (unsigned)cdiv(N, 128));
+  if (N % 128 == 0)
+    hipLaunchKernelGGL((skinny_wgrad_adam_kernel<JL, true>), grid, dim3(256), 0, as_stream(stream), dz, lddz, x, ldx,
+                       W, exp_avg, exp_avg_sq, ldw, M, N, K, beta1, beta2, eps, grad_scale, coef_dev);
+  else
+    hipLaunchKernelGGL((skinny_wgrad_adam_kernel<JL, false>), grid, dim3(256), 0, as_stream(stream), dz, lddz, x, ldx,
+                       W, exp_avg, exp_avg_sq, ldw, M, N, K, beta1, beta2, eps, grad_scale, coef_dev);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_wgrad_adam");
 }

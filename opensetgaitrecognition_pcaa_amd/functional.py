@@ -551,15 +551,29 @@ def linear_act_forward(x, lin, act, mode="fp32"):
 
 
 def linear_act_backward(x, a_out, lin, act, d_out, need_dx=True, dW_out=None, db_out=None, dx_init=None,
-                        mode="fp32", d_is_pre=False, fuse_elu_in=False):
+                        mode="fp32", d_is_pre=False, fuse_elu_in=False, update=None):
     """d_out is the gradient w.r.t. the layer output (d_is_pre: already w.r.t. its
     pre-activation).  Returns (dW, db, dx).  fuse_elu_in (skinny path only, x = ELU output of
     the layer below): dx is multiplied by ELU'(x), i.e. it is the gradient w.r.t. that layer's
-    pre-activation -- the caller passes it on with d_is_pre=True."""
+    pre-activation -- the caller passes it on with d_is_pre=True.
+    ``update`` (skinny path only): callable ``update(dz, x)`` that forms the weight gradient AND applies the
+    optimizer to the weight in one kernel (ops.skinny_linear_wgrad_adam_); it is called after the layer's dgrad
+    -- which reads the weight it overwrites -- has been enqueued, and dW is returned as None."""
     M, K = x.shape
     N = lin.weight.shape[0]
     dz = ops.elu_bwd_from_out(d_out, a_out) if (act == ACT_ELU and not d_is_pre) else d_out
     dz2 = dz.view(M, N)
+    if update is not None:
+        if not _skinny(mode, M, N, K):
+            raise RuntimeError("linear_act_backward: a fused weight update is only served by the skinny path")
+        with _on_wgrad_stream(dz2):
+            db = ops.colsum(dz2, out=db_out)
+        dx = None
+        if need_dx:
+            dx = ops.skinny_linear_dgrad(dz2, lin.weight, a_prev=x if fuse_elu_in else None, out=dx_init,
+                                         accumulate=dx_init is not None)
+        update(dz2, x)
+        return None, db, dx
     if _skinny(mode, M, N, K):
         if dW_out is not None and db_out is not None:
             # the weight-gradient write stream (and the bias gradient) beside the dgrad read stream of the same layer
@@ -920,10 +934,12 @@ def decoder_forward(dec, z, mode=None):
     return out, acts
 
 
-def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=None, mode=None, after_layer=None):
+def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=None, mode=None, after_layer=None,
+                     updates=None):
     """``grads_out`` {"denseI.weight"/"denseI.bias": destination}: for a padded decoder (see decoder_forward)
     these are the PADDED gradient tensors; without grads_out the returned gradients are cut to the parameter
-    shapes."""
+    shapes.  ``updates`` {layer number: update(dz, x)}: those layers' weight gradients are formed and consumed by
+    the caller's fused optimizer kernel (linear_act_backward) and come back as None."""
     mode = get_precision() if mode is None else mode
     padded = getattr(dec, "_pcaa_pad", None)
     layers = padded or dec.dense_layers()
@@ -944,14 +960,15 @@ def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=Non
         dW, db, d = linear_act_backward(acts[i], acts[i + 1], lin, ACT_ELU if i < 4 else ACT_NONE, d,
                                         need_dx=(i > 0 or need_dz), dW_out=dW_out, db_out=db_out,
                                         dx_init=dz_init if i == 0 else None, mode=mode, d_is_pre=pre,
-                                        fuse_elu_in=fuse)
+                                        fuse_elu_in=fuse, update=(updates or {}).get(i + 1))
         pre = fuse
         if after_layer is not None:
             after_layer(i + 1)       # trainer hook: layer i+1's weight / bias gradients are enqueued
-        dW = dW.view_as(lin.weight)
+        dW = dW.view_as(lin.weight) if dW is not None else None
         if padded and grads_out is None:
             ref = dec.dense_layers()[i]                  # cut the padding off: gradients in the parameter shapes
-            dW, db = dW[:ref.weight.shape[0], :ref.weight.shape[1]], db[:ref.bias.shape[0]]
+            db = db[:ref.bias.shape[0]]
+            dW = dW[:ref.weight.shape[0], :ref.weight.shape[1]] if dW is not None else None
         g[nm + ".weight"], g[nm + ".bias"] = dW, db
     return g, d
 

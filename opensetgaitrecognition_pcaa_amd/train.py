@@ -165,8 +165,12 @@ class PCAATrainer:
 
     def __init__(self, config, n_classes=None, device="cuda", variant="v4", precision=None,
                  process_group=None, sync_bn=False, learn_centroids=False, dp_zero=False, grad_compress=None,
-                 force_collectives=False):
-        """Data-parallel options (``process_group`` given): ``dp_zero`` True = sharded decoder optimizer
+                 force_collectives=False, fused_decoder_update=True):
+        """``fused_decoder_update`` (single process, bf16 mode): the decoder's wide weight gradients are formed and
+        consumed by one kernel per layer that applies Adam in place (pcaa_skinny_linear_wgrad_adam) -- those
+        gradients never exist in ``flat_g.g``; pass False to keep them (gradient inspection, parity tests: the
+        resulting parameters are bit-identical either way).
+        Data-parallel options (``process_group`` given): ``dp_zero`` True = sharded decoder optimizer
         (reduce-scatter, Adam on 1/world of the decoder, all-gather; default off); ``grad_compress="bf16"`` = the decoder's gradient buckets cross the wire as bf16 (half the
         bytes; fp32 master gradients, moments and weights; each bucket is rounded once before the sum and the sum
         is accumulated in bf16 by the collective: relative error of a reduced element ~2^-8).
@@ -192,6 +196,7 @@ class PCAATrainer:
                 self._sync_bn_group = process_group
         self._dp_zero_arg = bool(dp_zero)
         self._force_collectives = bool(force_collectives)
+        self.fused_decoder_update = bool(fused_decoder_update)
         if grad_compress not in (None, "bf16"):
             raise ValueError("grad_compress must be None or 'bf16'")
         self.grad_compress = grad_compress
@@ -262,8 +267,12 @@ class PCAATrainer:
         if self.decoder_projection_head is not None:
             g_named += [("GPH." + n, p) for n, p in self.decoder_projection_head.named_parameters()]
         # bn1..bn4 of the decoder never receive a gradient: torch.optim.Adam skips them
+        # order inside the buffer: first layer and all biases, then the wide weights -- with the fused
+        # weight-gradient + Adam kernels what is left for the plain Adam pass is one contiguous range
         if self.decoder is not None:
-            g_named += [("G." + n, p) for n, p in self.decoder.named_parameters() if n.startswith("dense")]
+            dec_named = [("G." + n, p) for n, p in self.decoder.named_parameters() if n.startswith("dense")]
+            is_small = lambda n: n.startswith("G.dense1.") or n.endswith(".bias")
+            g_named += [(n, p) for n, p in dec_named if is_small(n)] + [(n, p) for n, p in dec_named if not is_small(n)]
         # Decoder widths that are not multiples of 64 (N=150, the reference's default: 1125 ... 18000) keep the
         # weight-streaming kernels away -- rows of 1125 floats are not even 16-B aligned.  The weights are then
         # STORED zero-padded to multiples of 64 in both dimensions and the decoder runs in the padded widths
@@ -336,6 +345,18 @@ class PCAATrainer:
         # latency-bound temporal-conv / MLP-head backward kernels instead of after everything.
         dec_names = [i for i, nm in enumerate(self.flat_g.names) if nm.startswith("G.")]
         self._dec_start = self.flat_g.offsets[dec_names[0]] if dec_names else self.flat_g.total
+        # layer number -> (lo, hi, W, exp_avg, exp_avg_sq) of the weights a fused update may take over (views of
+        # the flat buffers in the STORED, i.e. possibly padded, shape)
+        self._dec_fused = {}
+        if self.decoder is not None:
+            fg = self.flat_g
+            for i in range(2, len(self.decoder.dense_layers()) + 1):
+                nm = f"G.dense{i}.weight"
+                k = fg.names.index(nm)
+                o, n = fg.offsets[k], fg.sizes[k]
+                shp = tuple(fg.padded[nm][0].shape) if nm in fg.padded else tuple(fg.params[k].shape)
+                self._dec_fused[i] = (o, (o + n + _ALIGN - 1) // _ALIGN * _ALIGN,      # up to the next parameter's offset
+                                      fg.p[o:o + n].view(shp), fg.m[o:o + n].view(shp), fg.v[o:o + n].view(shp))
         self._side_adam_blocks = 256
         self._dp_chunks = 4
         # data-parallel bucketing: one all-reduce per decoder layer, issued as soon as that layer's gradient is
@@ -597,15 +618,27 @@ class PCAATrainer:
                 with torch.cuda.stream(self._wg):
                     early_buckets.append((lo, hi, self._allreduce(fg.g[lo:hi], async_op=True)))
 
+        # Single process: the wide decoder layers' weight gradients go straight into Adam (one kernel per layer forms
+        # dW in registers and updates W / exp_avg / exp_avg_sq in place: 24 B per parameter instead of 4 + 28).  The
+        # backward only notes each layer's operands; the kernels run on the Adam side stream once the decoder backward
+        # -- whose dgrads read the weights they overwrite -- is enqueued (measured, same box, ms/step: unfused 6.27-6.30
+        # | behind each layer's own dgrad 6.13-6.18, the decoder backward section 276 -> 634 us | here 6.12-6.14).
+        updates, fused_ranges, deferred = None, [], []
+        if self.fused_decoder_update and not collective and self._side is not None and mode == "bf16":
+            for layer, (lo, hi, Wv, mv, vv) in self._dec_fused.items():
+                if F_hip._skinny(mode, B, Wv.shape[0], Wv.shape[1]):
+                    updates = updates or {}
+                    updates[layer] = lambda dz2, x, t=(Wv, mv, vv): deferred.append((dz2, x) + t)
+                    fused_ranges.append((lo, hi))
         if self.decoder_projection_head is not None:
             # the head's own backward (dh -> dsup, dW, db) runs inside the heads' backward launch below
             _, dh = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads, mode=mode,
-                                           after_layer=layer_hook)
+                                           after_layer=layer_hook, updates=updates)
             if joined is not None:
                 torch.cuda.current_stream().wait_event(joined)
         else:
             _, dsup = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads, dz_init=dsup,
-                                             mode=mode, after_layer=layer_hook)
+                                             mode=mode, after_layer=layer_hook, updates=updates)
         # The decoder's gradients are final here (the projection head's follow with the encoder's: its backward
         # runs in the MLP heads' launch).  Data-parallel: their all-reduce goes out now, in a few chunks (the
         # collectives of one communicator run in order), so that the side-stream Adam of chunk i overlaps the
@@ -679,13 +712,24 @@ class PCAATrainer:
                     self._side.wait_event(ready)        # everything enqueued on the main stream so far
                     if self._wg is not None:
                         self._side.wait_stream(self._wg)   # ... and the decoder weight gradients on the wgrad stream
+                    for dz2, x, Wv, mv, vv in deferred:
+                        dz2.record_stream(self._side)
+                        x.record_stream(self._side)
+                        ops.skinny_linear_wgrad_adam_(dz2, x, Wv, mv, vv, *self.betas_g(), 1e-8, self.flat_g.coef_dev, gs)
                     for lo, hi, work in pending:
                         if hi <= self._dec_start:
                             continue                    # the projection-head slice is updated on the main stream
                         if work is not None:
                             work.wait()                 # side stream waits for THIS chunk's all-reduce only
-                        self.flat_g.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs, lo=max(lo, self._dec_start),
-                                         hi=hi, advance=False, max_blocks=self._side_adam_blocks)
+                        # what the fused kernels did not take: [lo, hi) minus their ranges
+                        a = max(lo, self._dec_start)
+                        for flo, fhi in sorted(fused_ranges) + [(hi, hi)]:
+                            if flo > a:
+                                self.flat_g.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs, lo=a, hi=min(flo, hi),
+                                                 advance=False, max_blocks=self._side_adam_blocks)
+                            a = max(a, fhi)
+                            if a >= hi:
+                                break
                     ev = torch.cuda.Event()
                     ev.record(self._side)
                     done.append(ev)

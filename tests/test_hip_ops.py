@@ -423,6 +423,27 @@ def test_adam_matches_reference_formula():
         assert torch.allclose(pd.cpu(), params["p"], rtol=1e-6, atol=1e-7), s
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 256, 128), (37, 192, 160), (5, 128, 1024), (64, 960, 1920)])
+def test_skinny_wgrad_adam_equals_wgrad_then_adam_bitwise(M, N, K):
+    """pcaa_skinny_linear_wgrad_adam == pcaa_skinny_linear_wgrad followed by pcaa_adam_step_dev, bit for bit
+    (parameters and both moments), over three optimizer steps with changing gradients."""
+    from opensetgaitrecognition_pcaa_amd.train import StepCount
+    W0 = _rand((N, K), 300, 0.05).to(DEV)
+    Wa, Wb = W0.clone(), W0.clone()
+    ma, va, mb, vb = (torch.zeros_like(W0) for _ in range(4))
+    ca, cb = StepCount(DEV), StepCount(DEV)
+    for s in range(3):
+        dz = _rand((M, N), 301 + 2 * s, 0.3).to(DEV)
+        x = _rand((M, K), 302 + 2 * s, 1.0).to(DEV)
+        ca.advance(1e-3, 0.9, 0.99)
+        cb.advance(1e-3, 0.9, 0.99)
+        dW = ops.skinny_linear_wgrad(dz, x)
+        ops.adam_step_dev_(Wa, dW, ma, va, 0.9, 0.99, 1e-8, ca.coef_dev)
+        ops.skinny_linear_wgrad_adam_(dz, x, Wb, mb, vb, 0.9, 0.99, 1e-8, cb.coef_dev)
+        assert torch.equal(Wa, Wb) and torch.equal(ma, mb) and torch.equal(va, vb), s
+    assert not torch.equal(Wa, W0)
+
+
 def test_cross_entropy_and_preds():
     B, K = 37, 6
     x = _rand((B, K), 70, 3.0)

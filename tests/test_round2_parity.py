@@ -32,9 +32,10 @@ def _cfg(B, N, K):
     return cfg
 
 
-def _v4_trainer(B, N, C, K, seeds, precision, variant="v4"):
+def _v4_trainer(B, N, C, K, seeds, precision, variant="v4", fused=False):
+    """``fused=False``: the decoder's weight gradients stay in ``flat_g.g`` (the tests here inspect them)."""
     constants.NFEATURES = C
-    tr = PCAATrainer(_cfg(B, N, K), precision=precision, variant=variant)
+    tr = PCAATrainer(_cfg(B, N, K), precision=precision, variant=variant, fused_decoder_update=fused)
     mods = [m for m in (tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head,
                         tr.discriminator_projection_head) if m is not None]
     for mod, seed in zip(mods, seeds):
@@ -71,9 +72,9 @@ def full_size_oracle():
     return ref, st, means
 
 
-def _full_step(precision, means):
+def _full_step(precision, means, fused=False):
     B, N, C, K = FULL["B"], FULL["N"], FULL["C"], FULL["K"]
-    tr, _ = _v4_trainer(B, N, C, K, FULL["seeds"], precision)
+    tr, _ = _v4_trainer(B, N, C, K, FULL["seeds"], precision, fused=fused)
     tr.set_prior_means(means)
     tr.finalize()
     tr.train()
@@ -367,3 +368,48 @@ def test_reference_d_step_body_runs_unmodified_on_the_drop_in_critic(tag):
     dl.backward()
     assert (z.grad.cpu() - zc.grad).abs().max().item() <= 2e-4 * zc.grad.abs().max().item()
     opt.step()          # and the optimizer of the caller steps on those gradients
+
+
+@pytest.mark.parametrize("B,N", [(6, 32), (64, 128)])
+def test_fused_decoder_update_performs_the_unfused_step(B, N):
+    """bf16 mode, single process: the decoder's wide layers take their Adam update inside the weight-gradient
+    kernel (pcaa_skinny_linear_wgrad_adam; bit-identical to wgrad -> Adam at the op level, tests/test_hip_ops.py).
+    At the trainer level two runs of the SAME step already differ by the order of the fp64 statistics atomics
+    (rounding noise that Adam's sign-like first steps turn into +-lr), so the fused run is held to the gate two
+    unfused runs meet: three steps from identical state, eager and (small size) under hipGraph replay."""
+    C, K, steps, lr = 4, 4, 3, 1e-4
+    saved = constants.NFEATURES
+    means = O.sample_distant_points(32, K, 10, 10).float()
+    states = []
+    try:
+        for fused, graphed in ((False, False), (True, False)) + (((True, True),) if N == 32 else ()):
+            tr, _ = _v4_trainer(B, N, C, K, [0, 1, 2, 3, 4], "bf16", fused=fused)
+            tr.set_prior_means(means)
+            tr.finalize()
+            tr.train()
+            for s in range(steps):
+                args = (syn.synthetic_pcs(B, T, N, C, seed=500 + s).to(DEV).permute(0, 3, 1, 2),
+                        syn.synthetic_labels(B, K, seed=510 + s).to(DEV), syn.synthetic_z0(B, 32, seed=520 + s).to(DEV),
+                        syn.synthetic_alphas(B, seed=530 + s).to(DEV))
+                out = (tr.step_graphed if graphed else tr.step)(*args)
+            torch.cuda.synchronize()
+            fg = tr.flat_g
+            lo = min(v[0] for v in tr._dec_fused.values())
+            if fused:
+                assert float(fg.g[lo:].abs().max()) == 0.0, "fused layers must not write a weight gradient"
+            else:
+                assert float(fg.g[lo:].abs().max()) > 0.0
+            states.append((fg.p[lo:].clone(), fg.m[lo:].clone(), fg.v[lo:].clone(), out["rec_loss"].item()))
+            del tr
+            torch.cuda.empty_cache()
+    finally:
+        constants.NFEATURES = saved
+    base = states[0]
+    for other in states[1:]:
+        dp = (base[0] - other[0]).abs()
+        assert float(dp.max()) <= 2 * lr * steps + 1e-7, float(dp.max())
+        assert float(dp.mean()) <= 0.1 * lr * steps, float(dp.mean())     # a missing / doubled update: ~lr per step
+        for k in (1, 2):
+            rel = float((base[k] - other[k]).norm() / base[k].norm())
+            assert rel <= 2e-2, (k, rel)
+        assert abs(base[3] - other[3]) <= 2e-2 * abs(base[3])

@@ -13,12 +13,13 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--precision", default="bf16")
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--points", type=int, default=128)
+ap.add_argument("--fused", default="on", choices=["on", "off"], help="decoder weight-gradient + Adam fusion")
 a = ap.parse_args()
 B, N, C, K, T = a.batch, a.points, 4, 8, constants.NSTEPS
 constants.NFEATURES = C
 cfg = dict(constants.CONFIG); cfg.update(NMAX=N, TRAIN_CLASSES=list(range(K)), BATCH_SIZE=B)
 F_hip.set_precision(a.precision)
-tr = PCAATrainer(cfg, device="cuda", precision=a.precision)
+tr = PCAATrainer(cfg, device="cuda", precision=a.precision, fused_decoder_update=a.fused != "off")
 for i, m in enumerate((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head, tr.discriminator_projection_head)):
     syn.deterministic_fill_(m, i)
 tr.set_prior_means(sample_distant_points(32, K, 10, 10)); tr.finalize(); tr.train()
@@ -42,4 +43,11 @@ for k, v in agg.items():
     v = sorted(v)[len(v) // 2]
     tot += v
     print(f"{k:44s} {v * 1e3:9.1f} us (median of {a.steps})")
-print(f"{'sum':44s} {tot * 1e3:9.1f} us")
+print(f"{'sum':44s} {tot * 1e3:9.1f} us   (fused={a.fused})")
+t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t0.record()
+for _ in range(a.steps):
+    tr.step(pcs, gt, z0, al)
+t1.record()
+torch.cuda.synchronize()
+print(f"{'un-marked step':44s} {t0.elapsed_time(t1) / a.steps * 1e3:9.1f} us")
