@@ -413,6 +413,9 @@ def main():
                        "global_batch": B * world, "precision": a.precision,
                        "parallelism": f"dp{world}", "sync_bn": bool(a.sync_bn), "finite_loss": loss_ok,
                        "hip_graph": bool(use_graph),
+                       # single process, bf16: the decoder's wide weight gradients are consumed by a fused Adam kernel
+                       "decoder_update": "fused wgrad+adam" if (tr.fused_decoder_update and world == 1 and
+                                                                 a.precision == "bf16" and not a.dp_force) else "wgrad, adam",
                        # gradient / parameter exchanges of one step: number of collectives, payload bytes, and what a
                        # ring moves per rank and direction for them (2 (w-1)/w x payload for an all-reduce; the
                        # reduce-scatter + all-gather pair of --dp-mode zero moves the same)

@@ -370,13 +370,14 @@ def test_reference_d_step_body_runs_unmodified_on_the_drop_in_critic(tag):
     opt.step()          # and the optimizer of the caller steps on those gradients
 
 
-@pytest.mark.parametrize("B,N", [(6, 32), (64, 128)])
+@pytest.mark.parametrize("B,N", [(6, 32), (16, 150), (64, 128)])
 def test_fused_decoder_update_performs_the_unfused_step(B, N):
     """bf16 mode, single process: the decoder's wide layers take their Adam update inside the weight-gradient
     kernel (pcaa_skinny_linear_wgrad_adam; bit-identical to wgrad -> Adam at the op level, tests/test_hip_ops.py).
     At the trainer level two runs of the SAME step already differ by the order of the fp64 statistics atomics
     (rounding noise that Adam's sign-like first steps turn into +-lr), so the fused run is held to the gate two
-    unfused runs meet: three steps from identical state, eager and (small size) under hipGraph replay."""
+    unfused runs meet: three steps from identical state, eager and (small size) under hipGraph replay.  N=150 is the
+    reference's default: decoder widths 1125 ... 18000, stored zero-padded to multiples of 64 (ragged-tile kernels)."""
     C, K, steps, lr = 4, 4, 3, 1e-4
     saved = constants.NFEATURES
     means = O.sample_distant_points(32, K, 10, 10).float()
