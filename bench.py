@@ -294,6 +294,8 @@ def main():
     constants.NFEATURES = C
     F_hip.set_precision(a.precision)
     tr, cfg = build_trainer(a, N, dev, pg, a.precision)
+    decoder_update = "fused wgrad+adam" if (tr.fused_decoder_update and world == 1 and a.precision == "bf16"
+                                            and not a.dp_force) else "wgrad, adam"
     # inputs resident in HBM (point-major storage, [B,C,T,N] view), different data per rank
     pcs = syn.synthetic_pcs(B, T, N, C, seed=1234 + rank).to(dev).permute(0, 3, 1, 2)
     gt = syn.synthetic_labels(B, K, seed=1235 + rank).to(dev)
@@ -414,8 +416,7 @@ def main():
                        "parallelism": f"dp{world}", "sync_bn": bool(a.sync_bn), "finite_loss": loss_ok,
                        "hip_graph": bool(use_graph),
                        # single process, bf16: the decoder's wide weight gradients are consumed by a fused Adam kernel
-                       "decoder_update": "fused wgrad+adam" if (tr.fused_decoder_update and world == 1 and
-                                                                 a.precision == "bf16" and not a.dp_force) else "wgrad, adam",
+                       "decoder_update": decoder_update,
                        # gradient / parameter exchanges of one step: number of collectives, payload bytes, and what a
                        # ring moves per rank and direction for them (2 (w-1)/w x payload for an all-reduce; the
                        # reduce-scatter + all-gather pair of --dp-mode zero moves the same)

@@ -368,13 +368,14 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restri
 // (common.h adam_update) and writes the three back -- 24 B per parameter instead of 4 (dW store) + 28 (Adam pass).  One 32 x 32 fragment's
 // operands (48 dwords per lane) are in flight while the previous fragment is updated.  Single-process training only:
 // a data-parallel step needs the reduced gradient before the update.
-template <int JL, bool FULLN>
+template <int JL, bool FULLN, int NB>
 __global__ __launch_bounds__(256) void skinny_wgrad_adam_kernel(const float* __restrict__ dz, long lddz,
                                                                 const float* __restrict__ x, long ldx,
                                                                 float* __restrict__ W, float* __restrict__ mo,
                                                                 float* __restrict__ vo, long ldw, int M, int N, int K,
                                                                 float b1, float b2, float eps, float grad_scale,
                                                                 const float* __restrict__ coef) {
+  static_assert(NB == 2 || NB == 4, "fragment buffers: a ring of 2 or 4 (index = fragment number mod NB, static)");
   __shared__ __attribute__((aligned(16))) bf16x8 apan[4][4][64];      // [row fragment i][k-step s][lane]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
   const int n0 = blockIdx.y * 128;
@@ -407,9 +408,29 @@ __global__ __launch_bounds__(256) void skinny_wgrad_adam_kernel(const float* __r
   for (int s = 0; s < 4; ++s)
 #pragma unroll
     for (int e = 0; e < 8; ++e) br[s][e] = x[xoff[s][e]];
+
+  // the wave's fragments f = 4 j + i (32 rows x 32 columns each), NB - 1 of them in flight ahead of the update
+  const unsigned row0 = (unsigned)(n0 + 4 * h);
+  unsigned o0 = row0 * (unsigned)ldw + (unsigned)kb + l31;
+  float pw[NB][16], pm[NB][16], pv[NB][16];
+  const int nfrag = 4 * jn;
+  auto fetch = [&](int f, int b) {                         // b = f % NB, static at every call site
+    if (f >= nfrag) return;
+    const unsigned base = o0 + 32u * (unsigned)(f >> 2);
+    const int i = f & 3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned rr = 32 * i + (r & 3) + 8 * (r >> 2);
+      if (FULLN || row0 + rr < (unsigned)N) {
+        const unsigned o = base + rr * (unsigned)ldw;
+        pw[b][r] = W[o]; pm[b][r] = mo[o]; pv[b][r] = vo[o];
+      }
+    }
+  };
+#pragma unroll
+  for (int f = 0; f < NB - 1; ++f) fetch(f, f);
   __syncthreads();
 
-  const unsigned row0 = (unsigned)(n0 + 4 * h);
   for (int j = 0; j < jn; ++j) {
     bf16x8 bf[4];
 #pragma unroll
@@ -421,24 +442,7 @@ __global__ __launch_bounds__(256) void skinny_wgrad_adam_kernel(const float* __r
 #pragma unroll
         for (int e = 0; e < 8; ++e) br[s][e] = xn[xoff[s][e]];
     }
-    const long tile = kb + 32 * j;                         // uniform
-    float* Wj = W + tile;
-    float* mj = mo + tile;
-    float* vj = vo + tile;
-    unsigned o0 = row0 * (unsigned)ldw + l31;
-    asm volatile("" : "+v"(o0) : : "memory");
-    float pw[2][16], pm[2][16], pv[2][16];
-    auto fetch = [&](int i, int b) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned rr = 32 * i + (r & 3) + 8 * (r >> 2);
-        if (FULLN || row0 + rr < (unsigned)N) {
-          const unsigned o = o0 + rr * (unsigned)ldw;
-          pw[b][r] = Wj[o]; pm[b][r] = mj[o]; pv[b][r] = vj[o];
-        }
-      }
-    };
-    fetch(0, 0);
+    asm volatile("" : "+v"(o0) : : "memory");              // keeps the 64 row offsets out of registers (see wgrad)
     f32x16 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -449,19 +453,20 @@ __global__ __launch_bounds__(256) void skinny_wgrad_adam_kernel(const float* __r
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apan[i][s][lane], bf[s], acc[i], 0, 0, 0);
+    const unsigned base = o0 + 32u * (unsigned)j;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int b = i & 1;
-      if (i + 1 < 4) fetch(i + 1, b ^ 1);
+      const int b = i % NB;
+      fetch(4 * j + i + NB - 1, (i + NB - 1) % NB);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const unsigned rr = 32 * i + (r & 3) + 8 * (r >> 2);
         if (FULLN || row0 + rr < (unsigned)N) {
-          const unsigned o = o0 + rr * (unsigned)ldw;
+          const unsigned o = base + rr * (unsigned)ldw;
           adam_update(pw[b][r], pm[b][r], pv[b][r], acc[i][r] * grad_scale, b1, b2, eps, step_size, inv_bc2_sqrt);
-          Wj[o] = pw[b][r];
-          mj[o] = pm[b][r];
-          vj[o] = pv[b][r];
+          W[o] = pw[b][r];
+          mo[o] = pm[b][r];
+          vo[o] = pv[b][r];
         }
       }
     }
@@ -598,13 +603,16 @@ extern "C" int pcaa_skinny_linear_wgrad_adam(const float* dz, long lddz, const f
   PCAA_CHECK_ARG(lddz >= N && ldx >= K && ldw >= K, "pcaa_skinny_linear_wgrad_adam: bad leading dimensions");
   PCAA_CHECK_ARG((long)M * lddz < (1L << 31) && (long)M * ldx < (1L << 31) && (long)N * ldw < (1L << 30),
                  "pcaa_skinny_linear_wgrad_adam: operands beyond 32-bit offsets");
-  constexpr int JL = 4;
+  // measured alone on the four wide layers of the bench shape (tools/skinny_lab.py): 0.81 ms fused against 0.97 ms
+  // (weight gradient 0.17 + Adam 0.80), 5.0 TB/s on the 7680 -> 15360 layer; a ring of 4 fragment buffers (three
+  // fragments in flight) or 8 column steps per wave: 0.83 / 0.88 / 0.86 ms -- not kept
+  constexpr int JL = 4, NB = 2;
   const dim3 grid((unsigned)cdiv(K, 4 * 32 * JL), (unsigned)cdiv(N, 128));
   if (N % 128 == 0)
-    hipLaunchKernelGGL((skinny_wgrad_adam_kernel<JL, true>), grid, dim3(256), 0, as_stream(stream), dz, lddz, x, ldx,
-                       W, exp_avg, exp_avg_sq, ldw, M, N, K, beta1, beta2, eps, grad_scale, coef_dev);
+    hipLaunchKernelGGL((skinny_wgrad_adam_kernel<JL, true, NB>), grid, dim3(256), 0, as_stream(stream), dz, lddz, x,
+                       ldx, W, exp_avg, exp_avg_sq, ldw, M, N, K, beta1, beta2, eps, grad_scale, coef_dev);
   else
-    hipLaunchKernelGGL((skinny_wgrad_adam_kernel<JL, false>), grid, dim3(256), 0, as_stream(stream), dz, lddz, x, ldx,
-                       W, exp_avg, exp_avg_sq, ldw, M, N, K, beta1, beta2, eps, grad_scale, coef_dev);
+    hipLaunchKernelGGL((skinny_wgrad_adam_kernel<JL, false, NB>), grid, dim3(256), 0, as_stream(stream), dz, lddz, x,
+                       ldx, W, exp_avg, exp_avg_sq, ldw, M, N, K, beta1, beta2, eps, grad_scale, coef_dev);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_wgrad_adam");
 }

@@ -423,7 +423,7 @@ def test_adam_matches_reference_formula():
         assert torch.allclose(pd.cpu(), params["p"], rtol=1e-6, atol=1e-7), s
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 256, 128), (37, 192, 160), (5, 128, 1024), (64, 960, 1920)])
+@pytest.mark.parametrize("M,N,K", [(64, 256, 128), (37, 192, 160), (5, 128, 1024), (64, 960, 1920), (16, 4544, 2304)])
 def test_skinny_wgrad_adam_equals_wgrad_then_adam_bitwise(M, N, K):
     """pcaa_skinny_linear_wgrad_adam == pcaa_skinny_linear_wgrad followed by pcaa_adam_step_dev, bit for bit
     (parameters and both moments), over three optimizer steps with changing gradients."""

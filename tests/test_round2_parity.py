@@ -412,5 +412,5 @@ def test_fused_decoder_update_performs_the_unfused_step(B, N):
         assert float(dp.mean()) <= 0.1 * lr * steps, float(dp.mean())     # a missing / doubled update: ~lr per step
         for k in (1, 2):
             rel = float((base[k] - other[k]).norm() / base[k].norm())
-            assert rel <= 2e-2, (k, rel)
+            assert rel <= 5e-2, (k, rel)      # the moments carry the bf16-mode gradient noise of three steps (~2e-2)
         assert abs(base[3] - other[3]) <= 2e-2 * abs(base[3])

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Decoder weight update in isolation: weight gradient -> Adam (two kernels) against the fused kernel, per decoder
+layer of the bench shape, alone on the GPU: ms and GB/s of the bytes each really moves.
+
+    python tools/skinny_lab.py [--points 128] [--batch 64]"""
+import argparse, ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from opensetgaitrecognition_pcaa_amd import _lib, ops
+from opensetgaitrecognition_pcaa_amd.train import StepCount
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--points", type=int, default=128)
+ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--reps", type=int, default=20)
+a = ap.parse_args()
+lib = _lib.load()
+S = 30 * 4 * a.points
+widths = [S // 16, S // 8, S // 4, S // 2, S]
+M = a.batch
+dev = "cuda"
+
+
+def timed(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+tot = {}
+for K, N in zip(widths[:-1], widths[1:]):
+    g = torch.Generator(device="cpu").manual_seed(N)
+    dz = (torch.randn(M, N, generator=g) * 0.1).to(dev)
+    x = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) * 0.02).to(dev)
+    m, v, dW = torch.zeros_like(W), torch.zeros_like(W), torch.empty_like(W)
+    c = StepCount(dev)
+    c.advance(1e-4, 0.9, 0.99)
+    n = N * K
+    t_w = timed(lambda: ops.skinny_linear_wgrad(dz, x, out=dW), a.reps)
+    t_a = timed(lambda: ops.adam_step_dev_(W.view(-1), dW.view(-1), m.view(-1), v.view(-1), 0.9, 0.99, 1e-8, c.coef_dev, 1.0, 256), a.reps)
+    print(f"[{K}->{N}] wgrad {t_w:.3f} ms ({4 * n / t_w / 1e9:.2f} TB/s)   adam(256 blocks) {t_a:.3f} ms ({28 * n / t_a / 1e9:.2f} TB/s)"
+          f"   sum {t_w + t_a:.3f}")
+    tot["unfused"] = tot.get("unfused", 0) + t_w + t_a
+    t_f = timed(lambda: ops.skinny_linear_wgrad_adam_(dz, x, W, m, v, 0.9, 0.99, 1e-8, c.coef_dev), a.reps)
+    print(f"[{K}->{N}] fused: {t_f:.3f} ms ({24 * n / t_f / 1e9:.2f} TB/s)")
+    tot["fused"] = tot.get("fused", 0) + t_f
+    del dz, x, W, m, v, dW
+print("totals (ms):", {k: round(t, 3) for k, t in tot.items()})
