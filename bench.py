@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--grad-compress", default="none", choices=["none", "bf16"],
                     help="decoder gradient buckets cross the wire as bf16 (fp32 master gradients)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--decoder-update", default="fused", choices=["fused", "plain"],
+                    help="single process, bf16: decoder weight gradient + Adam in one kernel (default) or as two passes")
     ap.add_argument("--no-parity-mode", action="store_true",
                     help="skip the fp32 parity-mode leg (same workload in the mode the 1e-4 parity tests run in)")
     ap.add_argument("--no-batcher-leg", action="store_true",
@@ -63,7 +65,7 @@ def parse():
     ap.add_argument("--graph", default=os.environ.get("PCAA_GRAPH", "auto"), choices=["on", "off", "auto"],
                     help="replay the step as a captured hipGraph (PCAATrainer.step_graphed): auto = where the eager step is "
                          "bound by the host's enqueues (PCAATrainer.prefers_graph: below ~80 K points per step; "
-                         "profiles/r02_graph_vs_eager.txt); at the default workload eager is 2-3 % faster")
+                         "profiles/r02_graph_vs_eager.txt); at the default workload eager is 2-3 %% faster")
     return ap.parse_args()
 
 
@@ -135,7 +137,7 @@ def build_trainer(a, N, dev, pg, precision):
     tr = PCAATrainer(cfg, device=dev, precision=precision, process_group=pg, sync_bn=a.sync_bn,
                      dp_zero=(a.dp_mode == "zero") and pg is not None,
                      grad_compress=None if a.grad_compress == "none" else a.grad_compress,
-                     force_collectives=a.dp_force)
+                     force_collectives=a.dp_force, fused_decoder_update=a.decoder_update == "fused")
     for i, m in enumerate((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head,
                            tr.discriminator_projection_head)):
         syn.deterministic_fill_(m, i)

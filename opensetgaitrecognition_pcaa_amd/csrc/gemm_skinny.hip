@@ -378,10 +378,10 @@ __global__ __launch_bounds__(256) void skinny_wgrad_adam_kernel(const float* __r
   static_assert(NB == 2 || NB == 4, "fragment buffers: a ring of 2 or 4 (index = fragment number mod NB, static)");
   __shared__ __attribute__((aligned(16))) bf16x8 apan[4][4][64];      // [row fragment i][k-step s][lane]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  const float step_size = coef[0], inv_bc2_sqrt = coef[1];
   const int n0 = blockIdx.y * 128;
   const int kb = (blockIdx.x * 4 + wave) * (32 * JL);
   const int jn = kb < K ? min(JL, (K - kb) / 32) : 0;
-  const float step_size = coef[0], inv_bc2_sqrt = coef[1];
   {
     const int s = wave;
 #pragma unroll
@@ -606,13 +606,20 @@ extern "C" int pcaa_skinny_linear_wgrad_adam(const float* dz, long lddz, const f
   // measured alone on the four wide layers of the bench shape (tools/skinny_lab.py): 0.81 ms fused against 0.97 ms
   // (weight gradient 0.17 + Adam 0.80), 5.0 TB/s on the 7680 -> 15360 layer; a ring of 4 fragment buffers (three
   // fragments in flight) or 8 column steps per wave: 0.83 / 0.88 / 0.86 ms -- not kept
-  constexpr int JL = 4, NB = 2;
-  const dim3 grid((unsigned)cdiv(K, 4 * 32 * JL), (unsigned)cdiv(N, 128));
-  if (N % 128 == 0)
-    hipLaunchKernelGGL((skinny_wgrad_adam_kernel<JL, true, NB>), grid, dim3(256), 0, as_stream(stream), dz, lddz, x,
-                       ldx, W, exp_avg, exp_avg_sq, ldw, M, N, K, beta1, beta2, eps, grad_scale, coef_dev);
-  else
-    hipLaunchKernelGGL((skinny_wgrad_adam_kernel<JL, false, NB>), grid, dim3(256), 0, as_stream(stream), dz, lddz, x,
-                       ldx, W, exp_avg, exp_avg_sq, ldw, M, N, K, beta1, beta2, eps, grad_scale, coef_dev);
+  // columns per wave = 32 JL: the widest that still gives the chip >= 1024 workgroups (every fragment is a full
+  // memory round trip for its wave: the 960 -> 1920 layer took 47 us in 30 workgroups of 4 x 4 fragments per wave)
+  constexpr int NB = 2;
+  auto ntile = [&](int jl) { return cdiv(K, 4 * 32 * jl) * cdiv(N, 128); };
+  const int jl = ntile(4) >= 1024 ? 4 : (ntile(2) >= 1024 ? 2 : 1);
+#define WA_LAUNCH(JL, FULL)                                                                                       \
+  hipLaunchKernelGGL((skinny_wgrad_adam_kernel<JL, FULL, NB>), dim3((unsigned)cdiv(K, 4 * 32 * JL), (unsigned)cdiv(N, 128)), \
+                     dim3(256), 0, as_stream(stream), dz, lddz, x, ldx, W, exp_avg, exp_avg_sq, ldw, M, N, K, beta1,  \
+                     beta2, eps, grad_scale, coef_dev)
+  if (N % 128 == 0) {
+    if (jl == 4) WA_LAUNCH(4, true); else if (jl == 2) WA_LAUNCH(2, true); else WA_LAUNCH(1, true);
+  } else {
+    if (jl == 4) WA_LAUNCH(4, false); else if (jl == 2) WA_LAUNCH(2, false); else WA_LAUNCH(1, false);
+  }
+#undef WA_LAUNCH
   PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_wgrad_adam");
 }
