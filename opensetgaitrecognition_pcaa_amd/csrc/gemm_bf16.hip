@@ -288,16 +288,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_big_kernel(GemmParams p) {
 //     16 rows x 4 granules -- both conflict-free with this swizzle).
 //   RC image [64 k][256 rows] (512-B rows): 16-B granule c of k-row k holds global row-granule
 //     c ^ 4*(k&3)     -> the 4 k-rows of a transpose read land on disjoint bank quarters.
-// One barrier per 64-deep step: the DMA pieces of step t+1 are issued between the MFMAs of step t
-// (one 1-KB piece per wave in front of every 8th of the step's MFMAs) and waited for at the barrier.
+// One barrier per 64-deep step.  Ring: THREE stages of the A operand, two of B (5 x 32 KB = all 160 KB of the LDS):
+// between the MFMAs of step t a wave issues its pieces of B(t+1) and then of A(t+2) (one 1-KB piece in front of every
+// 8th of the step's MFMAs); at the barrier it waits with a counted vmcnt(4) -- everything but its four youngest
+// pieces, A(t+2).  See the kernel for why the depth goes to A, and tools/microbench/cu_load_bw.hip for the
+// bytes-in-flight curve of a CU that motivates it.
 //
 // Measured and rejected (tools/gemm_lab.py history): touching the streamed operand's lines in L2
 // a few K steps ahead with one plain global_load_dword per lane and step (a software L2 prefetch behind a counted
-// vmcnt(1)) made every shape 3-10 % SLOWER -- the stream is not bound by HBM latency.
+// vmcnt(1)) made every shape 3-10 % SLOWER (those loads queue in front of the pieces); round 1's five-slot ring gave
+// the third stage to B -- the L2-resident weights -- and measured nothing.
 // ===========================================================================
 constexpr int D_TILE = 256 * 64;                       // elements per operand per stage (32 KB)
 constexpr int EP_PITCH = 72;                           // bf16 elements per row of a wave's epilogue image (144 B)
-constexpr int D_LDS_BYTES = 8 * 128 * EP_PITCH * 2;    // 147456 >= 2 stages x 2 operands x 32 KB = 131072
+constexpr int D_LDS_BYTES = 5 * D_TILE * 2;            // 163840: A in a ring of three stages, B of two -- all of the LDS
+static_assert(D_LDS_BYTES >= 8 * 128 * EP_PITCH * 2, "the epilogue parks the tile in the ring's memory");
 
 // one of the 4 pieces a wave moves per tile
 template <int LAY>
@@ -697,8 +702,11 @@ __device__ __forceinline__ bf16x8 dma_load_frag(const bf16_t* s, int off, int ks
 }
 
 // end of a K step: the next stage's DMA pieces have landed (every wave waits for its own, then the barrier)
-__device__ __forceinline__ void step_barrier() {
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+// every wave waits for its own pieces of the stage the next step reads, then the barrier; keep_far: the wave's four
+// youngest pieces (the A stage two steps ahead) stay in flight
+__device__ __forceinline__ void step_barrier(bool keep_far) {
+  if (keep_far) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 template <typename TC, int ALAY, int BLAY, int EPI, int MF, bool BUF>
@@ -738,13 +746,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
       else dma_piece<BLAY>(B, p.ldb, tn * BN, p.N, k0, s_tile, wave, lane, j);
     }
   };
-  auto tile = [&](int k0, bf16_t* sA_) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) piece(0, k0, sA_, j);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) piece(1, k0, sA_ + D_TILE, j);
-  };
-
+  // LDS images of the operands' stages: slots A0 A1 A2 B0 B1 (5 x 32 KB = all of the LDS).  A -- the operand
+  // streamed from HBM in the forward / dgrad products: a quarter of its lines miss the L2 and take ~2 us -- has THREE
+  // stages and is requested TWO K steps ahead; B (there: the L2-resident weights) keeps two.  A stage lands as a
+  // whole only when its slowest piece has: with one step of distance the step waited for that HBM round trip
+  // (2 750 cycles for a stage against 2 048 of MFMA, round 1's stamps); same-box A/B of the two rings on the three
+  // PointNet shapes: forward +9..12 %, fused dgrad +8..12 %, wgrad (both operands streamed) +3..4 %.
+  auto slotA = [&](int i) { return smem + i * D_TILE; };
+  auto slotB = [&](int i) { return smem + (3 + i) * D_TILE; };
   typename L::vec acc[L::MB][L::NB];
 #pragma unroll
   for (int i = 0; i < L::MB; ++i)
@@ -753,8 +762,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < L::NR; ++r) acc[i][j][r] = 0.f;
 
-  if (nt > 0) tile(kbeg, smem);
-  step_barrier();
+  if (nt > 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) piece(0, kbeg, slotA(0), j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) piece(1, kbeg, slotB(0), j);
+    if (nt > 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) piece(0, kbeg + BK, slotA(1), j);
+    }
+  }
+  step_barrier(nt > 1);
+  int ia = 0;                                   // A slot of the current step (t mod 3)
 
   if constexpr (MF == 32) {
     const int l31 = lane & 31, half = lane >> 5;
@@ -773,12 +792,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
     // per fragment) and issues the whole next stage at the top of the step
     constexpr bool kFine = ALAY == KC;
     for (int t = 0; t < nt; ++t) {
-      const bf16_t* sA = smem + (t & 1) * 2 * D_TILE;
-      const bf16_t* sB = sA + D_TILE;
-      bf16_t* nA = smem + ((t + 1) & 1) * 2 * D_TILE;
-      const int k0 = kbeg + (t + 1) * BK;
-      const bool more = t + 1 < nt;
-      if (more && !kFine) tile(k0, nA);
+      const bf16_t* sA = slotA(ia);
+      const bf16_t* sB = slotB(t & 1);
+      bf16_t* nA = slotA(ia == 0 ? 2 : ia - 1);            // stage t + 2
+      bf16_t* nB = slotB((t + 1) & 1);                     // stage t + 1
+      const int k0 = kbeg + (t + 1) * BK, k0A = k0 + BK;
+      const bool more = t + 1 < nt, moreA = t + 2 < nt;
+      if (!kFine && more) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) piece(1, k0, nB, j);
+      }
       // software-pipelined fragment reads: the 6 ds_reads of k-step ks+1 are issued before the 8
       // MFMAs of k-step ks, so only the first read group of a stage exposes LDS latency
       bf16x8 af[2][4], bfr[2][2];
@@ -799,10 +822,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-          if (kFine && more) {
-            const int pc = 2 * ks + g;
-            if (pc < 4) piece(0, k0, nA, pc);
-            else piece(1, k0, nA + D_TILE, pc - 4);
+          if (kFine) {
+            const int pc = 2 * ks + g;                     // B first: the four youngest pieces are A's
+            if (pc < 4) { if (more) piece(1, k0, nB, pc); }
+            else if (moreA) piece(0, k0A, nA, pc - 4);
+          } else if (moreA && ks >= 2) {
+            piece(0, k0A, nA, 2 * (ks - 2) + g);           // the far stage: requested in the second half of the step
           }
 #pragma unroll
           for (int i = 2 * g; i < 2 * g + 2; ++i)
@@ -812,7 +837,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      step_barrier();
+      step_barrier(moreA);
+      ia = ia == 2 ? 0 : ia + 1;
     }
   } else {
     // ---- 16x16x32 fragments: lane holds 8 consecutive k of row (lane & 15); k-granule 4*s2 + (lane >> 4)
@@ -825,11 +851,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) kofs[s2] = ((4 * s2 + q) ^ (l15 >> 1)) * 8;
     for (int t = 0; t < nt; ++t) {
-      const bf16_t* sA = smem + (t & 1) * 2 * D_TILE;
-      const bf16_t* sB = sA + D_TILE;
-      bf16_t* nA = smem + ((t + 1) & 1) * 2 * D_TILE;
-      const int k0 = kbeg + (t + 1) * BK;
-      const bool more = t + 1 < nt;
+      const bf16_t* sA = slotA(ia);
+      const bf16_t* sB = slotB(t & 1);
+      bf16_t* nA = slotA(ia == 0 ? 2 : ia - 1);            // stage t + 2
+      bf16_t* nB = slotB((t + 1) & 1);                     // stage t + 1
+      const int k0 = kbeg + (t + 1) * BK, k0A = k0 + BK;
+      const bool more = t + 1 < nt, moreA = t + 2 < nt;
       // a step = 2 k-halves (32 deep) x 2 row-halves (64 rows): 4 blocks of 16 MFMAs; fragment reads of the next
       // block are issued before the MFMAs of the current one; two DMA pieces per block, one per 8 MFMAs
       bf16x8 af[2][4], bfr[2][4];
@@ -852,10 +879,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-          if (more) {
-            const int pc = 2 * blk + g;
-            if (pc < 4) piece(0, k0, nA, pc);
-            else piece(1, k0, nA + D_TILE, pc - 4);
+          {
+            const int pc = 2 * blk + g;                    // B first: the four youngest pieces are A's
+            if (pc < 4) { if (more) piece(1, k0, nB, pc); }
+            else if (moreA) piece(0, k0A, nA, pc - 4);
           }
 #pragma unroll
           for (int i = 2 * g; i < 2 * g + 2; ++i)
@@ -865,7 +892,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      step_barrier();
+      step_barrier(moreA);
+      ia = ia == 2 ? 0 : ia + 1;
     }
   }
   if constexpr (EPI == EPI_DGRAD_BN || EPI == EPI_DGRAD_BN_POINTS) {

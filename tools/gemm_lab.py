@@ -22,8 +22,15 @@ from opensetgaitrecognition_pcaa_amd import _lib, ops  # noqa: E402
 from opensetgaitrecognition_pcaa_amd._lib import KC, PCAA_BF16, RC  # noqa: E402
 
 
-def lab_set(*_):
-    pass
+def lab_set(v, *_):
+    """temporary lab builds export pcaa_lab_set (0 = shipped kernel); without it only variant 0 is meaningful"""
+    from opensetgaitrecognition_pcaa_amd import _lib
+    import ctypes
+    fn = getattr(_lib.load(), "pcaa_lab_set", None)
+    if fn is not None:
+        fn.argtypes = [ctypes.c_int]
+        fn.restype = None
+        fn(int(v))
 
 
 def timeit(fn, iters):
