@@ -25,7 +25,7 @@ constexpr int BM = 128, BN = 128;
 constexpr int KC = PCAA_LAYOUT_KC, RC = PCAA_LAYOUT_RC;
 
 __device__ __forceinline__ void tile_coords(int M, int N, int& tm, int& tn) {
-  xcd_tile_coords((M + BM - 1) / BM, (N + BN - 1) / BN, tm, tn);
+  xcd_tile_coords((M + BM - 1) / BM, (N + BN - 1) / BN, blockIdx.x, tm, tn);
 }
 
 // ---------------------------------------------------------------------------

@@ -21,6 +21,8 @@
 //               the 32 lanes of a half cover all 64 banks exactly once.
 #include <hip/hip_ext.h>
 
+#include <type_traits>
+
 #include "gemm_common.h"
 
 namespace {
@@ -302,7 +304,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_big_kernel(GemmParams p) {
 constexpr int D_TILE = 256 * 64;                       // elements per operand per stage (32 KB)
 constexpr int EP_PITCH = 72;                           // bf16 elements per row of a wave's epilogue image (144 B)
 constexpr int D_LDS_BYTES = 5 * D_TILE * 2;            // 163840: A in a ring of three stages, B of two -- all of the LDS
-static_assert(D_LDS_BYTES >= 8 * 128 * EP_PITCH * 2, "the epilogue parks the tile in the ring's memory");
 
 // one of the 4 pieces a wave moves per tile
 template <int LAY>
@@ -394,37 +395,46 @@ __device__ __forceinline__ float dpp_swap_neighbour(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 
-// A wave parks its 128 x 64 accumulator sub-tile as a row-major bf16 image [128][EP_PITCH] in its own LDS
-// region: neighbouring lanes exchange one value (DPP quad_perm [1,0,3,2]) so that every lane owns two adjacent
-// columns of one row -> v_cvt_pk_bf16_f32 + ds_write_b32 (64 per lane instead of 128 ds_write_b16); the 144-B
-// pitch keeps the writes of both layouts at 2-way bank conflicts (free for ds_write_b32) and rows 16-B aligned
-// for the row-contiguous 16-B reads that follow.  F(value, i, j) is applied to every element first.
-template <int MF, typename F>
-__device__ __forceinline__ void park_bf16(typename AccLayout<MF>::vec (&acc)[AccLayout<MF>::MB][AccLayout<MF>::NB],
-                                          bf16_t* wave_img, int lane, F f) {
+// A wave parks its 128 x 64 accumulator sub-tile 32 rows at a time as a row-major bf16 image [32][EP_PITCH] in its
+// own LDS region (4.5 KB; the eight regions + the statistics scratch live in the two ring slots the NEXT tile's
+// first stages do not use, see the kernel): neighbouring lanes exchange one value (DPP quad_perm [1,0,3,2]) so that
+// every lane owns two adjacent columns of one row -> v_cvt_pk_bf16_f32 + ds_write_b32; the 144-B pitch keeps the
+// writes at 2-way bank conflicts (free for ds_write_b32) and rows 16-B aligned for the row-contiguous 16-B reads that
+// follow.  Everything is wave-local (LDS operations of a wave execute in order): no workgroup barrier.
+// F(value, j) is applied to every element first.  CHUNK (compile time) selects rows [32 CHUNK, 32 CHUNK + 32).
+constexpr int EP_CHUNK_ROWS = 32;
+constexpr int EP_WAVE_ELEMS = EP_CHUNK_ROWS * EP_PITCH;            // bf16 elements of one wave's image
+constexpr int EP_RED_OFFSET = 8 * EP_WAVE_ELEMS;                   // statistics scratch behind the eight images
+static_assert(EP_RED_OFFSET * 2 + 2 * 2 * 256 * 4 <= 2 * D_TILE * 2, "the epilogue lives in the ring's last two slots");
+template <int MF, int CHUNK, typename F>
+__device__ __forceinline__ void park_chunk(typename AccLayout<MF>::vec (&acc)[AccLayout<MF>::MB][AccLayout<MF>::NB],
+                                           bf16_t* wave_img, int lane, F f) {
   typedef AccLayout<MF> L;
+  constexpr int BPC = EP_CHUNK_ROWS / L::BR;                       // accumulator row blocks per chunk
   uint32_t* w32 = reinterpret_cast<uint32_t*>(wave_img);
   const bool odd = lane & 1;
   // mine = {row R, row R+1} of my column as two bf16; theirs = the same of the neighbouring column (one DPP move).
-  // even lane stores row R: (mine.lo, theirs.lo); odd lane stores row R+1: (theirs.hi, mine.hi) -- one v_perm_b32 with
-  // a per-lane byte selector instead of three selects per pair (the epilogue is VALU-issue bound: ~1000 vector
-  // instructions per wave and tile at 2 cycles each with both waves of a SIMD in it)
+  // even lane stores row R: (mine.lo, theirs.lo); odd lane stores row R+1: (theirs.hi, mine.hi) -- one v_perm_b32
+  // with a per-lane byte selector
   const uint32_t sel = odd ? 0x03020706u : 0x05040100u;       // bytes 0-3 = mine (S1), 4-7 = theirs (S0)
 #pragma unroll
   for (int j = 0; j < L::NB; ++j) {
     const int colw = (L::col(j, lane) & ~1) >> 1;            // 32-bit word index of the column pair
 #pragma unroll
-    for (int i = 0; i < L::MB; ++i)
+    for (int ii = 0; ii < BPC; ++ii)
 #pragma unroll
       for (int r = 0; r < L::NR; r += 2) {
+        const int i = CHUNK * BPC + ii;
         const uint32_t mine = pack2(f(acc[i][j][r], j), f(acc[i][j][r + 1], j));
         const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, true);
         const uint32_t packed = __builtin_amdgcn_perm(theirs, mine, sel);
-        const int row = L::row(i, r, lane) + (odd ? 1 : 0);
+        const int row = L::row(ii, r, lane) + (odd ? 1 : 0);
         w32[row * (EP_PITCH / 2) + colw] = packed;
       }
   }
 }
+// workgroup barrier that leaves vector-memory operations (the next tile's LDS-DMA pieces, this tile's C stores) alone
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Full-tile epilogue (M, N multiples of 256: no bounds checks).
 //   bf16 out : park_bf16, then 16-B-per-lane row-contiguous stores (8 lanes = one whole 128-B line per row).
@@ -437,11 +447,11 @@ __device__ __forceinline__ void epilogue_full_tile(const GemmParams& p,
                                                    typename AccLayout<MF>::vec (&acc)[AccLayout<MF>::MB][AccLayout<MF>::NB],
                                                    bf16_t* smem, int tm, int tn, int tid, int split) {
   typedef AccLayout<MF> L;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const bool add_bias = p.bias != nullptr && (!p.atomic || split == 0);
   if constexpr (sizeof(TC) == 2) {
-    bf16_t* w = smem + wave * 128 * EP_PITCH;
+    bf16_t* w = smem + wave * EP_WAVE_ELEMS;              // smem: the epilogue's LDS region
     float bv[L::NB], esc[L::NB], esh[L::NB];
 #pragma unroll
     for (int j = 0; j < L::NB; ++j) {
@@ -450,25 +460,31 @@ __device__ __forceinline__ void epilogue_full_tile(const GemmParams& p,
       esc[j] = AFFINE ? p.ep_scale[gc] : 1.f;
       esh[j] = AFFINE ? p.ep_shift[gc] : 0.f;
     }
-    if constexpr (AFFINE) {
-      park_bf16<MF>(acc, w, lane, [&](float v, int j) {
-        v = fmaf(v + bv[j], esc[j], esh[j]);
-        return v > 0.f ? v : __expf(v) - 1.f;
-      });
-    } else if (add_bias) {                   // (uniform) the BatchNorm layers pass no bias: keep 128 adds out of their way
-      park_bf16<MF>(acc, w, lane, [&](float v, int j) { return v + bv[j]; });
-    } else {
-      park_bf16<MF>(acc, w, lane, [](float v, int) { return v; });
-    }
-    __syncthreads();
     bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + (long)(tm * BM + wm * 128) * p.ldc + tn * BN + wn * 64;
     const int cg = (lane & 7) * 8, r0 = lane >> 3;
+    auto chunk = [&](auto CH) {
+      constexpr int c = decltype(CH)::value;
+      if constexpr (AFFINE) {
+        park_chunk<MF, c>(acc, w, lane, [&](float v, int j) {
+          v = fmaf(v + bv[j], esc[j], esh[j]);
+          return v > 0.f ? v : __expf(v) - 1.f;
+        });
+      } else if (add_bias) {                 // (uniform) the BatchNorm layers pass no bias: keep the adds out of their way
+        park_chunk<MF, c>(acc, w, lane, [&](float v, int j) { return v + bv[j]; });
+      } else {
+        park_chunk<MF, c>(acc, w, lane, [](float v, int) { return v; });
+      }
 #pragma unroll
-    for (int pass = 0; pass < 16; ++pass) {
-      const int row = pass * 8 + r0;
-      *reinterpret_cast<uint4*>(C + (long)row * p.ldc + cg) = *reinterpret_cast<const uint4*>(&w[row * EP_PITCH + cg]);
-    }
-    __syncthreads();   // the statistics reduction reuses this LDS
+      for (int pass = 0; pass < EP_CHUNK_ROWS / 8; ++pass) {
+        const int row = pass * 8 + r0;
+        *reinterpret_cast<uint4*>(C + (long)(c * EP_CHUNK_ROWS + row) * p.ldc + cg) =
+            *reinterpret_cast<const uint4*>(&w[row * EP_PITCH + cg]);
+      }
+    };
+    chunk(std::integral_constant<int, 0>{});
+    chunk(std::integral_constant<int, 1>{});
+    chunk(std::integral_constant<int, 2>{});
+    chunk(std::integral_constant<int, 3>{});
   } else {
     float* C = reinterpret_cast<float*>(p.C) + (long)split * p.c_split_stride +
                (long)(tm * BM + wm * 128) * p.ldc + tn * BN + wn * 64;
@@ -496,9 +512,9 @@ __device__ __forceinline__ void epilogue_colstats(const GemmParams& p,
                                                   typename AccLayout<MF>::vec (&acc)[AccLayout<MF>::MB][AccLayout<MF>::NB],
                                                   unsigned char* smem_raw, int tm, int tn, int tid) {
   typedef AccLayout<MF> L;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  float* red = reinterpret_cast<float*>(smem_raw);   // [2 stats][2 wm][256 cols]
+  float* red = reinterpret_cast<float*>(smem_raw) + EP_RED_OFFSET / 2;   // [2 stats][2 wm][256 cols], behind the images
   typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int j = 0; j < L::NB; ++j) {
@@ -519,7 +535,7 @@ __device__ __forceinline__ void epilogue_colstats(const GemmParams& p,
       red[(1 * 2 + wm) * 256 + col] = s2;
     }
   }
-  __syncthreads();
+  lds_barrier();
   const int stat = tid >> 8, col = tid & 255;
   const double v = (double)red[(stat * 2 + 0) * 256 + col] + (double)red[(stat * 2 + 1) * 256 + col];
   unsafeAtomicAdd(&p.colstats[((long)(tm % p.nrep) * 2 + stat) * p.N + tn * BN + col], v);
@@ -537,7 +553,7 @@ __device__ __forceinline__ void epilogue_affine_meanpool(const GemmParams& p,
   typedef AccLayout<MF> L;
   constexpr int BPG = 32 * IPG / L::BR;          // accumulator row-blocks per group
   static_assert(L::MB % BPG == 0, "groups must not straddle waves");
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   float* out = reinterpret_cast<float*>(p.C);
   const float inv_n = 1.f / (32 * IPG);
@@ -581,11 +597,9 @@ template <int MF, bool POINTS>
 __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p,
                                                   typename AccLayout<MF>::vec (&acc)[AccLayout<MF>::MB][AccLayout<MF>::NB],
                                                   bf16_t* smem, int tm, int tn, int tid) {
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  bf16_t* w = smem + wave * 128 * EP_PITCH;
-  park_bf16<MF>(acc, w, lane, [](float v, int) { return v; });
-  __syncthreads();
+  bf16_t* w = smem + wave * EP_WAVE_ELEMS;                // smem: the epilogue's LDS region
   const int cg = (lane & 7) * 8, r0 = lane >> 3;
   const long tile_off = (long)(tm * BM + wm * 128) * p.ldc + tn * BN + wn * 64;
   bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + tile_off;
@@ -599,7 +613,7 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p,
 #pragma unroll
     for (int e = 0; e < 4; ++e) { sc[4 * q + e] = a[e]; sh[4 * q + e] = b[e]; mu[4 * q + e] = c[e]; rs[4 * q + e] = d[e]; }
   }
-  uint4 yv[16];
+  uint4 yv[2][EP_CHUNK_ROWS / 8];          // the stored pre-activations of one chunk, requested one chunk ahead
   f32x4 xv[16][2];
   float w1[8][8];
   const int xc = p.ep_xc;
@@ -618,41 +632,55 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p,
     for (int j = 0; j < 8; ++j)
 #pragma unroll
       for (int c = 0; c < 8; ++c) w1[j][c] = c < xc ? p.ep_w1[(long)(gcol + j) * xc + c] : 0.f;
-  } else {
-#pragma unroll
-    for (int pass = 0; pass < 16; ++pass)
-      yv[pass] = *reinterpret_cast<const uint4*>(Y + (long)(pass * 8 + r0) * p.ldc + cg);
   }
+  auto load_y = [&](int ch, int b) {
+#pragma unroll
+    for (int ps = 0; ps < EP_CHUNK_ROWS / 8; ++ps)
+      yv[b][ps] = *reinterpret_cast<const uint4*>(Y + (long)(ch * EP_CHUNK_ROWS + ps * 8 + r0) * p.ldc + cg);
+  };
+  if (!POINTS) load_y(0, 0);
   float s1[8], s2[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+  // 32 rows at a time through the wave's LDS image (wave-local: no workgroup barrier)
+  auto chunk = [&](auto CH) {
+    constexpr int ch = decltype(CH)::value;
+    if (!POINTS && ch < 3) load_y(ch + 1, (ch + 1) & 1);
+    park_chunk<MF, ch>(acc, w, lane, [](float v, int) { return v; });
 #pragma unroll
-  for (int pass = 0; pass < 16; ++pass) {
-    const int row = pass * 8 + r0;
-    float da[8], yy[8], dz[8];
-    unpack8(*reinterpret_cast<const uint4*>(&w[row * EP_PITCH + cg]), da);
-    if (POINTS) {
+    for (int ps = 0; ps < EP_CHUNK_ROWS / 8; ++ps) {
+      constexpr int per = EP_CHUNK_ROWS / 8;
+      const int pass = ch * per + ps;                      // 8-row pass of the wave's 128 rows
+      const int lrow = ps * 8 + r0, row = pass * 8 + r0;
+      float da[8], yy[8], dz[8];
+      unpack8(*reinterpret_cast<const uint4*>(&w[lrow * EP_PITCH + cg]), da);
+      if (POINTS) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float a = 0.f;
+        for (int j = 0; j < 8; ++j) {
+          float a = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) a = fmaf(w1[j][c], xv[pass][c >> 2][c & 3], a);   // same order as pointnet_in.hip
-        yy[j] = a;
+          for (int c = 0; c < 8; ++c) a = fmaf(w1[j][c], xv[pass][c >> 2][c & 3], a);   // same order as pointnet_in.hip
+          yy[j] = a;
+        }
+      } else {
+        unpack8(yv[ch & 1][ps], yy);
       }
-    } else {
-      unpack8(yv[pass], yy);
-    }
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const float z = yy[c] * sc[c] + sh[c];
-      dz[c] = da[c] * (z > 0.f ? 1.f : __expf(z));
-      s1[c] += dz[c];
-      s2[c] += dz[c] * ((yy[c] - mu[c]) * rs[c]);
+      for (int c = 0; c < 8; ++c) {
+        const float z = yy[c] * sc[c] + sh[c];
+        dz[c] = da[c] * (z > 0.f ? 1.f : __expf(z));
+        s1[c] += dz[c];
+        s2[c] += dz[c] * ((yy[c] - mu[c]) * rs[c]);
+      }
+      uint4 o;
+      o.x = pack2(dz[0], dz[1]); o.y = pack2(dz[2], dz[3]); o.z = pack2(dz[4], dz[5]); o.w = pack2(dz[6], dz[7]);
+      *reinterpret_cast<uint4*>(C + (long)row * p.ldc + cg) = o;
     }
-    uint4 o;
-    o.x = pack2(dz[0], dz[1]); o.y = pack2(dz[2], dz[3]); o.z = pack2(dz[4], dz[5]); o.w = pack2(dz[6], dz[7]);
-    *reinterpret_cast<uint4*>(C + (long)row * p.ldc + cg) = o;
-  }
+  };
+  chunk(std::integral_constant<int, 0>{});
+  chunk(std::integral_constant<int, 1>{});
+  chunk(std::integral_constant<int, 2>{});
+  chunk(std::integral_constant<int, 3>{});
   // lanes with equal (lane & 7) hold the same 8 columns: fold the 8 row lanes
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
@@ -662,8 +690,7 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p,
       s2[c] += __shfl_xor(s2[c], o, 64);
     }
   }
-  __syncthreads();                       // every wave is done with its LDS image
-  float* red = reinterpret_cast<float*>(smem);      // [2 stats][2 wm][256 cols]
+  float* red = reinterpret_cast<float*>(smem) + EP_RED_OFFSET / 2;      // [2 stats][2 wm][256 cols], behind the images
   if (lane < 8) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -671,7 +698,7 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p,
       red[(1 * 2 + wm) * 256 + wn * 64 + cg + c] = s2[c];
     }
   }
-  __syncthreads();
+  lds_barrier();
   const int stat = tid >> 8, col = tid & 255;
   const double v = (double)red[(stat * 2 + 0) * 256 + col] + (double)red[(stat * 2 + 1) * 256 + col];
   unsafeAtomicAdd(&p.colstats[((long)(tm % p.nrep) * 2 + stat) * p.N + tn * BN + col], v);
@@ -719,8 +746,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: piece indices and LDS bases are SGPR math
   const int wm = wave >> 2, wn = wave & 3;
+  // Tiles: a launch without K splits may start fewer workgroups than tiles (one per CU); workgroup b then walks the
+  // tiles b, b + gridDim.x, ... of the XCD-aware order (gridDim.x is a multiple of 8: all of them on b's XCD, and
+  // the workgroups of an XCD are on neighbouring tiles at any time, as with one workgroup per tile).
+  constexpr bool PERSIST = ALAY == KC;             // the wgrad (RC x RC) launches split K: one tile per workgroup
+  const int nbm = p.M / BM, nbn = p.N / BN;
+  int vb = blockIdx.x;
   int tm, tn;
-  const int split = block_coords(p, p.M / BM, p.N / BN, tm, tn);
+  const int split = block_coords(p, nbm, nbn, tm, tn);
 
   const int kbeg = split * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
@@ -736,52 +769,74 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
     piece_lane_offsets<ALAY>(p.lda, lane, voA);
     piece_lane_offsets<BLAY>(p.ldb, lane, voB);
   }
+  // per-lane constants of the K loop are rebuilt at the top of every tile from an opaque copy of the lane id, so that
+  // they do not stay in registers across the epilogue (which needs them all: accumulators + 64 of operands)
+  int ln = lane;
   // one 1-KB piece of the A (which = 0) or B (1) tile of the K step starting at k0 into stage image s_tile
-  auto piece = [&](int which, int k0, bf16_t* s_tile, int j) {
+  auto piece_of = [&](int tmx, int tnx, int which, int k0, bf16_t* s_tile, int j) {
     if (BUF) {
-      if (which == 0) dma_piece_buf<ALAY>(rA, p.lda, tm * BM, k0, s_tile, wave, voA, j);
-      else dma_piece_buf<BLAY>(rB, p.ldb, tn * BN, k0, s_tile, wave, voB, j);
+      if (which == 0) dma_piece_buf<ALAY>(rA, p.lda, tmx * BM, k0, s_tile, wave, voA, j);
+      else dma_piece_buf<BLAY>(rB, p.ldb, tnx * BN, k0, s_tile, wave, voB, j);
     } else {
-      if (which == 0) dma_piece<ALAY>(A, p.lda, tm * BM, p.M, k0, s_tile, wave, lane, j);
-      else dma_piece<BLAY>(B, p.ldb, tn * BN, p.N, k0, s_tile, wave, lane, j);
+      if (which == 0) dma_piece<ALAY>(A, p.lda, tmx * BM, p.M, k0, s_tile, wave, lane, j);
+      else dma_piece<BLAY>(B, p.ldb, tnx * BN, p.N, k0, s_tile, wave, lane, j);
     }
   };
+  auto piece = [&](int which, int k0, bf16_t* s_tile, int j) { piece_of(tm, tn, which, k0, s_tile, j); };
   // LDS images of the operands' stages: slots A0 A1 A2 B0 B1 (5 x 32 KB = all of the LDS).  A -- the operand
   // streamed from HBM in the forward / dgrad products: a quarter of its lines miss the L2 and take ~2 us -- has THREE
   // stages and is requested TWO K steps ahead; B (there: the L2-resident weights) keeps two.  A stage lands as a
   // whole only when its slowest piece has: with one step of distance the step waited for that HBM round trip
   // (2 750 cycles for a stage against 2 048 of MFMA, round 1's stamps); same-box A/B of the two rings on the three
   // PointNet shapes: forward +9..12 %, fused dgrad +8..12 %, wgrad (both operands streamed) +3..4 %.
-  auto slotA = [&](int i) { return smem + i * D_TILE; };
-  auto slotB = [&](int i) { return smem + (3 + i) * D_TILE; };
+  // Order in memory: A0 A1 B0 | A2 B1.  A tile's FIRST stages -- A(0), B(0), A(1) -- go to the first three slots;
+  // the epilogue works in the last two (64 KB: eight 4.5-KB wave images + the statistics scratch), so a workgroup
+  // that has another tile to do requests that tile's first stages BEFORE its epilogue and they land beside it.
+  auto slotA = [&](int i) { return smem + (i < 2 ? i : 3) * D_TILE; };
+  auto slotB = [&](int i) { return smem + (i == 0 ? 2 : 4) * D_TILE; };
+  bf16_t* epi = smem + 3 * D_TILE;
+  // first stages of tile (tmx, tnx): the order the first barrier's counted wait relies on
+  auto first_stages = [&](int tmx, int tnx) {
+    if (nt > 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) piece_of(tmx, tnx, 0, kbeg, slotA(0), j);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) piece_of(tmx, tnx, 1, kbeg, slotB(0), j);
+      if (nt > 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) piece_of(tmx, tnx, 0, kbeg + BK, slotA(1), j);
+      }
+    }
+  };
   typename L::vec acc[L::MB][L::NB];
+  first_stages(tm, tn);
+  bool primed = false;             // this tile's first stages were requested during the previous tile's epilogue
+  for (;;) {
 #pragma unroll
   for (int i = 0; i < L::MB; ++i)
 #pragma unroll
     for (int j = 0; j < L::NB; ++j)
 #pragma unroll
       for (int r = 0; r < L::NR; ++r) acc[i][j][r] = 0.f;
-
-  if (nt > 0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) piece(0, kbeg, slotA(0), j);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) piece(1, kbeg, slotB(0), j);
-    if (nt > 1) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) piece(0, kbeg + BK, slotA(1), j);
+  // first tile: A(1) -- the four youngest pieces -- may stay in flight; later tiles: the stages have had the whole
+  // epilogue to land, and the epilogue's C stores share the counter: everything
+  step_barrier(!primed && nt > 1);
+  if (PERSIST) {
+    asm volatile("" : "+v"(ln));
+    if (BUF) {
+      piece_lane_offsets<ALAY>(p.lda, ln, voA);
+      piece_lane_offsets<BLAY>(p.ldb, ln, voB);
     }
   }
-  step_barrier(nt > 1);
   int ia = 0;                                   // A slot of the current step (t mod 3)
 
   if constexpr (MF == 32) {
-    const int l31 = lane & 31, half = lane >> 5;
+    const int l31 = ln & 31, half = ln >> 5;
     int offA[4], offB[2], kofs[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) offA[i] = dma_frag_offset<ALAY>(wm * 128 + i * 32, lane);
+    for (int i = 0; i < 4; ++i) offA[i] = dma_frag_offset<ALAY>(wm * 128 + i * 32, ln);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) offB[j] = dma_frag_offset<BLAY>(wn * 64 + j * 32, lane);
+    for (int j = 0; j < 2; ++j) offB[j] = dma_frag_offset<BLAY>(wn * 64 + j * 32, ln);
     {
       const int swz = (l31 >> 1) & 7;
 #pragma unroll
@@ -842,7 +897,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
     }
   } else {
     // ---- 16x16x32 fragments: lane holds 8 consecutive k of row (lane & 15); k-granule 4*s2 + (lane >> 4)
-    const int l15 = lane & 15, q = lane >> 4;
+    const int l15 = ln & 15, q = ln >> 4;
     int offA[8], offB[4], kofs[2];
 #pragma unroll
     for (int i = 0; i < 8; ++i) offA[i] = (wm * 128 + i * 16 + l15) * 64;
@@ -896,15 +951,33 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
       ia = ia == 2 ? 0 : ia + 1;
     }
   }
+  // the next tile of this workgroup: its first stages go out now and land beside the epilogue
+  const int vb2 = vb + (int)gridDim.x;
+  const bool has_next = PERSIST && !p.split_fast && vb2 < nbm * nbn;
+  int tm2 = 0, tn2 = 0;
+  if (has_next) {
+    xcd_tile_coords(nbm, nbn, vb2, tm2, tn2);
+    first_stages(tm2, tn2);
+  }
+  // the epilogue's per-lane address arithmetic must not be hoisted out of the tile loop (it would sit in ~40
+  // registers through the K loop): it is derived from an opaque copy of the thread id
+  int te = tid;
+  if (PERSIST) asm volatile("" : "+v"(te));
   if constexpr (EPI == EPI_DGRAD_BN || EPI == EPI_DGRAD_BN_POINTS) {
-    epilogue_dgrad_bn<MF, EPI == EPI_DGRAD_BN_POINTS>(p, acc, smem, tm, tn, tid);
+    epilogue_dgrad_bn<MF, EPI == EPI_DGRAD_BN_POINTS>(p, acc, epi, tm, tn, te);
   } else if constexpr (EPI == EPI_AFFINE) {
-    epilogue_full_tile<TC, MF, true>(p, acc, smem, tm, tn, tid, split);
+    epilogue_full_tile<TC, MF, true>(p, acc, epi, tm, tn, te, split);
   } else if constexpr (EPI == EPI_POOL1 || EPI == EPI_POOL2 || EPI == EPI_POOL4) {
-    epilogue_affine_meanpool<MF, EPI == EPI_POOL1 ? 1 : (EPI == EPI_POOL2 ? 2 : 4)>(p, acc, tm, tn, tid);
+    epilogue_affine_meanpool<MF, EPI == EPI_POOL1 ? 1 : (EPI == EPI_POOL2 ? 2 : 4)>(p, acc, tm, tn, te);
   } else {
-    epilogue_full_tile<TC, MF, false>(p, acc, smem, tm, tn, tid, split);
-    if (p.colstats != nullptr) epilogue_colstats<MF>(p, acc, smem_raw, tm, tn, tid);
+    epilogue_full_tile<TC, MF, false>(p, acc, epi, tm, tn, te, split);
+    if (p.colstats != nullptr) epilogue_colstats<MF>(p, acc, reinterpret_cast<unsigned char*>(epi), tm, tn, te);
+  }
+  if (!has_next) break;
+  vb = vb2;
+  tm = tm2;
+  tn = tn2;
+  primed = true;
   }
 }
 
@@ -931,8 +1004,24 @@ bool launch_dma_inst(const GemmParams& p, dim3 grid, hipStream_t s) {
   return true;
 }
 
+// Launches without K splits start one workgroup per CU (a multiple of 8: the XCD-aware tile order) and let each
+// walk its share of the tiles: no dispatch gap between a CU's tiles, and the next tile's first stages are requested
+// before the epilogue (see the kernel).
+static unsigned persistent_grid(long ntiles) {
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      n = 256;
+    ncu = n >= 8 ? n / 8 * 8 : 8;
+  }
+  return (unsigned)(ntiles < ncu ? ntiles : ncu);
+}
+
 template <typename TC, int ALAY, int BLAY, int EPI>
-bool launch_dma(const GemmParams& p, dim3 grid, hipStream_t s) {
+bool launch_dma(const GemmParams& p, dim3 grid_in, hipStream_t s) {
+  dim3 grid = grid_in;
+  if (!p.split_fast && grid.z == 1) grid.x = persistent_grid((long)grid.x);
   // buffer addressing needs each operand below 4 GiB (32-bit offsets); the flat form serves anything larger.  Same-box
   // A/B (profiles/r02_gemm_lab2.txt): forward / fused dgrad +1..3 %, wgrad (whole stage issued at the top of the step:
   // 8 pieces x ~7 VALU each in front of the first MFMA) +2.6 / +7.3 / +10.1 % on the three PointNet shapes.

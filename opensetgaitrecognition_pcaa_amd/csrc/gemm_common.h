@@ -24,9 +24,8 @@ struct GemmParams {
 // XCD-aware, bijective block -> (tile_m, tile_n) map: the 8 XCDs (blocks b, b+8,
 // ... share one) each walk a contiguous range of tiles with the N-tiles of one
 // M-panel adjacent, so an A panel is re-read from that XCD's L2.
-__device__ __forceinline__ void xcd_tile_coords(int nbm, int nbn, int& tm, int& tn) {
+__device__ __forceinline__ void xcd_tile_coords(int nbm, int nbn, int bid, int& tm, int& tn) {
   const int nb = nbm * nbn;
-  const int bid = blockIdx.x;
   const int q = nb >> 3, r = nb & 7;
   const int xcd = bid & 7, idx = bid >> 3;
   const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -44,7 +43,7 @@ __device__ __forceinline__ int block_coords(const GemmParams& p, int nbm, int nb
     tn = t - tm * nbn;
     return s;
   }
-  xcd_tile_coords(nbm, nbn, tm, tn);
+  xcd_tile_coords(nbm, nbn, blockIdx.x, tm, tn);
   return blockIdx.z;
 }
 
