@@ -395,6 +395,7 @@ static int gemm_impl(int math,
   PCAA_CHECK_ARG(!colstats || nrep >= 1, "pcaa_gemm: nrep must be >= 1 with colstats");
 
   GemmParams p;
+  memset(&p, 0, sizeof(p));
   p.A = A; p.B = B; p.C = C;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K;

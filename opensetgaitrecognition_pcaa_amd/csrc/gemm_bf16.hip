@@ -405,7 +405,7 @@ __device__ __forceinline__ float dpp_swap_neighbour(float v) {
 constexpr int EP_CHUNK_ROWS = 32;
 constexpr int EP_WAVE_ELEMS = EP_CHUNK_ROWS * EP_PITCH;            // bf16 elements of one wave's image
 constexpr int EP_RED_OFFSET = 8 * EP_WAVE_ELEMS;                   // statistics scratch behind the eight images
-static_assert(EP_RED_OFFSET * 2 + 2 * 2 * 256 * 4 <= 2 * D_TILE * 2, "the epilogue lives in the ring's last two slots");
+static_assert(EP_RED_OFFSET * 2 + 2 * 2 * 256 * 4 + 16 <= 2 * D_TILE * 2, "the epilogue lives in the ring's last two slots");
 template <int MF, int CHUNK, typename F>
 __device__ __forceinline__ void park_chunk(typename AccLayout<MF>::vec (&acc)[AccLayout<MF>::MB][AccLayout<MF>::NB],
                                            bf16_t* wave_img, int lane, F f) {
@@ -811,7 +811,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   typename L::vec acc[L::MB][L::NB];
   first_stages(tm, tn);
   bool primed = false;             // this tile's first stages were requested during the previous tile's epilogue
+  // Which tile next?  With p.sched the workgroups of an XCD draw tickets from that XCD's counter (positions
+  // gridDim.x / 8, ... of its range: the first gridDim.x / 8 are the workgroups' own first tiles), so a workgroup
+  // that got its CU late -- the chip shared with another stream's kernels or a collective -- simply does fewer
+  // tiles.  Thread 0 draws the ticket at the top of a tile (the round trip hides under the K loop) and hands it
+  // to the other waves through LDS when the loop is over.  Every workgroup ends on a ticket beyond the range; the
+  // last one to finish resets the counters for the next launch.  No waiting on other workgroups anywhere.
+  int* const sched = PERSIST && !p.split_fast && (int)gridDim.x < nbm * nbn ? p.sched : nullptr;
+  int* const ticket_lds = reinterpret_cast<int*>(epi + EP_RED_OFFSET) + 2 * 2 * 256;      // behind the statistics scratch
   for (;;) {
+  int ticket = 0;
+  if (sched != nullptr && tid == 0) ticket = atomicAdd(&sched[vb & 7], 1);
 #pragma unroll
   for (int i = 0; i < L::MB; ++i)
 #pragma unroll
@@ -952,7 +962,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
     }
   }
   // the next tile of this workgroup: its first stages go out now and land beside the epilogue
-  const int vb2 = vb + (int)gridDim.x;
+  int vb2 = vb + (int)gridDim.x;
+  if (sched != nullptr) {
+    if (tid == 0) *ticket_lds = ticket;
+    lds_barrier();
+    vb2 = (vb & 7) + 8 * ((int)(gridDim.x >> 3) + __builtin_amdgcn_readfirstlane(*ticket_lds));
+  }
   const bool has_next = PERSIST && !p.split_fast && vb2 < nbm * nbn;
   int tm2 = 0, tn2 = 0;
   if (has_next) {
@@ -973,7 +988,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
     epilogue_full_tile<TC, MF, false>(p, acc, epi, tm, tn, te, split);
     if (p.colstats != nullptr) epilogue_colstats<MF>(p, acc, reinterpret_cast<unsigned char*>(epi), tm, tn, te);
   }
-  if (!has_next) break;
+  if (!has_next) {
+    if (sched != nullptr && tid == 0 && atomicAdd(&sched[8], 1) == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) atomicExch(&sched[i], 0);
+    }
+    break;
+  }
   vb = vb2;
   tm = tm2;
   tn = tn2;
@@ -1004,9 +1025,12 @@ bool launch_dma_inst(const GemmParams& p, dim3 grid, hipStream_t s) {
   return true;
 }
 
-// Launches without K splits start one workgroup per CU (a multiple of 8: the XCD-aware tile order) and let each
-// walk its share of the tiles: no dispatch gap between a CU's tiles, and the next tile's first stages are requested
-// before the epilogue (see the kernel).
+// Launches without K splits start one workgroup per CU (a multiple of 8: the XCD-aware tile order) and let them draw
+// their tiles: no dispatch gap between a CU's tiles, and the next tile's first stages are requested before the
+// epilogue (see the kernel).  The draw is dynamic (ticket counters, sched_slot): with FIXED shares a launch that does
+// not get every CU at once -- 8 CUs held by another stream's kernel for its duration, tools/gemm_contention.py -- took
+// 0.83 ms instead of 0.49 (the late workgroups run their whole share afterwards); with tickets 0.50-0.61 ms for 8-64
+// CUs held, i.e. the ideal 256 / (256 - H).  Price: one LDS hand-off + barrier per tile, 1-5 % on an idle chip.
 static unsigned persistent_grid(long ntiles) {
   static int ncu = 0;
   if (ncu == 0) {
@@ -1018,10 +1042,43 @@ static unsigned persistent_grid(long ntiles) {
   return (unsigned)(ntiles < ncu ? ntiles : ncu);
 }
 
+// Ticket counters of the tile loop: 16 ints per stream that launches these kernels (launches of one stream run in
+// order, and the last workgroup of a launch leaves its counters at zero).  Allocated once; never during a stream
+// capture (a captured first launch walks fixed shares instead).
+static int* sched_slot(hipStream_t s) {
+  constexpr int SLOTS = 16;
+  static int* base = nullptr;
+  static hipStream_t owner[SLOTS];
+  static int used = 0;
+  static bool failed = false;
+  if (failed) return nullptr;
+  if (base == nullptr) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&base), SLOTS * 16 * sizeof(int)) != hipSuccess ||
+        hipMemset(base, 0, SLOTS * 16 * sizeof(int)) != hipSuccess) {
+      base = nullptr;
+      failed = true;
+      return nullptr;
+    }
+  }
+  for (int i = 0; i < used; ++i)
+    if (owner[i] == s) return base + 16 * i;
+  if (used == SLOTS) return nullptr;
+  owner[used] = s;
+  return base + 16 * used++;
+}
+
 template <typename TC, int ALAY, int BLAY, int EPI>
-bool launch_dma(const GemmParams& p, dim3 grid_in, hipStream_t s) {
+bool launch_dma(const GemmParams& p_in, dim3 grid_in, hipStream_t s) {
   dim3 grid = grid_in;
-  if (!p.split_fast && grid.z == 1) grid.x = persistent_grid((long)grid.x);
+  GemmParams p = p_in;
+  p.sched = nullptr;
+  if (ALAY == KC && !p.split_fast && grid.z == 1) {
+    const unsigned g = persistent_grid((long)grid.x);
+    if (g < grid.x) p.sched = sched_slot(s);
+    grid.x = g;
+  }
   // buffer addressing needs each operand below 4 GiB (32-bit offsets); the flat form serves anything larger.  Same-box
   // A/B (profiles/r02_gemm_lab2.txt): forward / fused dgrad +1..3 %, wgrad (whole stage issued at the top of the step:
   // 8 pieces x ~7 VALU each in front of the first MFMA) +2.6 / +7.3 / +10.1 % on the three PointNet shapes.

@@ -18,6 +18,9 @@ struct GemmParams {
   // dgrad fused with the BatchNorm+ELU backward of the layer below (pcaa_gemm_dgrad_bn)
   const void* ep_y; const float* ep_scale; const float* ep_shift; const float* ep_mean; const float* ep_rstd;
   const float* ep_x; const float* ep_w1; int ep_xc;   // ep_y == NULL: y = x[M,xc] . W1[N,xc]^T is recomputed
+  // LDS-DMA kernel, one workgroup per CU: 9 zero-initialised ints (8 per-XCD tile tickets + a count of finished
+  // workgroups, reset by the last one); NULL: every workgroup walks a fixed share of the tiles
+  int* sched;
 
 };
 

@@ -444,6 +444,31 @@ def test_skinny_wgrad_adam_equals_wgrad_then_adam_bitwise(M, N, K):
     assert not torch.equal(Wa, W0)
 
 
+def test_gemm_tile_loop_with_two_launches_competing_for_the_cus():
+    """The LDS-DMA GEMM starts one workgroup per CU and lets them draw tiles from per-XCD ticket counters (one set per
+    stream).  Two such launches on two streams at once: each gets its CUs late / piecemeal, every tile must still be
+    computed exactly once by each, and the counters must be back at zero for the next launch."""
+    P, cin, cout = 61440, 512, 1024            # 960 tiles: more than the 256 workgroups
+    a = [(_rand((P, cin), 900 + i, 0.5)).to(DEV).bfloat16() for i in range(2)]
+    w = [(_rand((cout, cin), 910 + i, 0.05)).to(DEV).bfloat16() for i in range(2)]
+    ref = [(a[i].float() @ w[i].float().t()) for i in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    out = [torch.empty((P, cout), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(4):
+        for o in out:
+            o.zero_()
+        torch.cuda.synchronize()
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                for _ in range(2):                     # back-to-back launches on one stream reuse its counters
+                    ops.gemm(a[i], KC, w[i], KC, P, cout, cin, out=out[i], out_dtype=torch.bfloat16, math=PCAA_BF16)
+        torch.cuda.synchronize()
+        for i in range(2):
+            err = (out[i].float() - ref[i]).abs().max().item() / ref[i].abs().max().item()
+            assert err < 1e-2, (rep, i, err)
+
+
 def test_cross_entropy_and_preds():
     B, K = 37, 6
     x = _rand((B, K), 70, 3.0)
