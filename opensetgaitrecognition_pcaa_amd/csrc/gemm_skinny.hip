@@ -521,7 +521,7 @@ extern "C" int pcaa_skinny_splits(int kind, int M, int N, int K) {
 }
 
 extern "C" int pcaa_skinny_supported(int M, int N, int K) {
-  return M >= 1 && M <= 64 && N >= 128 && K >= 128 && N % 64 == 0 && K % 64 == 0 && (long)N * K < (1L << 31) - (1L << 20);
+  return M >= 1 && M <= 64 && N >= 128 && K >= 64 && N % 64 == 0 && K % 64 == 0 && (long)N * K < (1L << 31) - (1L << 20);
 }
 
 extern "C" int pcaa_skinny_linear_fwd(const float* x, long ldx, const float* W, long ldw, const float* bias, int act,

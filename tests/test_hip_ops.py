@@ -143,7 +143,7 @@ def test_gemm_bf16_lds_dma_exact_integers(lay, M, N, K, sk):
         assert torch.equal(Cb.float().cpu().double(), acc.float().bfloat16().double())
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 1920, 960), (64, 960, 1920), (37, 320, 704), (8, 128, 128), (1, 192, 256),
+@pytest.mark.parametrize("M,N,K", [(64, 1920, 960), (64, 960, 1920), (37, 320, 704), (8, 128, 128), (1, 192, 256), (64, 960, 64),
                                    (64, 15360 // 2, 7680 // 2)])
 def test_skinny_linear_layers_exact_integers(M, N, K):
     """batch-skinny (M <= 64) decoder kernels: weights streamed HBM -> MFMA fragments.  Small
