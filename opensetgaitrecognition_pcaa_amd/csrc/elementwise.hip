@@ -181,10 +181,11 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_stats_kernel(const float* __r
                                                                 const float* __restrict__ e1,
                                                                 const float* __restrict__ e2, float pool_scale,
                                                                 double* __restrict__ stats, int nrep, long groups,
-                                                                int ch) {
-  // thread = channel quad; the 32 groups of the block in trips of 8 with all 24 loads in flight (the first
-  // version walked them one dependent load at a time: 150 us beside the side-stream Adam)
-  const long g0 = (long)blockIdx.x * 32, g1 = min(groups, g0 + 32);
+                                                                int ch, int gpb) {
+  // thread = channel quad; the block's gpb groups in trips of 8 with all 24 loads in flight (the first version
+  // walked them one dependent load at a time: 150 us beside the side-stream Adam; 32 groups per block left the
+  // 1920-group PointNet case with 60 workgroups on 256 CUs: 50 us on the critical path)
+  const long g0 = (long)blockIdx.x * gpb, g1 = min(groups, g0 + gpb);
   for (int c = threadIdx.x * 4; c < ch; c += 1024) {
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
     for (long g = g0; g < g1; g += 8) {
@@ -579,8 +580,9 @@ extern "C" int pcaa_bn_pool_bwd_stats(const float* dpool, const float* e1, const
                                       double* stats, int nrep, long groups, int ch, void* stream) {
   PCAA_CHECK_ARG(dpool && e1 && e2 && stats, "pcaa_bn_pool_bwd_stats: null pointer");
   PCAA_CHECK_ARG(groups >= 1 && ch >= 4 && (ch & 3) == 0 && nrep >= 1, "pcaa_bn_pool_bwd_stats: ch must be a multiple of 4");
-  hipLaunchKernelGGL(bn_pool_bwd_stats_kernel, dim3((unsigned)cdiv(groups, 32)), dim3(256), 0, as_stream(stream),
-                     dpool, e1, e2, pool_scale, stats, nrep, groups, ch);
+  const int gpb = (int)std::max<long>(1, std::min<long>(32, groups / 256));      // >= 256 workgroups where there are groups for them
+  hipLaunchKernelGGL(bn_pool_bwd_stats_kernel, dim3((unsigned)cdiv(groups, gpb)), dim3(256), 0, as_stream(stream),
+                     dpool, e1, e2, pool_scale, stats, nrep, groups, ch, gpb);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_pool_bwd_stats");
 }
 
