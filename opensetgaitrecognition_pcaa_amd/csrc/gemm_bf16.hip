@@ -639,9 +639,21 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p,
       yv[b][ps] = *reinterpret_cast<const uint4*>(Y + (long)(ch * EP_CHUNK_ROWS + ps * 8 + r0) * p.ldc + cg);
   };
   if (!POINTS) load_y(0, 0);
-  float s1[8], s2[8];
+  // The element-wise part runs on column PAIRS with packed fp32 instructions (the epilogue is bound by vector-ALU issue):
+  // ELU'(z) = exp(min(z, 0)) = exp2(min(z log2e, 0)) with log2e folded into the affine coefficients (no compare / select),
+  // yhat = y rstd - mean rstd as one fused multiply-add.
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 sc2[4], sh2[4], rs2[4], nm2[4], s1[4], s2[4];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+  for (int q = 0; q < 4; ++q) {
+    constexpr float kLog2e = 1.4426950408889634f;
+    sc2[q] = f32x2{sc[2 * q] * kLog2e, sc[2 * q + 1] * kLog2e};
+    sh2[q] = f32x2{sh[2 * q] * kLog2e, sh[2 * q + 1] * kLog2e};
+    rs2[q] = f32x2{rs[2 * q], rs[2 * q + 1]};
+    nm2[q] = f32x2{-mu[2 * q] * rs[2 * q], -mu[2 * q + 1] * rs[2 * q + 1]};
+    s1[q] = f32x2{0.f, 0.f};
+    s2[q] = f32x2{0.f, 0.f};
+  }
   // 32 rows at a time through the wave's LDS image (wave-local: no workgroup barrier)
   auto chunk = [&](auto CH) {
     constexpr int ch = decltype(CH)::value;
@@ -666,11 +678,16 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p,
         unpack8(yv[ch & 1][ps], yy);
       }
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const float z = yy[c] * sc[c] + sh[c];
-        dz[c] = da[c] * (z > 0.f ? 1.f : __expf(z));
-        s1[c] += dz[c];
-        s2[c] += dz[c] * ((yy[c] - mu[c]) * rs[c]);
+      for (int q = 0; q < 4; ++q) {
+        const f32x2 yv2 = {yy[2 * q], yy[2 * q + 1]}, dav = {da[2 * q], da[2 * q + 1]};
+        f32x2 z2 = __builtin_elementwise_fma(yv2, sc2[q], sh2[q]);
+        z2 = __builtin_elementwise_min(z2, f32x2{0.f, 0.f});
+        const f32x2 g = {__builtin_amdgcn_exp2f(z2.x), __builtin_amdgcn_exp2f(z2.y)};
+        const f32x2 d2 = dav * g;
+        s1[q] += d2;
+        s2[q] = __builtin_elementwise_fma(d2, __builtin_elementwise_fma(yv2, rs2[q], nm2[q]), s2[q]);
+        dz[2 * q] = d2.x;
+        dz[2 * q + 1] = d2.y;
       }
       uint4 o;
       o.x = pack2(dz[0], dz[1]); o.y = pack2(dz[2], dz[3]); o.z = pack2(dz[4], dz[5]); o.w = pack2(dz[6], dz[7]);
@@ -682,20 +699,23 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p,
   chunk(std::integral_constant<int, 2>{});
   chunk(std::integral_constant<int, 3>{});
   // lanes with equal (lane & 7) hold the same 8 columns: fold the 8 row lanes
+  float t1[8], t2[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
+    t1[c] = s1[c >> 1][c & 1];
+    t2[c] = s2[c >> 1][c & 1];
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) {
-      s1[c] += __shfl_xor(s1[c], o, 64);
-      s2[c] += __shfl_xor(s2[c], o, 64);
+      t1[c] += __shfl_xor(t1[c], o, 64);
+      t2[c] += __shfl_xor(t2[c], o, 64);
     }
   }
   float* red = reinterpret_cast<float*>(smem) + EP_RED_OFFSET / 2;      // [2 stats][2 wm][256 cols], behind the images
   if (lane < 8) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      red[(0 * 2 + wm) * 256 + wn * 64 + cg + c] = s1[c];
-      red[(1 * 2 + wm) * 256 + wn * 64 + cg + c] = s2[c];
+      red[(0 * 2 + wm) * 256 + wn * 64 + cg + c] = t1[c];
+      red[(1 * 2 + wm) * 256 + wn * 64 + cg + c] = t2[c];
     }
   }
   lds_barrier();
