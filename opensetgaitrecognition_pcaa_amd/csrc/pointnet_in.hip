@@ -12,40 +12,44 @@ constexpr int FWD_ROWS = 128;    // points per workgroup (forward)
 constexpr int WG_ROWS = 256;     // points per workgroup (wgrad): 960 workgroups at P = 245760
 constexpr int BWD_ROWS = 128;   // points per workgroup of the recompute backward passes (1920 workgroups)
 
-template <typename T>
+// CP: point features padded to 4 or 8 (C <= 4 is the common case: half the multiply-adds of the padded-to-8 loop);
+// the product runs on column pairs with packed fp32 fused multiply-adds -- per element the same operations in the same
+// order as the scalar form (and as the backward's recomputation).
+template <typename T, int CP>
 __global__ __launch_bounds__(256) void pointnet_in_fwd_kernel(const float* __restrict__ x, int C,
                                                               const float* __restrict__ W,   // [cout, C]
                                                               const float* __restrict__ bias,
                                                               T* __restrict__ y, long P, int cout,
                                                               double* __restrict__ stats, int nrep) {
-  __shared__ float xs[FWD_ROWS * MAXC];
+  __shared__ float xs[FWD_ROWS * CP];
   __shared__ f32x4 red[2][256];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   const int qpr = cout >> 2, rl = 256 / qpr;
   const int cq = threadIdx.x % qpr, rlane = threadIdx.x / qpr;
   const long r0 = (long)blockIdx.x * FWD_ROWS;
   const int nrows = (int)min((long)FWD_ROWS, P - r0);
-  for (int e = threadIdx.x; e < FWD_ROWS * MAXC; e += 256) {
-    const int r = e / MAXC, c = e - r * MAXC;
+  for (int e = threadIdx.x; e < FWD_ROWS * CP; e += 256) {
+    const int r = e / CP, c = e - r * CP;
     xs[e] = (r < nrows && c < C) ? x[(r0 + r) * C + c] : 0.f;
   }
-  float w[4][MAXC];
+  f32x2 wlo[CP], whi[CP];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) w[j][c] = (c < C) ? W[(cq * 4 + j) * C + c] : 0.f;
+  for (int c = 0; c < CP; ++c) {
+    wlo[c] = f32x2{(c < C) ? W[(cq * 4 + 0) * C + c] : 0.f, (c < C) ? W[(cq * 4 + 1) * C + c] : 0.f};
+    whi[c] = f32x2{(c < C) ? W[(cq * 4 + 2) * C + c] : 0.f, (c < C) ? W[(cq * 4 + 3) * C + c] : 0.f};
+  }
   const f32x4 b = bias ? load4(bias + cq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
   for (int r = rlane; r < nrows; r += rl) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x2 alo = {0.f, 0.f}, ahi = {0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-      const float xv = xs[r * MAXC + c];
-      acc.x = fmaf(w[0][c], xv, acc.x);
-      acc.y = fmaf(w[1][c], xv, acc.y);
-      acc.z = fmaf(w[2][c], xv, acc.z);
-      acc.w = fmaf(w[3][c], xv, acc.w);
+    for (int c = 0; c < CP; ++c) {
+      const f32x2 xv = {xs[r * CP + c], xs[r * CP + c]};
+      alo = __builtin_elementwise_fma(wlo[c], xv, alo);
+      ahi = __builtin_elementwise_fma(whi[c], xv, ahi);
     }
+    const f32x4 acc = {alo.x, alo.y, ahi.x, ahi.y};
     s1 += acc;
     s2 += acc * acc;
     if (y) store4(y + (r0 + r) * cout + cq * 4, acc + b);     // y == NULL: statistics only (recompute path)
@@ -345,13 +349,13 @@ extern "C" int pcaa_pointnet_in_fwd(const float* x, int C, const float* W, const
   PCAA_CHECK_ARG(shape_ok(C, cout), "pcaa_pointnet_in_fwd: need C<=%d and cout/4 dividing 256 (C=%d cout=%d)", MAXC, C, cout);
   PCAA_CHECK_ARG(!stats || nrep >= 1, "pcaa_pointnet_in_fwd: bad nrep");
   const unsigned grid = (unsigned)cdiv(P, FWD_ROWS);
-  if (y_dtype == PCAA_F32)
-    hipLaunchKernelGGL(pointnet_in_fwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), x, C, W, bias,
-                       (float*)y, P, cout, stats, nrep);
-  else if (y_dtype == PCAA_BF16)
-    hipLaunchKernelGGL(pointnet_in_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), x, C, W, bias,
-                       (bf16_t*)y, P, cout, stats, nrep);
+#define LAUNCH_FWD(T, CP)                                                                                          \
+  hipLaunchKernelGGL((pointnet_in_fwd_kernel<T, CP>), dim3(grid), dim3(256), 0, as_stream(stream), x, C, W, bias, \
+                     (T*)y, P, cout, stats, nrep)
+  if (y_dtype == PCAA_F32) { if (C <= 4) LAUNCH_FWD(float, 4); else LAUNCH_FWD(float, 8); }
+  else if (y_dtype == PCAA_BF16) { if (C <= 4) LAUNCH_FWD(bf16_t, 4); else LAUNCH_FWD(bf16_t, 8); }
   else { pcaa_set_error("pcaa_pointnet_in_fwd: bad dtype"); return PCAA_ERR_INVALID_ARG; }
+#undef LAUNCH_FWD
   PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_fwd");
 }
 
