@@ -159,24 +159,6 @@ __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restric
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int c = 0; c < CP; ++c) acc[j][c] = 0.f;
-  // bf16 storage (throughput mode): these passes are bound by vector-ALU issue, not by HBM -- the recomputed product and
-  // ELU' run on column pairs with packed fp32 instructions; ELU'(z) = exp2(min(z log2e, 0)) with log2e folded into the
-  // affine coefficients (no compare / select).  Same products in the same order as the forward pass: y is bit-identical.
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  constexpr bool kPacked = sizeof(T) == 2;
-  f32x2 wlo[CP], whi[CP], sc2lo, sc2hi, sh2lo, sh2hi;
-  if constexpr (kPacked) {
-    constexpr float kLog2e = 1.4426950408889634f;
-#pragma unroll
-    for (int c = 0; c < CP; ++c) {
-      wlo[c] = f32x2{w[0][c], w[1][c]};
-      whi[c] = f32x2{w[2][c], w[3][c]};
-    }
-    sc2lo = f32x2{sc.x * kLog2e, sc.y * kLog2e};
-    sc2hi = f32x2{sc.z * kLog2e, sc.w * kLog2e};
-    sh2lo = f32x2{sh.x * kLog2e, sh.y * kLog2e};
-    sh2hi = f32x2{sh.z * kLog2e, sh.w * kLog2e};
-  }
   // 4 rows per trip: four independent gradient loads in flight per lane
   for (int r = rlane; r < nrows; r += 4 * rl) {
     f32x4 g[4];
@@ -187,30 +169,11 @@ __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restric
     for (int u = 0; u < 4; ++u) {
       if (r + u * rl >= nrows) break;
       const float* xr = xs + (r + u * rl) * CP;
-      f32x4 yv, d;
-      if constexpr (kPacked) {
-        f32x2 ylo = {0.f, 0.f}, yhi = {0.f, 0.f};
+      const f32x4 yv = point_dot<CP>(w, xr);
+      f32x4 d;
 #pragma unroll
-        for (int c = 0; c < CP; ++c) {
-          const f32x2 xv = {xr[c], xr[c]};
-          ylo = __builtin_elementwise_fma(wlo[c], xv, ylo);
-          yhi = __builtin_elementwise_fma(whi[c], xv, yhi);
-        }
-        yv = f32x4{ylo.x, ylo.y, yhi.x, yhi.y};
-        if (MODE == 2) {
-          d = g[u];                                          // da is already dz
-        } else {
-          const f32x2 zlo = __builtin_elementwise_min(__builtin_elementwise_fma(ylo, sc2lo, sh2lo), f32x2{0.f, 0.f});
-          const f32x2 zhi = __builtin_elementwise_min(__builtin_elementwise_fma(yhi, sc2hi, sh2hi), f32x2{0.f, 0.f});
-          d = g[u] * f32x4{__builtin_amdgcn_exp2f(zlo.x), __builtin_amdgcn_exp2f(zlo.y), __builtin_amdgcn_exp2f(zhi.x),
-                           __builtin_amdgcn_exp2f(zhi.y)};
-        }
-      } else {
-        yv = point_dot<CP>(w, xr);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          d[e] = MODE == 2 ? g[u][e] : g[u][e] * elu_grad_from_pre_t<T>(yv[e] * sc[e] + sh[e]);   // MODE 2: da is already dz
-      }
+      for (int e = 0; e < 4; ++e)
+        d[e] = MODE == 2 ? g[u][e] : g[u][e] * elu_grad_from_pre_t<T>(yv[e] * sc[e] + sh[e]);   // MODE 2: da is already dz
       if (MODE == 0) {
         s1 += d;
         s2 += d * ((yv - p0) * p1);
