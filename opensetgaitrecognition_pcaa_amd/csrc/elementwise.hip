@@ -175,6 +175,79 @@ __global__ __launch_bounds__(256) void bn_act_meanpool_kernel(const T* __restric
   }
 }
 
+// bf16 storage, whole rows per workgroup (ch = 1024: 256 threads x one channel quad): the streaming form of the kernel
+// above.  One workgroup per group means ~1900 short concurrent streams and reaches 3.3 TB/s (tools/elementwise_lab.py);
+// here ~4 workgroups per CU walk the groups (measured: 512 / 1024 / 1920 workgroups 0.136 / 0.118 / 0.123 ms against 0.157), every lane keeps two batches of UB rows in flight (the next batch is
+// requested before the current one is consumed), and the arithmetic runs on column pairs with packed fp32
+// instructions so that it fits beside the stream: with e = exp(min(z, 0)), ELU(z) = max(z, 0) + e - 1 and ELU'(z) = e --
+// one exponential (exp2, log2e folded into a second affine pair), no compare / select; the -1 leaves the loop.
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void bn_act_meanpool_stream_kernel(const bf16_t* __restrict__ y,
+                                                                     const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ rstd,
+                                                                     float* __restrict__ pooled, float* __restrict__ e1,
+                                                                     float* __restrict__ e2, long ngroups, int group_rows,
+                                                                     int ch) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int UB = 4;
+  constexpr float kLog2e = 1.4426950408889634f;
+  const int cq = threadIdx.x;                         // ch == 1024: one channel quad per thread, every row
+  const f32x4 sc = load4(scale + cq * 4), sh = load4(shift + cq * 4);
+  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = mu;
+  if (TRAIN) { mu = load4(mean + cq * 4); rs = load4(rstd + cq * 4); }
+  const f32x2 sclo = {sc.x, sc.y}, schi = {sc.z, sc.w}, shlo = {sh.x, sh.y}, shhi = {sh.z, sh.w};
+  const f32x2 sl2 = sclo * kLog2e, sh2 = schi * kLog2e, tl2 = shlo * kLog2e, th2 = shhi * kLog2e;
+  const f32x2 rslo = {rs.x, rs.y}, rshi = {rs.z, rs.w};
+  const f32x2 nmlo = {-mu.x * rs.x, -mu.y * rs.y}, nmhi = {-mu.z * rs.z, -mu.w * rs.w};
+  const f32x2 zero = {0.f, 0.f};
+  const int nb = group_rows / UB;                     // host-checked: group_rows % UB == 0
+  for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const bf16_t* base = y + g * (long)group_rows * ch + cq * 4;
+    f32x2 plo = zero, phi = zero, elo = zero, ehi = zero, qlo = zero, qhi = zero;
+    uint2 buf[2][UB];
+    auto fetch = [&](int b, int batch) {
+#pragma unroll
+      for (int u = 0; u < UB; ++u) buf[b][u] = *reinterpret_cast<const uint2*>(base + (long)(batch * UB + u) * ch);
+    };
+    auto consume = [&](int b) {
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const uint2 w = buf[b][u];
+        const f32x2 vlo = {__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u)};
+        const f32x2 vhi = {__uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u)};
+        const f32x2 zlo = __builtin_elementwise_fma(vlo, sclo, shlo), zhi = __builtin_elementwise_fma(vhi, schi, shhi);
+        const f32x2 mlo = __builtin_elementwise_min(__builtin_elementwise_fma(vlo, sl2, tl2), zero);
+        const f32x2 mhi = __builtin_elementwise_min(__builtin_elementwise_fma(vhi, sh2, th2), zero);
+        const f32x2 xlo = {__builtin_amdgcn_exp2f(mlo.x), __builtin_amdgcn_exp2f(mlo.y)};
+        const f32x2 xhi = {__builtin_amdgcn_exp2f(mhi.x), __builtin_amdgcn_exp2f(mhi.y)};
+        plo += __builtin_elementwise_max(zlo, zero) + xlo;
+        phi += __builtin_elementwise_max(zhi, zero) + xhi;
+        if (TRAIN) {
+          elo += xlo;
+          ehi += xhi;
+          qlo = __builtin_elementwise_fma(xlo, __builtin_elementwise_fma(vlo, rslo, nmlo), qlo);
+          qhi = __builtin_elementwise_fma(xhi, __builtin_elementwise_fma(vhi, rshi, nmhi), qhi);
+        }
+      }
+    };
+    fetch(0, 0);
+    for (int batch = 0; batch < nb; batch += 2) {
+      if (batch + 1 < nb) fetch(1, batch + 1);
+      consume(0);
+      if (batch + 2 < nb) fetch(0, batch + 2);
+      if (batch + 1 < nb) consume(1);
+    }
+    const float n = (float)group_rows, inv = 1.f / n;
+    store4(pooled + g * (long)ch + cq * 4, f32x4{(plo.x - n) * inv, (plo.y - n) * inv, (phi.x - n) * inv, (phi.y - n) * inv});
+    if (TRAIN) {
+      store4(e1 + g * (long)ch + cq * 4, f32x4{elo.x, elo.y, ehi.x, ehi.y});
+      store4(e2 + g * (long)ch + cq * 4, f32x4{qlo.x, qlo.y, qhi.x, qhi.y});
+    }
+  }
+}
+
 // stats[0][c] += sum_g dpool[g][c]*pool_scale*E1[g][c];  stats[1][c] += sum_g dpool[g][c]*pool_scale*E2[g][c]
 // grid: one block per 32 groups, thread = channel (strided over ch)
 __global__ __launch_bounds__(256) void bn_pool_bwd_stats_kernel(const float* __restrict__ dpool,
@@ -569,7 +642,17 @@ extern "C" int pcaa_bn_act_meanpool_fwd(const void* y, int dtype, const float* s
 #define LAUNCH_MP(T, TRAIN)                                                                                   \
   hipLaunchKernelGGL((bn_act_meanpool_kernel<T, TRAIN>), dim3((unsigned)groups), dim3(256), 0, s, (const T*)y, \
                      scale, shift, mean, rstd, pooled, e1, e2, group_rows, ch)
-  if (dtype == PCAA_F32) { if (train) LAUNCH_MP(float, true); else LAUNCH_MP(float, false); }
+  if (dtype == PCAA_BF16 && ch == 1024 && group_rows % 4 == 0 && groups >= 512) {
+    // the PointNet block's last layer at the shapes that matter: the streaming form
+    const unsigned grid = (unsigned)std::min<long>(groups, 1024);
+    if (train)
+      hipLaunchKernelGGL(bn_act_meanpool_stream_kernel<true>, dim3(grid), dim3(256), 0, s, (const bf16_t*)y, scale, shift,
+                         mean, rstd, pooled, e1, e2, groups, group_rows, ch);
+    else
+      hipLaunchKernelGGL(bn_act_meanpool_stream_kernel<false>, dim3(grid), dim3(256), 0, s, (const bf16_t*)y, scale, shift,
+                         mean, rstd, pooled, e1, e2, groups, group_rows, ch);
+  }
+  else if (dtype == PCAA_F32) { if (train) LAUNCH_MP(float, true); else LAUNCH_MP(float, false); }
   else if (dtype == PCAA_BF16) { if (train) LAUNCH_MP(bf16_t, true); else LAUNCH_MP(bf16_t, false); }
   else { pcaa_set_error("pcaa_bn_act_meanpool_fwd: bad dtype"); return PCAA_ERR_INVALID_ARG; }
 #undef LAUNCH_MP

@@ -42,6 +42,30 @@ __global__ __launch_bounds__(512) void stream_kernel(const unsigned char* __rest
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     acc.x = *(volatile unsigned*)(slot + lane * 4);
+  } else if (MODE == 2) {
+    // 8-B loads per lane: a wave instruction moves 512 B; the workgroup's 8 waves x 2 instructions cover the same 8-KB row
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 buf[2][2 * H];
+    const unsigned voff8 = lane * 8;
+    auto issue = [&](int b, int s) {
+      buf[b][2 * s] = *reinterpret_cast<const u32x2*>(base + pos + voff8);
+      buf[b][2 * s + 1] = *reinterpret_cast<const u32x2*>(base + pos + 512 + voff8);
+      pos += 8192; if (pos >= (unsigned)region_bytes) pos -= (unsigned)region_bytes;
+    };
+#pragma unroll
+    for (int s = 0; s < H; ++s) issue(0, s);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int s = 0; s < H; ++s) issue(1, s);
+#pragma unroll
+      for (int s = 0; s < 2 * H; ++s) { acc.x ^= buf[0][s].x; acc.y ^= buf[0][s].y; }
+#pragma unroll
+      for (int s = 0; s < H; ++s) issue(0, s);
+#pragma unroll
+      for (int s = 0; s < 2 * H; ++s) { acc.x ^= buf[1][s].x; acc.y ^= buf[1][s].y; }
+    }
+#pragma unroll
+    for (int s = 0; s < 2 * H; ++s) { acc.x ^= buf[0][s].x; acc.y ^= buf[0][s].y; }
   } else {
     u32x4 buf[2][H];
     auto issue = [&](int b, int s) {
@@ -84,7 +108,7 @@ static void run(const unsigned char* src, long region_bytes, int share, const ch
   const double bytes = (double)wgs * 8 * 1024.0 * (H + 2.0 * H * iters);
   const double gbs = bytes / best / 1e6;
   printf("%-8s %-4s in flight per CU %3d-%3d KB: %8.1f GB/s total, %6.2f GB/s per CU = %5.1f B/clk at 2.1 GHz (%.3f ms)\n",
-         MODE == 0 ? "lds-dma" : "vgpr", regime, 8 * H, 16 * H, gbs, gbs / wgs, gbs / wgs / 2.1, best);
+         MODE == 0 ? "lds-dma" : (MODE == 1 ? "vgpr" : "vgpr-8B"), regime, 8 * H, 16 * H, gbs, gbs / wgs, gbs / wgs / 2.1, best);
 }
 
 int main() {
@@ -96,6 +120,7 @@ int main() {
   hipMemset(sink, 0, 4);
   // hbm: 256 regions of 32 MB; l2: 8 regions of 2 MB shared by 32 workgroups each
 #define BOTH(H)                                              \
+  run<H, 2>(src, 32L << 20, 1, "hbm", sink);                 \
   run<H, 0>(src, 32L << 20, 1, "hbm", sink);                 \
   run<H, 1>(src, 32L << 20, 1, "hbm", sink);                 \
   run<H, 0>(src, 2L << 20, 32, "l2", sink);                  \
