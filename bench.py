@@ -50,8 +50,9 @@ def parse():
     ap.add_argument("--dp-force", action="store_true",
                     help="N=1 only: create a 1-rank RCCL group and issue the step's collectives on it (exercises the RCCL "
                          "calls and measures their fixed cost on one GPU)")
-    ap.add_argument("--grad-compress", default="none", choices=["none", "bf16"],
-                    help="decoder gradient buckets cross the wire as bf16 (fp32 master gradients)")
+    ap.add_argument("--grad-compress", default="auto", choices=["auto", "none", "bf16"],
+                    help="decoder gradient buckets cross the wire as bf16 (fp32 master gradients, moments and weights); auto "
+                         "= bf16 in the bf16 throughput mode, none in the fp32 parity mode (DESIGN.md section 6)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--decoder-update", default="fused", choices=["fused", "plain"],
                     help="single process, bf16: decoder weight gradient + Adam in one kernel (default) or as two passes")
@@ -66,7 +67,10 @@ def parse():
                     help="replay the step as a captured hipGraph (PCAATrainer.step_graphed): auto = where the eager step is "
                          "bound by the host's enqueues (PCAATrainer.prefers_graph: below ~80 K points per step; "
                          "profiles/r02_graph_vs_eager.txt); at the default workload eager is 2-3 %% faster")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.grad_compress == "auto":
+        a.grad_compress = "bf16" if a.precision == "bf16" else "none"
+    return a
 
 
 def cpu_baseline(B, N, C, K, T):
@@ -422,7 +426,8 @@ def main():
                        # gradient / parameter exchanges of one step: number of collectives, payload bytes, and what a
                        # ring moves per rank and direction for them (2 (w-1)/w x payload for an all-reduce; the
                        # reduce-scatter + all-gather pair of --dp-mode zero moves the same)
-                       "dp": {"mode": a.dp_mode if world > 1 else "none", "grad_compress": a.grad_compress,
+                       "dp": {"mode": a.dp_mode if world > 1 else "none",
+                              "grad_compress": a.grad_compress if (world > 1 or a.dp_force) else "none",
                               "collectives_per_step": comm["collectives"], "payload_bytes_per_step": comm["payload_bytes"],
                               "ring_wire_bytes_per_rank": (2.0 * (world - 1) / world * comm["payload_bytes"]
                                                            if a.dp_mode == "allreduce" else

@@ -512,8 +512,8 @@ __global__ void dtc_col2im_kernel(const float* __restrict__ dcol, float* __restr
 // lane in flight, so a SMALL grid (1-2 workgroups per CU) still saturates HBM -- which is what
 // lets the decoder's update run on a side stream beside the latency-bound temporal-conv / head
 // kernels without taking their wave slots (a 4096-block grid made those 2-7x slower).
-template <int U>
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+template <int U, typename TG = float>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const TG* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n,
                                                    float b1, float b2, float eps, float step_size,
                                                    float inv_bc2_sqrt, float grad_scale,
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long q = q0 + u * stride;
-      if (q < nq) { pv[u] = load4(p + q * 4); gv[u] = load4(g + q * 4); mv[u] = load4(m + q * 4); vv[u] = load4(v + q * 4); }
+      if (q < nq) { pv[u] = load4(p + q * 4); gv[u] = load4(g + q * 4); mv[u] = load4(m + q * 4); vv[u] = load4(v + q * 4); }   // g: fp32 or bf16 (load4 widens)
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const long i = (nq << 2) + threadIdx.x;
     float pp = p[i], mm = m[i], vv = v[i];
-    adam_update(pp, mm, vv, g[i] * grad_scale, b1, b2, eps, step_size, inv_bc2_sqrt);
+    adam_update(pp, mm, vv, (float)g[i] * grad_scale, b1, b2, eps, step_size, inv_bc2_sqrt);
     m[i] = mm;
     v[i] = vv;
     p[i] = pp;
@@ -985,6 +985,24 @@ static int launch_adam(float* param, const float* grad, float* exp_avg, float* e
     hipLaunchKernelGGL(adam_kernel<1>, dim3(grid_for(n >> 2, 256, cap)), dim3(256), 0, as_stream(stream), param, grad,
                        exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size, inv_bc2_sqrt, grad_scale, coef);
   PCAA_RETURN_LAUNCH_STATUS(what);
+}
+
+extern "C" int pcaa_adam_step_dev_g16(float* param, const void* grad_bf16, float* exp_avg, float* exp_avg_sq, long n,
+                                      float beta1, float beta2, float eps, const float* coef_dev, float grad_scale,
+                                      int max_blocks, void* stream) {
+  PCAA_CHECK_ARG(param && grad_bf16 && exp_avg && exp_avg_sq && coef_dev && n >= 1 && max_blocks >= 0,
+                 "pcaa_adam_step_dev_g16: bad args");
+  PCAA_CHECK_ARG(((uintptr_t)param % 16) == 0 && ((uintptr_t)grad_bf16 % 8) == 0 && ((uintptr_t)exp_avg % 16) == 0 &&
+                 ((uintptr_t)exp_avg_sq % 16) == 0, "pcaa_adam_step_dev_g16: buffers must be 16-B (gradient: 8-B) aligned");
+  const bf16_t* g = reinterpret_cast<const bf16_t*>(grad_bf16);
+  const int cap = max_blocks > 0 ? max_blocks : 256 * 16;
+  if (cap <= 1024)
+    hipLaunchKernelGGL((adam_kernel<4, bf16_t>), dim3(grid_for(n >> 4, 256, cap)), dim3(256), 0, as_stream(stream), param, g,
+                       exp_avg, exp_avg_sq, n, beta1, beta2, eps, 0.f, 0.f, grad_scale, coef_dev);
+  else
+    hipLaunchKernelGGL((adam_kernel<1, bf16_t>), dim3(grid_for(n >> 2, 256, cap)), dim3(256), 0, as_stream(stream), param, g,
+                       exp_avg, exp_avg_sq, n, beta1, beta2, eps, 0.f, 0.f, grad_scale, coef_dev);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_adam_step_dev_g16");
 }
 
 extern "C" int pcaa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,

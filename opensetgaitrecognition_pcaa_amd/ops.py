@@ -966,6 +966,20 @@ def adam_step_dev_(p, g, m, v, b1, b2, eps, coef_dev, grad_scale=1.0, max_blocks
           "pcaa_adam_step_dev")
 
 
+def adam_step_dev_g16_(p, g16, m, v, b1, b2, eps, coef_dev, grad_scale=1.0, max_blocks=0):
+    """adam_step_dev_ with a bf16 gradient (a reduced bf16 gradient bucket, consumed without widening it first)."""
+    for nm, t in (("p", p), ("m", m), ("v", v)):
+        _chk(t, f"adam_g16.{nm}", torch.float32)
+    _chk(g16, "adam_g16.g", torch.bfloat16)
+    _chk(coef_dev, "adam_g16.coef_dev", torch.float32)
+    n = p.numel()
+    if not (g16.numel() == m.numel() == v.numel() == n) or coef_dev.numel() != 2:
+        raise ValueError("adam_step_dev_g16_: size mismatch")
+    check(_lib.load().pcaa_adam_step_dev_g16(_p(p), _p(g16), _p(m), _p(v), n, float(b1), float(b2), float(eps),
+                                             _p(coef_dev), float(grad_scale), int(max_blocks), _s()),
+          "pcaa_adam_step_dev_g16")
+
+
 # ------------------------------------------------------------------ fused MLP heads (heads.hip)
 def heads_supported(B, K, d_in, d_sup, d_head, d_proj, backward):
     return bool(_lib.load().pcaa_heads_supported(int(B), int(K), int(d_in), int(d_sup), int(d_head), int(d_proj),

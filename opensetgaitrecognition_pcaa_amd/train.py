@@ -56,9 +56,11 @@ class _CompressedWork:
     def __init__(self, work, dst32, src16):
         self.work, self.dst32, self.src16, self.done = work, dst32, src16, False
 
-    def wait(self):
+    def wait(self, widen=True):
+        """``widen=False``: the caller consumes the bf16 sum itself (``src16``, FlatBuffer.adam(g16=...)) and marks the
+        work done; a later plain wait() then only waits."""
         self.work.wait()
-        if not self.done:
+        if not self.done and widen:
             self.dst32.copy_(self.src16)
             self.done = True
 
@@ -140,14 +142,18 @@ class FlatBuffer:
     def set_step(self, step):
         self.count.set(step)
 
-    def adam(self, lr, b1, b2, eps=1e-8, grad_scale=1.0, lo=0, hi=None, advance=True, max_blocks=0, count=None):
+    def adam(self, lr, b1, b2, eps=1e-8, grad_scale=1.0, lo=0, hi=None, advance=True, max_blocks=0, count=None, g16=None):
         """One Adam update of the elements [lo, hi) (default: everything).  ``advance=False``:
         a further range of the SAME optimizer step (the step count is shared).  ``count``: the
         :class:`StepCount` whose bias corrections apply (default: the buffer's main one)."""
         if advance:
             self.advance(lr, b1, b2)
         hi = self.total if hi is None else hi
-        if hi > lo:
+        if hi > lo and g16 is not None:
+            # ``g16``: a bf16 image of the whole gradient buffer (same element offsets) holding this range's gradient
+            ops.adam_step_dev_g16_(self.p[lo:hi], g16[lo:hi], self.m[lo:hi], self.v[lo:hi], b1, b2, eps,
+                                   (count or self.count).coef_dev, grad_scale, max_blocks)
+        elif hi > lo:
             ops.adam_step_dev_(self.p[lo:hi], self.g[lo:hi], self.m[lo:hi], self.v[lo:hi], b1, b2, eps,
                                (count or self.count).coef_dev, grad_scale, max_blocks)
 
@@ -719,14 +725,19 @@ class PCAATrainer:
                     for lo, hi, work in pending:
                         if hi <= self._dec_start:
                             continue                    # the projection-head slice is updated on the main stream
-                        if work is not None:
+                        g16 = None
+                        if isinstance(work, _CompressedWork) and (lo % 4 == 0):
+                            work.wait(widen=False)      # Adam reads the reduced bf16 bucket as it came off the wire
+                            work.done = True
+                            g16 = self._g16
+                        elif work is not None:
                             work.wait()                 # side stream waits for THIS chunk's all-reduce only
                         # what the fused kernels did not take: [lo, hi) minus their ranges
                         a = max(lo, self._dec_start)
                         for flo, fhi in sorted(fused_ranges) + [(hi, hi)]:
                             if flo > a:
                                 self.flat_g.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs, lo=a, hi=min(flo, hi),
-                                                 advance=False, max_blocks=self._side_adam_blocks)
+                                                 advance=False, max_blocks=self._side_adam_blocks, g16=g16)
                             a = max(a, fhi)
                             if a >= hi:
                                 break
