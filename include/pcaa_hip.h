@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PCAA_ABI_VERSION 8 /* pcaa_abi_version() of a library built from this header */
+#define PCAA_ABI_VERSION 9 /* pcaa_abi_version() of a library built from this header */
 
 #define PCAA_OK 0
 #define PCAA_ERR_INVALID_ARG 1
@@ -321,6 +321,10 @@ int pcaa_skinny_linear_dgrad(const float* dz, long lddz, const float* W, long ld
                              int K, int nsplit, void* stream);
 int pcaa_skinny_linear_wgrad(const float* dz, long lddz, const float* x, long ldx, float* dW, long lddw,
                              int M, int N, int K, void* stream);
+/* The same product written as bf16 (dW_bf16 [N, lddw] bf16, lddw even): the data-parallel step with bf16 gradient
+ * buckets produces the gradient in the form it crosses the wire in (no fp32 copy, no cast pass). */
+int pcaa_skinny_linear_wgrad_bf16(const float* dz, long lddz, const float* x, long ldx, void* dW_bf16, long lddw,
+                                  int M, int N, int K, void* stream);
 /* The same product fused with optimizer_G's Adam update of that weight (PCAA_ablation.py:1018-1021: backward,
  * then optimizer_G.step()): dW[N,K] = dz^T x stays in registers, W / exp_avg / exp_avg_sq [N,ldw] are read and
  * written in place -- torch.optim.Adam's update with the step-dependent scalars from coef_dev (pcaa_adam_advance),

@@ -284,10 +284,14 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
 // 32-bit element offsets from uniform base pointers (host-checked < 2^31) so loads and stores use
 // the SGPR-base + VGPR-offset form.  Rows m >= M: dz is zeroed after a clamped load, x is only
 // clamped (0 * finite = 0).
-template <int JL, bool FULLN>
+// TO = bf16 (the data-parallel step with bf16 gradient buckets: the gradient is produced in the form it crosses the wire
+// in, no fp32 copy and no cast pass): neighbouring lanes exchange one packed pair (DPP) so that every lane stores two
+// adjacent columns of one row as one dword -- 64-B runs per row and half-wave, the other half of the line follows with
+// the wave's next 32 columns.
+template <int JL, bool FULLN, typename TO = float>
 __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restrict__ dz, long lddz,
                                                            const float* __restrict__ x, long ldx,
-                                                           float* __restrict__ dW, long lddw, int M, int N,
+                                                           TO* __restrict__ dW, long lddw, int M, int N,
                                                            int K) {
   __shared__ __attribute__((aligned(16))) bf16x8 apan[4][4][64];      // [row fragment i][k-step s][lane]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
@@ -346,18 +350,36 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restri
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apan[i][s][lane], bf[s], acc[i], 0, 0, 0);
-    float* dj = dW + kb + 32 * j;                          // uniform
+    TO* dj = dW + kb + 32 * j;                             // uniform
     unsigned o0 = row0 * (unsigned)lddw + l31;
     // opaque to the optimiser: LICM otherwise hoists all 64 store offsets (and the 16 LDS
     // fragment reads, hence the memory clobber) out of the j loop -- 360 VGPRs, one wave per SIMD
     asm volatile("" : "+v"(o0) : : "memory");
+    if constexpr (sizeof(TO) == 4) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned rr = 32 * i + (r & 3) + 8 * (r >> 2);
-        if (FULLN || row0 + rr < (unsigned)N) dj[o0 + rr * (unsigned)lddw] = acc[i][r];
-      }
+        for (int r = 0; r < 16; ++r) {
+          const unsigned rr = 32 * i + (r & 3) + 8 * (r >> 2);
+          if (FULLN || row0 + rr < (unsigned)N) dj[o0 + rr * (unsigned)lddw] = acc[i][r];
+        }
+    } else {
+      const bool odd = lane & 1;
+      const uint32_t sel = odd ? 0x03020706u : 0x05040100u;      // bytes 0-3 = mine, 4-7 = the neighbouring column's
+      uint32_t* dj32 = reinterpret_cast<uint32_t*>(dj);
+      const unsigned w0 = (o0 & ~1u) >> 1;                        // dword index of my column pair in row row0
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          // rows rr, rr + 1 of my column as two bf16; even lane stores row rr: (mine.lo, theirs.lo), odd lane row rr + 1
+          const uint32_t mine = pk2(acc[i][r], acc[i][r + 1]);
+          const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, true);
+          const uint32_t packed = __builtin_amdgcn_perm(theirs, mine, sel);
+          const unsigned rr = 32 * i + (r & 3) + 8 * (r >> 2) + (odd ? 1u : 0u);
+          if (FULLN || row0 + rr < (unsigned)N) dj32[w0 + rr * (unsigned)(lddw >> 1)] = packed;
+        }
+    }
   }
 }
 
@@ -591,6 +613,27 @@ extern "C" int pcaa_skinny_linear_wgrad(const float* dz, long lddz, const float*
     hipLaunchKernelGGL((skinny_wgrad_kernel<JL, false>), grid, dim3(256), 0, as_stream(stream), dz, lddz, x, ldx, dW,
                        lddw, M, N, K);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_wgrad");
+}
+
+extern "C" int pcaa_skinny_linear_wgrad_bf16(const float* dz, long lddz, const float* x, long ldx, void* dW_bf16, long lddw,
+                                             int M, int N, int K, void* stream) {
+  PCAA_CHECK_ARG(dz && x && dW_bf16, "pcaa_skinny_linear_wgrad_bf16: null pointer");
+  PCAA_CHECK_ARG(M >= 1 && M <= 64 && N >= 1 && K >= 32 && K % 32 == 0,
+                 "pcaa_skinny_linear_wgrad_bf16: unsupported shape M=%d N=%d K=%d", M, N, K);
+  PCAA_CHECK_ARG(lddz >= N && ldx >= K && lddw >= K && lddw % 2 == 0 && ((uintptr_t)dW_bf16 % 4) == 0,
+                 "pcaa_skinny_linear_wgrad_bf16: bad leading dimensions / alignment");
+  PCAA_CHECK_ARG((long)M * lddz < (1L << 31) && (long)M * ldx < (1L << 31) && (long)N * lddw < (1L << 31),
+                 "pcaa_skinny_linear_wgrad_bf16: operands beyond 32-bit element offsets");
+  constexpr int JL = 4;
+  const dim3 grid((unsigned)cdiv(K, 4 * 32 * JL), (unsigned)cdiv(N, 128));
+  bf16_t* out = reinterpret_cast<bf16_t*>(dW_bf16);
+  if (N % 128 == 0)
+    hipLaunchKernelGGL((skinny_wgrad_kernel<JL, true, bf16_t>), grid, dim3(256), 0, as_stream(stream), dz, lddz, x, ldx, out,
+                       lddw, M, N, K);
+  else
+    hipLaunchKernelGGL((skinny_wgrad_kernel<JL, false, bf16_t>), grid, dim3(256), 0, as_stream(stream), dz, lddz, x, ldx, out,
+                       lddw, M, N, K);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_wgrad_bf16");
 }
 
 extern "C" int pcaa_skinny_linear_wgrad_adam(const float* dz, long lddz, const float* x, long ldx, float* W,

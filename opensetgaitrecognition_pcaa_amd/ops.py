@@ -682,10 +682,15 @@ def skinny_linear_wgrad(dz, x, out=None):
     if out is None:
         out = torch.empty((N, K), dtype=torch.float32, device=dz.device)
     else:
-        _chk(out, "skinny_wgrad.out", torch.float32)
-        if out.numel() != N * K:
-            raise ValueError("skinny_linear_wgrad: out size")
+        _chk(out, "skinny_wgrad.out")
+        if out.numel() != N * K or out.dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("skinny_linear_wgrad: out must hold N*K fp32 or bf16 elements")
     lib = _lib.load()
+    if out.dtype == torch.bfloat16:       # the gradient as it crosses the wire (bf16 gradient buckets)
+        _skinny_timed(lambda: check(lib.pcaa_skinny_linear_wgrad_bf16(_p(dz), dz.stride(0), _p(x), x.stride(0), _p(out), K,
+                                                                      M, N, K, _s()),
+                                    "pcaa_skinny_linear_wgrad_bf16"), 2.0 * M * N * K, 2 * N * K + 4 * (M * K + M * N))
+        return out
     _skinny_timed(lambda: check(lib.pcaa_skinny_linear_wgrad(_p(dz), dz.stride(0), _p(x), x.stride(0), _p(out), K,
                                                              M, N, K, _s()),
                                 "pcaa_skinny_linear_wgrad"), 2.0 * M * N * K, 4 * (N * K + M * K + M * N))

@@ -382,8 +382,13 @@ class PCAATrainer:
                             for _ in range(self._zero_chunks)]            # this rank's reduced gradient slice
             self._zero_p = [torch.empty(n // self.world, dtype=torch.float32, device=self.device)
                             for _ in range(self._zero_chunks)]            # staging of the updated slice for the gather
+        self._g16_direct = set()
         if self.grad_compress == "bf16" and self.pg is not None:
-            self._g16 = torch.empty(self.flat_g.total, dtype=torch.bfloat16, device=self.device)
+            self._g16 = torch.zeros(self.flat_g.total, dtype=torch.bfloat16, device=self.device)
+            # the wide decoder layers' weight gradients are produced as bf16 straight into the wire image
+            # (ops.skinny_linear_wgrad with a bf16 destination): layer -> (offset, bf16 view in the stored shape)
+            self._dec_grads16 = {i: (lo, self._g16[lo:lo + Wv.numel()].view(Wv.shape))
+                                 for i, (lo, hi, Wv, mv, vv) in self._dec_fused.items()}
         self._stats_pool = ops.StatsPool(self.device)
         self._flat_ready = True
         if self.pg is not None and self.world > 1:
@@ -447,7 +452,8 @@ class PCAATrainer:
                 # gradient buffer when the consumer waits for it
                 off = (t.data_ptr() - self.flat_g.g.data_ptr()) // 4
                 g16 = self._g16[off:off + t.numel()]
-                g16.copy_(t)
+                if off not in self._g16_direct:          # else: the weight-gradient kernel wrote the bf16 image itself
+                    g16.copy_(t)
                 self._count(2 * t.numel())
                 work = dist.all_reduce(g16, group=self.pg, async_op=async_op)
                 if not async_op:
@@ -636,14 +642,22 @@ class PCAATrainer:
                     updates = updates or {}
                     updates[layer] = lambda dz2, x, t=(Wv, mv, vv): deferred.append((dz2, x) + t)
                     fused_ranges.append((lo, hi))
+        dec_grads = self._dec_grads
+        self._g16_direct = set()
+        if collective and layer_hook is not None and self.grad_compress == "bf16" and mode == "bf16":
+            dec_grads = dict(dec_grads)
+            for layer, (lo, view16) in self._dec_grads16.items():
+                if F_hip._skinny(mode, B, view16.shape[0], view16.shape[1]):
+                    dec_grads[f"dense{layer}.weight"] = view16
+                    self._g16_direct.add(lo)
         if self.decoder_projection_head is not None:
             # the head's own backward (dh -> dsup, dW, db) runs inside the heads' backward launch below
-            _, dh = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads, mode=mode,
+            _, dh = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=dec_grads, mode=mode,
                                            after_layer=layer_hook, updates=updates)
             if joined is not None:
                 torch.cuda.current_stream().wait_event(joined)
         else:
-            _, dsup = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=self._dec_grads, dz_init=dsup,
+            _, dsup = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=dec_grads, dz_init=dsup,
                                              mode=mode, after_layer=layer_hook, updates=updates)
         # The decoder's gradients are final here (the projection head's follow with the encoder's: its backward
         # runs in the MLP heads' launch).  Data-parallel: their all-reduce goes out now, in a few chunks (the

@@ -444,6 +444,18 @@ def test_skinny_wgrad_adam_equals_wgrad_then_adam_bitwise(M, N, K):
     assert not torch.equal(Wa, W0)
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 256, 128), (37, 192, 160), (64, 960, 1920), (16, 4544, 2304)])
+def test_skinny_wgrad_bf16_output_is_the_rounded_fp32_gradient(M, N, K):
+    """pcaa_skinny_linear_wgrad_bf16 (the data-parallel step's bf16 gradient buckets are produced directly): the same
+    accumulators as the fp32 form, rounded to nearest-even once -- bit-identical to casting the fp32 gradient."""
+    dz = _rand((M, N), 700, 0.3).to(DEV)
+    x = _rand((M, K), 701, 1.0).to(DEV)
+    ref = ops.skinny_linear_wgrad(dz, x)
+    out = torch.full((N, K), float("nan"), dtype=torch.bfloat16, device=DEV)
+    got = ops.skinny_linear_wgrad(dz, x, out=out)
+    assert got.dtype == torch.bfloat16 and torch.equal(got, ref.bfloat16())
+
+
 def test_gemm_tile_loop_with_two_launches_competing_for_the_cus():
     """The LDS-DMA GEMM starts one workgroup per CU and lets them draw tiles from per-XCD ticket counters (one set per
     stream).  Two such launches on two streams at once: each gets its CUs late / piecemeal, every tile must still be
