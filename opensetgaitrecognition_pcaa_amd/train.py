@@ -169,6 +169,8 @@ class PCAATrainer:
     ``learn_centroids=True`` is the variant's stated intent instead (NOT the reference's behaviour): z stays
     attached, ``pcaa_disc_wgan_gp`` returns d(d_loss)/dz and the learner is trained by optimizer_D."""
 
+    _COMPRESS_MIN = 1 << 16       # gradient buckets below this many elements cross the wire as fp32
+
     def __init__(self, config, n_classes=None, device="cuda", variant="v4", precision=None,
                  process_group=None, sync_bn=False, learn_centroids=False, dp_zero=False, grad_compress=None,
                  force_collectives=False, fused_decoder_update=True):
@@ -445,12 +447,14 @@ class PCAATrainer:
     def _allreduce(self, t, async_op=False):
         if self.pg is not None and (self.world > 1 or self._force_collectives) and t.numel():
             import torch.distributed as dist
-            if (self.grad_compress == "bf16" and t.numel() >= (1 << 16)
-                    and t.data_ptr() >= self.flat_g.g.data_ptr() + 4 * self._dec_start
-                    and t.data_ptr() < self.flat_g.g.data_ptr() + 4 * self.flat_g.total):
+            in_dec = (t.data_ptr() >= self.flat_g.g.data_ptr() + 4 * self._dec_start
+                      and t.data_ptr() < self.flat_g.g.data_ptr() + 4 * self.flat_g.total)
+            off = (t.data_ptr() - self.flat_g.g.data_ptr()) // 4 if in_dec else -1
+            # a bucket whose weight gradient exists ONLY as the bf16 wire image (_g16_direct) must take the compressed
+            # path whatever its size: its fp32 range was never written
+            if self.grad_compress == "bf16" and in_dec and (t.numel() >= self._COMPRESS_MIN or off in self._g16_direct):
                 # decoder gradient bucket: round to bf16 once, sum on the wire in bf16, widen back into the fp32
                 # gradient buffer when the consumer waits for it
-                off = (t.data_ptr() - self.flat_g.g.data_ptr()) // 4
                 g16 = self._g16[off:off + t.numel()]
                 if off not in self._g16_direct:          # else: the weight-gradient kernel wrote the bf16 image itself
                     g16.copy_(t)
@@ -460,6 +464,7 @@ class PCAATrainer:
                     t.copy_(g16)
                     return None
                 return _CompressedWork(work, t, g16)
+            assert off not in self._g16_direct, "a bf16-direct gradient bucket reached the fp32 all-reduce"
             self._count(t.numel() * t.element_size())
             return dist.all_reduce(t, group=self.pg, async_op=async_op)
         return None
@@ -647,7 +652,8 @@ class PCAATrainer:
         if collective and layer_hook is not None and self.grad_compress == "bf16" and mode == "bf16":
             dec_grads = dict(dec_grads)
             for layer, (lo, view16) in self._dec_grads16.items():
-                if F_hip._skinny(mode, B, view16.shape[0], view16.shape[1]):
+                # same size rule as _allreduce's compressed path: one predicate decides both
+                if F_hip._skinny(mode, B, view16.shape[0], view16.shape[1]) and view16.numel() >= self._COMPRESS_MIN:
                     dec_grads[f"dense{layer}.weight"] = view16
                     self._g16_direct.add(lo)
         if self.decoder_projection_head is not None:
