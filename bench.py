@@ -11,11 +11,22 @@ Workload at every N: BASELINE config[1], B=64 sequences per GPU, T=30, N=128
 points, C=4 features, K=8 classes, inputs resident in HBM before the timed
 region; data parallel over N GPUs (weak scaling: global batch 64*N, RCCL
 all-reduce of the flat gradient buffers).  One JSON line on rank 0.
+
+At N=1 the same line also carries the other BASELINE configs as extra keys, each
+measured in this run (none of them is ``value``): ``parity_mode`` (config[1] in the
+exact-fp32 mode the 1e-4 parity tests run in), ``sweep`` (config[3], the
+point-subsampling sweep N in {32,64,128,256}), ``infer`` (config[4], open-set
+inference at B=1024), ``c5`` (config[1] with the C=5 feature set BASELINE's wording
+names), ``with_batcher`` (datasets.py batch collation inside the loop),
+``gpu_sections`` (where the step's time goes on the main stream) and
+``cpu_baseline`` (the oracle on this host's cores: 1 warm-up + 3 timed steps,
+median, per-phase breakdown).
 """
 import argparse
 import itertools
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -34,6 +45,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--windows", type=int, default=5,
+                    help="the timed region (exactly --steps steps between barrier + synchronize) is repeated this many "
+                         "times; ms_per_step / value are the MEDIAN window, all windows are in config.windows_ms_per_step")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--points", type=int, default=128)
@@ -42,8 +56,8 @@ def parse():
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="train", choices=["train", "sweep", "infer"],
-                    help="train: BASELINE config[1] (default, the driver's line); sweep: config[3], the point-subsampling "
-                         "sweep N in {32,64,128,256} of the train step; infer: config[4], open-set inference at B=1024")
+                    help="train: BASELINE config[1] (default, the driver's line, with the other configs as extra keys); "
+                         "sweep / infer: config[3] / config[4] as a line of their own")
     ap.add_argument("--dp-mode", default="allreduce", choices=["allreduce", "zero"],
                     help="data-parallel exchange of the decoder gradients: per-layer all-reduce buckets (default) or "
                          "reduce-scatter + sharded Adam + all-gather (ZeRO-1)")
@@ -60,22 +74,29 @@ def parse():
                     help="skip the fp32 parity-mode leg (same workload in the mode the 1e-4 parity tests run in)")
     ap.add_argument("--no-batcher-leg", action="store_true",
                     help="skip the leg that assembles every step's batch from the HBM-resident packed store")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the sweep / infer / c5 / gpu_sections legs of the default line")
     ap.add_argument("--backend", default=os.environ.get("PCAA_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on a one-GPU box "
                          "together with PCAA_BENCH_DEVICE=0, which puts every rank on that GPU)")
     ap.add_argument("--graph", default=os.environ.get("PCAA_GRAPH", "auto"), choices=["on", "off", "auto"],
                     help="replay the step as a captured hipGraph (PCAATrainer.step_graphed): auto = where the eager step is "
-                         "bound by the host's enqueues (PCAATrainer.prefers_graph: below ~80 K points per step; "
-                         "profiles/r02_graph_vs_eager.txt); at the default workload eager is 2-3 %% faster")
+                         "bound by the host's enqueues (PCAATrainer.prefers_graph)")
     a = ap.parse_args()
     if a.grad_compress == "auto":
         a.grad_compress = "bf16" if a.precision == "bf16" else "none"
+    a.windows = max(1, a.windows)
     return a
 
 
-def cpu_baseline(B, N, C, K, T):
-    """The oracle (plain-PyTorch restatement of the reference, kind="port")
-    timed on this host's cores for ONE full train step of the same workload."""
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (plain-PyTorch restatement of the reference, kind="port") on this host's cores
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_baseline(B, N, C, K, T, budget_s=75.0):
+    """BASELINE.md section 3 / SURVEY 8d protocol: identical synthetic tensors, 1 warm-up + 3 timed full V4 train
+    steps (loop body PCAA_ablation.py:882-1021), median, with the per-phase breakdown.  The thread count is picked
+    on a small calibration batch first (torch's CPU kernels do not scale to every core of a big host).  The sample is
+    bounded to ~``budget_s`` seconds of CPU work: the batch is cut to B/2 or B/4 when 4 full-batch steps do not fit."""
     from opensetgaitrecognition_pcaa_amd import constants, models, synthetic as syn
     from oracle import pcaa_oracle as O
     ncpu = os.cpu_count() or 1
@@ -97,26 +118,43 @@ def cpu_baseline(B, N, C, K, T):
     z0 = syn.synthetic_z0(B, 32, seed=1236)
     al = syn.synthetic_alphas(B, seed=1237)
 
-    def run(b, threads):
+    def run(b, threads, phases=None):
         torch.set_num_threads(threads)
         t0 = time.perf_counter()
-        O.v4_train_step(st, pcs[:b], gt[:b], z0[:b], al[:b], cfg)
+        O.v4_train_step(st, pcs[:b], gt[:b], z0[:b], al[:b], cfg, phase_seconds=phases)
         return time.perf_counter() - t0
 
-    # torch's CPU kernels do not scale to every core of a big host (256 threads
-    # ran this step 10x slower than 32): pick the best thread count on a small
-    # sub-batch first, then time the bounded sample with it.
     cal_b = min(8, B)
-    trials = {t: run(cal_b, t) for t in sorted({min(ncpu, t) for t in (16, 32, 64)})}
+    cands = sorted({min(ncpu, t) for t in (8, 16, 32, 64)})
+    run(cal_b, cands[-1])                                   # first touch of every weight / allocator warm-up
+    trials = {t: run(cal_b, t) for t in cands}
     threads = min(trials, key=trials.get)
-    sample_b = B if trials[threads] * (B / cal_b) < 45.0 else max(cal_b, B // 4)
-    dt = run(sample_b, threads)
-    return {"value": sample_b / dt, "unit": "sequences/s", "cores": threads, "kind": "port",
-            "sample": f"1 full V4 train step (oracle, plain PyTorch fp32) at B={sample_b} of the workload's {B}, "
-                      f"N={N}, C={C}: {dt:.1f} s; {threads} threads (best of {sorted(trials)} on a B={cal_b} "
-                      f"calibration step) on a {ncpu}-CPU host, torch {torch.__version__}"}
+    est_full = trials[threads] * (B / cal_b)                # s per step at the full batch (Adam does not scale with B:
+    sample_b = B                                            # the estimate is an upper bound)
+    while sample_b > cal_b and 4 * est_full * (sample_b / B) > budget_s:
+        sample_b //= 2
+    run(sample_b, threads)                                  # warm-up
+    times, phases = [], []
+    for _ in range(3):
+        ph = {}
+        times.append(run(sample_b, threads, ph))
+        phases.append(ph)
+    med = statistics.median(times)
+    pmed = {k: statistics.median(p[k] for p in phases) for k in phases[0]}
+    return {"value": sample_b / med, "unit": "sequences/s", "cores": threads, "kind": "port",
+            "protocol": "1 warm-up + 3 timed full V4 train steps, median",
+            "seconds_per_step": times, "median_s": med,
+            "phases_s": pmed,
+            "phases_frac": {k: v / sum(pmed.values()) for k, v in pmed.items()},
+            "sample": f"oracle (plain PyTorch fp32: einsum / matmul contractions, measured on par with ATen's conv2d on "
+                      f"this torch) at B={sample_b} of the workload's {B}, N={N}, C={C}; {threads} threads (best of "
+                      f"{cands} on a warm B={cal_b} calibration step: "
+                      f"{ {t: round(v, 2) for t, v in trials.items()} } s) on a {ncpu}-CPU host, torch {torch.__version__}"}
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# algorithmic work
+# ---------------------------------------------------------------------------------------------------------------
 def pointnet_train_flops(P):
     """2 FLOP/MAC x 1.837 M MAC per point forward, x3 for forward + dgrad + wgrad."""
     return 3 * 2 * 1.837e6 * P
@@ -132,7 +170,40 @@ def step_algorithmic(tr, B, T, N):
     return flops, nbytes
 
 
-def build_trainer(a, N, dev, pg, precision):
+def step_fracs(tr, B, T, N, ms):
+    flops, nbytes = step_algorithmic(tr, B, T, N)
+    mf = flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS
+    hf = nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS
+    return {"step_flops": flops, "step_hbm_bytes": nbytes, "mfma_frac": mf, "hbm_frac": hf,
+            "bound": "hbm" if nbytes / PEAK_HBM_GBS / 1e9 > flops / PEAK_BF16_TFLOPS / 1e12 else "mfma"}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# construction helpers
+# ---------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def device_fill_(module, seed):
+    """Random-init weights of the architecture drawn on the device (the extra legs: a 627 M-parameter decoder takes
+    ~10 s of numpy draws on the host; the parity-tested main leg keeps synthetic.deterministic_fill_)."""
+    for i, (name, t) in enumerate(module.state_dict().items()):
+        if not t.dtype.is_floating_point:
+            t.zero_()
+            continue
+        g = torch.Generator(device=t.device)
+        g.manual_seed(1000 * seed + i)
+        if name.endswith("running_var"):
+            t.copy_(0.5 + torch.rand(t.shape, generator=g, device=t.device))
+        elif name.endswith("running_mean"):
+            t.copy_(0.1 * torch.randn(t.shape, generator=g, device=t.device))
+        elif t.dim() == 1:
+            r = torch.randn(t.shape, generator=g, device=t.device)
+            t.copy_(1.0 + 0.1 * r if name.endswith("weight") else 0.05 * r)
+        else:
+            fan_in = t[0].numel()
+            t.copy_(torch.randn(t.shape, generator=g, device=t.device) / fan_in ** 0.5)
+
+
+def build_trainer(a, N, dev, pg, precision, fill="deterministic"):
     from opensetgaitrecognition_pcaa_amd import constants, synthetic as syn
     from opensetgaitrecognition_pcaa_amd.train import PCAATrainer
     from opensetgaitrecognition_pcaa_amd.utils import sample_distant_points
@@ -144,74 +215,80 @@ def build_trainer(a, N, dev, pg, precision):
                      force_collectives=a.dp_force, fused_decoder_update=a.decoder_update == "fused")
     for i, m in enumerate((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head,
                            tr.discriminator_projection_head)):
-        syn.deterministic_fill_(m, i)
+        if fill == "deterministic":
+            syn.deterministic_fill_(m, i)
+        else:
+            device_fill_(m, i)
     tr.set_prior_means(sample_distant_points(32, a.classes, 10, 10))
     tr.finalize()
     tr.train()
     return tr, cfg
 
 
-def workload_sweep(a, dev):
-    """BASELINE config[3]: the train step at N in {32,64,128,256} (train_pointsubsampling.py path), B=64, one GPU.
-    Small N replays the step as a hipGraph (the eager step is bound by the host's ~120 enqueues there)."""
-    from opensetgaitrecognition_pcaa_amd import constants, functional as F_hip, synthetic as syn
-    B, C, K, T = a.batch, a.features, a.classes, constants.NSTEPS
-    constants.NFEATURES = C
-    F_hip.set_precision(a.precision)
-    entries, tot_seq, tot_s = [], 0, 0.0
-    for N in (32, 64, 128, 256):
-        tr, _ = build_trainer(a, N, dev, None, a.precision)
-        pcs = syn.synthetic_pcs(B, T, N, C, seed=1234).to(dev).permute(0, 3, 1, 2)
-        gt = syn.synthetic_labels(B, K, seed=1235).to(dev)
-        z0, al = syn.synthetic_z0(B, 32, seed=1236).to(dev), syn.synthetic_alphas(B, seed=1237).to(dev)
-        graph = a.graph == "on" or (a.graph == "auto" and tr.prefers_graph(B, N))
-        run = (lambda: tr.step_graphed(pcs, gt, z0, al, warmup=0)) if graph else (lambda: tr.step(pcs, gt, z0, al))
-        for _ in range(max(a.warmup, 3)):
-            tr.step(pcs, gt, z0, al)
-        run()
+def make_inputs(B, T, N, C, K, dev, rank=0):
+    """inputs resident in HBM (point-major storage, [B,C,T,N] view), different data per rank (SURVEY 8d seeds)"""
+    from opensetgaitrecognition_pcaa_amd import synthetic as syn
+    pcs = syn.synthetic_pcs(B, T, N, C, seed=1234 + rank).to(dev).permute(0, 3, 1, 2)
+    gt = syn.synthetic_labels(B, K, seed=1235 + rank).to(dev)
+    z0 = syn.synthetic_z0(B, 32, seed=1236 + rank).to(dev)
+    al = syn.synthetic_alphas(B, seed=1237 + rank).to(dev)
+    return pcs, gt, z0, al
+
+
+def time_single_gpu(run, steps, windows):
+    """``windows`` timed regions of exactly ``steps`` calls each, synchronize on both sides -> ms per step of each."""
+    out = []
+    for _ in range(windows):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
-            out = run()
+        for _ in range(steps):
+            r = run()
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        flops, nbytes = step_algorithmic(tr, B, T, N)
-        ms = dt / a.steps * 1e3
-        entries.append({"N": N, "ms_per_step": ms, "value": B * a.steps / dt, "hip_graph": bool(graph),
-                        "finite_loss": bool(torch.isfinite(out["tot_loss"]).item()),
-                        "step_flops": flops, "step_hbm_bytes": nbytes,
-                        "mfma_frac": flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                        "hbm_frac": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                        "bound": "hbm" if nbytes / PEAK_HBM_GBS / 1e9 > flops / PEAK_BF16_TFLOPS / 1e12 else "mfma"})
-        tot_seq += B * a.steps
-        tot_s += dt
+        out.append((time.perf_counter() - t0) / steps * 1e3)
+    return out, r
+
+
+def spread(ms_list):
+    return {"median": statistics.median(ms_list), "min": min(ms_list), "max": max(ms_list), "windows": len(ms_list)}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# extra legs of the default line (single GPU)
+# ---------------------------------------------------------------------------------------------------------------
+def leg_train_shape(a, dev, N, C, steps, windows, warmup=3):
+    """The bf16 train step at another shape (sweep points, C=5): ms per step (median window) + whole-step fractions."""
+    from opensetgaitrecognition_pcaa_amd import constants
+    B, K, T = a.batch, a.classes, constants.NSTEPS
+    c_saved = constants.NFEATURES
+    constants.NFEATURES = C
+    try:
+        tr, _ = build_trainer(a, N, dev, None, a.precision, fill="device")
+        pcs, gt, z0, al = make_inputs(B, T, N, C, K, dev)
+        graph = a.graph == "on" or (a.graph == "auto" and tr.prefers_graph(B, N))
+        run = (lambda: tr.step_graphed(pcs, gt, z0, al, warmup=0)) if graph else (lambda: tr.step(pcs, gt, z0, al))
+        for _ in range(warmup):
+            tr.step(pcs, gt, z0, al)
+        run()
+        ms_list, out = time_single_gpu(run, steps, windows)
+        ms = statistics.median(ms_list)
+        ent = {"N": N, "C": C, "B": B, "ms_per_step": ms, "value": B / ms * 1e3, "unit": "sequences/s",
+               "windows_ms_per_step": ms_list, "steps": steps, "hip_graph": bool(graph),
+               "finite_loss": bool(torch.isfinite(out["tot_loss"]).item())}
+        ent.update(step_fracs(tr, B, T, N, ms))
+        ent["frac"] = max(ent["mfma_frac"], ent["hbm_frac"])
         del tr
         torch.cuda.empty_cache()
-    worst = min(entries, key=lambda e: max(e["mfma_frac"], e["hbm_frac"]))
-    line = {"metric": "gait sequences/sec (train step), point-subsampling sweep", "value": tot_seq / tot_s,
-            "unit": "sequences/s", "n_gpus": 1, "steps": a.steps, "warmup": max(a.warmup, 3),
-            "ms_per_step": tot_s / (4 * a.steps) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if a.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"PCAA V4 train step at N in (32,64,128,256), B={B} T={T} C={C} K={K}, BASELINE config[3]; "
-                                   "value = all sequences / all time", "sweep": entries},
-            "roofline": {"bound": worst["bound"], "achieved": worst["step_flops"] / (worst["ms_per_step"] * 1e-3) / 1e12
-                         if worst["bound"] == "mfma" else worst["step_hbm_bytes"] / (worst["ms_per_step"] * 1e-3) / 1e9,
-                         "peak": PEAK_BF16_TFLOPS if worst["bound"] == "mfma" else PEAK_HBM_GBS,
-                         "unit": "TFLOP/s" if worst["bound"] == "mfma" else "GB/s",
-                         "frac": max(worst["mfma_frac"], worst["hbm_frac"]), "traffic": None,
-                         "note": f"whole-step algorithmic work / step time at the sweep's worst point (N={worst['N']}); "
-                                 "per-N figures in config.sweep"}}
-    print(json.dumps(line), flush=True)
+        return ent
+    finally:
+        constants.NFEATURES = c_saved
 
 
-def workload_infer(a, dev):
+def leg_infer(a, dev, steps, windows, with_cpu=False):
     """BASELINE config[4]: eval-mode CGEncoder (BatchNorm + ELU [+ mean-pool] in the GEMM epilogues) -> fp64 mixture
     likelihood -> k=6 window vote on B=1024 sequences resident in HBM; one step = one batch."""
-    from opensetgaitrecognition_pcaa_amd import constants, functional as F_hip, inference, models, ops, synthetic as syn
+    from opensetgaitrecognition_pcaa_amd import constants, inference, models, ops, synthetic as syn
     from opensetgaitrecognition_pcaa_amd.utils import sample_distant_points
     B, N, C, K, T = 1024, a.points, a.features, a.classes, constants.NSTEPS
-    constants.NFEATURES = C
-    F_hip.set_precision(a.precision)
     enc = models.CGEncoder(K, nmax_points=N, use_projection_head=True).float()
     syn.deterministic_fill_(enc, 0)
     enc = enc.to(dev).eval()
@@ -223,37 +300,32 @@ def workload_infer(a, dev):
         scorer.threshold = 1e-30
         return scorer.vote(lik, preds, 6, K), lik
 
-    for _ in range(max(a.warmup, 2)):
+    for _ in range(2):
         step()
     torch.cuda.synchronize()
     timer = ops.LaunchTimer(only_prefix="gemm_bf16_dma_kernel" if a.precision == "bf16" else "gemm_f32_kernel")
     ops.set_timer(timer)
     step()
     ops.set_timer(None)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        votes, lik = step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    ms_list, (votes, lik) = time_single_gpu(step, steps, windows)
+    ms = statistics.median(ms_list)
     agg = timer.summary()
     name, r = max(agg.items(), key=lambda kv: kv[1]["ms"])
     peak = PEAK_BF16_TFLOPS if name.startswith("gemm_bf16") else PEAK_F32_TFLOPS
     achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
     flops_seq = 2 * 1.837e6 * T * N + 2 * 572928 * T
-    line = {"metric": "gait sequences/sec (open-set inference)", "value": B * a.steps / dt, "unit": "sequences/s",
-            "n_gpus": 1, "steps": a.steps, "warmup": max(a.warmup, 2), "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if a.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"open-set inference: eval CGEncoder + joint likelihood + k=6 vote, B={B} T={T} N={N} C={C} "
-                                   f"K={K}, BASELINE config[4]", "finite": bool(torch.isfinite(lik).all().item()),
-                       "windows": int(votes.numel()), "algorithmic_gflop_per_sequence": flops_seq / 1e9,
-                       "whole_path_mfma_frac": flops_seq * B / (dt / a.steps) / 1e12 / PEAK_BF16_TFLOPS},
-            "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None, "launches_per_step": r["launches"],
-                         "avg_launch_ms": r["ms"] / r["launches"],
-                         "algorithmic_flop_per_launch": r["flops"] / r["launches"]}}
-    if not a.no_cpu_baseline:
+    ent = {"workload": f"open-set inference: eval CGEncoder + joint likelihood + k=6 vote, B={B} T={T} N={N} C={C} K={K}, "
+                       "BASELINE config[4]",
+           "ms_per_step": ms, "value": B / ms * 1e3, "unit": "sequences/s", "windows_ms_per_step": ms_list, "steps": steps,
+           "finite": bool(torch.isfinite(lik).all().item()), "windows_voted": int(votes.numel()),
+           "algorithmic_gflop_per_sequence": flops_seq / 1e9,
+           # whole path against the MFMA peak (14.14 GFLOP per sequence), and its dominant kernel alone
+           "frac": flops_seq * B / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "bound": "mfma",
+           "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                        "frac": achieved / peak, "traffic": None, "launches_per_step": r["launches"],
+                        "avg_launch_ms": r["ms"] / r["launches"],
+                        "algorithmic_flop_per_launch": r["flops"] / r["launches"]}}
+    if with_cpu:
         from oracle import pcaa_oracle as O
         sd = {k: v.detach().cpu().clone() for k, v in enc.state_dict().items()}
         xb = pcs[:64].cpu().contiguous()
@@ -262,11 +334,85 @@ def workload_infer(a, dev):
         with torch.no_grad():
             O.cg_encoder_forward(xb, sd, True, training=False)
         d = time.perf_counter() - t1
-        line["cpu_baseline"] = {"value": 64 / d, "unit": "sequences/s", "cores": torch.get_num_threads(), "kind": "port",
-                                "sample": f"oracle eval-mode encoder forward on 64 of the 1024 sequences: {d:.1f} s"}
+        ent["cpu_baseline"] = {"value": 64 / d, "unit": "sequences/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"oracle eval-mode encoder forward on 64 of the 1024 sequences: {d:.1f} s"}
+    del scorer, enc
+    torch.cuda.empty_cache()
+    return ent
+
+
+def leg_sections(tr, inputs, steps=10):
+    """HIP events at the section boundaries of the MAIN stream (functional.set_marks; tools/step_sections.py):
+    median microseconds per section -- the GPU side of cpu_baseline's phase breakdown."""
+    from opensetgaitrecognition_pcaa_amd import functional as F_hip
+    marks = []
+    F_hip.set_marks(marks)
+    try:
+        for _ in range(steps):
+            tr.step(*inputs)
+        torch.cuda.synchronize()
+    finally:
+        F_hip.set_marks(None)
+    agg = {}
+    for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+        agg.setdefault(f"{n0} -> {n1}", []).append(e0.elapsed_time(e1) * 1e3)
+    us = {k: statistics.median(v) for k, v in agg.items()}
+
+    def tot(*keys):
+        return sum(v for k, v in us.items() if any(k.startswith(p) for p in keys))
+    # the CPU phases' counterparts (the critic's D-step runs on its own stream beside decoder forward / Chamfer /
+    # decoder backward and costs the main stream nothing; the decoder's Adam runs beside the temporal block's backward)
+    return {"us": us,
+            "phases_us": {"encoder_fwd": tot("enc_fwd.begin", "enc_fwd.pointnet", "enc_fwd.dtc"),
+                          "d_step": 0.0,
+                          "decoder_chamfer": tot("heads_fwd", "dec_fwd"),
+                          "backward": tot("chamfer", "dec_bwd", "enc_bwd.heads", "enc_bwd.dtc"),
+                          "adam_g": tot("enc_bwd.pointnet", "adam+join")},
+            "note": "median over %d steps of event intervals on the main stream; D-step: critic stream, hidden" % steps}
+
+
+def workload_sweep(a, dev):
+    """BASELINE config[3] as a line of its own: the train step at N in {32,64,128,256}, B=64, one GPU."""
+    from opensetgaitrecognition_pcaa_amd import constants, functional as F_hip
+    B, C, K, T = a.batch, a.features, a.classes, constants.NSTEPS
+    F_hip.set_precision(a.precision)
+    entries = [leg_train_shape(a, dev, N, C, a.steps, a.windows, max(a.warmup, 3)) for N in (32, 64, 128, 256)]
+    tot_ms = sum(e["ms_per_step"] for e in entries)
+    worst = min(entries, key=lambda e: e["frac"])
+    line = {"metric": "gait sequences/sec (train step), point-subsampling sweep", "value": 4 * B / tot_ms * 1e3,
+            "unit": "sequences/s", "n_gpus": 1, "steps": a.steps, "warmup": max(a.warmup, 3),
+            "ms_per_step": tot_ms / 4, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if a.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"PCAA V4 train step at N in (32,64,128,256), B={B} T={T} C={C} K={K}, BASELINE config[3]; "
+                                   "value = all sequences / all time", "sweep": entries},
+            "roofline": {"bound": worst["bound"], "achieved": worst["step_flops"] / (worst["ms_per_step"] * 1e-3) / 1e12
+                         if worst["bound"] == "mfma" else worst["step_hbm_bytes"] / (worst["ms_per_step"] * 1e-3) / 1e9,
+                         "peak": PEAK_BF16_TFLOPS if worst["bound"] == "mfma" else PEAK_HBM_GBS,
+                         "unit": "TFLOP/s" if worst["bound"] == "mfma" else "GB/s",
+                         "frac": worst["frac"], "traffic": None,
+                         "note": f"whole-step algorithmic work / step time at the sweep's worst point (N={worst['N']}); "
+                                 "per-N figures in config.sweep"}}
     print(json.dumps(line), flush=True)
 
 
+def workload_infer(a, dev):
+    from opensetgaitrecognition_pcaa_amd import constants, functional as F_hip
+    constants.NFEATURES = a.features
+    F_hip.set_precision(a.precision)
+    ent = leg_infer(a, dev, a.steps, a.windows, with_cpu=not a.no_cpu_baseline)
+    line = {"metric": "gait sequences/sec (open-set inference)", "value": ent["value"], "unit": "sequences/s",
+            "n_gpus": 1, "steps": a.steps, "warmup": 2, "ms_per_step": ent["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if a.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {k: ent[k] for k in ("workload", "finite", "windows_voted", "algorithmic_gflop_per_sequence",
+                                           "windows_ms_per_step")} | {"whole_path_mfma_frac": ent["frac"]},
+            "roofline": ent["roofline"]}
+    if "cpu_baseline" in ent:
+        line["cpu_baseline"] = ent["cpu_baseline"]
+    print(json.dumps(line), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 def main():
     a = parse()
     if a.workload != "train":
@@ -279,9 +425,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
-    from opensetgaitrecognition_pcaa_amd import constants, functional as F_hip, ops, synthetic as syn
-    from opensetgaitrecognition_pcaa_amd.train import PCAATrainer
-    from opensetgaitrecognition_pcaa_amd.utils import sample_distant_points
+    from opensetgaitrecognition_pcaa_amd import constants, functional as F_hip, ops
 
     dev_index = int(os.environ.get("PCAA_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(dev_index)
@@ -302,16 +446,19 @@ def main():
     tr, cfg = build_trainer(a, N, dev, pg, a.precision)
     decoder_update = "fused wgrad+adam" if (tr.fused_decoder_update and world == 1 and a.precision == "bf16"
                                             and not a.dp_force) else "wgrad, adam"
-    # inputs resident in HBM (point-major storage, [B,C,T,N] view), different data per rank
-    pcs = syn.synthetic_pcs(B, T, N, C, seed=1234 + rank).to(dev).permute(0, 3, 1, 2)
-    gt = syn.synthetic_labels(B, K, seed=1235 + rank).to(dev)
-    z0 = syn.synthetic_z0(B, 32, seed=1236 + rank).to(dev)
-    al = syn.synthetic_alphas(B, seed=1237 + rank).to(dev)
+    pcs, gt, z0, al = make_inputs(B, T, N, C, K, dev, rank)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(seconds):
+        if world > 1:
+            t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return seconds
 
     use_graph = a.graph == "on" or (a.graph == "auto" and world == 1 and tr.prefers_graph(B, N))
     run_step = tr.step
@@ -321,35 +468,34 @@ def main():
         # capture (the step is recorded, then replayed once: one more real, untimed step)
         out = tr.step_graphed(pcs, gt, z0, al, warmup=0)
         run_step = tr.step_graphed
-    barrier()
     timer = None
     if not a.no_kernel_timing:
         # HIP events on the kernel family the roofline reports: the start/stop events ride on the launch
         # itself (hipExtLaunchKernelGGL through pcaa_time_next_gemm), i.e. they are the kernel's own begin/end
         # timestamps -- the quantity rocprofv3's kernel trace reports -- on the stream it is launched on
         timer = ops.LaunchTimer(only_prefix="gemm_bf16_dma_kernel" if a.precision == "bf16" else "gemm_f32_kernel")
-        ops.set_timer(timer)
-    # the launches of the first `timed_steps` steps of the timed region carry the events
-    # (graph mode: those steps run eagerly -- events cannot be read back from inside a replayed graph --
-    # and the remaining steps of the timed region are graph replays)
+    # the launches of the first `timed_steps` steps of the FIRST window carry the events
+    # (graph mode: those steps run eagerly -- events cannot be read back from inside a replayed graph)
     timed_steps = min(a.steps, 2 if use_graph else 4) if timer is not None else 0
-    host_s = 0.0
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        if i == timed_steps:
-            ops.set_timer(None)
-        h0 = time.perf_counter()
-        out = tr.step(pcs, gt, z0, al) if i < timed_steps else run_step(pcs, gt, z0, al)
-        host_s += time.perf_counter() - h0
-    barrier()
-    dt = time.perf_counter() - t0
-    ops.set_timer(None)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    windows_s, host_s = [], 0.0
+    for w in range(a.windows):
+        barrier()
+        if w == 0 and timer is not None:
+            ops.set_timer(timer)
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            if w == 0 and i == timed_steps:
+                ops.set_timer(None)
+            h0 = time.perf_counter()
+            out = tr.step(pcs, gt, z0, al) if (w == 0 and i < timed_steps) else run_step(pcs, gt, z0, al)
+            host_s += time.perf_counter() - h0
+        barrier()
+        windows_s.append(max_over_ranks(time.perf_counter() - t0))
+        ops.set_timer(None)
+    dt = statistics.median(windows_s)
     loss_ok = bool(torch.isfinite(out["tot_loss"]).item())
     comm = dict(tr.comm)
+    single = world == 1 and not a.dp_force
 
     def timed_leg(trainer, batches, steps, warmup):
         """warmup untimed + steps timed trainer steps; ``batches`` yields (pcs, gt).  Same bracket as the main
@@ -362,18 +508,18 @@ def main():
         for _ in range(steps):
             trainer.step(*next(it), z0, al)
         barrier()
-        d = time.perf_counter() - t_0
-        if world > 1:
-            tt = torch.tensor([d], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            d = float(tt.item())
-        return d
+        return max_over_ranks(time.perf_counter() - t_0)
+
+    sections = None
+    if single and not a.no_extra_legs and not use_graph:
+        sections = leg_sections(tr, (pcs, gt, z0, al))
 
     batcher_leg = None
     if not a.no_batcher_leg and not use_graph and world == 1:
         # datasets.py batch collation inside the timed loop: a packed point-major store of `pool` synthetic crops
         # resident in HBM, every step's batch gathered from it in the DataLoader's shuffled order
         # (DeviceBatcher = pcaa_gather_rows), then the same train step
+        from opensetgaitrecognition_pcaa_amd import synthetic as syn
         from opensetgaitrecognition_pcaa_amd.batcher import DeviceBatcher
         pool = 64 * B
         store = syn.synthetic_pcs(pool, T, N, C, seed=4321 + rank).to(dev)
@@ -390,12 +536,14 @@ def main():
                                 "pcaa_gather_rows per batch"}
         del store, loader
 
+    agg = timer.summary() if timer is not None else None
+    del tr
+    torch.cuda.empty_cache()
+
     parity_leg = None
     if a.precision == "bf16" and not a.no_parity_mode and not use_graph and world == 1:
         # the SAME workload in fp32 parity mode (exact-fp32 MFMA, fp32 activations): the mode the 1e-4 / bit-exact
         # label tests run in (tests/test_round2_parity.py::test_config1_full_size_fp32_step_vs_oracle)
-        del tr
-        torch.cuda.empty_cache()
         F_hip.set_precision("fp32")
         tr32, _ = build_trainer(a, N, dev, pg, "fp32")
         psteps = max(1, min(a.steps, 10))
@@ -407,6 +555,16 @@ def main():
         del tr32
         torch.cuda.empty_cache()
         F_hip.set_precision(a.precision)
+
+    sweep = infer = c5 = None
+    if single and not a.no_extra_legs and a.precision == "bf16":
+        esteps = max(1, min(a.steps, 10))
+        # BASELINE config[3]: the point-subsampling sweep (train_pointsubsampling.py:19-71), 10 steps x 3 windows each
+        sweep = [leg_train_shape(a, dev, n, C, esteps, 3) for n in (32, 64, 128, 256)]
+        # BASELINE config[4]: open-set inference at B=1024 (inference_PCAA.py:382-469)
+        infer = leg_infer(a, dev, max(1, min(a.steps, 5)), 3)
+        # config[1] with the five features its wording names (x, y, z, doppler, power dB)
+        c5 = leg_train_shape(a, dev, N, 5, esteps, 3)
 
     if rank == 0:
         ms = dt / a.steps * 1e3
@@ -421,6 +579,10 @@ def main():
                        "global_batch": B * world, "precision": a.precision,
                        "parallelism": f"dp{world}", "sync_bn": bool(a.sync_bn), "finite_loss": loss_ok,
                        "hip_graph": bool(use_graph),
+                       # the timed region (exactly `steps` steps, barrier + synchronize on both sides, max over ranks)
+                       # was run `windows` times back to back: ms_per_step / value are the median window
+                       "windows_ms_per_step": [w / a.steps * 1e3 for w in windows_s],
+                       "windows": spread([w / a.steps * 1e3 for w in windows_s]),
                        # single process, bf16: the decoder's wide weight gradients are consumed by a fused Adam kernel
                        "decoder_update": decoder_update,
                        # gradient / parameter exchanges of one step: number of collectives, payload bytes, and what a
@@ -433,14 +595,24 @@ def main():
                                                            if a.dp_mode == "allreduce" else
                                                            1.0 * (world - 1) / world * comm["payload_bytes"])},
                        # time the host spends enqueueing one step (no synchronisation inside step())
-                       "host_enqueue_ms_per_step": host_s / a.steps * 1e3},
+                       "host_enqueue_ms_per_step": host_s / (a.steps * a.windows) * 1e3},
         }
         if parity_leg is not None:
             line["parity_mode"] = parity_leg
         if batcher_leg is not None:
             line["with_batcher"] = batcher_leg
-        if timer is not None:
-            agg = timer.summary()
+        if sweep is not None:
+            line["sweep"] = {"workload": f"BASELINE config[3]: V4 train step at N in (32,64,128,256), B={B} C={C} bf16; frac = "
+                                         "whole-step algorithmic FLOPs / bytes (SURVEY 8d) over the step time against the MFMA / "
+                                         "HBM peak, the larger of the two", "points": sweep}
+        if infer is not None:
+            line["infer"] = infer
+        if c5 is not None:
+            c5["workload"] = f"BASELINE config[1] at C=5 (x, y, z, doppler, power): B={B} N={N} bf16"
+            line["c5"] = c5
+        if sections is not None:
+            line["gpu_sections"] = sections
+        if agg:
             dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
             name, r = dom
             peak = PEAK_BF16_TFLOPS if name.startswith("gemm_bf16") else PEAK_F32_TFLOPS
@@ -455,11 +627,11 @@ def main():
                     pmc = json.load(f)
                 if pmc.get("workload") == f"B={B} T={T} N={N} C={C} K={K} {a.precision}" and name in pmc["kernels"]:
                     traffic = pmc["kernels"][name]["hbm_bytes_per_launch"]
-            except (OSError, ValueError, KeyError):
+            except (OSError, ValueError, KeyError, IndexError):
                 pass
             line["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak,
                                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                                "traffic_unit": "HBM bytes per launch (PMC)",
+                                "traffic_unit": "HBM bytes per launch (PMC, from the committed rocprofv3 passes)",
                                 "algorithmic_flop_per_launch": r["flops"] / r["launches"],
                                 "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
                                 "timed_steps": timed_steps,
@@ -471,6 +643,11 @@ def main():
                                                 for k, v in agg.items() if k != name}}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(B, N, C, K, T)
+            if sections is not None:
+                # the two breakdowns side by side, per phase: CPU seconds (at the sample's batch) and GPU microseconds
+                cb = line["cpu_baseline"]
+                cb["phases_vs_gpu"] = {k: {"cpu_s": cb["phases_s"].get(k), "gpu_us": sections["phases_us"].get(k)}
+                                       for k in cb["phases_s"]}
         print(json.dumps(line), flush=True)
     if pg is not None:
         dist.destroy_process_group()
