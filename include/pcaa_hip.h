@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PCAA_ABI_VERSION 9 /* pcaa_abi_version() of a library built from this header */
+#define PCAA_ABI_VERSION 10 /* pcaa_abi_version() of a library built from this header */
 
 #define PCAA_OK 0
 #define PCAA_ERR_INVALID_ARG 1
@@ -188,6 +188,24 @@ int pcaa_bn_bwd_finalize(const double* stats, int nrep, long count, const float*
                          float* coef, float* dgamma, float* dbeta, int ch, void* stream);
 int pcaa_bn_bwd_dy(const void* dz, const void* y, void* dy, int dtype, const float* coef,
                    long rows, int ch, void* stream);
+/* The finalize CARRIED BY THE PRODUCER of the statistics (round 3; csrc/bn_tail.h).  pcaa_bn_tail_arm_fwd / _bwd
+ * note the arguments of pcaa_bn_finalize / pcaa_bn_bwd_finalize on the calling thread; the NEXT launch on that thread
+ * that accumulates into exactly this `stats` buffer and can carry a tail (pcaa_gemm on the LDS-DMA path with colstats,
+ * pcaa_gemm_dgrad_bn, pcaa_pointnet_in_fwd (statistics only), pcaa_pointnet_in_bwd_stats, pcaa_bn_pool_bwd_stats,
+ * pcaa_dtc_conv_fwd / _dgrad without K split) takes it: its last workgroup to finish (agent-scope arrival counter,
+ * `counter`: one zero-initialised word, left at zero) writes the coefficients, and the separate finalize launch
+ * -- 5-8 us on the critical path, 20 per train step -- is gone.  pcaa_bn_tail_pending() == 1 after the producer's
+ * call means it did not take the tail: call pcaa_bn_tail_disarm() and the stand-alone finalize. */
+int pcaa_bn_tail_arm_fwd(const double* stats, int nrep, long count, const float* lin_bias,
+                         const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, long long* num_batches_tracked,
+                         float momentum, float eps,
+                         float* scale, float* shift, float* mean, float* rstd, int ch, unsigned* counter);
+int pcaa_bn_tail_arm_bwd(const double* stats, int nrep, long count, const float* gamma,
+                         const float* mean, const float* rstd,
+                         float* coef, float* dgamma, float* dbeta, int ch, unsigned* counter);
+int pcaa_bn_tail_pending(void);
+int pcaa_bn_tail_disarm(void);
 /* Two-pass form that never materialises dz: first pcaa_bn_act_bwd_dz with dz == NULL
  * (statistics only), then dy = coef0 * (da * ELU'(y*scale+shift)) + coef1 * y + coef2 here
  * (da / dpool as in pcaa_bn_act_bwd_dz; dy may alias da). */

@@ -6,6 +6,7 @@
 #include <stdarg.h>
 
 #include "common.h"
+#include "bn_tail.h"
 
 // ---------------------------------------------------------------- error string
 static thread_local char g_err[512] = "";
@@ -254,7 +255,8 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_stats_kernel(const float* __r
                                                                 const float* __restrict__ e1,
                                                                 const float* __restrict__ e2, float pool_scale,
                                                                 double* __restrict__ stats, int nrep, long groups,
-                                                                int ch, int gpb) {
+                                                                int ch, int gpb, BnTail tail) {
+  __shared__ int tail_flag;
   // thread = channel quad; the block's gpb groups in trips of 8 with all 24 loads in flight (the first version
   // walked them one dependent load at a time: 150 us beside the side-stream Adam; 32 groups per block left the
   // 1920-group PointNet case with 60 workgroups on 256 CUs: 50 us on the critical path)
@@ -287,6 +289,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_stats_kernel(const float* __r
       unsafeAtomicAdd(&stats[((long)(blockIdx.x % nrep) * 2 + 1) * ch + c + e], s2[e]);
     }
   }
+  bn_tail_run(tail, threadIdx.x, 256, gridDim.x, &tail_flag);
 }
 
 // ---------------------------------------------------------------- dz = da * ELU'(z) + BN-backward statistics
@@ -665,7 +668,7 @@ extern "C" int pcaa_bn_pool_bwd_stats(const float* dpool, const float* e1, const
   PCAA_CHECK_ARG(groups >= 1 && ch >= 4 && (ch & 3) == 0 && nrep >= 1, "pcaa_bn_pool_bwd_stats: ch must be a multiple of 4");
   const int gpb = (int)std::max<long>(1, std::min<long>(32, groups / 256));      // >= 256 workgroups where there are groups for them
   hipLaunchKernelGGL(bn_pool_bwd_stats_kernel, dim3((unsigned)cdiv(groups, gpb)), dim3(256), 0, as_stream(stream),
-                     dpool, e1, e2, pool_scale, stats, nrep, groups, ch, gpb);
+                     dpool, e1, e2, pool_scale, stats, nrep, groups, ch, gpb, pcaa_take_bn_tail(stats));
   PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_pool_bwd_stats");
 }
 
@@ -767,6 +770,55 @@ extern "C" int pcaa_bn_bwd_finalize(const double* stats, int nrep, long count, c
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(ch, 256)), dim3(256), 0, as_stream(stream),
                      stats, nrep, 1.0 / (double)count, gamma, mean, rstd, coef, dgamma, dbeta, ch);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_bwd_finalize");
+}
+
+// ---------------------------------------------------------------- finalize carried by the producer (bn_tail.h)
+namespace {
+thread_local BnTail g_tail = {};
+}
+BnTail pcaa_take_bn_tail(const double* stats) {
+  BnTail t = {};
+  if (g_tail.kind != 0 && g_tail.stats == stats) {
+    t = g_tail;
+    g_tail.kind = 0;
+  }
+  return t;
+}
+extern "C" int pcaa_bn_tail_arm_fwd(const double* stats, int nrep, long count, const float* lin_bias,
+                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                    long long* num_batches_tracked, float momentum, float eps, float* scale,
+                                    float* shift, float* mean, float* rstd, int ch, unsigned* counter) {
+  PCAA_CHECK_ARG(stats && gamma && beta && scale && shift && mean && rstd && counter, "pcaa_bn_tail_arm_fwd: null pointer");
+  PCAA_CHECK_ARG(nrep >= 1 && count >= 1 && ch >= 1, "pcaa_bn_tail_arm_fwd: bad sizes");
+  PCAA_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "pcaa_bn_tail_arm_fwd: running stats must come together");
+  BnTail t = {};
+  t.kind = 1; t.nrep = nrep; t.ch = ch; t.counter = counter; t.stats = stats;
+  t.inv_count = 1.0 / (double)count;
+  t.unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+  t.lin_bias = lin_bias; t.gamma = gamma; t.beta = beta;
+  t.running_mean = running_mean; t.running_var = running_var; t.nbt = num_batches_tracked;
+  t.momentum = momentum; t.eps = eps;
+  t.scale = scale; t.shift = shift; t.mean = mean; t.rstd = rstd;
+  g_tail = t;
+  return PCAA_OK;
+}
+extern "C" int pcaa_bn_tail_arm_bwd(const double* stats, int nrep, long count, const float* gamma, const float* mean,
+                                    const float* rstd, float* coef, float* dgamma, float* dbeta, int ch,
+                                    unsigned* counter) {
+  PCAA_CHECK_ARG(stats && gamma && mean && rstd && coef && counter, "pcaa_bn_tail_arm_bwd: null pointer");
+  PCAA_CHECK_ARG(nrep >= 1 && count >= 1 && ch >= 1, "pcaa_bn_tail_arm_bwd: bad sizes");
+  BnTail t = {};
+  t.kind = 2; t.nrep = nrep; t.ch = ch; t.counter = counter; t.stats = stats;
+  t.inv_count = 1.0 / (double)count;
+  t.gamma = gamma; t.mean = const_cast<float*>(mean); t.rstd = const_cast<float*>(rstd);
+  t.coef = coef; t.dgamma = dgamma; t.dbeta = dbeta;
+  g_tail = t;
+  return PCAA_OK;
+}
+extern "C" int pcaa_bn_tail_pending(void) { return g_tail.kind != 0 ? 1 : 0; }
+extern "C" int pcaa_bn_tail_disarm(void) {
+  g_tail.kind = 0;
+  return PCAA_OK;
 }
 
 extern "C" int pcaa_bn_bwd_dy(const void* dz, const void* y, void* dy, int dtype, const float* coef,

@@ -1020,6 +1020,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   tn = tn2;
   primed = true;
   }
+  // this workgroup's tiles are done: if the launch carries the BatchNorm finalize of its statistics, the last
+  // workgroup to get here runs it (bn_tail.h)
+  if constexpr (PERSIST && (EPI == EPI_PLAIN || EPI == EPI_DGRAD_BN || EPI == EPI_DGRAD_BN_POINTS))
+    bn_tail_run(p.tail, tid, NTHREADS, gridDim.x, ticket_lds + 1);
 }
 
 // MFMA shape per instantiation.  KC x KC (forward / dgrad): v_mfma_f32_16x16x32_bf16 -- same cycles per FLOP as
@@ -1094,10 +1098,14 @@ bool launch_dma(const GemmParams& p_in, dim3 grid_in, hipStream_t s) {
   dim3 grid = grid_in;
   GemmParams p = p_in;
   p.sched = nullptr;
+  p.tail = BnTail{};
   if (ALAY == KC && !p.split_fast && grid.z == 1) {
     const unsigned g = persistent_grid((long)grid.x);
     if (g < grid.x) p.sched = sched_slot(s);
     grid.x = g;
+    // every workgroup of such a launch owns at least one tile and adds to colstats: the launch can carry the finalize
+    if ((EPI == EPI_PLAIN || EPI == EPI_DGRAD_BN || EPI == EPI_DGRAD_BN_POINTS) && p.colstats != nullptr && grid.y == 1)
+      p.tail = pcaa_take_bn_tail(p.colstats);
   }
   // buffer addressing needs each operand below 4 GiB (32-bit offsets); the flat form serves anything larger.  Same-box
   // A/B (profiles/r02_gemm_lab2.txt): forward / fused dgrad +1..3 %, wgrad (whole stage issued at the top of the step:

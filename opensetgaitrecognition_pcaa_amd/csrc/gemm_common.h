@@ -2,6 +2,7 @@
 // and gemm_bf16.hip (256x256-tile bf16 kernel).
 #pragma once
 #include "common.h"
+#include "bn_tail.h"
 
 struct GemmParams {
   const void* A; const void* B; void* C;
@@ -21,7 +22,9 @@ struct GemmParams {
   // LDS-DMA kernel, one workgroup per CU: 9 zero-initialised ints (8 per-XCD tile tickets + a count of finished
   // workgroups, reset by the last one); NULL: every workgroup walks a fixed share of the tiles
   int* sched;
-
+  // the BatchNorm finalize of the statistics this launch accumulates (colstats), run by its last workgroup
+  // (bn_tail.h); kind 0: none.  Only the LDS-DMA kernel's KC x KC instantiations carry one.
+  BnTail tail{};
 };
 
 // XCD-aware, bijective block -> (tile_m, tile_n) map: the 8 XCDs (blocks b, b+8,

@@ -4,6 +4,7 @@
 // (wgrad), not MFMA work: FMAs from registers, the point tile of each
 // workgroup staged once in LDS, BatchNorm statistics as in the GEMM epilogue.
 #include "common.h"
+#include "bn_tail.h"
 
 namespace {
 
@@ -20,9 +21,10 @@ __global__ __launch_bounds__(256) void pointnet_in_fwd_kernel(const float* __res
                                                               const float* __restrict__ W,   // [cout, C]
                                                               const float* __restrict__ bias,
                                                               T* __restrict__ y, long P, int cout,
-                                                              double* __restrict__ stats, int nrep) {
+                                                              double* __restrict__ stats, int nrep, BnTail tail) {
   __shared__ float xs[FWD_ROWS * CP];
   __shared__ f32x4 red[2][256];
+  __shared__ int tail_flag;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   const int qpr = cout >> 2, rl = 256 / qpr;
   const int cq = threadIdx.x % qpr, rlane = threadIdx.x / qpr;
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(256) void pointnet_in_fwd_kernel(const float* __res
       unsafeAtomicAdd(&stats[((long)(blockIdx.x % nrep) * 2 + stat) * cout + cc], v);
     }
   }
+  bn_tail_run(tail, threadIdx.x, 256, gridDim.x, &tail_flag);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -139,7 +142,8 @@ __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restric
                                                               const float* __restrict__ rstd,     // MODE 0
                                                               const float* __restrict__ coef,     // MODE 1: [3][cout]
                                                               double* __restrict__ stats, int nrep,
-                                                              float* __restrict__ dW, long P, int cout) {
+                                                              float* __restrict__ dW, long P, int cout, BnTail tail) {
+  __shared__ int tail_flag;
   __shared__ float xs[1024 * CP];     // points [WG_ROWS][CP], later the [rl][cout][CP] row-lane combine (rl*cout = 1024)
   const int qpr = cout >> 2, rl = 256 / qpr;
   const int cq = threadIdx.x % qpr, rlane = threadIdx.x / qpr;
@@ -202,6 +206,7 @@ __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restric
       for (int l = 0; l < rl; ++l) v += (double)red[stat * 256 + l * qpr + (cc >> 2)][cc & 3];
       unsafeAtomicAdd(&stats[((long)(blockIdx.x % nrep) * 2 + stat) * cout + cc], v);
     }
+    bn_tail_run(tail, threadIdx.x, 256, gridDim.x, &tail_flag);
   } else {
     float* red = xs;                     // [rl][cout][CP]
 #pragma unroll
@@ -312,9 +317,10 @@ extern "C" int pcaa_pointnet_in_fwd(const float* x, int C, const float* W, const
   PCAA_CHECK_ARG(shape_ok(C, cout), "pcaa_pointnet_in_fwd: need C<=%d and cout/4 dividing 256 (C=%d cout=%d)", MAXC, C, cout);
   PCAA_CHECK_ARG(!stats || nrep >= 1, "pcaa_pointnet_in_fwd: bad nrep");
   const unsigned grid = (unsigned)cdiv(P, FWD_ROWS);
+  const BnTail tail = stats ? pcaa_take_bn_tail(stats) : BnTail{};
 #define LAUNCH_FWD(T, CP)                                                                                          \
   hipLaunchKernelGGL((pointnet_in_fwd_kernel<T, CP>), dim3(grid), dim3(256), 0, as_stream(stream), x, C, W, bias, \
-                     (T*)y, P, cout, stats, nrep)
+                     (T*)y, P, cout, stats, nrep, tail)
   if (y_dtype == PCAA_F32) { if (C <= 4) LAUNCH_FWD(float, 4); else LAUNCH_FWD(float, 8); }
   else if (y_dtype == PCAA_BF16) { if (C <= 4) LAUNCH_FWD(bf16_t, 4); else LAUNCH_FWD(bf16_t, 8); }
   else { pcaa_set_error("pcaa_pointnet_in_fwd: bad dtype"); return PCAA_ERR_INVALID_ARG; }
@@ -370,10 +376,11 @@ extern "C" int pcaa_pointnet_in_bwd_stats(const void* da, int dtype, const float
                  "pcaa_pointnet_in_bwd_stats: bad args");
   PCAA_CHECK_ARG(shape_ok(C, cout), "pcaa_pointnet_in_bwd_stats: need C<=%d and cout/4 dividing 256 (C=%d cout=%d)", MAXC, C, cout);
   const unsigned grid = (unsigned)cdiv(P, BWD_ROWS);
+  const BnTail tail = pcaa_take_bn_tail(stats);
   if (dtype == PCAA_F32)
-    LAUNCH_BWD(float, 0, (const float*)da, x, C, W, scale, shift, mean, rstd, nullptr, stats, nrep, nullptr, P, cout);
+    LAUNCH_BWD(float, 0, (const float*)da, x, C, W, scale, shift, mean, rstd, nullptr, stats, nrep, nullptr, P, cout, tail);
   else if (dtype == PCAA_BF16)
-    LAUNCH_BWD(bf16_t, 0, (const bf16_t*)da, x, C, W, scale, shift, mean, rstd, nullptr, stats, nrep, nullptr, P, cout);
+    LAUNCH_BWD(bf16_t, 0, (const bf16_t*)da, x, C, W, scale, shift, mean, rstd, nullptr, stats, nrep, nullptr, P, cout, tail);
   else { pcaa_set_error("pcaa_pointnet_in_bwd_stats: bad dtype"); return PCAA_ERR_INVALID_ARG; }
   PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_bwd_stats");
 }
@@ -385,13 +392,13 @@ extern "C" int pcaa_pointnet_in_bwd_wgrad(const void* da, int dtype, const float
   PCAA_CHECK_ARG(shape_ok(C, cout), "pcaa_pointnet_in_bwd_wgrad: need C<=%d and cout/4 dividing 256 (C=%d cout=%d)", MAXC, C, cout);
   const unsigned grid = (unsigned)cdiv(P, BWD_ROWS);
   if (dtype == PCAA_F32 && !dz_is_pre)
-    LAUNCH_BWD(float, 1, (const float*)da, x, C, W, scale, shift, nullptr, nullptr, coef, nullptr, 1, dW, P, cout);
+    LAUNCH_BWD(float, 1, (const float*)da, x, C, W, scale, shift, nullptr, nullptr, coef, nullptr, 1, dW, P, cout, BnTail{});
   else if (dtype == PCAA_F32)
-    LAUNCH_BWD(float, 2, (const float*)da, x, C, W, scale, shift, nullptr, nullptr, coef, nullptr, 1, dW, P, cout);
+    LAUNCH_BWD(float, 2, (const float*)da, x, C, W, scale, shift, nullptr, nullptr, coef, nullptr, 1, dW, P, cout, BnTail{});
   else if (dtype == PCAA_BF16 && !dz_is_pre)
-    LAUNCH_BWD(bf16_t, 1, (const bf16_t*)da, x, C, W, scale, shift, nullptr, nullptr, coef, nullptr, 1, dW, P, cout);
+    LAUNCH_BWD(bf16_t, 1, (const bf16_t*)da, x, C, W, scale, shift, nullptr, nullptr, coef, nullptr, 1, dW, P, cout, BnTail{});
   else if (dtype == PCAA_BF16)
-    LAUNCH_BWD(bf16_t, 2, (const bf16_t*)da, x, C, W, scale, shift, nullptr, nullptr, coef, nullptr, 1, dW, P, cout);
+    LAUNCH_BWD(bf16_t, 2, (const bf16_t*)da, x, C, W, scale, shift, nullptr, nullptr, coef, nullptr, 1, dW, P, cout, BnTail{});
   else { pcaa_set_error("pcaa_pointnet_in_bwd_wgrad: bad dtype"); return PCAA_ERR_INVALID_ARG; }
   PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_bwd_wgrad");
 }

@@ -179,6 +179,8 @@ def test_bf16_buckets_small_decoder_match_uncompressed():
     moved = 0
     for key, v in a[0]["params"].items():
         w = b[0]["params"][key]
+        if "running_" in key:
+            continue            # BatchNorm running statistics follow the activations (bf16 noise), not an optimizer step
         # three Adam steps of lr 1e-4: a parameter updated from a garbage / zero gradient differs by ~3e-4 on most
         # elements; bf16 rounding of the reduced bucket flips the sign of the update on few
         assert np.abs(v - w).mean() <= 5e-5, (key, np.abs(v - w).mean())
@@ -258,3 +260,168 @@ def test_data_parallel_loop_equals_single_process_loop(tmp_path):
             tol = 2e-3 if "Accuracy" not in k else 0.13          # one flipped argmax in 8/16 samples at most
             assert abs(h1[e][k] - h2[e][k]) <= tol * max(abs(h1[e][k]), 1.0), (e, k, h1[e][k], h2[e][k])
     assert "dp2_E.pt" in out[2][0]["files"] and "config.pkl" in out[2][0]["files"]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the data-parallel step AT THE BENCHMARKED SHAPE (B=64 per rank, N=128): per-layer bucket hooks at full size,
+# the bf16-direct weight-gradient buckets, 16 statistics replicas under SyncBN -- against the CPU oracle's
+# single-process step on the 128-sequence global batch
+# ---------------------------------------------------------------------------------------------------------
+SHAPE = dict(B=64, N=128, C=4, K=8, seeds=[0, 1, 2, 3, 4])
+_SHAPE_KEYS = ("d_loss", "gp", "rec_loss", "loss_g", "sup_loss", "tot_loss")
+_SHAPE_GRADS = ("E.pc_block.pointnet2.module.0.weight", "E.pc_block.pointnet4.module.0.weight",
+                "E.tc_block.dtc3.conv1d.weight", "E.MLP_sup1.0.weight", "GPH.0.weight", "G.dense1.weight")
+
+
+def _shape_cfg(B):
+    from opensetgaitrecognition_pcaa_amd import constants
+    cfg = dict(constants.CONFIG)
+    cfg.update(NMAX=SHAPE["N"], TRAIN_CLASSES=list(range(SHAPE["K"])), BATCH_SIZE=B, LR=1e-4, B1=0.9, B2=0.99,
+               GP_WEIGHT=15, ADV_WEIGHT=1, SUP_LATENT_DIM=32)
+    return cfg
+
+
+def _shape_inputs(world):
+    from opensetgaitrecognition_pcaa_amd import constants, synthetic as syn
+    Bg, N, C, K = SHAPE["B"] * world, SHAPE["N"], SHAPE["C"], SHAPE["K"]
+    return (syn.synthetic_pcs(Bg, constants.NSTEPS, N, C, seed=1234), syn.synthetic_labels(Bg, K, seed=1235),
+            syn.synthetic_z0(Bg, 32, seed=1236), syn.synthetic_alphas(Bg, seed=1237))
+
+
+def _shape_worker(rank, world, port, q, precision, compress, means_np):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        sys.path.insert(0, ROOT)
+        import torch.distributed as dist
+        from opensetgaitrecognition_pcaa_amd import constants, dist as pdist, synthetic as syn
+        from opensetgaitrecognition_pcaa_amd.train import PCAATrainer
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        constants.NFEATURES = SHAPE["C"]
+        tr = PCAATrainer(_shape_cfg(SHAPE["B"]), device="cuda:0", precision=precision, process_group=dist.group.WORLD,
+                         sync_bn=True, grad_compress=compress)
+        for mod, seed in zip((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head,
+                              tr.discriminator_projection_head), SHAPE["seeds"]):
+            syn.deterministic_fill_(mod, seed)
+        tr.set_prior_means(torch.from_numpy(means_np))
+        tr.finalize()
+        tr.train()
+        pcs, gt, z0, al = (pdist.shard_rows(t, rank, world).contiguous() for t in _shape_inputs(world))
+        out = tr.step(pcs.cuda().permute(0, 3, 1, 2), gt.cuda(), z0.cuda(), al.cuda())
+        torch.cuda.synchronize()
+        lv = torch.stack([out[k].detach().double().reshape(()) for k in _SHAPE_KEYS]).cpu()
+        dist.all_reduce(lv)
+        flat = tr.flat_g.p.detach().cpu()
+        ref = flat.clone()
+        dist.broadcast(ref, src=0)
+        rec = {"losses": (lv / world).numpy(), "preds": out["preds"].cpu().numpy(),
+               "sup_fvs": out["sup_fvs"].cpu().numpy(), "replicas_equal": bool(torch.equal(flat, ref)),
+               "comm": dict(tr.comm), "g16_direct": len(tr._g16_direct)}
+        if rank == 0:
+            # the reduced gradients are sums over the ranks of per-shard means: / world = the global-batch mean
+            rec["grads"] = {n: (tr.flat_g.grad_views[n].detach().cpu() / world).numpy() for n in _SHAPE_GRADS}
+            rec["params"] = {n: tr.flat_g.params[tr.flat_g.names.index(n)].detach().cpu().numpy()
+                             for n in ("E.MLP_sup1.0.weight", "E.pc_block.pointnet2.module.0.weight", "GPH.0.weight")}
+            w5 = tr.decoder.dense5.weight.detach()
+            rec["dense5_rows"] = w5[:: w5.shape[0] // 16][:16].cpu().numpy()
+        q.put((rank, rec, None))
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, None, traceback.format_exc() + repr(e)))
+
+
+_SHAPE_ORACLE = {}
+
+
+def _shape_oracle(world):
+    """oracle.v4_train_step on the 128-sequence global batch (about a minute of host CPU), once per session"""
+    if world in _SHAPE_ORACLE:
+        return _SHAPE_ORACLE[world]
+    sys.path.insert(0, ROOT)
+    from opensetgaitrecognition_pcaa_amd import constants, models, synthetic as syn
+    from oracle import pcaa_oracle as O
+    saved = constants.NFEATURES
+    constants.NFEATURES = SHAPE["C"]
+    K, N, C = SHAPE["K"], SHAPE["N"], SHAPE["C"]
+    mods = (models.CGEncoder(K, nmax_points=N, use_projection_head=True).float(),
+            models.CGDecoder(input_dim=64, nmax_points=N).float(), models.CGDiscriminator(K).float(),
+            torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.ELU()).float(),
+            torch.nn.Sequential(torch.nn.Linear(64, 32), torch.nn.ELU()).float())
+    constants.NFEATURES = saved
+    for m, s in zip(mods, SHAPE["seeds"]):
+        syn.deterministic_fill_(m, s)
+    means = O.sample_distant_points(32, K, 10, 10).float()
+    st = O.V4State(*({k: v.detach().clone() for k, v in m.state_dict().items()} for m in mods), means, C,
+                   constants.NSTEPS, N, K)
+    pcs, gt, z0, al = _shape_inputs(world)
+    ref = O.v4_train_step(st, pcs.permute(0, 3, 1, 2), gt, z0, al, _shape_cfg(SHAPE["B"] * world))
+    keep = {"losses": np.array([ref[k].item() for k in _SHAPE_KEYS]), "preds": ref["preds"].numpy(),
+            "sup_fvs": ref["sup_fvs"].numpy(), "out_labels": ref["out_labels"].numpy(),
+            "grads": {n: ref["g_grads"][n].numpy() for n in _SHAPE_GRADS},
+            "params": {"E.MLP_sup1.0.weight": st.enc["MLP_sup1.0.weight"].numpy().copy(),
+                       "E.pc_block.pointnet2.module.0.weight": st.enc["pc_block.pointnet2.module.0.weight"].numpy().copy(),
+                       "GPH.0.weight": st.gph["0.weight"].numpy().copy()},
+            "dense5_rows": st.dec["dense5.weight"][:: st.dec["dense5.weight"].shape[0] // 16][:16].numpy().copy(),
+            "means": means.numpy()}
+    del ref, st
+    _SHAPE_ORACLE[world] = keep
+    return keep
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("precision,compress", [("fp32", None), ("bf16", "bf16")])
+def test_two_rank_step_at_bench_shape_vs_oracle(precision, compress):
+    """B=64 per rank, N=128, SyncBN, 2 ranks (gloo; both on the one GPU): the step bench.py runs per rank at N GPUs,
+    against the oracle's single-process step on the 128-sequence global batch.  fp32 mode: 1e-4 on losses and
+    embeddings, labels bit-exact, gradients 5e-4; ("bf16", "bf16") is bench.py's data-parallel default (bf16
+    PointNet, decoder buckets as bf16 with the bf16-direct weight-gradient kernels) at the bf16 tolerance."""
+    world = 2
+    ref = _shape_oracle(world)
+    ctx = mp.get_context("spawn")
+    port, q = _free_port(), ctx.Queue()
+    procs = [ctx.Process(target=_shape_worker, args=(r, world, port, q, precision, compress, ref["means"]))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, rec, err = q.get(timeout=900)
+        assert err is None, f"rank {rank}: {err}"
+        res[rank] = rec
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    exact = precision == "fp32"
+    assert all(res[r]["replicas_equal"] for r in range(world))
+    ltol = 1e-4 if exact else 2e-2
+    assert np.allclose(res[0]["losses"], ref["losses"], rtol=ltol, atol=1e-5 if exact else 2e-2), (res[0]["losses"], ref["losses"])
+    preds = np.concatenate([res[r]["preds"] for r in range(world)])
+    fvs = np.concatenate([res[r]["sup_fvs"] for r in range(world)])
+    scale = np.abs(ref["sup_fvs"]).max()
+    if exact:
+        top2 = np.sort(ref["out_labels"], axis=1)[:, -2:]
+        tied = (top2[:, 1] - top2[:, 0]) <= 1e-4 * np.abs(ref["out_labels"]).max()
+        assert np.array_equal(preds[~tied], ref["preds"][~tied]), "argmax labels must be bit-exact"
+        assert np.abs(fvs - ref["sup_fvs"]).max() <= 1e-4 * scale
+    else:
+        assert np.abs(fvs - ref["sup_fvs"]).max() <= 5e-2 * scale
+        assert (preds == ref["preds"]).mean() >= 0.9
+        assert res[0]["g16_direct"] >= 3, "the wide decoder layers must have used the bf16-direct wire image"
+    gtol = 5e-4 if exact else 5e-2
+    for n in _SHAPE_GRADS:
+        if compress == "bf16" and n.startswith("G."):
+            continue        # compressed buckets are consumed by Adam as the reduced bf16 image: the fp32 range stays local
+        a, b = res[0]["grads"][n].astype(np.float64), ref["grads"][n].astype(np.float64)
+        rel = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
+        assert rel <= gtol, (n, rel)
+    # post-Adam parameters (first Adam step = +-lr per element: sign flips of rounding-noise gradients are rare)
+    for n, b in list(ref["params"].items()) + [("dense5_rows", ref["dense5_rows"])]:
+        a = res[0]["dense5_rows"] if n == "dense5_rows" else res[0]["params"][n]
+        err = np.abs(a.astype(np.float64) - b.astype(np.float64))
+        assert err.max() <= 5e-5 * np.abs(b).max() + 2.0e-4 * 1.001, (n, err.max())
+        assert err.mean() <= (2e-6 if exact else 3e-5), (n, err.mean())
+    comm = res[0]["comm"]
+    assert comm["collectives"] >= 7
+    if compress == "bf16":
+        assert comm["payload_bytes"] < 0.6 * 4 * 159_300_000

@@ -14,12 +14,24 @@ ap.add_argument("--precision", default="bf16")
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--points", type=int, default=128)
 ap.add_argument("--fused", default="on", choices=["on", "off"], help="decoder weight-gradient + Adam fusion")
+ap.add_argument("--dp-force", action="store_true", help="1-rank RCCL group: the data-parallel step's collectives and hand-offs")
+ap.add_argument("--grad-compress", default="bf16", choices=["none", "bf16"])
+ap.add_argument("--dp-mode", default="allreduce", choices=["allreduce", "zero"])
 a = ap.parse_args()
+pg = None
+if a.dp_force:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0), rank=0, world_size=1)
+    pg = dist.group.WORLD
 B, N, C, K, T = a.batch, a.points, 4, 8, constants.NSTEPS
 constants.NFEATURES = C
 cfg = dict(constants.CONFIG); cfg.update(NMAX=N, TRAIN_CLASSES=list(range(K)), BATCH_SIZE=B)
 F_hip.set_precision(a.precision)
-tr = PCAATrainer(cfg, device="cuda", precision=a.precision, fused_decoder_update=a.fused != "off")
+tr = PCAATrainer(cfg, device="cuda", precision=a.precision, fused_decoder_update=a.fused != "off", process_group=pg,
+                 force_collectives=a.dp_force, grad_compress=None if a.grad_compress == "none" else a.grad_compress,
+                 dp_zero=a.dp_mode == "zero" and pg is not None)
 for i, m in enumerate((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head, tr.discriminator_projection_head)):
     syn.deterministic_fill_(m, i)
 tr.set_prior_means(sample_distant_points(32, K, 10, 10)); tr.finalize(); tr.train()
