@@ -24,6 +24,7 @@
 // the expm1f), plain-FMA register tiles 80 (the non-packed fp32 VALU peaks at half the fp32-MFMA rate).
 // The first column tile also writes the im2col matrix the BACKWARD's weight gradient contracts with.
 #include "common.h"
+#include "bn_tail.h"
 
 namespace {
 
@@ -39,6 +40,7 @@ struct DtcFwdParams {
   double* stats;        // [nrep][2][cout] fp64 sums (sum, sum of squares) or null
   int B, T, cin, cout, dil, nrep;
   long slab_stride;     // gridDim.z > 1: split z writes its partial product to y + z*slab_stride
+  BnTail tail;          // the BatchNorm finalize of ``stats``, run by the last workgroup (bn_tail.h); kind 0: none
 };
 
 constexpr int CC = 32;              // input channels per chunk: 3*CC = 96-deep contraction per trip
@@ -61,6 +63,7 @@ __global__ __launch_bounds__(256) void dtc_fwd_kernel(DtcFwdParams p) {
   __shared__ __attribute__((aligned(16))) float a_lds[(ROWS + 1) * (MAX_CR + 4)];   // later: the 4 partial tiles
   __shared__ __attribute__((aligned(16))) float Ws[32 * WP];
   __shared__ float red[2][8][32];
+  __shared__ int tail_flag;
   static_assert(4 * ROWS * 33 <= (ROWS + 1) * (MAX_CR + 4), "partial tiles alias the sequence tile");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
@@ -185,6 +188,7 @@ __global__ __launch_bounds__(256) void dtc_fwd_kernel(DtcFwdParams p) {
       }
     }
   }
+  bn_tail_run(p.tail, tid, 256, gridDim.x * gridDim.y * gridDim.z, &tail_flag);
 }
 
 // ------------------------------------------------------------------ backward w.r.t. the layer input
@@ -207,6 +211,7 @@ struct DtcDgradParams {
   double* ep_stats; int nrep;
   int B, T, cin, cout, dil;
   long slab_stride;
+  BnTail tail;          // the BatchNorm-backward finalize of ``ep_stats`` (bn_tail.h); kind 0: none
 };
 
 constexpr int DG_MAX_CR = 512;                       // contraction channels per workgroup (dynamic LDS)
@@ -336,6 +341,7 @@ __global__ __launch_bounds__(256) void dtc_dgrad_kernel(DtcDgradParams p, int ti
       }
     }
   }
+  bn_tail_run(p.tail, tid, 256, gridDim.x * gridDim.y * gridDim.z, reinterpret_cast<int*>(red + 2 * 8 * 32));
 }
 
 }  // namespace
@@ -369,7 +375,8 @@ extern "C" int pcaa_dtc_conv_fwd(const float* src, const float* scale, const flo
                  "(pcaa_dtc_conv_ksplit)", MAX_CR);
   PCAA_CHECK_ARG(ksplit == 1 || (stats == nullptr && slab_stride >= (long)B * T * cout),
                  "pcaa_dtc_conv_fwd: ksplit > 1 writes slabs (no statistics): slab_stride >= B*T*cout");
-  DtcFwdParams p{src, scale, shift, W, y, col, stats, B, T, cin, cout, dilation, nrep, ksplit > 1 ? slab_stride : 0};
+  DtcFwdParams p{src, scale, shift, W, y, col, stats, B, T, cin, cout, dilation, nrep, ksplit > 1 ? slab_stride : 0,
+                 (stats != nullptr && ksplit == 1) ? pcaa_take_bn_tail(stats) : BnTail{}};
   hipLaunchKernelGGL(dtc_fwd_kernel, dim3(B, (cout + 31) / 32, ksplit), dim3(256), 0, as_stream(stream), p);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_dtc_conv_fwd");
 }
@@ -404,10 +411,10 @@ extern "C" int pcaa_dtc_conv_dgrad(const float* dy, const float* dz, const float
   PCAA_CHECK_ARG(!ep || (ksplit == 1 && ep_y && ep_scale && ep_shift && ep_mean && ep_rstd && nrep >= 1),
                  "pcaa_dtc_conv_dgrad: the epilogue needs ksplit == 1 and ep_y, ep_scale, ep_shift, ep_mean, ep_rstd");
   const int tile = dg_tile_floats(per_z);
-  const size_t lds = (size_t)(tile + 32 * WP + 2 * 8 * 32) * sizeof(float);
+  const size_t lds = (size_t)(tile + 32 * WP + 2 * 8 * 32 + 4) * sizeof(float);     // + the finalize flag
   static bool configured = false;
   if (!configured) {
-    const size_t cap = (size_t)(dg_tile_floats(DG_MAX_CR) + 32 * WP + 2 * 8 * 32) * sizeof(float);
+    const size_t cap = (size_t)(dg_tile_floats(DG_MAX_CR) + 32 * WP + 2 * 8 * 32 + 4) * sizeof(float);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(dtc_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)cap) != hipSuccess) {
       pcaa_set_error("pcaa_dtc_conv_dgrad: cannot raise the dynamic LDS limit");
@@ -416,7 +423,8 @@ extern "C" int pcaa_dtc_conv_dgrad(const float* dy, const float* dz, const float
     configured = true;
   }
   DtcDgradParams p{dy, dz, y, coef, dy_out, W, out, ep_y, ep_scale, ep_shift, ep_mean, ep_rstd, ep_stats, nrep,
-                   B, T, cin, cout, dilation, ksplit > 1 ? slab_stride : 0};
+                   B, T, cin, cout, dilation, ksplit > 1 ? slab_stride : 0,
+                   ep ? pcaa_take_bn_tail(ep_stats) : BnTail{}};
   hipLaunchKernelGGL(dtc_dgrad_kernel, dim3(B, (cin + 31) / 32, ksplit), dim3(256), lds, as_stream(stream), p, tile);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_dtc_conv_dgrad");
 }

@@ -21,6 +21,7 @@
 //               the 32 lanes of a half cover all 64 banks exactly once.
 #include <hip/hip_ext.h>
 
+#include <cstddef>
 #include <type_traits>
 
 #include "gemm_common.h"
@@ -1022,8 +1023,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   }
   // this workgroup's tiles are done: if the launch carries the BatchNorm finalize of its statistics, the last
   // workgroup to get here runs it (bn_tail.h)
-  if constexpr (PERSIST && (EPI == EPI_PLAIN || EPI == EPI_DGRAD_BN || EPI == EPI_DGRAD_BN_POINTS))
-    bn_tail_run(p.tail, tid, NTHREADS, gridDim.x, ticket_lds + 1);
+  if constexpr (PERSIST && (EPI == EPI_PLAIN || EPI == EPI_DGRAD_BN || EPI == EPI_DGRAD_BN_POINTS)) {
+    // read from the kernel-argument segment HERE, through a pointer the compiler cannot see through: referenced as
+    // p.tail its 20 fields are fetched at kernel entry and sit in (spilled) SGPRs through the whole tile loop
+    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    const BnTail tail = *reinterpret_cast<const BnTail*>(ka + offsetof(GemmParams, tail));
+    bn_tail_run(tail, tid, NTHREADS, gridDim.x, ticket_lds + 1);
+  }
 }
 
 // MFMA shape per instantiation.  KC x KC (forward / dgrad): v_mfma_f32_16x16x32_bf16 -- same cycles per FLOP as

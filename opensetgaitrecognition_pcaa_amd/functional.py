@@ -83,6 +83,12 @@ def _sync_stats(stats, count):
     return count * dist.get_world_size(g)
 
 
+def _sync_fn():
+    """the ``sync`` argument of ops.BnTailFwd / BnTailBwd: None unless SyncBN is on (then the statistics are all-reduced
+    before a stand-alone finalize; the producer cannot carry it)"""
+    return _sync_stats if _SYNC_BN["group"] is not None else None
+
+
 def _require_gpu(x, what):
     if not isinstance(x, torch.Tensor) or not x.is_cuda:
         raise RuntimeError(f"{what}: input must live on the HIP device; this package has no CPU path "
@@ -116,17 +122,20 @@ def _linear_bn(a_in, W2d, lin_bias, bn, training, mode, first_layer):
     rows, cin = a_in.shape
     cout = W2d.shape[0]
     stats = ops.new_stats(cout, a_in.device) if training else None
+    # the finalize of these statistics rides on the launch that produces them where that launch can carry it
+    # (csrc/bn_tail.h: its last workgroup writes the coefficients); else tail.resolve() ran the stand-alone kernel
+    tail = ops.BnTailFwd(rows, lin_bias, bn, cout, sync=_sync_fn()) if training else None
     use_bf16 = (mode == "bf16") and a_in.dtype == torch.bfloat16 and cin % 8 == 0
     out_dtype = torch.bfloat16 if (mode == "bf16" and first_layer is not None) else torch.float32
     if first_layer is not None and a_in.dtype == torch.float32 and cin <= 8 and ops.pointnet_in_ok(cin, cout):
         # raw points -> first PointNet layer: C-wide contraction, HBM-bound streaming kernel
-        y = ops.pointnet_in_fwd(a_in, W2d, None, out_dtype, stats)
+        y = ops.pointnet_in_fwd(a_in, W2d, None, out_dtype, stats, tail=tail)
     elif use_bf16:
         # bf16 shadow of the weights so both operands stream by LDS-DMA (the transposed copy
         # serves the dgrad GEMM of the backward pass)
         w16, wt16 = ops.cast_bf16(W2d, True, training)
         _W16_CACHE[W2d.data_ptr()] = wt16
-        y = ops.gemm(a_in, KC, w16, KC, rows, cout, cin, colstats=stats, out_dtype=out_dtype, math=PCAA_BF16)
+        y = ops.gemm(a_in, KC, w16, KC, rows, cout, cin, colstats=stats, out_dtype=out_dtype, math=PCAA_BF16, tail=tail)
     else:
         tiles = ((rows + 127) // 128) * ((cout + 127) // 128)
         sk = ops.pick_split_k(rows, cout, cin, target_blocks=512)
@@ -134,12 +143,12 @@ def _linear_bn(a_in, W2d, lin_bias, bn, training, mode, first_layer):
                 and 256 % (cout // 4) == 0 and cout <= 1024):
             # few output tiles, long K (the temporal block): split K through slabs; the reduction
             # pass also produces the BatchNorm statistics the GEMM epilogue would have
-            y = ops.gemm_slabs(a_in, KC, W2d, KC, rows, cout, cin, sk, math=PCAA_F32, colstats=stats)
+            y = ops.gemm_slabs(a_in, KC, W2d, KC, rows, cout, cin, sk, math=PCAA_F32, colstats=stats, tail=tail)
         else:
-            y = ops.gemm(a_in, KC, W2d, KC, rows, cout, cin, colstats=stats, out_dtype=out_dtype, math=PCAA_F32)
+            y = ops.gemm(a_in, KC, W2d, KC, rows, cout, cin, colstats=stats, out_dtype=out_dtype, math=PCAA_F32, tail=tail)
     if training:
-        count = _sync_stats(stats, rows)
-        scale, shift, mean, rstd = ops.bn_finalize(stats, count, lin_bias, bn, cout)
+        scale, shift, mean, rstd = tail.out
+        count = tail.count_out
     else:
         scale, shift = ops.bn_eval_coeffs(bn, cout, lin_bias)
         mean = rstd = None
@@ -165,9 +174,10 @@ def pointnet_forward(xp2d, layers, training, mode, pool_rows=0):
             rows = a.shape[0]
             if training:
                 stats = ops.new_stats(cout, a.device)
-                ops.pointnet_in_fwd(a, W2d, None, None, stats)
-                count = _sync_stats(stats, rows)
-                scale, shift, mean, rstd = ops.bn_finalize(stats, count, conv.bias, bn, cout)
+                tail = ops.BnTailFwd(rows, conv.bias, bn, cout, sync=_sync_fn())
+                ops.pointnet_in_fwd(a, W2d, None, None, stats, tail=tail)
+                scale, shift, mean, rstd = tail.out
+                count = tail.count_out
             else:
                 scale, shift = ops.bn_eval_coeffs(bn, cout, conv.bias)
                 mean = rstd = None
@@ -213,10 +223,11 @@ def pointnet_forward(xp2d, layers, training, mode, pool_rows=0):
 class _FusedGrad:
     """What the fused dgrad (ops.gemm_dgrad_bn) hands to the layer below instead of da:
     dz = da * ELU'(z) and that layer's BatchNorm-backward statistics."""
-    __slots__ = ("dz", "stats")
+    __slots__ = ("dz", "stats", "fin")
 
-    def __init__(self, dz, stats):
-        self.dz, self.stats = dz, stats
+    def __init__(self, dz, stats, fin=None):
+        # fin: (coef, dgamma, dbeta) of that layer when the producing launch carried its finalize (ops.BnTailBwd)
+        self.dz, self.stats, self.fin = dz, stats, fin
 
 
 # Side stream for the SMALL weight-gradient products (temporal block, MLP heads): they only feed the
@@ -271,7 +282,8 @@ _FUSE_DGRAD_POINTS = False
 
 
 def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool_scale=1.0,
-                       need_dinput=True, lhs=None, outs=None, below=None, below_W=None, dgrad_fn=None):
+                       need_dinput=True, lhs=None, outs=None, below=None, below_W=None, dgrad_fn=None,
+                       below_bn=None, below_outs=None):
     """Backward of one (linear, BN, ELU) layer.  ``lhs`` is the GEMM's left
     operand ([rows, K]: the input activation or the im2col matrix).  ``outs`` =
     (dW, dgamma, dbeta) destination views (dW PRE-ZEROED: the trainer's flat
@@ -286,9 +298,12 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
     dgrad_done = False
     if isinstance(da, _FusedGrad):
         stats = da.stats
-        _sync_stats(stats, 0)
-        coef, dgamma, dbeta = ops.bn_bwd_finalize(stats, s.rows, bn, s.mean, s.rstd, cout,
-                                                  dgamma=outs[1] if outs else None, dbeta=outs[2] if outs else None)
+        if da.fin is not None:
+            coef, dgamma, dbeta = da.fin          # finalized by the launch that produced the statistics
+        else:
+            _sync_stats(stats, 0)
+            coef, dgamma, dbeta = ops.bn_bwd_finalize(stats, s.rows, bn, s.mean, s.rstd, cout,
+                                                      dgamma=outs[1] if outs else None, dbeta=outs[2] if outs else None)
         if need_dinput and dgrad_fn is not None and getattr(dgrad_fn, "forms_dy", False):
             # the adjoint kernel forms dy = c0*dz + c1*y + c2 while it stages its operand and hands it back
             # for the weight gradient: no separate elementwise pass
@@ -302,15 +317,15 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
         if da is not None and da.dtype != y.dtype:
             da = da.to(y.dtype)
         pool_e = getattr(s, "pool_e", None)
+        tail = ops.BnTailBwd(s.rows, bn, s.mean, s.rstd, cout, dgamma=outs[1] if outs else None,
+                             dbeta=outs[2] if outs else None, sync=_sync_fn())
         if dpool is not None and pool_e is not None:
             # mean-pooled layer: the statistics follow from the forward's per-group sums, y is not re-read
-            stats = ops.bn_pool_bwd_stats(dpool, pool_e, pool_scale)
+            ops.bn_pool_bwd_stats(dpool, pool_e, pool_scale, tail=tail)
         else:
-            stats = ops.bn_act_bwd_stats(y, s.scale, s.shift, s.mean, s.rstd, da=da, dpool=dpool,
-                                         group_rows=group_rows, pool_scale=pool_scale)
-        _sync_stats(stats, 0)
-        coef, dgamma, dbeta = ops.bn_bwd_finalize(stats, s.rows, bn, s.mean, s.rstd, cout,
-                                                  dgamma=outs[1] if outs else None, dbeta=outs[2] if outs else None)
+            ops.bn_act_bwd_stats(y, s.scale, s.shift, s.mean, s.rstd, da=da, dpool=dpool,
+                                 group_rows=group_rows, pool_scale=pool_scale, tail=tail)
+        coef, dgamma, dbeta = tail.out
         dy = ops.bn_bwd_dy_fused(y, s.scale, s.shift, coef, da=da, dpool=dpool, group_rows=group_rows,
                                  pool_scale=pool_scale, out=da)
     K = lhs.shape[1]
@@ -348,9 +363,15 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
             if (_FUSE_DGRAD_BN and below is not None and below.y is not None and below.y.dtype == torch.bfloat16
                     and below.mean is not None and tuple(below.y.shape) == (rows_local, K)
                     and ops.gemm_dgrad_bn_supported(rows_local, K, cout)):
-                # dgrad fused with ELU' and the BatchNorm-backward statistics of the layer below
+                # dgrad fused with ELU' and the BatchNorm-backward statistics of the layer below (and, when the caller
+                # handed that layer's BatchNorm over, their finalize)
+                btail = None
+                if below_bn is not None:
+                    btail = ops.BnTailBwd(below.rows, below_bn, below.mean, below.rstd, K,
+                                          dgamma=below_outs[1] if below_outs else None,
+                                          dbeta=below_outs[2] if below_outs else None, sync=_sync_fn())
                 d_lhs = _FusedGrad(*ops.gemm_dgrad_bn(dy, Wt, below.y, below.scale, below.shift, below.mean,
-                                                      below.rstd))
+                                                      below.rstd, tail=btail), fin=btail.out if btail else None)
             elif (_FUSE_DGRAD_BN and below is not None and below.y is None and below_W is not None
                   and below.mean is not None and below.a_in.dtype == torch.float32
                   and below.a_in.shape[0] == rows_local and ops.gemm_dgrad_bn_supported(rows_local, K, cout)):
@@ -383,6 +404,9 @@ def pointnet_backward(saves, layers, mode, d_last=None, dpool=None, pool_rows=0,
         W2d = conv.weight.view(s.cout, s.cin)
         need_in = li > 0 or need_dx
         outs = _layer_outs(gout, f"{prefix}{li + 1}.", "module.0.weight", "module.1.weight", "module.1.bias")
+        # the layer below: its BatchNorm and gradient destinations, for the finalize the fused dgrad can carry
+        below_bn = layers[li - 1].module[1] if li > 0 else None
+        below_outs = _layer_outs(gout, f"{prefix}{li}.", "module.0.weight", "module.1.weight", "module.1.bias") if li > 0 else None
         # weight of the layer below when that layer is a recompute layer whose backward will not need dx
         below_W = None
         if _FUSE_DGRAD_POINTS and li == 1 and saves[0].y is None and not need_dx:
@@ -392,10 +416,17 @@ def pointnet_backward(saves, layers, mode, d_last=None, dpool=None, pool_rows=0,
             # recompute path of the first layer: two passes over da (one, when the dgrad above already applied
             # ELU' and reduced the statistics), nothing else is read or written
             fused = isinstance(da, _FusedGrad)
-            stats = da.stats if fused else ops.pointnet_in_bwd_stats(da, s.a_in, W2d, s.scale, s.shift, s.mean, s.rstd)
-            _sync_stats(stats, 0)
-            coef, dg, db = ops.bn_bwd_finalize(stats, s.rows, bn, s.mean, s.rstd, s.cout,
-                                               dgamma=outs[1] if outs else None, dbeta=outs[2] if outs else None)
+            if fused and da.fin is not None:
+                coef, dg, db = da.fin
+            elif fused:
+                _sync_stats(da.stats, 0)
+                coef, dg, db = ops.bn_bwd_finalize(da.stats, s.rows, bn, s.mean, s.rstd, s.cout,
+                                                   dgamma=outs[1] if outs else None, dbeta=outs[2] if outs else None)
+            else:
+                tail = ops.BnTailBwd(s.rows, bn, s.mean, s.rstd, s.cout, dgamma=outs[1] if outs else None,
+                                     dbeta=outs[2] if outs else None, sync=_sync_fn())
+                ops.pointnet_in_bwd_stats(da, s.a_in, W2d, s.scale, s.shift, s.mean, s.rstd, tail=tail)
+                coef, dg, db = tail.out
             dW = ops.pointnet_in_bwd_wgrad(da.dz if fused else da, s.a_in, W2d, s.scale, s.shift, coef,
                                            out=outs[0].view(s.cout, s.cin) if outs else None, out_is_zero=True,
                                            dz_is_pre=fused)
@@ -404,13 +435,13 @@ def pointnet_backward(saves, layers, mode, d_last=None, dpool=None, pool_rows=0,
             dW, dg, db, dprev = _bn_layer_backward(s, bn, W2d, mode, dpool=dpool, group_rows=pool_rows,
                                                    pool_scale=1.0 / pool_rows, need_dinput=need_in, lhs=s.a_in,
                                                    outs=outs, below=saves[li - 1] if li > 0 else None,
-                                                   below_W=below_W)
+                                                   below_W=below_W, below_bn=below_bn, below_outs=below_outs)
         else:
             if s.y is None:      # recompute layer, but the caller wants the gradient w.r.t. the points: rebuild y
                 s.y = ops.pointnet_in_fwd(s.a_in, W2d, None, da.dtype)
             dW, dg, db, dprev = _bn_layer_backward(s, bn, W2d, mode, da=da, need_dinput=need_in, lhs=s.a_in,
                                                    outs=outs, below=saves[li - 1] if li > 0 else None,
-                                                   below_W=below_W)
+                                                   below_W=below_W, below_bn=below_bn, below_outs=below_outs)
         # the conv bias gradient is analytically zero (BatchNorm removes the mean)
         zb = gout[f"{prefix}{li + 1}.module.0.bias"] if gout is not None else torch.zeros_like(conv.bias)
         grads.append({"module.0.weight": dW.view_as(conv.weight), "module.0.bias": zb,
@@ -439,11 +470,12 @@ def dtc_forward(a2d, B, T, layers, training, pool_time):
         if fused:
             # one launch: implicit im2col + BN/ELU of the previous layer on load + contraction + statistics
             stats = ops.new_stats(cout, a.device) if training else None
+            tail = ops.BnTailFwd(a.shape[0], conv.bias, bn, cout, sync=_sync_fn()) if training else None
             y, col = ops.dtc_conv_fwd(a, prev[0] if prev else None, prev[1] if prev else None, W2d, B, T,
-                                      layer.dilation, stats=stats, want_col=training)
+                                      layer.dilation, stats=stats, want_col=training, tail=tail)
             if training:
-                count = _sync_stats(stats, y.shape[0])
-                scale, shift, mean, rstd = ops.bn_finalize(stats, count, conv.bias, bn, cout)
+                scale, shift, mean, rstd = tail.out
+                count = tail.count_out
             else:
                 scale, shift = ops.bn_eval_coeffs(bn, cout, conv.bias)
                 mean = rstd = None
@@ -485,12 +517,20 @@ def dtc_backward(saves, layers, B, T, d_last=None, dpool=None, need_dx=True, gou
         dgrad_fn = None
         if fused:
             sb = saves[li - 1] if (li > 0 and s.cout <= 512 and saves[li - 1].mean is not None) else None
+            sb_bn = layers[li - 1].batch_norm if sb is not None else None
+            sb_outs = _layer_outs(gout, f"{prefix}{li}.", "conv1d.weight", "batch_norm.weight", "batch_norm.bias") \
+                if sb is not None else None
 
-            def dgrad_fn(dy, dz=None, y=None, coef=None, W2d=W2d, s=s, sb=sb):
+            def dgrad_fn(dy, dz=None, y=None, coef=None, W2d=W2d, s=s, sb=sb, sb_bn=sb_bn, sb_outs=sb_outs):
+                btail = None
+                if sb is not None:
+                    btail = ops.BnTailBwd(sb.rows, sb_bn, sb.mean, sb.rstd, s.cin,
+                                          dgamma=sb_outs[1] if sb_outs else None, dbeta=sb_outs[2] if sb_outs else None,
+                                          sync=_sync_fn())
                 out, stats, dy_used = ops.dtc_conv_dgrad(
                     dy, W2d, B, T, s.cin, s.dil, dz=dz, y=y, coef=coef, want_dy=dy is None,
-                    below=(sb.y, sb.scale, sb.shift, sb.mean, sb.rstd) if sb else None)
-                return (_FusedGrad(out, stats) if sb else out), dy_used
+                    below=(sb.y, sb.scale, sb.shift, sb.mean, sb.rstd) if sb else None, tail=btail)
+                return (_FusedGrad(out, stats, fin=btail.out) if sb else out), dy_used
 
             dgrad_fn.forms_dy = s.cout <= 512
         if li == len(layers) - 1 and dpool is not None:

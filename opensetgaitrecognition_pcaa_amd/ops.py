@@ -152,11 +152,14 @@ class StatsPool:
         self.off = 0
 
     def take(self, ch):
+        # + 2 doubles: the arrival counter of a finalize carried by the producer (BnTailFwd / BnTailBwd below), zeroed
+        # with the statistics by begin(); 16-B granularity keeps every buffer aligned
         n = NREP * 2 * ch
-        if self.off + n > self.buf.numel():
+        if self.off + n + 2 > self.buf.numel():
             return None
         v = self.buf[self.off:self.off + n].view(NREP, 2, ch)
-        self.off += n
+        v._pcaa_counter = self.buf[self.off + n:self.off + n + 1].view(torch.int32)
+        self.off += n + 2
         return v
 
 
@@ -173,7 +176,92 @@ def new_stats(ch, device):
         v = STATS_POOL.take(ch)
         if v is not None:
             return v
-    return torch.zeros((NREP, 2, ch), dtype=torch.float64, device=device)
+    buf = torch.zeros(NREP * 2 * ch + 2, dtype=torch.float64, device=device)
+    v = buf[:NREP * 2 * ch].view(NREP, 2, ch)
+    v._pcaa_counter = buf[NREP * 2 * ch:NREP * 2 * ch + 1].view(torch.int32)
+    return v
+
+
+# ------------------------------------------------------------------ finalize carried by the producer (csrc/bn_tail.h)
+# A BnTailFwd / BnTailBwd describes the BatchNorm finalize of the statistics a launch is about to accumulate.  The
+# producer's wrapper calls arm(stats) right before its launch and resolve(stats) right after: if the launch could carry
+# the tail (its last workgroup then writes the coefficients) resolve() has nothing to do, otherwise -- SyncBN (``sync``:
+# the statistics are all-reduced first), a producer or shape that does not carry tails -- it runs the stand-alone kernel.
+TAILS = {"enabled": True, "taken": 0, "standalone": 0}
+
+
+class BnTailFwd:
+    def __init__(self, count, lin_bias, bn, ch, sync=None, update_running=True):
+        self.count, self.lin_bias, self.bn, self.ch, self.sync, self.update_running = count, lin_bias, bn, ch, sync, update_running
+        self.out = None
+        self.armed = False
+        self.count_out = count            # the count the statistics were averaged over (global under SyncBN)
+
+    def arm(self, stats):
+        counter = getattr(stats, "_pcaa_counter", None)
+        if self.sync is not None or counter is None or not TAILS["enabled"]:
+            return
+        dev, bn, ch = stats.device, self.bn, self.ch
+        scale = torch.empty(ch, dtype=torch.float32, device=dev)
+        self.out = (scale, torch.empty_like(scale), torch.empty_like(scale), torch.empty_like(scale))
+        rm = bn.running_mean if self.update_running else None
+        rv = bn.running_var if self.update_running else None
+        nbt = bn.num_batches_tracked if self.update_running else None
+        check(_lib.load().pcaa_bn_tail_arm_fwd(_p(stats), NREP, int(self.count), _p(self.lin_bias), _p(bn.weight), _p(bn.bias),
+                                               _p(rm), _p(rv), _p(nbt), BN_MOMENTUM if bn.momentum is None else bn.momentum,
+                                               bn.eps, *(_p(t) for t in self.out), ch, _p(counter)), "pcaa_bn_tail_arm_fwd")
+        self.armed = True
+
+    def resolve(self, stats):
+        """-> (scale, shift, mean, rstd)"""
+        lib = _lib.load()
+        if self.armed and not lib.pcaa_bn_tail_pending():
+            TAILS["taken"] += 1
+            return self.out
+        if self.armed:
+            lib.pcaa_bn_tail_disarm()
+        count = self.sync(stats, self.count) if self.sync is not None else self.count
+        self.count_out = count
+        TAILS["standalone"] += 1
+        self.out = bn_finalize(stats, count, self.lin_bias, self.bn, self.ch, self.update_running)
+        return self.out
+
+
+class BnTailBwd:
+    def __init__(self, count, bn, mean, rstd, ch, dgamma=None, dbeta=None, sync=None):
+        self.count, self.bn, self.mean, self.rstd, self.ch, self.sync = count, bn, mean, rstd, ch, sync
+        self.dgamma, self.dbeta = dgamma, dbeta
+        self.out = None
+        self.armed = False
+
+    def arm(self, stats):
+        counter = getattr(stats, "_pcaa_counter", None)
+        if self.sync is not None or counter is None or not TAILS["enabled"]:
+            return
+        dev, ch = stats.device, self.ch
+        coef = torch.empty((3, ch), dtype=torch.float32, device=dev)
+        dgamma = torch.empty(ch, dtype=torch.float32, device=dev) if self.dgamma is None else self.dgamma
+        dbeta = torch.empty(ch, dtype=torch.float32, device=dev) if self.dbeta is None else self.dbeta
+        self.out = (coef, dgamma, dbeta)
+        check(_lib.load().pcaa_bn_tail_arm_bwd(_p(stats), NREP, int(self.count), _p(self.bn.weight), _p(self.mean),
+                                               _p(self.rstd), _p(coef), _p(dgamma), _p(dbeta), ch, _p(counter)),
+              "pcaa_bn_tail_arm_bwd")
+        self.armed = True
+
+    def resolve(self, stats):
+        """-> (coef, dgamma, dbeta)"""
+        lib = _lib.load()
+        if self.armed and not lib.pcaa_bn_tail_pending():
+            TAILS["taken"] += 1
+            return self.out
+        if self.armed:
+            lib.pcaa_bn_tail_disarm()
+        if self.sync is not None:
+            self.sync(stats, 0)
+        TAILS["standalone"] += 1
+        self.out = bn_bwd_finalize(stats, self.count, self.bn, self.mean, self.rstd, self.ch, dgamma=self.dgamma,
+                                   dbeta=self.dbeta)
+        return self.out
 
 
 # ------------------------------------------------------------------ GEMM
@@ -185,9 +273,10 @@ def _dma_key(out_dtype, layout):
 
 
 def gemm(A, a_layout, B, b_layout, M, N, K, *, lda=None, ldb=None, out=None, out_dtype=torch.float32,
-         bias=None, colstats=None, split_k=1, accumulate=False, math=PCAA_F32):
+         bias=None, colstats=None, split_k=1, accumulate=False, math=PCAA_F32, tail=None):
     """out[M,N] (=|+=) A(M,K) . B(K,N) (+bias).  A/B are 2-D contiguous tensors
-    whose storage order is given by the layout flag (see pcaa_hip.h)."""
+    whose storage order is given by the layout flag (see pcaa_hip.h).  ``tail``: the BatchNorm finalize of
+    ``colstats`` (BnTailFwd), carried by this launch when it can be."""
     _chk(A, "gemm.A", dim=2)
     _chk(B, "gemm.B", dim=2)
     ea = (M, K) if a_layout == KC else (K, M)
@@ -228,6 +317,8 @@ def gemm(A, a_layout, B, b_layout, M, N, K, *, lda=None, ldb=None, out=None, out
         timer = timer if timer.wants(key) else None
     if timer is not None:
         ev = _begin_timing(key)
+    if tail is not None:
+        tail.arm(colstats)
     check(lib.pcaa_gemm(math, _p(A), _dt(A), a_layout, lda, _p(B), _dt(B), b_layout, ldb,
                         _p(out), _dt(out), N, M, N, K, _p(bias), _p(colstats), NREP,
                         int(split_k), int(bool(accumulate)), _s()), "pcaa_gemm")
@@ -235,11 +326,13 @@ def gemm(A, a_layout, B, b_layout, M, N, K, *, lda=None, ldb=None, out=None, out
         ev.end()
         nbytes = A.numel() * A.element_size() + B.numel() * B.element_size() + out.numel() * out.element_size()
         timer.records.append((key, 2.0 * M * N * K, float(nbytes), ev))
+    if tail is not None:
+        tail.resolve(colstats)
     return out
 
 
 def gemm_slabs(A, a_layout, B, b_layout, M, N, K, split_k, out=None, accumulate=False, math=PCAA_BF16,
-               colstats=None):
+               colstats=None, tail=None):
     """Split-K product without atomics: every split writes its partial [M,N] slab, a second
     launch sums the slabs into ``out`` (=|+=).  Used for the long-K weight gradients, where the
     atomic epilogue (256 KB of fp32 atomics per workgroup) cost as much as the MFMA loop."""
@@ -278,6 +371,8 @@ def gemm_slabs(A, a_layout, B, b_layout, M, N, K, split_k, out=None, accumulate=
         _chk(colstats, "gemm_slabs.colstats", torch.float64)
         check(lib.pcaa_splitk_reduce_stats(_p(slabs), ns, stride, _p(out), _p(colstats), NREP, M, N, _s()),
               "pcaa_splitk_reduce_stats")
+        if tail is not None:
+            tail.resolve(colstats)
         return out
     check(lib.pcaa_splitk_reduce(_p(slabs), ns, stride, stride, _p(out), int(bool(accumulate)), _s()),
           "pcaa_splitk_reduce")
@@ -319,7 +414,7 @@ def gemm_dgrad_bn_supported(M, N, K):
     return bool(_lib.load().pcaa_gemm_dgrad_bn_supported(int(M), int(N), int(K)))
 
 
-def gemm_dgrad_bn(dy, Wt, y, scale, shift, mean, rstd, points=None, W1=None):
+def gemm_dgrad_bn(dy, Wt, y, scale, shift, mean, rstd, points=None, W1=None, tail=None):
     """dz[M,N] = (dy[M,K] @ Wt[N,K]^T) * ELU'(y*scale+shift) plus the BatchNorm-backward statistics of
     the layer that owns y -- the dgrad of the layer above fused with the first half of this layer's
     backward.  Returns (dz bf16, stats)."""
@@ -349,6 +444,8 @@ def gemm_dgrad_bn(dy, Wt, y, scale, shift, mean, rstd, points=None, W1=None):
     timer = timer if (timer is not None and timer.wants(key)) else None
     if timer is not None:
         ev = _begin_timing(key)
+    if tail is not None:
+        tail.arm(stats)
     check(_lib.load().pcaa_gemm_dgrad_bn(_p(dy), dy.stride(0), _p(Wt), Wt.stride(0), _p(y), _p(dz), dz.stride(0),
                                          _p(scale), _p(shift), _p(mean), _p(rstd), _p(stats), NREP, M, N, K,
                                          _p(points) if y is None else None, xc, _p(W1) if y is None else None, _s()),
@@ -357,6 +454,8 @@ def gemm_dgrad_bn(dy, Wt, y, scale, shift, mean, rstd, points=None, W1=None):
         ev.end()
         nbytes = 2 * (M * K + N * K + 2 * M * N)
         timer.records.append((key, 2.0 * M * N * K, float(nbytes), ev))
+    if tail is not None:
+        tail.resolve(stats)
     return dz, stats
 
 
@@ -382,8 +481,8 @@ def pointnet_in_ok(C, cout):
     return 1 <= C <= 8 and cout % 4 == 0 and cout <= 1024 and 256 % (cout // 4) == 0
 
 
-def pointnet_in_fwd(x2d, W2d, bias, out_dtype, stats=None):
-    """y[P,cout] = x2d[P,C] . W2d[cout,C]^T + bias (+ BatchNorm statistics)."""
+def pointnet_in_fwd(x2d, W2d, bias, out_dtype, stats=None, tail=None):
+    """y[P,cout] = x2d[P,C] . W2d[cout,C]^T + bias (+ BatchNorm statistics; ``tail``: their finalize, BnTailFwd)."""
     _chk(x2d, "pointnet_in.x", torch.float32, 2)
     _chk(W2d, "pointnet_in.W", torch.float32, 2)
     P, C = x2d.shape
@@ -393,12 +492,20 @@ def pointnet_in_fwd(x2d, W2d, bias, out_dtype, stats=None):
     if out_dtype is None:                    # statistics only (recompute path): y is never stored
         if stats is None:
             raise ValueError("pointnet_in_fwd: statistics-only call needs stats")
+        if tail is not None:
+            tail.arm(stats)
         check(_lib.load().pcaa_pointnet_in_fwd(_p(x2d), C, _p(W2d), None, None, PCAA_F32, P, cout, _p(stats), NREP,
                                                _s()), "pcaa_pointnet_in_fwd(stats)")
+        if tail is not None:
+            tail.resolve(stats)
         return None
     y = torch.empty((P, cout), dtype=out_dtype, device=x2d.device)
+    if tail is not None and stats is not None:
+        tail.arm(stats)
     check(_lib.load().pcaa_pointnet_in_fwd(_p(x2d), C, _p(W2d), _p(bias), _p(y), _dt(y), P, cout, _p(stats), NREP, _s()),
           "pcaa_pointnet_in_fwd")
+    if tail is not None and stats is not None:
+        tail.resolve(stats)
     return y
 
 
@@ -416,7 +523,7 @@ def pointnet_in_apply(x2d, W2d, scale, shift, out_dtype):
     return a
 
 
-def pointnet_in_bwd_stats(da, x2d, W2d, scale, shift, mean, rstd):
+def pointnet_in_bwd_stats(da, x2d, W2d, scale, shift, mean, rstd, tail=None):
     _chk(da, "pointnet_in_bwd_stats.da", dim=2)
     _chk(x2d, "pointnet_in_bwd_stats.x", torch.float32, 2)
     P, cout = da.shape
@@ -424,9 +531,13 @@ def pointnet_in_bwd_stats(da, x2d, W2d, scale, shift, mean, rstd):
     if x2d.shape[0] != P or tuple(W2d.shape) != (cout, C) or not pointnet_in_ok(C, cout):
         raise ValueError("pointnet_in_bwd_stats: unsupported shape")
     stats = new_stats(cout, da.device)
+    if tail is not None:
+        tail.arm(stats)
     check(_lib.load().pcaa_pointnet_in_bwd_stats(_p(da), _dt(da), _p(x2d), C, _p(W2d), _p(scale), _p(shift), _p(mean),
                                                  _p(rstd), _p(stats), NREP, P, cout, _s()),
           "pcaa_pointnet_in_bwd_stats")
+    if tail is not None:
+        tail.resolve(stats)
     return stats
 
 
@@ -515,7 +626,7 @@ def bn_act_meanpool_fwd(y, scale, shift, groups, group_rows, mean=None, rstd=Non
     return out if e is None else (out, e)
 
 
-def bn_pool_bwd_stats(dpool, e, pool_scale):
+def bn_pool_bwd_stats(dpool, e, pool_scale, tail=None):
     """BatchNorm-backward statistics of a mean-pooled layer from the forward's (e1, e2) sums."""
     _chk(dpool, "bn_pool_bwd_stats.dpool", torch.float32, 2)
     _chk(e, "bn_pool_bwd_stats.e", torch.float32, 3)
@@ -523,8 +634,12 @@ def bn_pool_bwd_stats(dpool, e, pool_scale):
     if tuple(e.shape) != (2, groups, ch):
         raise ValueError("bn_pool_bwd_stats: e shape")
     stats = new_stats(ch, dpool.device)
+    if tail is not None:
+        tail.arm(stats)
     check(_lib.load().pcaa_bn_pool_bwd_stats(_p(dpool), _p(e[0]), _p(e[1]), float(pool_scale), _p(stats), NREP,
                                              groups, ch, _s()), "pcaa_bn_pool_bwd_stats")
+    if tail is not None:
+        tail.resolve(stats)
     return stats
 
 
@@ -547,7 +662,7 @@ def bn_act_bwd_dz(y, scale, shift, mean, rstd, *, da=None, dpool=None, group_row
     return dz, stats
 
 
-def bn_act_bwd_stats(y, scale, shift, mean, rstd, *, da=None, dpool=None, group_rows=0, pool_scale=1.0):
+def bn_act_bwd_stats(y, scale, shift, mean, rstd, *, da=None, dpool=None, group_rows=0, pool_scale=1.0, tail=None):
     """Statistics-only pass of the BatchNorm backward (sum dz, sum dz*yhat): reads, writes nothing."""
     _chk(y, "bn_act_bwd_stats.y", dim=2)
     rows, ch = y.shape
@@ -555,6 +670,8 @@ def bn_act_bwd_stats(y, scale, shift, mean, rstd, *, da=None, dpool=None, group_
     check(_lib.load().pcaa_bn_act_bwd_dz(_p(da), _p(dpool), int(group_rows), float(pool_scale), _p(y), None,
                                          _dt(y), _p(scale), _p(shift), _p(mean), _p(rstd), _p(stats), NREP,
                                          rows, ch, _s()), "pcaa_bn_act_bwd_dz(stats)")
+    if tail is not None:
+        tail.resolve(stats)
     return stats
 
 
@@ -1049,7 +1166,7 @@ def dtc_conv_supported(T, cin, cout):
     return bool(_lib.load().pcaa_dtc_conv_supported(int(T), int(cin), int(cout)))
 
 
-def dtc_conv_fwd(src, scale, shift, W2d, B, T, dilation, stats=None, want_col=False):
+def dtc_conv_fwd(src, scale, shift, W2d, B, T, dilation, stats=None, want_col=False, tail=None):
     """One DilTempConv1d layer forward in one launch (see pcaa_dtc_conv_fwd): returns (y, col or None)."""
     _chk(src, "dtc_conv_fwd.src", torch.float32, 2)
     _chk(W2d, "dtc_conv_fwd.W", torch.float32, 2)
@@ -1078,15 +1195,21 @@ def dtc_conv_fwd(src, scale, shift, W2d, B, T, dilation, stats=None, want_col=Fa
         if stats is not None:
             check(lib.pcaa_splitk_reduce_stats(_p(slabs), ksplit, stride, _p(y), _p(stats), NREP, rows, cout, _s()),
                   "pcaa_splitk_reduce_stats")
+            if tail is not None:
+                tail.resolve(stats)
         else:
             check(lib.pcaa_splitk_reduce(_p(slabs), ksplit, stride, stride, _p(y), 0, _s()), "pcaa_splitk_reduce")
         return y, col
+    if tail is not None and stats is not None:
+        tail.arm(stats)
     check(lib.pcaa_dtc_conv_fwd(_p(src), _p(scale), _p(shift), _p(W2d), _p(y), _p(col), _p(stats), NREP,
                                 B, T, cin, cout, int(dilation), 1, 0, _s()), "pcaa_dtc_conv_fwd")
+    if tail is not None and stats is not None:
+        tail.resolve(stats)
     return y, col
 
 
-def dtc_conv_dgrad(dy, W2d, B, T, cin, dilation, dz=None, y=None, coef=None, want_dy=False, below=None):
+def dtc_conv_dgrad(dy, W2d, B, T, cin, dilation, dz=None, y=None, coef=None, want_dy=False, below=None, tail=None):
     """Adjoint of the causal dilated convolution w.r.t. its input in one launch (pcaa_dtc_conv_dgrad).
     ``dy`` [B*T,cout], or None with ``dz``, ``y``, ``coef``: dy is formed on load (``want_dy``: also returned).
     ``below`` = (y, scale, shift, mean, rstd) of the layer below: the result is that layer's dz and its
@@ -1127,7 +1250,11 @@ def dtc_conv_dgrad(dy, W2d, B, T, cin, dilation, dz=None, y=None, coef=None, wan
               "pcaa_dtc_conv_dgrad")
         check(lib.pcaa_splitk_reduce(_p(slabs), ks, stride, stride, _p(out), 0, _s()), "pcaa_splitk_reduce")
     else:
+        if tail is not None and stats is not None:
+            tail.arm(stats)
         check(lib.pcaa_dtc_conv_dgrad(_p(dy), _p(dz), _p(y), _p(coef), _p(dy_out), _p(W2d), _p(out), *[_p(t) for t in ep],
                                       _p(stats), NREP, B, T, cin, cout, int(dilation), 1, 0, _s()),
               "pcaa_dtc_conv_dgrad")
+        if tail is not None and stats is not None:
+            tail.resolve(stats)
     return out, stats, (dy if dy is not None else dy_out)

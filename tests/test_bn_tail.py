@@ -1,0 +1,135 @@
+"""The BatchNorm finalize carried by the launch that produces the statistics (csrc/bn_tail.h, round 3): the last
+workgroup of the producer writes the coefficients instead of a stand-alone bn_finalize / bn_bwd_finalize launch.
+Same arithmetic on the same replica sums, so the two forms must agree to the noise of the fp64 atomics' order."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import T
+from opensetgaitrecognition_pcaa_amd import constants, functional as F_hip, ops, synthetic as syn
+from opensetgaitrecognition_pcaa_amd._lib import KC, PCAA_BF16
+from opensetgaitrecognition_pcaa_amd.train import PCAATrainer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _bn(ch, seed):
+    bn = torch.nn.BatchNorm1d(ch).to(DEV)
+    syn.deterministic_fill_(bn, seed)
+    return bn
+
+
+@pytest.mark.parametrize("cin,cout", [(512, 512), (512, 1024)])
+def test_gemm_carries_forward_finalize_repeatedly(cin, cout):
+    """the LDS-DMA GEMM with the statistics epilogue, 30 launches back to back from pre-read (L2-warm) statistics
+    buffers: the carried finalize equals the stand-alone kernel every time (a stale or early read of another
+    workgroup's atomics would show as a wrong mean / rstd on some launch)"""
+    P = 256 * 240                                   # 240 row tiles x cout/256 column tiles: every CU gets several
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = (torch.randn(P, cin, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(cout, cin, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(cout, device=DEV, generator=g) * 0.1
+    taken0 = ops.TAILS["taken"]
+    for it in range(30):
+        bn_a, bn_b = _bn(cout, 7), _bn(cout, 7)
+        stats = ops.new_stats(cout, DEV)
+        _ = stats.sum().item()                      # the statistics lines are in this XCD's L2 / the host waited
+        tail = ops.BnTailFwd(P, bias, bn_a, cout)
+        y = ops.gemm(x, KC, w, KC, P, cout, cin, colstats=stats, out_dtype=torch.bfloat16, math=PCAA_BF16, tail=tail)
+        ref = ops.bn_finalize(stats, P, bias, bn_b, cout)
+        torch.cuda.synchronize()
+        for a, b, nm in zip(tail.out, ref, ("scale", "shift", "mean", "rstd")):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), (it, nm, (a - b).abs().max().item())
+        assert torch.allclose(bn_a.running_mean, bn_b.running_mean, rtol=1e-6, atol=1e-7)
+        assert torch.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-6, atol=1e-7)
+        assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 1
+        assert int(stats._pcaa_counter.item()) == 0, "the finalizer leaves the arrival counter at zero"
+    assert ops.TAILS["taken"] - taken0 == 30, "the LDS-DMA launch must have carried every finalize"
+    # sanity of the values themselves against torch
+    yf = y.float()
+    assert torch.allclose(tail.out[2], yf.mean(0), rtol=2e-2, atol=2e-3)
+
+
+def test_small_producers_carry_their_finalize():
+    """pointnet_in (forward statistics, backward statistics) and the mean-pool backward statistics"""
+    P, C, cout = 64 * 30 * 32, 4, 512
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x = torch.randn(P, C, device=DEV, generator=g)
+    W = torch.randn(cout, C, device=DEV, generator=g) * 0.5
+    bias = torch.randn(cout, device=DEV, generator=g) * 0.1
+    bn_a, bn_b = _bn(cout, 3), _bn(cout, 3)
+    t0 = ops.TAILS["taken"]
+    stats = ops.new_stats(cout, DEV)
+    tail = ops.BnTailFwd(P, bias, bn_a, cout)
+    ops.pointnet_in_fwd(x, W, None, None, stats, tail=tail)
+    ref = ops.bn_finalize(stats, P, bias, bn_b, cout)
+    for a, b in zip(tail.out, ref):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    scale, shift, mean, rstd = ref
+    da = (torch.randn(P, cout, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+    btail = ops.BnTailBwd(P, bn_a, mean, rstd, cout)
+    st2 = ops.pointnet_in_bwd_stats(da, x, W, scale, shift, mean, rstd, tail=btail)
+    ref2 = ops.bn_bwd_finalize(st2, P, bn_b, mean, rstd, cout)
+    for a, b in zip(btail.out, ref2):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    # mean-pool backward statistics
+    groups, ch = 1920, 1024
+    dpool = torch.randn(groups, ch, device=DEV, generator=g)
+    e = torch.randn(2, groups, ch, device=DEV, generator=g)
+    bn_c = _bn(ch, 4)
+    m2, r2 = torch.randn(ch, device=DEV, generator=g), torch.rand(ch, device=DEV, generator=g) + 0.5
+    ptail = ops.BnTailBwd(groups * 128, bn_c, m2, r2, ch)
+    st3 = ops.bn_pool_bwd_stats(dpool, e, 1.0 / 128, tail=ptail)
+    ref3 = ops.bn_bwd_finalize(st3, groups * 128, bn_c, m2, r2, ch)
+    for a, b in zip(ptail.out, ref3):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    assert ops.TAILS["taken"] - t0 == 3
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_train_step_with_and_without_carried_finalizes(precision):
+    """one V4 train step from the same state with the finalizes carried by their producers and as stand-alone
+    launches: same losses, same parameters (to the order noise of the fp64 atomics)"""
+    B, N, C, K = 8, 32, 4, 4
+    outs = {}
+    for enabled in (True, False):
+        ops.TAILS["enabled"] = enabled
+        try:
+            constants.NFEATURES = C
+            cfg = dict(constants.CONFIG)
+            cfg.update(NMAX=N, TRAIN_CLASSES=list(range(K)), BATCH_SIZE=B)
+            tr = PCAATrainer(cfg, precision=precision)
+            for i, m in enumerate((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head,
+                                   tr.discriminator_projection_head)):
+                syn.deterministic_fill_(m, 50 + i)
+            tr.sample_prior_means()
+            tr.finalize()
+            tr.train()
+            t0, s0 = ops.TAILS["taken"], ops.TAILS["standalone"]
+            for s in range(2):
+                out = tr.step(syn.synthetic_pcs(B, T, N, C, seed=60 + s).to(DEV).permute(0, 3, 1, 2),
+                              syn.synthetic_labels(B, K, seed=70 + s).to(DEV), syn.synthetic_z0(B, 32, seed=80 + s).to(DEV),
+                              syn.synthetic_alphas(B, seed=90 + s).to(DEV))
+            torch.cuda.synchronize()
+            outs[enabled] = ({k: out[k].item() for k in ("d_loss", "rec_loss", "sup_loss", "tot_loss")},
+                             tr.flat_g.p.detach().clone(), {k: v.detach().clone() for k, v in tr.encoder.state_dict().items()},
+                             ops.TAILS["taken"] - t0, ops.TAILS["standalone"] - s0)
+            del tr
+        finally:
+            ops.TAILS["enabled"] = True
+    (la, pa, sa, taken, alone), (lb, pb, sb, taken_off, alone_off) = outs[True], outs[False]
+    print(f"{precision}: finalizes per 2 steps carried {taken} / stand-alone {alone}  (switch off: {taken_off} / {alone_off})")
+    assert taken_off == 0 and alone_off == 40
+    # bf16: everything but the K-split first temporal layer (its statistics come from the slab reduction); fp32: the
+    # exact-fp32 GEMM kernels and the two-pass BatchNorm backward of PointNet layers 2-3 do not carry tails
+    assert taken >= (36 if precision == "bf16" else 26) and taken + alone == 40
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-5 * abs(lb[k]) + 1e-6, (k, la[k], lb[k])
+    assert (pa - pb).abs().max().item() <= 2.5e-4          # an Adam step flips where a gradient is rounding noise
+    assert (pa - pb).abs().mean().item() <= 1e-7
+    for k in sa:
+        if sa[k].dtype.is_floating_point:
+            assert torch.allclose(sa[k], sb[k], rtol=1e-4, atol=3e-4), k
+        else:
+            assert torch.equal(sa[k], sb[k]), k
