@@ -134,6 +134,18 @@ int pcaa_pointnet_in_apply(const float* x, int C, const float* W, const float* s
 int pcaa_pointnet_in_bwd_stats(const void* da, int dtype, const float* x, int C, const float* W,
                                const float* scale, const float* shift, const float* mean, const float* rstd,
                                double* stats, int nrep, long P, int cout, void* stream);
+/* One pass instead of the two (round 3): the weight gradient is linear in dy and y = x.W^T, so
+ *   dW = c0 (.) (dz^T x) + c1 (.) (W . x^T x) + c2 (x) sum_p x.
+ * pcaa_pointnet_in_bwd_onepass reduces the statistics AND G[cout,C] += dz^T.x (G zero-initialised) from one read of
+ * da; pcaa_points_moments accumulates mom[pcaa_points_moments_size()] (zero-initialised fp64: x^T x at [k*8 + c], the
+ * sums at [64 + c]); pcaa_pointnet_in_bwd_combine forms dW (=) from G, the moments and pcaa_bn_bwd_finalize's coef. */
+int pcaa_pointnet_in_bwd_onepass(const void* da, int dtype, const float* x, int C, const float* W,
+                                 const float* scale, const float* shift, const float* mean, const float* rstd,
+                                 double* stats, int nrep, float* G, long P, int cout, void* stream);
+int pcaa_points_moments_size(void);
+int pcaa_points_moments(const float* x, int C, long P, double* mom, void* stream);
+int pcaa_pointnet_in_bwd_combine(const float* G, const float* W, const double* mom, const float* coef,
+                                 float* dW, int cout, int C, void* stream);
 int pcaa_pointnet_in_bwd_wgrad(const void* da, int dtype, const float* x, int C, const float* W,
                                const float* scale, const float* shift, const float* coef, float* dW,
                                long P, int cout, int dz_is_pre /* da already is dz (pcaa_gemm_dgrad_bn) */,
@@ -191,7 +203,7 @@ int pcaa_bn_bwd_dy(const void* dz, const void* y, void* dy, int dtype, const flo
 /* The finalize CARRIED BY THE PRODUCER of the statistics (round 3; csrc/bn_tail.h).  pcaa_bn_tail_arm_fwd / _bwd
  * note the arguments of pcaa_bn_finalize / pcaa_bn_bwd_finalize on the calling thread; the NEXT launch on that thread
  * that accumulates into exactly this `stats` buffer and can carry a tail (pcaa_gemm on the LDS-DMA path with colstats,
- * pcaa_gemm_dgrad_bn, pcaa_pointnet_in_fwd (statistics only), pcaa_pointnet_in_bwd_stats, pcaa_bn_pool_bwd_stats,
+ * pcaa_gemm_dgrad_bn, pcaa_pointnet_in_fwd (statistics only), pcaa_pointnet_in_bwd_stats / _onepass, pcaa_bn_pool_bwd_stats,
  * pcaa_dtc_conv_fwd / _dgrad without K split) takes it: its last workgroup to finish (agent-scope arrival counter,
  * `counter`: one zero-initialised word, left at zero) writes the coefficients, and the separate finalize launch
  * -- 5-8 us on the critical path, 20 per train step -- is gone.  pcaa_bn_tail_pending() == 1 after the producer's

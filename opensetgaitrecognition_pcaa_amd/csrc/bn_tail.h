@@ -7,12 +7,11 @@
 //
 //   every wave: s_waitcnt vmcnt(0)            -- its statistics atomics have been performed (they execute at the
 //                                                memory side, MI355X_MICROARCH.md "Global float atomics")
-//   workgroup barrier; lane 0: agent-scope release fence, vmcnt(0), relaxed agent-scope fetch_add on the arrival
-//   counter; the workgroup that draws nblocks-1 is the finalizer:
-//   lane 0: agent-scope acquire fence (buffer_inv sc1), vmcnt(0); barrier; every replica word is then read with an
-//   agent-scope (sc1) load -- neither this CU's L1 nor this XCD's L2 can serve a stale copy
-//   (cdna_hip_programming.md Guideline 16; nobody ever waits for another workgroup, so no placement or dispatch-order
-//   assumption).  The counter is zeroed with the statistics (ops.StatsPool clears its whole used range once per step)
+//   workgroup barrier; lane 0: relaxed agent-scope fetch_add on the arrival counter; the workgroup that draws
+//   nblocks-1 is the finalizer: every replica word is then read with an agent-scope (sc1) load -- neither this CU's
+//   L1 nor this XCD's L2 can serve a stale copy (cdna_hip_programming.md Guideline 16, the "every payload byte
+//   written write-through / by atomics and drained, every load sc1" form: no release, no cache invalidate; nobody
+//   ever waits for another workgroup, so no placement or dispatch-order assumption).  The counter is zeroed with the statistics (ops.StatsPool clears its whole used range once per step)
 //   and reset by the finalizer, so a replayed hipGraph starts from zero as well.
 //
 // The arithmetic is the one of the stand-alone kernels (elementwise.hip), which remain for SyncBN (the all-reduce of
@@ -56,24 +55,38 @@ __device__ __forceinline__ void bn_tail_run(const BnTail& t, int tid, int nthrea
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // No release fence: the only bytes handed over are the statistics, and those were written by atomics, which
+    // execute at the memory side and leave nothing in this XCD's L2 (an agent-scope release here is a write-back of
+    // the WHOLE L2 -- measured: with the decoder's Adam streaming on a side stream it cost the temporal block's
+    // backward +190 us per step).
     const unsigned prev = __hip_atomic_fetch_add(t.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *flag = prev == nblocks - 1 ? 1 : 0;
   }
   __syncthreads();
   if (*flag == 0) return;
+  // Every load of a handed-over word below is an agent-scope (sc1) load, which neither this CU's L1 nor this XCD's
+  // L2 serves from a stale copy: no cache invalidate is needed (Guideline 16, "every load sc1"); the fence only keeps
+  // the compiler from moving them above the counter.
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(t.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t.kind == 1 && t.nbt != nullptr) *t.nbt += 1;
   }
-  __syncthreads();
   const int ch = t.ch;
   for (int c = tid; c < ch; c += nthreads) {
     double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < t.nrep; ++r) {
+    int r = 0;
+    for (; r + 8 <= t.nrep; r += 8) {          // 16 loads in flight (same summation order as replica_sums)
+      double a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a[u] = bn_tail_ld(t.stats + ((long)(r + u) * 2 + 0) * ch + c);
+        b[u] = bn_tail_ld(t.stats + ((long)(r + u) * 2 + 1) * ch + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s1 += a[u]; s2 += b[u]; }
+    }
+    for (; r < t.nrep; ++r) {
       s1 += bn_tail_ld(t.stats + ((long)r * 2 + 0) * ch + c);
       s2 += bn_tail_ld(t.stats + ((long)r * 2 + 1) * ch + c);
     }

@@ -132,7 +132,12 @@ __global__ __launch_bounds__(256) void pointnet_in_apply_kernel(const float* __r
 }
 
 // MODE 0: statistics {sum dz, sum dz*yhat}; MODE 1: dW += dy^T . x with dy = c0*dz + c1*y + c2;
-// MODE 2: as 1 with the incoming tensor already dz (ELU' applied by the fused dgrad epilogue)
+// MODE 2: as 1 with the incoming tensor already dz (ELU' applied by the fused dgrad epilogue);
+// MODE 3 (round 3): ONE pass instead of MODE 0 + MODE 1 -- the statistics AND G += dz^T . x.  The weight gradient is
+// linear in dy, and y = x . W^T, so
+//     dW = dy^T x = c0 (.) (dz^T x) + c1 (.) (W . x^T x) + c2 (x) sum_p x
+// needs, beside G = dz^T x, only the C x C second moments and the C sums of the points (points_moments_kernel); the
+// combination is pointnet_in_bwd_combine_kernel.  The second read of the [P, cout] gradient (252 MB, 0.1 ms) is gone.
 template <typename T, int MODE, int CP>
 __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restrict__ da, const float* __restrict__ x,
                                                               int C, const float* __restrict__ W,
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restric
   load_weights<CP>(w, W, C, cq);
   const f32x4 sc = load4(scale + cq * 4), sh = load4(shift + cq * 4);
   f32x4 p0, p1, p2 = {0.f, 0.f, 0.f, 0.f};
-  if (MODE == 0) { p0 = load4(mean + cq * 4); p1 = load4(rstd + cq * 4); }
+  if (MODE == 0 || MODE == 3) { p0 = load4(mean + cq * 4); p1 = load4(rstd + cq * 4); }
   else { p0 = load4(coef + cq * 4); p1 = load4(coef + cout + cq * 4); p2 = load4(coef + 2 * cout + cq * 4); }
   __syncthreads();
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
@@ -178,11 +183,12 @@ __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restric
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         d[e] = MODE == 2 ? g[u][e] : g[u][e] * elu_grad_from_pre_t<T>(yv[e] * sc[e] + sh[e]);   // MODE 2: da is already dz
-      if (MODE == 0) {
+      if (MODE == 0 || MODE == 3) {
         s1 += d;
         s2 += d * ((yv - p0) * p1);
-      } else {
-        const f32x4 dy = p0 * d + p1 * yv + p2;
+      }
+      if (MODE != 0) {
+        const f32x4 dy = MODE == 3 ? d : p0 * d + p1 * yv + p2;
 #pragma unroll
         for (int c = 0; c < CP; ++c) {
           const float xv = xr[c];
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restric
     }
   }
   __syncthreads();                       // xs is reused for the row-lane combine
-  if (MODE == 0) {
+  if (MODE == 0 || MODE == 3) {
     f32x4* red = reinterpret_cast<f32x4*>(xs);      // [2][256]
     red[threadIdx.x] = s1;
     red[256 + threadIdx.x] = s2;
@@ -206,8 +212,9 @@ __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restric
       for (int l = 0; l < rl; ++l) v += (double)red[stat * 256 + l * qpr + (cc >> 2)][cc & 3];
       unsafeAtomicAdd(&stats[((long)(blockIdx.x % nrep) * 2 + stat) * cout + cc], v);
     }
-    bn_tail_run(tail, threadIdx.x, 256, gridDim.x, &tail_flag);
-  } else {
+    if (MODE == 3) __syncthreads();      // the combine below reuses the same LDS
+  }
+  if (MODE != 0) {
     float* red = xs;                     // [rl][cout][CP]
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -221,6 +228,59 @@ __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restric
       atomicAdd(&dW[o], v);
     }
   }
+  if (MODE == 0 || MODE == 3) bn_tail_run(tail, threadIdx.x, 256, gridDim.x, &tail_flag);
+}
+
+// Second moments of the points for the one-pass backward: mom[k*MAXC + c] += sum_p x[p][k] x[p][c] (k, c < C),
+// mom[MAXC*MAXC + c] += sum_p x[p][c]; fp64 atomics, one set per workgroup.  x is 16 B per point: a 4 MB read.
+__global__ __launch_bounds__(256) void points_moments_kernel(const float* __restrict__ x, int C, long P,
+                                                             double* __restrict__ mom) {
+  __shared__ double red[4][MAXC * MAXC + MAXC];
+  float a[MAXC][MAXC], sm[MAXC];
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    sm[k] = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) a[k][c] = 0.f;
+  }
+  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < P; r += (long)gridDim.x * 256) {
+    float xv[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) xv[c] = c < C ? x[r * C + c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      sm[k] += xv[k];
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) a[k][c] = fmaf(xv[k], xv[c], a[k][c]);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const double v = wave_sum_d((double)a[k][c]);
+      if (lane == 0) red[wave][k * MAXC + c] = v;
+    }
+    const double v = wave_sum_d((double)sm[k]);
+    if (lane == 0) red[wave][MAXC * MAXC + k] = v;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < MAXC * MAXC + MAXC; o += 256)
+    unsafeAtomicAdd(&mom[o], (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]));
+}
+
+// dW[o][c] = c0[o] G[o][c] + c1[o] sum_k W[o][k] XtX[k][c] + c2[o] sum_p x[p][c]     (fp64 combination)
+__global__ void pointnet_in_bwd_combine_kernel(const float* __restrict__ G, const float* __restrict__ W,
+                                               const double* __restrict__ mom, const float* __restrict__ coef,
+                                               float* __restrict__ dW, int cout, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cout * C) return;
+  const int o = i / C, c = i - o * C;
+  double yx = 0.0;
+  for (int k = 0; k < C; ++k) yx += (double)W[o * C + k] * mom[k * MAXC + c];
+  dW[i] = (float)((double)coef[o] * (double)G[i] + (double)coef[cout + o] * yx +
+                  (double)coef[2 * cout + o] * mom[MAXC * MAXC + c]);
 }
 
 // dW[o][c] += sum_p dy[p][o] * x[p][c]
@@ -401,6 +461,43 @@ extern "C" int pcaa_pointnet_in_bwd_wgrad(const void* da, int dtype, const float
     LAUNCH_BWD(bf16_t, 2, (const bf16_t*)da, x, C, W, scale, shift, nullptr, nullptr, coef, nullptr, 1, dW, P, cout, BnTail{});
   else { pcaa_set_error("pcaa_pointnet_in_bwd_wgrad: bad dtype"); return PCAA_ERR_INVALID_ARG; }
   PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_bwd_wgrad");
+}
+
+/* One-pass backward of the recompute layer (round 3): statistics AND G = dz^T . x from one read of da
+ * (pointnet_in_bwd_kernel MODE 3), then pcaa_pointnet_in_bwd_combine with the points' moments. */
+extern "C" int pcaa_pointnet_in_bwd_onepass(const void* da, int dtype, const float* x, int C, const float* W,
+                                            const float* scale, const float* shift, const float* mean,
+                                            const float* rstd, double* stats, int nrep, float* G, long P, int cout,
+                                            void* stream) {
+  PCAA_CHECK_ARG(da && x && W && scale && shift && mean && rstd && stats && G && P >= 1 && nrep >= 1,
+                 "pcaa_pointnet_in_bwd_onepass: bad args");
+  PCAA_CHECK_ARG(shape_ok(C, cout), "pcaa_pointnet_in_bwd_onepass: need C<=%d and cout/4 dividing 256 (C=%d cout=%d)", MAXC, C, cout);
+  const unsigned grid = (unsigned)cdiv(P, BWD_ROWS);
+  const BnTail tail = pcaa_take_bn_tail(stats);
+  if (dtype == PCAA_F32)
+    LAUNCH_BWD(float, 3, (const float*)da, x, C, W, scale, shift, mean, rstd, nullptr, stats, nrep, G, P, cout, tail);
+  else if (dtype == PCAA_BF16)
+    LAUNCH_BWD(bf16_t, 3, (const bf16_t*)da, x, C, W, scale, shift, mean, rstd, nullptr, stats, nrep, G, P, cout, tail);
+  else { pcaa_set_error("pcaa_pointnet_in_bwd_onepass: bad dtype"); return PCAA_ERR_INVALID_ARG; }
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_bwd_onepass");
+}
+
+extern "C" int pcaa_points_moments_size(void) { return MAXC * MAXC + MAXC; }
+
+extern "C" int pcaa_points_moments(const float* x, int C, long P, double* mom, void* stream) {
+  PCAA_CHECK_ARG(x && mom && C >= 1 && C <= MAXC && P >= 1, "pcaa_points_moments: bad args");
+  long g = cdiv(P, 256 * 4);
+  if (g > 512) g = 512;
+  hipLaunchKernelGGL(points_moments_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), x, C, P, mom);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_points_moments");
+}
+
+extern "C" int pcaa_pointnet_in_bwd_combine(const float* G, const float* W, const double* mom, const float* coef,
+                                            float* dW, int cout, int C, void* stream) {
+  PCAA_CHECK_ARG(G && W && mom && coef && dW && cout >= 1 && C >= 1 && C <= MAXC, "pcaa_pointnet_in_bwd_combine: bad args");
+  hipLaunchKernelGGL(pointnet_in_bwd_combine_kernel, dim3((unsigned)cdiv((long)cout * C, 256)), dim3(256), 0,
+                     as_stream(stream), G, W, mom, coef, dW, cout, C);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_bwd_combine");
 }
 
 extern "C" int pcaa_cast_bf16(const float* src, void* dst, void* dst_t, int R, int C, void* stream) {

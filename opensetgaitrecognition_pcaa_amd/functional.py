@@ -13,6 +13,7 @@ Numerics modes (``set_precision``):
     bf16 MFMA pipe with fp32 accumulation; everything else fp32.
 """
 import contextlib
+import os
 import itertools
 
 import torch
@@ -279,6 +280,8 @@ _FUSE_DGRAD_BN = True
 # ops.gemm_dgrad_bn(points=...) exist and are tested) measured slower: the layer-2 dgrad went 0.195 -> 0.361 ms
 # (64 FMAs + 192 live registers per lane in the epilogue) to save a 0.10 ms statistics pass -> off.
 _FUSE_DGRAD_POINTS = False
+# first PointNet layer, bf16 mode: one pass over the incoming gradient instead of two (ops.pointnet_in_bwd_onepass)
+_ONEPASS_IN_BWD = os.environ.get("PCAA_ONEPASS_IN_BWD", "1") != "0"
 
 
 def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool_scale=1.0,
@@ -425,6 +428,18 @@ def pointnet_backward(saves, layers, mode, d_last=None, dpool=None, pool_rows=0,
             else:
                 tail = ops.BnTailBwd(s.rows, bn, s.mean, s.rstd, s.cout, dgamma=outs[1] if outs else None,
                                      dbeta=outs[2] if outs else None, sync=_sync_fn())
+                if _ONEPASS_IN_BWD and da.dtype == torch.bfloat16 and outs is not None and outs[0].is_contiguous():
+                    # bf16 throughput mode: statistics and G = dz^T.x from ONE read of da; the weight gradient is then a
+                    # combination of G with the points' second moments (exact-fp32 mode keeps the two passes: there
+                    # dy is formed per element before the contraction, as the oracle's autograd does)
+                    dW = ops.pointnet_in_bwd_onepass(da, s.a_in, W2d, s.scale, s.shift, s.mean, s.rstd, tail,
+                                                     out=outs[0].view(s.cout, s.cin))
+                    coef, dg, db = tail.out
+                    zb = gout[f"{prefix}{li + 1}.module.0.bias"] if gout is not None else torch.zeros_like(conv.bias)
+                    grads.append({"module.0.weight": dW.view_as(conv.weight), "module.0.bias": zb,
+                                  "module.1.weight": dg, "module.1.bias": db})
+                    da = None
+                    continue
                 ops.pointnet_in_bwd_stats(da, s.a_in, W2d, s.scale, s.shift, s.mean, s.rstd, tail=tail)
                 coef, dg, db = tail.out
             dW = ops.pointnet_in_bwd_wgrad(da.dz if fused else da, s.a_in, W2d, s.scale, s.shift, coef,

@@ -5,6 +5,7 @@ assume (device, dtype, contiguity, shapes) on the host BEFORE launching, and
 launches on torch's current stream.  torch is used for allocation only.
 """
 import ctypes
+import os
 
 import torch
 
@@ -187,7 +188,7 @@ def new_stats(ch, device):
 # producer's wrapper calls arm(stats) right before its launch and resolve(stats) right after: if the launch could carry
 # the tail (its last workgroup then writes the coefficients) resolve() has nothing to do, otherwise -- SyncBN (``sync``:
 # the statistics are all-reduced first), a producer or shape that does not carry tails -- it runs the stand-alone kernel.
-TAILS = {"enabled": True, "taken": 0, "standalone": 0}
+TAILS = {"enabled": os.environ.get("PCAA_BN_TAIL", "1") != "0", "taken": 0, "standalone": 0}
 
 
 class BnTailFwd:
@@ -539,6 +540,41 @@ def pointnet_in_bwd_stats(da, x2d, W2d, scale, shift, mean, rstd, tail=None):
     if tail is not None:
         tail.resolve(stats)
     return stats
+
+
+def points_moments(x2d):
+    """fp64 second moments and sums of the points (pcaa_points_moments) for pointnet_in_bwd_onepass."""
+    _chk(x2d, "points_moments.x", torch.float32, 2)
+    lib = _lib.load()
+    mom = torch.zeros(lib.pcaa_points_moments_size(), dtype=torch.float64, device=x2d.device)
+    check(lib.pcaa_points_moments(_p(x2d), x2d.shape[1], x2d.shape[0], _p(mom), _s()), "pcaa_points_moments")
+    return mom
+
+
+def pointnet_in_bwd_onepass(da, x2d, W2d, scale, shift, mean, rstd, tail, mom=None, out=None):
+    """Backward of the recompute layer from ONE read of the incoming gradient: BatchNorm-backward statistics (their
+    finalize: ``tail``, an ops.BnTailBwd) and G = dz^T.x in one launch, then dW = c0*G + c1*(W.x^T x) + c2*sum x.
+    Returns dW [cout, C] (``out`` is overwritten)."""
+    _chk(da, "pointnet_in_bwd_onepass.da", dim=2)
+    _chk(x2d, "pointnet_in_bwd_onepass.x", torch.float32, 2)
+    P, cout = da.shape
+    C = x2d.shape[1]
+    if x2d.shape[0] != P or tuple(W2d.shape) != (cout, C) or not pointnet_in_ok(C, cout):
+        raise ValueError("pointnet_in_bwd_onepass: unsupported shape")
+    lib = _lib.load()
+    if mom is None:
+        mom = points_moments(x2d)
+    stats = new_stats(cout, da.device)
+    G = torch.zeros((cout, C), dtype=torch.float32, device=da.device)
+    tail.arm(stats)
+    check(lib.pcaa_pointnet_in_bwd_onepass(_p(da), _dt(da), _p(x2d), C, _p(W2d), _p(scale), _p(shift), _p(mean), _p(rstd),
+                                           _p(stats), NREP, _p(G), P, cout, _s()), "pcaa_pointnet_in_bwd_onepass")
+    coef, _, _ = tail.resolve(stats)
+    if out is None:
+        out = torch.empty((cout, C), dtype=torch.float32, device=da.device)
+    check(lib.pcaa_pointnet_in_bwd_combine(_p(G), _p(W2d), _p(mom), _p(coef), _p(out), cout, C, _s()),
+          "pcaa_pointnet_in_bwd_combine")
+    return out
 
 
 def pointnet_in_bwd_wgrad(da, x2d, W2d, scale, shift, coef, out=None, out_is_zero=False, dz_is_pre=False):

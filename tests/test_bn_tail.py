@@ -44,7 +44,7 @@ def test_gemm_carries_forward_finalize_repeatedly(cin, cout):
         assert torch.allclose(bn_a.running_mean, bn_b.running_mean, rtol=1e-6, atol=1e-7)
         assert torch.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-6, atol=1e-7)
         assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 1
-        assert int(stats._pcaa_counter.item()) == 0, "the finalizer leaves the arrival counter at zero"
+        assert int(stats._pcaa_counter[0].item()) == 0, "the finalizer leaves the arrival counter at zero"
     assert ops.TAILS["taken"] - taken0 == 30, "the LDS-DMA launch must have carried every finalize"
     # sanity of the values themselves against torch
     yf = y.float()
@@ -133,3 +133,40 @@ def test_train_step_with_and_without_carried_finalizes(precision):
             assert torch.allclose(sa[k], sb[k], rtol=1e-4, atol=3e-4), k
         else:
             assert torch.equal(sa[k], sb[k]), k
+
+
+@pytest.mark.parametrize("C", [4, 5])
+def test_pointnet_in_onepass_backward_equals_two_passes(C):
+    """first PointNet layer, bf16 mode: statistics + G = dz^T.x from one read of the gradient, then
+    dW = c0*G + c1*(W.x^T x) + c2*sum x -- against the two-pass form (statistics; then dy formed per element and
+    contracted with the points) and against an fp64 evaluation of the same formulas."""
+    P, cout = 64 * 30 * 64, 512
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(P, C, device=DEV, generator=g) * torch.tensor([1.0, 1.0, 0.5, 1.0, 10.0][:C], device=DEV)
+    W = torch.randn(cout, C, device=DEV, generator=g) * 0.5
+    bn = _bn(cout, 5)
+    stats = ops.new_stats(cout, DEV)
+    ops.pointnet_in_fwd(x, W, None, None, stats)
+    scale, shift, mean, rstd = ops.bn_finalize(stats, P, None, bn, cout, update_running=False)
+    da = (torch.randn(P, cout, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+    # two passes
+    st = ops.pointnet_in_bwd_stats(da, x, W, scale, shift, mean, rstd)
+    coef, dg, db = ops.bn_bwd_finalize(st, P, bn, mean, rstd, cout)
+    dW2 = ops.pointnet_in_bwd_wgrad(da, x, W, scale, shift, coef)
+    # one pass
+    tail = ops.BnTailBwd(P, bn, mean, rstd, cout)
+    dW1 = ops.pointnet_in_bwd_onepass(da, x, W, scale, shift, mean, rstd, tail)
+    coef1, dg1, db1 = tail.out
+    assert torch.allclose(coef1, coef, rtol=1e-5, atol=1e-7) and torch.allclose(dg1, dg, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(db1, db, rtol=1e-5, atol=1e-5)
+    # fp64 reference of dy^T x
+    xd, Wd = x.double(), W.double()
+    y = xd @ Wd.t()
+    z = y * scale.double() + shift.double()
+    dz = da.double() * torch.where(z > 0, torch.ones_like(z), torch.exp(z))
+    dy = coef[0].double() * dz + coef[1].double() * y + coef[2].double()
+    ref = dy.t() @ xd
+    den = ref.norm().item()
+    e1, e2 = (dW1.double() - ref).norm().item() / den, (dW2.double() - ref).norm().item() / den
+    print(f"C={C}: one-pass rel-l2 {e1:.2e}, two-pass rel-l2 {e2:.2e}")
+    assert e1 <= 2e-3 and e2 <= 2e-3
