@@ -418,6 +418,24 @@ int pcaa_heads_bwd(const float* x4, const float* sup_fv, const float* h, const f
                    float* dW1, float* db1, float* dWh, float* dbh, float* dW2, float* db2, float* dWg,
                    float* dbg, float* dx4, int B, int K, void* stream);
 
+/* ------------------------------------------------------------------ OR-CED baseline heads (round 3)
+ * ORCEDEncoder's three Linear heads and the reparametrisation (reference models.py:489-505):
+ *   mu = x4.Wmu^T + bmu, logvar = x4.Wlv^T + blv, sup_fv = mu + eps*exp(0.5*logvar), logits = sup_fv.Wc^T + bc
+ * (x4 [B,d_in], eps [B,d_lat]: the caller's randn draw), their backward (any of d_logits / d_sup / d_mu / d_logvar may
+ * be NULL = zero; ws: 2*B*d_lat floats of scratch; dx4 may be NULL), and CG_kl_divergence (utils.py:72-85):
+ *   loss = mean_b( -0.5 sum_j (1 + logvar - (mu - mu_k)^2 - exp(logvar)) ),  gradients scaled by gscale / B. */
+int pcaa_orced_heads_supported(int B, int K, int d_in, int d_lat);
+int pcaa_orced_heads_fwd(const float* x4, const float* Wmu, const float* bmu, const float* Wlv, const float* blv,
+                         const float* eps, const float* Wc, const float* bc, float* mu, float* logvar, float* sup_fv,
+                         float* logits, int B, int K, int d_in, int d_lat, void* stream);
+int pcaa_orced_heads_bwd(const float* x4, const float* eps, const float* logvar, const float* sup_fv,
+                         const float* Wmu, const float* Wlv, const float* Wc, const float* d_logits,
+                         const float* d_sup, const float* d_mu, const float* d_logvar, float* ws, float* dWmu,
+                         float* dbmu, float* dWlv, float* dblv, float* dWc, float* dbc, float* dx4, int B, int K,
+                         int d_in, int d_lat, void* stream);
+int pcaa_orced_kl(const float* mu, const float* logvar, const float* mu_k, float* loss, float* d_mu,
+                  float* d_logvar, float* d_muk, float gscale, int B, int d_lat, void* stream);
+
 /* ------------------------------------------------------------------ optimizer
  * torch.optim.Adam (no weight decay, no amsgrad; PCAA_ablation.py:820-833) on a
  * flat fp32 buffer. `step` is the 1-based step count after this update.  max_blocks (0 =

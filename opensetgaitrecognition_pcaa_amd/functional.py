@@ -894,6 +894,80 @@ class _TrunkFn(torch.autograd.Function):
         return (None, None) + tuple(g.get(n) for n in ctx.names)
 
 
+class _OrcedHeadsFn(torch.autograd.Function):
+    """ORCEDEncoder's MLP_mu / MLP_logvar, the reparametrisation and MLP_classification (models.py:489-505) in one
+    launch (csrc/orced.hip); backward in two."""
+
+    @staticmethod
+    def forward(ctx, x4, eps, Wmu, bmu, Wlv, blv, Wc, bc):
+        x4, eps = x4.contiguous(), eps.contiguous().float()
+        logits, sup, mu, logvar = ops.orced_heads_fwd(x4, Wmu, bmu, Wlv, blv, eps, Wc, bc)
+        ctx.save_for_backward(x4, eps, logvar, sup, Wmu, Wlv, Wc)
+        return logits, sup, mu, logvar
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_logits, d_sup, d_mu, d_logvar):
+        x4, eps, logvar, sup, Wmu, Wlv, Wc = ctx.saved_tensors
+        c = lambda t: None if t is None else t.contiguous().float()
+        dx4, dWmu, dbmu, dWlv, dblv, dWc, dbc = ops.orced_heads_bwd(x4, eps, logvar, sup, Wmu, Wlv, Wc, c(d_logits), c(d_sup),
+                                                                    c(d_mu), c(d_logvar), need_dx=ctx.needs_input_grad[0])
+        return dx4, None, dWmu, dbmu, dWlv, dblv, dWc, dbc
+
+
+def orced_heads(enc, x4, eps):
+    """(logits, sup_fv, vae_mu, vae_logvar) of an ORCEDEncoder from its trunk output and the caller's eps draw"""
+    _require_gpu(x4, "ORCEDEncoder heads")
+    lm, ll, lc = enc.MLP_mu[0], enc.MLP_logvar[0], enc.MLP_classification[0]
+    return _OrcedHeadsFn.apply(x4, eps, lm.weight, lm.bias, ll.weight, ll.bias, lc.weight, lc.bias)
+
+
+class _KlFn(torch.autograd.Function):
+    """CG_kl_divergence (utils.py:72-85): forward and the three gradients in one launch each."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, mu_k):
+        mu, logvar, mu_k = mu.contiguous().float(), logvar.contiguous().float(), mu_k.contiguous().float()
+        ctx.save_for_backward(mu, logvar, mu_k)
+        return ops.orced_kl(mu, logvar, mu_k)[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        mu, logvar, mu_k = ctx.saved_tensors
+        # the upstream gradient is a device scalar: read it here (OR-CED's loop synchronises on .item() every step anyway)
+        _, (dm, dl, dk) = ops.orced_kl(mu, logvar, mu_k, want_loss=False, gscale=float(g))
+        return dm, dl, dk
+
+
+def cg_kl_divergence(mu, logvar, mu_k):
+    _require_gpu(mu, "CG_kl_divergence")
+    return _KlFn.apply(mu, logvar, mu_k)
+
+
+class _CeFn(torch.autograd.Function):
+    """torch.nn.functional.cross_entropy (mean) on the device kernel of the PCAA step (pcaa_cross_entropy: loss and
+    softmax - onehot gradient in the same launch)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        logits = logits.contiguous().float()
+        loss, dl, _ = ops.cross_entropy(logits, target, want_loss=True, want_grad=True, grad_scale=1.0)
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None
+
+
+def cross_entropy_loss(logits, target):
+    _require_gpu(logits, "cross_entropy_loss")
+    return _CeFn.apply(logits, target)
+
+
 def encoder_trunk(enc, x):
     _require_gpu(x, "ORCEDEncoder")
     if x.dim() != 4 or x.shape[3] != enc.nmax_points:

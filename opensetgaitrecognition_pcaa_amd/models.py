@@ -190,8 +190,9 @@ class ORCEDEncoder(torch.nn.Module):
     """OR-CED baseline encoder (reference models.py:446-505): the CGEncoder trunk, then ``MLP_mu`` / ``MLP_logvar``
     (Linear 512 -> 32, no activation), the reparametrisation ``sup_fv = mu + eps * exp(0.5 logvar)`` with
     ``eps = torch.randn_like(logvar)`` drawn in BOTH train and eval mode, and ``MLP_classification`` (Linear 32 -> K,
-    no activation).  forward(x[B,C,T,N]) -> (out_classes, sup_fv, vae_mu, vae_logvar).  The trunk runs on the HIP
-    kernels (functional.encoder_trunk); the three tiny heads and the sampling are plain torch device ops."""
+    no activation).  forward(x[B,C,T,N]) -> (out_classes, sup_fv, vae_mu, vae_logvar).  The trunk runs on the PointNet /
+    temporal-block kernels (functional.encoder_trunk), the three heads and the reparametrisation on
+    pcaa_orced_heads_fwd / _bwd (round 3; the normal draw itself is torch's device generator, as in the reference)."""
 
     def __init__(self, n_out_labels, nmax_points=None):
         super().__init__()
@@ -207,11 +208,10 @@ class ORCEDEncoder(torch.nn.Module):
 
     def forward(self, x):
         x4 = F_hip.encoder_trunk(self, x)
-        vae_mu = self.MLP_mu(x4)
-        vae_logvar = self.MLP_logvar(x4)
-        eps = torch.randn_like(vae_logvar)
-        sup_fv = vae_mu + eps * torch.exp(0.5 * vae_logvar)
-        return self.MLP_classification(sup_fv), sup_fv, vae_mu, vae_logvar
+        # the reference's draw (models.py:497: torch.randn_like(vae_logvar), [B, 32] from the device generator, in train
+        # AND eval mode); the three heads and the reparametrisation are one launch (csrc/orced.hip)
+        eps = torch.randn_like(x4[:, :constants.SUP_LATENT_DIM])
+        return F_hip.orced_heads(self, x4, eps)
 
 
 class ORCEDDecoder(CGDecoder):

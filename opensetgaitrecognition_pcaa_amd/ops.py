@@ -1007,6 +1007,60 @@ def cross_entropy(logits, target=None, want_loss=True, want_grad=False, grad_sca
     return loss, dl, pr
 
 
+# ------------------------------------------------------------------ OR-CED heads (csrc/orced.hip)
+def orced_heads_fwd(x4, Wmu, bmu, Wlv, blv, eps, Wc, bc):
+    """-> (logits [B,K], sup_fv, mu, logvar [B,L])"""
+    for t, nm in ((x4, "x4"), (Wmu, "Wmu"), (Wlv, "Wlv"), (eps, "eps"), (Wc, "Wc")):
+        _chk(t, f"orced_heads_fwd.{nm}", torch.float32, 2)
+    B, d_in = x4.shape
+    L, K = Wmu.shape[0], Wc.shape[0]
+    lib = _lib.load()
+    if (tuple(Wmu.shape) != (L, d_in) or tuple(Wlv.shape) != (L, d_in) or tuple(eps.shape) != (B, L)
+            or tuple(Wc.shape) != (K, L) or not lib.pcaa_orced_heads_supported(B, K, d_in, L)):
+        raise ValueError("orced_heads_fwd: unsupported shapes")
+    mu = torch.empty((B, L), dtype=torch.float32, device=x4.device)
+    logvar, sup = torch.empty_like(mu), torch.empty_like(mu)
+    logits = torch.empty((B, K), dtype=torch.float32, device=x4.device)
+    check(lib.pcaa_orced_heads_fwd(_p(x4), _p(Wmu), _p(bmu), _p(Wlv), _p(blv), _p(eps), _p(Wc), _p(bc), _p(mu), _p(logvar),
+                                   _p(sup), _p(logits), B, K, d_in, L, _s()), "pcaa_orced_heads_fwd")
+    return logits, sup, mu, logvar
+
+
+def orced_heads_bwd(x4, eps, logvar, sup, Wmu, Wlv, Wc, d_logits, d_sup, d_mu, d_logvar, need_dx=True):
+    """-> (dx4 or None, dWmu, dbmu, dWlv, dblv, dWc, dbc)"""
+    B, d_in = x4.shape
+    L, K = Wmu.shape[0], Wc.shape[0]
+    dev = x4.device
+    for t in (d_logits, d_sup, d_mu, d_logvar):
+        if t is not None:
+            _chk(t, "orced_heads_bwd.grad", torch.float32, 2)
+    ws = torch.empty(2 * B * L, dtype=torch.float32, device=dev)
+    dWmu, dWlv = torch.empty_like(Wmu), torch.empty_like(Wlv)
+    dbmu = torch.empty(L, dtype=torch.float32, device=dev)
+    dblv = torch.empty_like(dbmu)
+    dWc = torch.empty_like(Wc)
+    dbc = torch.empty(K, dtype=torch.float32, device=dev)
+    dx4 = torch.empty_like(x4) if need_dx else None
+    check(_lib.load().pcaa_orced_heads_bwd(_p(x4), _p(eps), _p(logvar), _p(sup), _p(Wmu), _p(Wlv), _p(Wc), _p(d_logits),
+                                           _p(d_sup), _p(d_mu), _p(d_logvar), _p(ws), _p(dWmu), _p(dbmu), _p(dWlv), _p(dblv),
+                                           _p(dWc), _p(dbc), _p(dx4), B, K, d_in, L, _s()), "pcaa_orced_heads_bwd")
+    return dx4, dWmu, dbmu, dWlv, dblv, dWc, dbc
+
+
+def orced_kl(mu, logvar, mu_k, want_loss=True, gscale=None):
+    """CG_kl_divergence and (``gscale`` given: the upstream gradient) its gradients w.r.t. mu, logvar, mu_k."""
+    for t in (mu, logvar, mu_k):
+        _chk(t, "orced_kl", torch.float32, 2)
+    B, L = mu.shape
+    if tuple(logvar.shape) != (B, L) or tuple(mu_k.shape) != (B, L):
+        raise ValueError("orced_kl: shape mismatch")
+    loss = torch.empty((), dtype=torch.float32, device=mu.device) if want_loss else None
+    grads = (torch.empty_like(mu), torch.empty_like(mu), torch.empty_like(mu)) if gscale is not None else (None, None, None)
+    check(_lib.load().pcaa_orced_kl(_p(mu), _p(logvar), _p(mu_k), _p(loss), _p(grads[0]), _p(grads[1]), _p(grads[2]),
+                                    float(gscale if gscale is not None else 0.0), B, L, _s()), "pcaa_orced_kl")
+    return loss, grads
+
+
 # ------------------------------------------------------------------ discriminator
 def _disc_params(m):
     lin = (m.model[0], m.model[2], m.model[4])

@@ -4,9 +4,10 @@
 
 What runs where: the PointNet / temporal-conv trunk of ``ORCEDEncoder``, ``ORCEDDecoder``, the sequence Chamfer loss,
 ``GaussianMeanLearner`` and Adam are the HIP kernels of the PCAA path (through the drop-in modules' autograd
-Functions and a :class:`~.train.FlatBuffer`); the [B,32]-sized pieces -- the three Linear heads, the
-reparametrisation draw, cross-entropy, KL and the triplet term -- are plain torch device ops (tiny library calls:
-plumbing next to a 1 TFLOP trunk).  The open-set test is host numpy / scipy in float64, as in the reference.
+Functions and a :class:`~.train.FlatBuffer`); since round 3 so are the [B,32]-sized pieces: the three Linear heads with
+the reparametrisation (``pcaa_orced_heads_fwd / _bwd``), cross-entropy (``pcaa_cross_entropy``) and the KL term
+(``pcaa_orced_kl``).  What stays on torch device ops: the normal draw itself (the reference's ``torch.randn_like``) and
+the triplet term (below: parity unpinned).  The open-set test is host numpy / scipy in float64, as in the reference.
 
 The triplet term restates ``pytorch_metric_learning==1.6.0`` (requirements.txt; NOT installed here, not vendored in
 the reference): ``miners.MultiSimilarityMiner()`` (epsilon 0.1 on cosine similarity) feeding
@@ -23,6 +24,7 @@ import torch
 import torch.nn.functional as TF
 
 from . import constants
+from . import functional as F_hip
 from .models import GaussianMeanLearner, ORCEDDecoder, ORCEDEncoder
 from .train import FlatBuffer, _NullRun, _wandb
 from .utils import CG_kl_divergence, SeqChamferLoss, save_model
@@ -75,6 +77,12 @@ def triplet_margin_loss(embeddings, labels, pairs, margin):
     return loss[nz].mean() if nz.any() else embeddings.sum() * 0.0
 
 
+def _predicted(logits):
+    """argmax(softmax(logits)) with the first index on ties (train_ORCED.py:181) on the PCAA step's kernel"""
+    from . import ops
+    return ops.cross_entropy(logits.detach().contiguous().float(), None, want_loss=False, want_preds=True)[2]
+
+
 # ---------------------------------------------------------------------------------------------------------
 # training loop (train_ORCED.py:21-280)
 # ---------------------------------------------------------------------------------------------------------
@@ -87,12 +95,12 @@ def orced_losses(encoder, decoder, mean_learner, pcs, gt_labels, config, kl_mult
     rec_pcs = decoder(sup_fvs)
     mu_gts = mean_learner(TF.one_hot(gt_labels, num_classes=K).float())
     rec = config["REC_W"] * chamfer(rec_pcs, pcs)
-    sup = config["CE_W"] * TF.cross_entropy(logits, gt_labels)
+    sup = config["CE_W"] * F_hip.cross_entropy_loss(logits, gt_labels)
     nfv = TF.normalize(sup_fvs, p=2, dim=1)
     trip = config["TRIPLET_W"] * triplet_margin_loss(nfv, gt_labels, multi_similarity_miner(nfv, gt_labels),
                                                      config["TRIPLET_MARGIN"])
     kl = config["KL_W"] * CG_kl_divergence(vae_mu, vae_logvar, mu_gts) * kl_multiplier
-    preds = torch.argmax(torch.softmax(logits, dim=1), dim=1)
+    preds = _predicted(logits)
     return {"rec": rec, "sup": sup, "trip": trip, "kl": kl, "tot": rec + sup + trip + kl, "preds": preds}
 
 
@@ -154,7 +162,7 @@ def train_ORCED(config=None, dataset_factory=None, log_fn=None, device=None):
                 logits, sup_fv, _, _ = encoder(pcs)
                 v_rec.append(config["REC_W"] * chamfer(decoder(sup_fv), pcs))
                 v_ce.append(config["CE_W"] * TF.cross_entropy(logits, gt_labels))
-                v_hat.append(torch.argmax(torch.softmax(logits, dim=1), dim=1)); v_y.append(gt_labels)
+                v_hat.append(_predicted(logits)); v_y.append(gt_labels)
         mean = lambda xs: float(torch.stack(xs).double().mean().item()) if xs else float("nan")
         record = {
             "Reconstruction Loss Train": mean(acc["rec"]), "Reconstruction Loss Valid": mean(v_rec),
@@ -277,7 +285,7 @@ def ORCED_inference(model_names, generate_dataset=True, device=None):
         def run(pcs):
             logits, sup_fvs, _, _ = encoder(pcs)
             rec_err = chamfer(decoder(sup_fvs), pcs, avg_out=False)
-            return torch.argmax(torch.softmax(logits, dim=1), dim=1), sup_fvs.cpu().numpy(), rec_err.cpu().numpy()
+            return _predicted(logits), sup_fvs.cpu().numpy(), rec_err.cpu().numpy()
 
         fv, re, pl, gl = [], [], [], []
         with torch.no_grad():

@@ -148,3 +148,37 @@ def test_orced_loop_and_inference_run(tmp_path, monkeypatch):
     preds = np.load("figures/ORCED_t/ensemble_ood_final_preds_fixed.npy")
     labels = np.load("figures/ORCED_t/ensemble_ood_final_labels_fixed.npy")
     assert preds.shape == labels.shape and len(classes) in labels and preds.max() <= len(classes)
+
+
+@pytest.mark.gpu
+def test_orced_heads_and_kl_kernels_vs_torch_autograd():
+    """pcaa_orced_heads_fwd / _bwd and pcaa_orced_kl against the same expressions in torch (fp64 autograd): the three
+    Linear heads, the reparametrisation, and CG_kl_divergence with all upstream gradients present."""
+    from opensetgaitrecognition_pcaa_amd import functional as F_hip
+    dev, B, K, D, L = "cuda", 11, 6, 512, 32
+    g = torch.Generator(device=dev).manual_seed(4)
+    r = lambda *s, sc=1.0: (torch.randn(*s, device=dev, generator=g) * sc)
+    x4, eps = r(B, D), r(B, L)
+    Wmu, bmu, Wlv, blv, Wc, bc = r(L, D, sc=0.05), r(L, sc=0.1), r(L, D, sc=0.02), r(L, sc=0.1), r(K, L, sc=0.2), r(K, sc=0.1)
+    mk = r(B, L)
+    leaves = [t.clone().requires_grad_(True) for t in (x4, Wmu, bmu, Wlv, blv, Wc, bc, mk)]
+    logits, sup, mu, lv = F_hip._OrcedHeadsFn.apply(leaves[0], eps, *leaves[1:7])
+    kl = F_hip.cg_kl_divergence(mu, lv, leaves[7])
+    wl, ws = r(B, K), r(B, L)
+    tot = (logits * wl).sum() + (sup * ws).sum() + 0.7 * kl + F_hip.cross_entropy_loss(logits, torch.arange(B, device=dev) % K)
+    tot.backward()
+    # fp64 reference
+    ref = [t.detach().double().clone().requires_grad_(True) for t in (x4, Wmu, bmu, Wlv, blv, Wc, bc, mk)]
+    rmu = ref[0] @ ref[1].t() + ref[2]
+    rlv = ref[0] @ ref[3].t() + ref[4]
+    rsup = rmu + eps.double() * torch.exp(0.5 * rlv)
+    rlogits = rsup @ ref[5].t() + ref[6]
+    rkl = torch.mean(-0.5 * torch.sum(1 + rlv - (rmu - ref[7]) ** 2 - torch.exp(rlv), dim=1))
+    rtot = (rlogits * wl.double()).sum() + (rsup * ws.double()).sum() + 0.7 * rkl + \
+        torch.nn.functional.cross_entropy(rlogits, torch.arange(B, device=dev) % K)
+    rtot.backward()
+    for a, b, nm in ((logits, rlogits, "logits"), (sup, rsup, "sup_fv"), (mu, rmu, "mu"), (lv, rlv, "logvar"), (kl, rkl, "kl")):
+        assert torch.allclose(a.double(), b, rtol=1e-5, atol=1e-5), nm
+    for a, b, nm in zip(leaves, ref, ("x4", "Wmu", "bmu", "Wlv", "blv", "Wc", "bc", "mu_k")):
+        err = (a.grad.double() - b.grad).abs().max().item()
+        assert err <= 1e-4 * b.grad.abs().max().item() + 1e-6, (nm, err)
