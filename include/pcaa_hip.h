@@ -37,6 +37,7 @@ extern "C" {
 
 #define PCAA_F32 0
 #define PCAA_BF16 1
+#define PCAA_SPLIT_F16 2 /* the [hi | lo] 16-bit image of an fp32 tensor (pcaa_gemm_split3): accepted where a call says so */
 
 /* operand storage order for pcaa_gemm */
 #define PCAA_LAYOUT_KC 0 /* contraction index contiguous: A[m*ld + k], B[n*ld + k] */
@@ -417,6 +418,30 @@ int pcaa_heads_bwd(const float* x4, const float* sup_fv, const float* h, const f
                    const float* Wg, const float* d_logits, const float* d_sup, const float* d_hproj,
                    float* dW1, float* db1, float* dWh, float* dbh, float* dW2, float* db2, float* dWg,
                    float* dbg, float* dx4, int B, int K, void* stream);
+
+/* ------------------------------------------------------------------ split-operand parity mode (round 3, "fp16x3")
+ * A parity-grade product without the 1/16-rate fp32 MFMA: an fp32 operand e is kept as hi = fp16(s e),
+ * lo = fp16(s e - hi) -- its "[hi | lo] image": for a row-major [rows, ch] tensor a 16-bit [rows, 2 ch] with lo at
+ * column ch + c (the same bytes as the fp32 tensor); s (img_scale) is a power of two that keeps the tensor in fp16's
+ * normal range (activations 1, weights 2^8, gradients 2^16) -- and the product is hi.hi + lo.hi + hi.lo on the f16
+ * MFMA pipe (the bf16 rate), fp32 accumulate, times out_scale = 1 / (s_A s_B): 22 mantissa bits per operand.
+ * pcaa_gemm_split3: C[M,N] fp32 = A.B^T from images; layout KC: A [M, 2K], B [N, 2K]; RC: A [K, 2M], B [K, 2N]
+ * (contraction over the rows: the weight gradient); colstats as pcaa_gemm.  pcaa_gemm_slabs_split3: slab split-K
+ * (pcaa_gemm_split3_num_splits slabs, reduce with pcaa_splitk_reduce).  Whole 256x256 tiles, K % 64 == 0.
+ * Producers of images: pcaa_split_f16 (any fp32 matrix, optionally transposed), pcaa_bn_act_fwd_split,
+ * pcaa_bn_bwd_dy_fused_split, pcaa_pointnet_in_apply with a_dtype = PCAA_SPLIT_F16 (img_scale 1). */
+int pcaa_gemm_split3_supported(int M, int N, int K);
+int pcaa_gemm_split3(const void* A, const void* B, int layout, long lda, long ldb, float* C, long ldc, int M,
+                     int N, int K, double* colstats, int nrep, float out_scale, void* stream);
+int pcaa_gemm_split3_num_splits(int K, int split_k);
+int pcaa_gemm_slabs_split3(const void* A, const void* B, int layout, long lda, long ldb, float* slabs,
+                           long slab_stride, int M, int N, int K, int split_k, float out_scale, void* stream);
+int pcaa_split_f16(const float* src, void* dst_img, long rows, int ch, int transpose, float img_scale, void* stream);
+int pcaa_bn_act_fwd_split(const float* y, void* a_img, const float* scale, const float* shift, long rows,
+                          int ch, float img_scale, void* stream);
+int pcaa_bn_bwd_dy_fused_split(const float* da, const float* dpool, int group_rows, float pool_scale,
+                               const float* y, void* dy_img, const float* scale, const float* shift,
+                               const float* coef, long rows, int ch, float img_scale, void* stream);
 
 /* ------------------------------------------------------------------ OR-CED baseline heads (round 3)
  * ORCEDEncoder's three Linear heads and the reparametrisation (reference models.py:489-505):

@@ -72,6 +72,22 @@ __device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
   b.x = (bf16_t)v.x; b.y = (bf16_t)v.y; b.z = (bf16_t)v.z; b.w = (bf16_t)v.w;
   *reinterpret_cast<bf16x4*>(p) = b;
 }
+// [hi | lo] fp16 image of fp32 values, the operand format of pcaa_gemm_split3: row r of an fp32 [rows, ch] tensor is
+// stored as hi = fp16(s v) at img[r][c] and lo = fp16(s v - hi) at img[r][ch + c] (same bytes as the fp32 row);
+// s is a power of two that puts the tensor's values into fp16's normal range (activations 1, weights 2^8,
+// gradients 2^16): hi + lo then carries 22 mantissa bits, against 16 for a bf16 pair.
+typedef _Float16 split_t;
+typedef _Float16 split_x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store4_split(split_t* img, size_t row, unsigned ch, unsigned c, f32x4 v, float s) {
+  v *= s;
+  split_x4 hi, lo;
+  hi.x = (split_t)v.x; hi.y = (split_t)v.y; hi.z = (split_t)v.z; hi.w = (split_t)v.w;
+  lo.x = (split_t)(v.x - (float)hi.x); lo.y = (split_t)(v.y - (float)hi.y);
+  lo.z = (split_t)(v.z - (float)hi.z); lo.w = (split_t)(v.w - (float)hi.w);
+  split_t* p = img + row * 2 * (size_t)ch + c;
+  *reinterpret_cast<split_x4*>(p) = hi;
+  *reinterpret_cast<split_x4*>(p + ch) = lo;
+}
 __device__ __forceinline__ float load1(const float* p) { return *p; }
 __device__ __forceinline__ float load1(const bf16_t* p) { return (float)*p; }
 __device__ __forceinline__ void store1(float* p, float v) { *p = v; }

@@ -118,6 +118,42 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
   }
 }
 
+// fp32 y -> the [hi | lo] fp16 image of a = ELU(y*scale+shift) (split parity mode: a only feeds GEMMs)
+__global__ __launch_bounds__(256) void bn_act_fwd_split_kernel(const float* __restrict__ y, split_t* __restrict__ a,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, unsigned nquads,
+                                                               unsigned qpr, float img_scale) {
+  const unsigned q0 = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+  const unsigned c = (q0 % qpr) << 2, ch = qpr << 2, rstep = stride / qpr;
+  unsigned r = q0 / qpr;
+  const f32x4 sc = load4(scale + c), sh = load4(shift + c);
+  for (unsigned q = q0; q < nquads; q += stride, r += rstep) {
+    const f32x4 v = load4(y + (size_t)q * 4);
+    store4_split(a, r, ch, c, f32x4{elu_f(v.x * sc.x + sh.x), elu_f(v.y * sc.y + sh.y), elu_f(v.z * sc.z + sh.z),
+                                     elu_f(v.w * sc.w + sh.w)}, img_scale);
+  }
+}
+
+// fp32 [rows, ch] -> its [hi | lo] fp16 image [rows, 2 ch] (of value * img_scale); transpose != 0: the image of the TRANSPOSED matrix, [ch, 2 rows]
+// (weights: a few MB)
+__global__ void split_f16_kernel(const float* __restrict__ src, split_t* __restrict__ dst, long rows, int ch,
+                                  int transpose, float img_scale) {
+  const long n = rows * ch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / ch;
+    const int c = (int)(i - r * ch);
+    const float v = src[i] * img_scale;
+    const split_t hi = (split_t)v, lo = (split_t)(v - (float)hi);
+    if (transpose) {
+      dst[(long)c * 2 * rows + r] = hi;
+      dst[(long)c * 2 * rows + rows + r] = lo;
+    } else {
+      dst[r * 2 * ch + c] = hi;
+      dst[r * 2 * ch + ch + c] = lo;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- mean-pool of ELU(BN(y)) over group_rows
 // one workgroup per (group, 1024-channel slab): thread = channel quad x row lane
 // TRAIN: also emits, per (group, channel), E1 = sum_r ELU'(z) and E2 = sum_r ELU'(z) * yhat.  The
@@ -633,6 +669,28 @@ extern "C" int pcaa_bn_act_fwd(const void* y, void* a, int dtype, const float* s
   PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_act_fwd");
 }
 
+extern "C" int pcaa_bn_act_fwd_split(const float* y, void* a_img, const float* scale, const float* shift, long rows,
+                                     int ch, float img_scale, void* stream) {
+  PCAA_CHECK_ARG(y && a_img && scale && shift, "pcaa_bn_act_fwd_split: null pointer");
+  PCAA_CHECK_ARG(rows >= 1 && ch >= 4 && (ch & 3) == 0, "pcaa_bn_act_fwd_split: ch must be a multiple of 4");
+  const long nq = rows * (ch >> 2);
+  PCAA_CHECK_ARG(nq < (1L << 31), "pcaa_bn_act_fwd_split: tensor too large for 32-bit quad indices");
+  const int grid = col_invariant_grid(nq, ch >> 2);
+  hipLaunchKernelGGL(bn_act_fwd_split_kernel, dim3(grid), dim3(256), 0, as_stream(stream), y, (split_t*)a_img, scale, shift,
+                     (unsigned)nq, (unsigned)(ch >> 2), img_scale);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_act_fwd_split");
+}
+
+extern "C" int pcaa_split_f16(const float* src, void* dst_img, long rows, int ch, int transpose, float img_scale,
+                               void* stream) {
+  PCAA_CHECK_ARG(src && dst_img && rows >= 1 && ch >= 1, "pcaa_split_f16: bad args");
+  long g = cdiv(rows * ch, 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), src, (split_t*)dst_img, rows, ch,
+                     transpose, img_scale);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_split_f16");
+}
+
 extern "C" int pcaa_bn_act_meanpool_fwd(const void* y, int dtype, const float* scale, const float* shift,
                                         const float* mean, const float* rstd, float* pooled, float* e1, float* e2,
                                         long groups, int group_rows, int ch, void* stream) {
@@ -697,14 +755,14 @@ extern "C" int pcaa_bn_act_bwd_dz(const void* da, const float* dpool, int group_
 namespace {
 // dy = c0 * (da * ELU'(y*scale+shift)) + c1 * y + c2 in ONE pass: dz is never materialised
 // (the statistics pass before it reads da and y but writes nothing)
-template <typename T, bool POOL>
+template <typename T, bool POOL, bool SPLIT = false>
 __global__ __launch_bounds__(256) void bn_bwd_dy_fused_kernel(const T* __restrict__ da,
                                                               const float* __restrict__ dpool, unsigned group_rows,
                                                               float pool_scale, const T* __restrict__ y,
                                                               T* __restrict__ dy, const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
                                                               const float* __restrict__ coef, unsigned nquads,
-                                                              unsigned qpr, unsigned ch) {
+                                                              unsigned qpr, unsigned ch, float img_scale = 1.f) {
   // column-invariant grid (see bn_act_fwd_kernel): coefficients in registers, rows advance by a
   // constant; the pooled variant's group index is one 32-bit division per quad
   const unsigned q0 = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
@@ -721,6 +779,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dy_fused_kernel(const T* __restric
   unsigned grp = POOL ? r / group_rows : 0u, rem = POOL ? r - grp * group_rows : 0u;
   const unsigned gstep = POOL ? rstep / group_rows : 0u, rrem = POOL ? rstep - gstep * group_rows : 0u;
   unsigned cur_group = 0xffffffffu;
+  unsigned rr = r;
   f32x4 gpool = {0.f, 0.f, 0.f, 0.f};
   for (unsigned q = q0; q < nquads; q += stride) {
     const f32x4 yv = load4(y + (size_t)q * 4);
@@ -747,7 +806,13 @@ __global__ __launch_bounds__(256) void bn_bwd_dy_fused_kernel(const T* __restric
       e = f32x4{elu_grad_from_pre(yv.x * sc.x + sh.x), elu_grad_from_pre(yv.y * sc.y + sh.y),
                 elu_grad_from_pre(yv.z * sc.z + sh.z), elu_grad_from_pre(yv.w * sc.w + sh.w)};
     }
-    store4(dy + (size_t)q * 4, k0 * (g * e) + k1 * yv + k2);
+    if constexpr (SPLIT) {
+      // dy as the [hi | lo] bf16 image (its only readers are the split-fp16 GEMMs); dy points at the image
+      store4_split(reinterpret_cast<split_t*>(dy), rr, ch, c, k0 * (g * e) + k1 * yv + k2, img_scale);
+      rr += rstep;
+    } else {
+      store4(dy + (size_t)q * 4, k0 * (g * e) + k1 * yv + k2);
+    }
   }
 }
 }  // namespace
@@ -772,6 +837,30 @@ extern "C" int pcaa_bn_bwd_dy_fused(const void* da, const float* dpool, int grou
   else { pcaa_set_error("pcaa_bn_bwd_dy_fused: bad dtype"); return PCAA_ERR_INVALID_ARG; }
 #undef LAUNCH_DYF
   PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_bwd_dy_fused");
+}
+
+/* fp32 in, dy written as its [hi | lo] bf16 image [rows, 2 ch] (split-fp16 parity mode) */
+extern "C" int pcaa_bn_bwd_dy_fused_split(const float* da, const float* dpool, int group_rows, float pool_scale,
+                                          const float* y, void* dy_img, const float* scale, const float* shift,
+                                          const float* coef, long rows, int ch, float img_scale, void* stream) {
+  PCAA_CHECK_ARG((da != nullptr) != (dpool != nullptr), "pcaa_bn_bwd_dy_fused_split: exactly one of da / dpool");
+  PCAA_CHECK_ARG(y && dy_img && scale && shift && coef, "pcaa_bn_bwd_dy_fused_split: null pointer");
+  PCAA_CHECK_ARG(rows >= 1 && ch >= 4 && (ch & 3) == 0, "pcaa_bn_bwd_dy_fused_split: ch must be a multiple of 4");
+  PCAA_CHECK_ARG(!dpool || group_rows >= 1, "pcaa_bn_bwd_dy_fused_split: bad group_rows");
+  PCAA_CHECK_ARG((const void*)da != dy_img, "pcaa_bn_bwd_dy_fused_split: the image cannot alias da");
+  const long nq = rows * (ch >> 2);
+  PCAA_CHECK_ARG(nq < (1L << 31), "pcaa_bn_bwd_dy_fused_split: tensor too large for 32-bit quad indices");
+  const int grid = col_invariant_grid(nq, ch >> 2);
+  hipStream_t s = as_stream(stream);
+  if (dpool)
+    hipLaunchKernelGGL((bn_bwd_dy_fused_kernel<float, true, true>), dim3(grid), dim3(256), 0, s, da, dpool,
+                       (unsigned)group_rows, pool_scale, y, (float*)dy_img, scale, shift, coef, (unsigned)nq,
+                       (unsigned)(ch >> 2), (unsigned)ch, img_scale);
+  else
+    hipLaunchKernelGGL((bn_bwd_dy_fused_kernel<float, false, true>), dim3(grid), dim3(256), 0, s, da, dpool,
+                       (unsigned)group_rows, pool_scale, y, (float*)dy_img, scale, shift, coef, (unsigned)nq,
+                       (unsigned)(ch >> 2), (unsigned)ch, img_scale);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_bwd_dy_fused_split");
 }
 
 extern "C" int pcaa_bn_bwd_finalize(const double* stats, int nrep, long count, const float* gamma,

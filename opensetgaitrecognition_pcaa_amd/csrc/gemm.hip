@@ -478,6 +478,71 @@ extern "C" int pcaa_gemm_slabs(int math,
                    nullptr, 0, split_k, 0, slab_stride, stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split product (round 3): both fp32 operands are given as [hi | lo] fp16 images (pcaa_split_f16:
+// hi = fp16(s e), lo = fp16(s e - hi), s a power of two) and the product is hi.hi + lo.hi + hi.lo on the f16 MFMA
+// pipe (the bf16 rate) with fp32 accumulation: three passes of the LDS-DMA kernel's K loop over the same tile (one
+// launch, K' = 3K), relative error of a product ~2^-21 -- the parity-grade mode that does not need the 1/16-rate fp32
+// MFMA.  (A bf16 pair carries 16 mantissa bits: 4.5e-6 per product, and the first PointNet layer's weight gradient
+// missed the 5e-4 gate at 5.7e-4; the fp16 pair carries 22.)  out_scale = 1 / (s_A s_B).  KC operands: [rows, 2K] (lo at column K + k); RC operands: [K, 2 rows] (lo at column rows + r).
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int pcaa_gemm_split3_supported(int M, int N, int K) {
+  return M > 0 && N > 0 && K > 0 && (M % 256) == 0 && (N % 256) == 0 && (K % 64) == 0;
+}
+
+static int gemm_split3_impl(const void* A, const void* B, int layout, long lda, long ldb, void* C, long ldc, int M, int N,
+                            int K, double* colstats, int nrep, int split_k, long c_split_stride, float out_scale,
+                            void* stream) {
+  PCAA_CHECK_ARG(A && B && C, "pcaa_gemm_split3: null operand");
+  PCAA_CHECK_ARG(layout == KC || layout == RC, "pcaa_gemm_split3: bad layout");
+  PCAA_CHECK_ARG(pcaa_gemm_split3_supported(M, N, K), "pcaa_gemm_split3: M, N must be multiples of 256 and K of 64 "
+                 "(M=%d N=%d K=%d)", M, N, K);
+  PCAA_CHECK_ARG((long)K * 3 < (1L << 31), "pcaa_gemm_split3: K too large");
+  const long a_cols = layout == KC ? 2L * K : 2L * M, b_cols = layout == KC ? 2L * K : 2L * N;
+  PCAA_CHECK_ARG(lda >= a_cols && ldb >= b_cols && ldc >= N && (lda % 8) == 0 && (ldb % 8) == 0,
+                 "pcaa_gemm_split3: leading dimensions must cover the [hi | lo] images");
+  PCAA_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "pcaa_gemm_split3: 16-B aligned operands");
+  PCAA_CHECK_ARG(!(colstats && (split_k > 1 || c_split_stride)), "pcaa_gemm_split3: column statistics need a single K pass");
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.B = B; p.C = C;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = 3 * K;
+  p.colstats = colstats; p.nrep = nrep > 0 ? nrep : 1;
+  p.seg_len = K;
+  p.out_scale = out_scale;
+  const long half_a = layout == KC ? K : M, half_b = layout == KC ? K : N;
+  p.seg_off_a[0] = 0; p.seg_off_a[1] = half_a; p.seg_off_a[2] = 0;        // hi, lo, hi
+  p.seg_off_b[0] = 0; p.seg_off_b[1] = 0;      p.seg_off_b[2] = half_b;   // hi, hi, lo
+  p.c_split_stride = c_split_stride;
+  p.atomic = 0;
+  int kps = 0;
+  const int nsplit = gemm_num_splits(PCAA_BF16, 3 * K, split_k, &kps);
+  p.k_per_split = kps;
+  const long ntiles = cdiv(M, 256) * cdiv(N, 256);
+  if (!pcaa_launch_gemm_bf16_big(p, PCAA_BF16, layout, PCAA_BF16, layout, PCAA_F32, nsplit, as_stream(stream))) {
+    pcaa_set_error("pcaa_gemm_split3: shape not served by the LDS-DMA kernel (ntiles %ld, nsplit %d)", ntiles, nsplit);
+    return PCAA_ERR_INVALID_ARG;
+  }
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_gemm_split3");
+}
+
+extern "C" int pcaa_gemm_split3(const void* A, const void* B, int layout, long lda, long ldb, float* C, long ldc, int M,
+                                int N, int K, double* colstats, int nrep, float out_scale, void* stream) {
+  return gemm_split3_impl(A, B, layout, lda, ldb, C, ldc, M, N, K, colstats, nrep, 1, 0, out_scale, stream);
+}
+
+extern "C" int pcaa_gemm_split3_num_splits(int K, int split_k) {
+  int kps = 0;
+  return gemm_num_splits(PCAA_BF16, 3 * K, split_k, &kps);
+}
+
+extern "C" int pcaa_gemm_slabs_split3(const void* A, const void* B, int layout, long lda, long ldb, float* slabs,
+                                      long slab_stride, int M, int N, int K, int split_k, float out_scale, void* stream) {
+  PCAA_CHECK_ARG(slabs && slab_stride >= (long)M * N, "pcaa_gemm_slabs_split3: slab stride must cover an M x N tile");
+  return gemm_split3_impl(A, B, layout, lda, ldb, slabs, N, M, N, K, nullptr, 0, split_k, slab_stride, out_scale, stream);
+}
+
 extern "C" int pcaa_gemm_dgrad_bn_supported(int M, int N, int K) {
   return M > 0 && N > 0 && K > 0 && (M % 256) == 0 && (N % 256) == 0 && (K % 64) == 0;
 }

@@ -358,10 +358,10 @@ __device__ __forceinline__ void piece_lane_offsets(long ld, int lane, unsigned (
 // wave (scalar) and j select the piece p = 4 wave + j; row0 / k0 as in dma_piece
 template <int LAY>
 __device__ __forceinline__ void dma_piece_buf(buf_rsrc_t rsrc, long ld, int row0, int k0, bf16_t* s_tile, int wave,
-                                              const unsigned (&voff)[2], int j) {
+                                              const unsigned (&voff)[2], int j, long extra = 0) {
   const int p = wave * 4 + j;
-  const unsigned soff = LAY == KC ? (unsigned)(((long)(row0 + 8 * p) * ld + k0) * 2)
-                                  : (unsigned)(((long)(k0 + 2 * p) * ld + row0) * 2);
+  const unsigned soff = LAY == KC ? (unsigned)(((long)(row0 + 8 * p) * ld + k0 + extra) * 2)
+                                  : (unsigned)(((long)(k0 + 2 * p) * ld + row0 + extra) * 2);
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(s_tile + p * 512), 16,
                                            voff[j & 1], soff, 0, 0);
 }
@@ -749,6 +749,27 @@ __device__ __forceinline__ bf16x8 dma_load_frag(const bf16_t* s, int off, int ks
   return u.v;
 }
 
+// the two MFMA shapes on bf16 operands, or (F16: the split-operand instantiations) on fp16 operands -- same operand
+// bytes, same lane maps, same rate; only the element format differs
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (F16) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+}
+
 // end of a K step: the next stage's DMA pieces have landed (every wave waits for its own, then the barrier)
 // every wave waits for its own pieces of the stage the next step reads, then the barrier; keep_far: the wave's four
 // youngest pieces (the A stage two steps ahead) stay in flight
@@ -757,7 +778,7 @@ __device__ __forceinline__ void step_barrier(bool keep_far) {
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <typename TC, int ALAY, int BLAY, int EPI, int MF, bool BUF>
+template <typename TC, int ALAY, int BLAY, int EPI, int MF, bool BUF, bool SPLIT = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   typedef AccLayout<MF> L;
   static_assert(MF == 32 || (ALAY == KC && BLAY == KC), "the 16x16x32 fragments are built for KC operands");
@@ -785,8 +806,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   buf_rsrc_t rA = make_rsrc(A, 0), rB = make_rsrc(B, 0);
   unsigned voA[2] = {0, 0}, voB[2] = {0, 0};
   if (BUF) {
-    rA = make_rsrc(A, (long)(ALAY == KC ? p.M : p.K) * p.lda * 2);
-    rB = make_rsrc(B, (long)(BLAY == KC ? p.N : p.K) * p.ldb * 2);
+    const int krows = SPLIT ? p.seg_len : p.K;           // rows of a row-contracted operand as it lies in memory
+    rA = make_rsrc(A, (long)(ALAY == KC ? p.M : krows) * p.lda * 2);
+    rB = make_rsrc(B, (long)(BLAY == KC ? p.N : krows) * p.ldb * 2);
     piece_lane_offsets<ALAY>(p.lda, lane, voA);
     piece_lane_offsets<BLAY>(p.ldb, lane, voB);
   }
@@ -795,12 +817,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   int ln = lane;
   // one 1-KB piece of the A (which = 0) or B (1) tile of the K step starting at k0 into stage image s_tile
   auto piece_of = [&](int tmx, int tnx, int which, int k0, bf16_t* s_tile, int j) {
+    long extra = 0;
+    if constexpr (SPLIT) {
+      // split-fp16 operands: K step k0 of the 3 * seg_len long contraction lies in segment seg (scalar arithmetic:
+      // k0 is wave-uniform); that segment's hi / lo half of the operand starts `extra` elements further on
+      const int seg = (k0 >= p.seg_len ? 1 : 0) + (k0 >= 2 * p.seg_len ? 1 : 0);
+      k0 -= seg * p.seg_len;
+      const long* so = which == 0 ? p.seg_off_a : p.seg_off_b;
+      extra = seg == 0 ? so[0] : (seg == 1 ? so[1] : so[2]);
+    }
     if (BUF) {
-      if (which == 0) dma_piece_buf<ALAY>(rA, p.lda, tmx * BM, k0, s_tile, wave, voA, j);
-      else dma_piece_buf<BLAY>(rB, p.ldb, tnx * BN, k0, s_tile, wave, voB, j);
+      if (which == 0) dma_piece_buf<ALAY>(rA, p.lda, tmx * BM, k0, s_tile, wave, voA, j, extra);
+      else dma_piece_buf<BLAY>(rB, p.ldb, tnx * BN, k0, s_tile, wave, voB, j, extra);
     } else {
-      if (which == 0) dma_piece<ALAY>(A, p.lda, tmx * BM, p.M, k0, s_tile, wave, lane, j);
-      else dma_piece<BLAY>(B, p.ldb, tnx * BN, p.N, k0, s_tile, wave, lane, j);
+      if (which == 0) dma_piece<ALAY>(A + extra, p.lda, tmx * BM, p.M, k0, s_tile, wave, lane, j);
+      else dma_piece<BLAY>(B + extra, p.ldb, tnx * BN, p.N, k0, s_tile, wave, lane, j);
     }
   };
   auto piece = [&](int which, int k0, bf16_t* s_tile, int j) { piece_of(tm, tn, which, k0, s_tile, j); };
@@ -919,7 +950,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
           for (int i = 2 * g; i < 2 * g + 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = mfma_32x32x16<SPLIT>(af[cur][i], bfr[cur][j], acc[i][j]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -974,7 +1005,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
           for (int i = 2 * g; i < 2 * g + 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              acc[4 * h + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][i], bfr[s2 & 1][j], acc[4 * h + i][j], 0, 0, 0);
+              acc[4 * h + i][j] = mfma_16x16x32<SPLIT>(af[cur][i], bfr[s2 & 1][j], acc[4 * h + i][j]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -994,6 +1025,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   if (has_next) {
     xcd_tile_coords(nbm, nbn, vb2, tm2, tn2);
     first_stages(tm2, tn2);
+  }
+  if constexpr (SPLIT) {
+    // the operand images hold value * 2^k: back to the value's scale (exact power of two)
+    const float os = p.out_scale;
+#pragma unroll
+    for (int i = 0; i < L::MB; ++i)
+#pragma unroll
+      for (int j = 0; j < L::NB; ++j)
+#pragma unroll
+        for (int r = 0; r < L::NR; ++r) acc[i][j][r] *= os;
   }
   // the epilogue's per-lane address arithmetic must not be hoisted out of the tile loop (it would sit in ~40
   // registers through the K loop): it is derived from an opaque copy of the thread id
@@ -1037,11 +1078,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
 // 32x32x16, but the chip holds a higher clock on it (MI355X_MICROARCH.md, DVFS item 7); same-box A/B on the three
 // PointNet shapes (median of 5 interleaved rounds): forward +9.2 / -0.7 / +2.6 %, fused dgrad +4.4 / +4.0 / +1.9 %.
 // RC x RC (wgrad) keeps 32x32x16: its fragments come from ds_read_b64_tr_b16 pairs laid out for that shape.
-template <typename TC, int ALAY, int BLAY, int EPI, bool BUF>
+template <typename TC, int ALAY, int BLAY, int EPI, bool BUF, bool SPLIT = false>
 bool launch_dma_inst(const GemmParams& p, dim3 grid, hipStream_t s) {
   constexpr int MF = ALAY == KC ? 16 : 32;
   static bool configured = false;
-  auto kern = gemm_bf16_dma_kernel<TC, ALAY, BLAY, EPI, MF, BUF>;
+  auto kern = gemm_bf16_dma_kernel<TC, ALAY, BLAY, EPI, MF, BUF, SPLIT>;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             D_LDS_BYTES) != hipSuccess)
@@ -1117,8 +1158,17 @@ bool launch_dma(const GemmParams& p_in, dim3 grid_in, hipStream_t s) {
   // buffer addressing needs each operand below 4 GiB (32-bit offsets); the flat form serves anything larger.  Same-box
   // A/B (profiles/r02_gemm_lab2.txt): forward / fused dgrad +1..3 %, wgrad (whole stage issued at the top of the step:
   // 8 pieces x ~7 VALU each in front of the first MFMA) +2.6 / +7.3 / +10.1 % on the three PointNet shapes.
-  const long a_bytes = (long)(ALAY == KC ? p.M : p.K) * p.lda * 2, b_bytes = (long)(BLAY == KC ? p.N : p.K) * p.ldb * 2;
-  if (a_bytes < (1L << 32) && b_bytes < (1L << 32)) return launch_dma_inst<TC, ALAY, BLAY, EPI, true>(p, grid, s);
+  const int krows = p.seg_len > 0 ? p.seg_len : p.K;
+  const long a_bytes = (long)(ALAY == KC ? p.M : krows) * p.lda * 2, b_bytes = (long)(BLAY == KC ? p.N : krows) * p.ldb * 2;
+  const bool buf = a_bytes < (1L << 32) && b_bytes < (1L << 32);
+  if constexpr (EPI == EPI_PLAIN && sizeof(TC) == 4) {
+    // split-fp16 operands (pcaa_gemm_split3): fp32 result only
+    if (p.seg_len > 0)
+      return buf ? launch_dma_inst<TC, ALAY, BLAY, EPI, true, true>(p, grid, s)
+                 : launch_dma_inst<TC, ALAY, BLAY, EPI, false, true>(p, grid, s);
+  }
+  if (p.seg_len > 0) return false;
+  if (buf) return launch_dma_inst<TC, ALAY, BLAY, EPI, true>(p, grid, s);
   return launch_dma_inst<TC, ALAY, BLAY, EPI, false>(p, grid, s);
 }
 
@@ -1203,6 +1253,7 @@ bool pcaa_launch_gemm_bf16_big(const GemmParams& p_in, int a_dtype, int a_layout
       return cf ? launch_dma<float, KC, KC, EPI_PLAIN>(p, grid, stream) : launch_dma<bf16_t, KC, KC, EPI_PLAIN>(p, grid, stream);
     if (cf) return launch_dma<float, RC, RC, EPI_PLAIN>(p, grid, stream);
   }
+  if (p.seg_len > 0) return false;       // split-fp16 operands are served by the LDS-DMA kernel only
   if (a_layout == KC && b_layout == KC) {
     // bf16 activations x fp32/bf16 weights (PointNet forward / dgrad), fp32 x fp32 (decoder forward)
     if (!af && bf && !cf) return launch<bf16_t, float, bf16_t, KC, KC>(p, grid, stream);

@@ -22,6 +22,14 @@ struct GemmParams {
   // LDS-DMA kernel, one workgroup per CU: 9 zero-initialised ints (8 per-XCD tile tickets + a count of finished
   // workgroups, reset by the last one); NULL: every workgroup walks a fixed share of the tiles
   int* sched;
+  // split-fp16 operands (pcaa_gemm_split3, round 3): the contraction runs over three segments of seg_len elements;
+  // in segment s operand A is read at element offset seg_off_a[s] and B at seg_off_b[s] (the hi / lo halves of the
+  // operands' [hi | lo] fp16 images: hi.hi + lo.hi + hi.lo on the f16 MFMA), K = 3 * seg_len.  seg_len == 0: plain
+  // bf16 operands.
+  int seg_len;
+  long seg_off_a[3], seg_off_b[3];
+  float out_scale;     // split operands are fp16 images of (value * 2^k): the accumulators are multiplied by this
+                       // (the exact power of two 2^-(ka + kb)) before the epilogue
   // the BatchNorm finalize of the statistics this launch accumulates (colstats), run by its last workgroup
   // (bn_tail.h); kind 0: none.  Only the LDS-DMA kernel's KC x KC instantiations carry one.
   BnTail tail{};

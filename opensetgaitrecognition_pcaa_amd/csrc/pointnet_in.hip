@@ -106,7 +106,7 @@ __device__ __forceinline__ f32x4 point_dot(const float (&w)[4][CP], const float*
   return acc;
 }
 
-template <typename T, int CP>
+template <typename T, int CP, bool SPLIT = false>
 __global__ __launch_bounds__(256) void pointnet_in_apply_kernel(const float* __restrict__ x, int C,
                                                                 const float* __restrict__ W,
                                                                 const float* __restrict__ scale,
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void pointnet_in_apply_kernel(const float* __r
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = elu_t<T>(acc[e] * sc[e] + sh[e]);
-    store4(a + (r0 + r) * cout + cq * 4, o);
+    if constexpr (SPLIT) store4_split(reinterpret_cast<split_t*>(a), (size_t)(r0 + r), cout, cq * 4, o, 1.f);   // [hi | lo] image
+    else store4(a + (r0 + r) * cout + cq * 4, o);
   }
 }
 
@@ -424,6 +425,15 @@ extern "C" int pcaa_pointnet_in_apply(const float* x, int C, const float* W, con
     LAUNCH_CP(pointnet_in_apply_kernel, float, x, C, W, scale, shift, (float*)a, P, cout);
   else if (a_dtype == PCAA_BF16)
     LAUNCH_CP(pointnet_in_apply_kernel, bf16_t, x, C, W, scale, shift, (bf16_t*)a, P, cout);
+  else if (a_dtype == PCAA_SPLIT_F16) {
+    // fp32 arithmetic, the activation written as its [hi | lo] bf16 image [P, 2 cout]
+    if (C <= 4)
+      hipLaunchKernelGGL((pointnet_in_apply_kernel<float, 4, true>), dim3(grid), dim3(256), 0, as_stream(stream), x, C, W,
+                         scale, shift, (float*)a, P, cout);
+    else
+      hipLaunchKernelGGL((pointnet_in_apply_kernel<float, 8, true>), dim3(grid), dim3(256), 0, as_stream(stream), x, C, W,
+                         scale, shift, (float*)a, P, cout);
+  }
   else { pcaa_set_error("pcaa_pointnet_in_apply: bad dtype"); return PCAA_ERR_INVALID_ARG; }
   PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_apply");
 }

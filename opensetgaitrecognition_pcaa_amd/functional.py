@@ -9,6 +9,12 @@ shapes (``[B,C,T,N]``, ``[B,C,T]``) as zero-copy permuted views.
 
 Numerics modes (``set_precision``):
   * ``"fp32"``  -- fp32 storage, exact-fp32 MFMA: the parity mode (1e-4 gate).
+  * ``"fp16x3"`` -- (round 3) parity-grade without the 1/16-rate fp32 MFMA: everything as in ``"fp32"`` except the
+    PointNet layers' 2-4 products, whose fp32 operands are kept as [hi | lo] fp16 images (times a power of two
+    that keeps them in fp16's normal range) and multiplied as hi.hi + lo.hi + hi.lo on the f16 MFMA pipe
+    (pcaa_gemm_split3; fp32 accumulation, 22 mantissa bits per operand): passes the fp32 mode's 1e-4 /
+    bit-exact-label / 5e-4-gradient gates unchanged (embedding error 2.0e-6 of scale against exact fp32's 2.5e-6 at
+    the benchmarked size) at about half its step time.
   * ``"bf16"``  -- PointNet activations stored in bf16, PointNet GEMMs on the
     bf16 MFMA pipe with fp32 accumulation; everything else fp32.
 """
@@ -22,7 +28,8 @@ from torch.autograd.function import once_differentiable
 from . import ops
 from ._lib import ACT_ELU, ACT_NONE, KC, PCAA_BF16, PCAA_F32, RC
 
-_W16_CACHE = {}     # weight data_ptr -> transposed bf16 shadow made in the forward pass of this step
+_W16_CACHE = {}           # weight data_ptr -> transposed bf16 shadow made in the forward pass of this step
+_WSPLIT_T_CACHE = {}      # fp16x3 mode: weight data_ptr -> SplitImage of W^T (forward -> backward of the same step)
 _PRECISION = {"mode": "fp32"}
 _SYNC_BN = {"group": None}
 
@@ -46,8 +53,8 @@ def mark(name):
 
 
 def set_precision(mode: str):
-    if mode not in ("fp32", "bf16"):
-        raise ValueError("precision must be 'fp32' or 'bf16'")
+    if mode not in ("fp32", "bf16", "fp16x3"):
+        raise ValueError("precision must be 'fp32', 'bf16' or 'fp16x3'")
     _PRECISION["mode"] = mode
 
 
@@ -128,7 +135,13 @@ def _linear_bn(a_in, W2d, lin_bias, bn, training, mode, first_layer):
     tail = ops.BnTailFwd(rows, lin_bias, bn, cout, sync=_sync_fn()) if training else None
     use_bf16 = (mode == "bf16") and a_in.dtype == torch.bfloat16 and cin % 8 == 0
     out_dtype = torch.bfloat16 if (mode == "bf16" and first_layer is not None) else torch.float32
-    if first_layer is not None and a_in.dtype == torch.float32 and cin <= 8 and ops.pointnet_in_ok(cin, cout):
+    if isinstance(a_in, ops.SplitImage):
+        # fp16x3 mode: both operands as [hi | lo] images, three bf16 MFMA passes, fp32 result
+        w_img = ops.split_f16(W2d)
+        if training:
+            _WSPLIT_T_CACHE[W2d.data_ptr()] = ops.split_f16(W2d, transpose=True)      # the dgrad's operand
+        y = ops.gemm_split3(a_in, w_img, KC, rows, cout, cin, colstats=stats, tail=tail)
+    elif first_layer is not None and a_in.dtype == torch.float32 and cin <= 8 and ops.pointnet_in_ok(cin, cout):
         # raw points -> first PointNet layer: C-wide contraction, HBM-bound streaming kernel
         y = ops.pointnet_in_fwd(a_in, W2d, None, out_dtype, stats, tail=tail)
     elif use_bf16:
@@ -164,6 +177,11 @@ def pointnet_forward(xp2d, layers, training, mode, pool_rows=0):
     saves = []
     a = xp2d
     nl = len(layers)
+    # fp16x3 mode: the activations between the layers are [hi | lo] images when every later product is one the
+    # LDS-DMA kernel serves (whole 256-tiles); else the layer stack runs in exact fp32
+    split = mode == "fp16x3" and nl > 1 and all(
+        ops.gemm_split3_supported(xp2d.shape[0], l.module[0].weight.shape[0], l.module[0].weight.shape[1])
+        and l.module[0].weight.shape[1] % 256 == 0 for l in layers[1:])
     for li, layer in enumerate(layers):
         conv, bn = layer.module[0], layer.module[1]
         cout, cin = conv.weight.shape[0], conv.weight.shape[1]
@@ -187,7 +205,8 @@ def pointnet_forward(xp2d, layers, training, mode, pool_rows=0):
             s.a_in, s.col, s.y, s.scale, s.shift, s.mean, s.rstd = a, None, None, scale, shift, mean, rstd
             s.rows, s.cin, s.cout, s.dil = count, cin, cout, 0
             saves.append(s)
-            a = ops.pointnet_in_apply(a, W2d, scale, shift, torch.bfloat16 if mode == "bf16" else torch.float32)
+            a = ops.pointnet_in_apply(a, W2d, scale, shift, torch.bfloat16 if mode == "bf16" else
+                                      (ops.SplitImage.dtype if split else torch.float32))
             continue
         last_pool = li == nl - 1 and pool_rows
         if (_FUSE_EVAL_EPILOGUE and not training and mode == "bf16" and a.dtype == torch.bfloat16
@@ -217,7 +236,7 @@ def pointnet_forward(xp2d, layers, training, mode, pool_rows=0):
             else:
                 out = ops.bn_act_meanpool_fwd(y, scale, shift, y.shape[0] // pool_rows, pool_rows)
             return out, saves
-        a = ops.bn_act_fwd(y, scale, shift)
+        a = ops.bn_act_fwd_split(y, scale, shift) if (split and li < nl - 1) else ops.bn_act_fwd(y, scale, shift)
     return a, saves
 
 
@@ -329,14 +348,22 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
             ops.bn_act_bwd_stats(y, s.scale, s.shift, s.mean, s.rstd, da=da, dpool=dpool,
                                  group_rows=group_rows, pool_scale=pool_scale, tail=tail)
         coef, dgamma, dbeta = tail.out
-        dy = ops.bn_bwd_dy_fused(y, s.scale, s.shift, coef, da=da, dpool=dpool, group_rows=group_rows,
-                                 pool_scale=pool_scale, out=da)
+        if isinstance(lhs, ops.SplitImage):
+            # fp16x3 mode: dy only feeds the two products below -> written as its [hi | lo] image
+            dy = ops.bn_bwd_dy_fused_split(y, s.scale, s.shift, coef, da=da, dpool=dpool, group_rows=group_rows,
+                                           pool_scale=pool_scale)
+        else:
+            dy = ops.bn_bwd_dy_fused(y, s.scale, s.shift, coef, da=da, dpool=dpool, group_rows=group_rows,
+                                     pool_scale=pool_scale, out=da)
     K = lhs.shape[1]
     dW_out = outs[0].view(cout, K) if outs else None
     # dW[cout, K] = dy^T . lhs   (contraction over the rows: both operands row-contiguous)
     wgrad_bf16 = (mode == "bf16" and dy.dtype == torch.bfloat16 and lhs.dtype == torch.bfloat16
                   and cout >= 256 and K >= 128 and cout % 8 == 0 and K % 8 == 0)
-    if lhs.dtype == torch.float32 and K <= 8 and s.col is None and ops.pointnet_in_ok(K, cout):
+    if isinstance(dy, ops.SplitImage):
+        sk = ops.pick_split_k(cout, K, 3 * rows_local, target_blocks=256, bk=64, tile=256)
+        dW = ops.gemm_slabs_split3(dy, lhs, cout, K, rows_local, sk, out=dW_out)
+    elif lhs.dtype == torch.float32 and K <= 8 and s.col is None and ops.pointnet_in_ok(K, cout):
         dW = ops.pointnet_in_wgrad(dy, lhs, out=dW_out, out_is_zero=True)
     elif wgrad_bf16:
         sk = ops.pick_split_k(cout, K, rows_local, target_blocks=256, bk=64, tile=256)
@@ -358,6 +385,11 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
         d_lhs = dgrad_fn(dy)              # the caller's own adjoint (temporal block: implicit col2im)
         if isinstance(d_lhs, tuple):
             d_lhs = d_lhs[0]
+    elif need_dinput and isinstance(dy, ops.SplitImage):
+        wt_img = _WSPLIT_T_CACHE.pop(W2d.data_ptr(), None)            # [K, 2 cout] image of W^T made by the forward
+        if wt_img is None or tuple(wt_img.shape) != (K, cout):
+            wt_img = ops.split_f16(W2d, transpose=True)
+        d_lhs = ops.gemm_split3(dy, wt_img, KC, rows_local, K, cout)
     elif need_dinput:
         if mode == "bf16" and dy.dtype == torch.bfloat16 and cout % 8 == 0:
             Wt = _W16_CACHE.pop(W2d.data_ptr(), None)      # bf16 [K, cout] made by the forward pass

@@ -12,6 +12,8 @@ import torch
 from . import _lib
 from ._lib import ACT_ELU, ACT_NONE, KC, PCAA_BF16, PCAA_F32, RC, check
 
+PCAA_SPLIT_F16 = 2      # include/pcaa_hip.h
+
 NREP = 16          # replicas of a BatchNorm statistics row (spreads fp64 atomics)
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -460,6 +462,123 @@ def gemm_dgrad_bn(dy, Wt, y, scale, shift, mean, rstd, points=None, W1=None, tai
     return dz, stats
 
 
+# ------------------------------------------------------------------ split-operand parity mode (pcaa_gemm_split3)
+# power-of-two image scales that keep each kind of tensor in fp16's normal range (|x| in 6e-5 .. 65504)
+SPLIT_SCALE_ACT = 1.0            # activations after BatchNorm + ELU: O(1)
+SPLIT_SCALE_WEIGHT = 256.0       # weights ~ 1/sqrt(fan_in): their lo halves would be fp16 subnormals unscaled
+SPLIT_SCALE_GRAD = 65536.0       # gradients of a batch-mean loss: 1e-8 .. 1e-2
+
+
+class SplitImage:
+    """The [hi | lo] fp16 image of an fp32 [rows, ch] tensor times ``scale`` (hi = fp16(s v), lo = fp16(s v - hi)):
+    ``img`` is fp16 [rows, 2 ch]; ``shape`` / ``device`` are those of the fp32 tensor it stands for."""
+    __slots__ = ("img", "rows", "ch", "scale")
+    dtype = "split_fp16"
+
+    def __init__(self, img, rows, ch, scale):
+        self.img, self.rows, self.ch, self.scale = img, rows, ch, float(scale)
+
+    @property
+    def shape(self):
+        return (self.rows, self.ch)
+
+    @property
+    def device(self):
+        return self.img.device
+
+    def float(self):
+        """the fp32 tensor the image stands for (tests)"""
+        return (self.img[:, :self.ch].float() + self.img[:, self.ch:].float()) / self.scale
+
+
+def split_image_empty(rows, ch, device, scale):
+    return SplitImage(torch.empty((rows, 2 * ch), dtype=torch.float16, device=device), rows, ch, scale)
+
+
+def split_f16(x2d, transpose=False, scale=SPLIT_SCALE_WEIGHT):
+    """fp32 [rows, ch] -> SplitImage of x2d (``transpose``: of x2d^T, without materialising the transpose)"""
+    _chk(x2d, "split_f16.x", torch.float32, 2)
+    rows, ch = x2d.shape
+    out = split_image_empty(ch, rows, x2d.device, scale) if transpose else split_image_empty(rows, ch, x2d.device, scale)
+    check(_lib.load().pcaa_split_f16(_p(x2d), _p(out.img), rows, ch, int(bool(transpose)), float(scale), _s()),
+          "pcaa_split_f16")
+    return out
+
+
+def gemm_split3_supported(M, N, K):
+    return bool(_lib.load().pcaa_gemm_split3_supported(int(M), int(N), int(K)))
+
+
+def gemm_split3(A, B, layout, M, N, K, colstats=None, tail=None, out=None):
+    """out[M,N] fp32 = A . B^T (layout KC: A [M,K], B [N,K]) or A^T . B (RC: A [K,M], B [K,N]) from SplitImages:
+    hi.hi + lo.hi + hi.lo on the f16 MFMA pipe, fp32 accumulate, rescaled by 1 / (A.scale B.scale)."""
+    ea = (M, K) if layout == KC else (K, M)
+    eb = (N, K) if layout == KC else (K, N)
+    if tuple(A.shape) != ea or tuple(B.shape) != eb:
+        raise ValueError(f"gemm_split3: operand shapes {A.shape} {B.shape} do not match M={M} N={N} K={K}")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    timer = TIMER
+    key = "gemm_bf16_dma_kernel<f32,split3>"
+    timer = timer if (timer is not None and timer.wants(key)) else None
+    if timer is not None:
+        ev = _begin_timing(key)
+    if tail is not None:
+        tail.arm(colstats)
+    check(_lib.load().pcaa_gemm_split3(_p(A.img), _p(B.img), layout, A.img.stride(0), B.img.stride(0), _p(out), N, M, N, K,
+                                       _p(colstats), NREP, 1.0 / (A.scale * B.scale), _s()), "pcaa_gemm_split3")
+    if timer is not None:
+        ev.end()
+        timer.records.append((key, 3 * 2.0 * M * N * K, float(4 * (A.img.numel() // 2 + B.img.numel() // 2 + M * N)), ev))
+    if tail is not None:
+        tail.resolve(colstats)
+    return out
+
+
+def gemm_slabs_split3(A, B, M, N, K, split_k, out=None):
+    """The weight-gradient form (RC x RC: A [K,M], B [K,N] SplitImages, contraction over the K rows) with slab split-K."""
+    if tuple(A.shape) != (K, M) or tuple(B.shape) != (K, N):
+        raise ValueError("gemm_slabs_split3: operand shapes")
+    lib = _lib.load()
+    ns = lib.pcaa_gemm_split3_num_splits(K, int(split_k))
+    stride = M * N
+    slabs = torch.empty(ns * stride, dtype=torch.float32, device=A.device)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    timer = TIMER
+    key = "gemm_bf16_dma_kernel<f32,split3>"
+    timer = timer if (timer is not None and timer.wants(key)) else None
+    if timer is not None:
+        ev = _begin_timing(key)
+    check(lib.pcaa_gemm_slabs_split3(_p(A.img), _p(B.img), RC, A.img.stride(0), B.img.stride(0), _p(slabs), stride, M, N, K,
+                                     int(split_k), 1.0 / (A.scale * B.scale), _s()), "pcaa_gemm_slabs_split3")
+    if timer is not None:
+        ev.end()
+        timer.records.append((key, 3 * 2.0 * M * N * K, float(4 * (A.img.numel() // 2 + B.img.numel() // 2) + ns * stride * 4), ev))
+    check(lib.pcaa_splitk_reduce(_p(slabs), ns, stride, stride, _p(out), 0, _s()), "pcaa_splitk_reduce")
+    return out
+
+
+def bn_act_fwd_split(y, scale, shift):
+    """a = ELU(y*scale+shift) as a SplitImage (fp32 y)"""
+    _chk(y, "bn_act_fwd_split.y", torch.float32, 2)
+    a = split_image_empty(y.shape[0], y.shape[1], y.device, SPLIT_SCALE_ACT)
+    check(_lib.load().pcaa_bn_act_fwd_split(_p(y), _p(a.img), _p(scale), _p(shift), y.shape[0], y.shape[1], a.scale, _s()),
+          "pcaa_bn_act_fwd_split")
+    return a
+
+
+def bn_bwd_dy_fused_split(y, scale, shift, coef, *, da=None, dpool=None, group_rows=0, pool_scale=1.0):
+    """bn_bwd_dy_fused with dy written as a SplitImage (fp32 y / da)"""
+    _chk(y, "bn_bwd_dy_fused_split.y", torch.float32, 2)
+    rows, ch = y.shape
+    dy = split_image_empty(rows, ch, y.device, SPLIT_SCALE_GRAD)
+    check(_lib.load().pcaa_bn_bwd_dy_fused_split(_p(da), _p(dpool), int(group_rows), float(pool_scale), _p(y), _p(dy.img),
+                                                 _p(scale), _p(shift), _p(coef), rows, ch, dy.scale, _s()),
+          "pcaa_bn_bwd_dy_fused_split")
+    return dy
+
+
 def pick_split_k(M, N, K, target_blocks=1024, bk=32, tile=128):
     tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
     if tiles >= target_blocks:
@@ -518,6 +637,11 @@ def pointnet_in_apply(x2d, W2d, scale, shift, out_dtype):
     cout = W2d.shape[0]
     if W2d.shape[1] != C or not pointnet_in_ok(C, cout):
         raise ValueError(f"pointnet_in_apply: unsupported shape C={C} cout={cout}")
+    if out_dtype == SplitImage.dtype:
+        a = split_image_empty(P, cout, x2d.device, SPLIT_SCALE_ACT)
+        check(_lib.load().pcaa_pointnet_in_apply(_p(x2d), C, _p(W2d), _p(scale), _p(shift), _p(a.img), PCAA_SPLIT_F16, P,
+                                                 cout, _s()), "pcaa_pointnet_in_apply(split)")
+        return a
     a = torch.empty((P, cout), dtype=out_dtype, device=x2d.device)
     check(_lib.load().pcaa_pointnet_in_apply(_p(x2d), C, _p(W2d), _p(scale), _p(shift), _p(a), _dt(a), P, cout, _s()),
           "pcaa_pointnet_in_apply")

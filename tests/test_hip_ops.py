@@ -733,3 +733,73 @@ def test_dtc_conv_dgrad_fused_bn_halves(B, T, cin, cout, d):
     assert torch.allclose(st[0], dz_ref.sum(0), rtol=1e-4, atol=1e-5 * scl * (B * T) ** 0.5)
     assert torch.allclose(st[1], (dz_ref * yhat).sum(0), rtol=1e-4, atol=1e-5 * scl * (B * T) ** 0.5 * yhat.abs().max().item())
 
+
+
+# ---------------------------------------------------------------------------------------------------------
+# split-fp16 products (round 3, precision "fp16x3")
+# ---------------------------------------------------------------------------------------------------------
+def test_gemm_split3_vs_fp64_both_layouts():
+    """pcaa_gemm_split3 / pcaa_gemm_slabs_split3 on [hi | lo] fp16 operand images: hi.hi + lo.hi + hi.lo must sit at
+    the fp32 level from the fp64 product (plain bf16 operands: ~2e-3; a bf16 pair: 4.5e-6, measured in round 3)."""
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(11)
+    M, N, K = 2048, 512, 1024
+    A = torch.randn(M, K, device=dev, generator=g)
+    B = torch.randn(N, K, device=dev, generator=g) * 0.05
+    ai, bi = ops.split_f16(A, scale=ops.SPLIT_SCALE_ACT), ops.split_f16(B)
+    assert tuple(ai.img.shape) == (M, 2 * K) and ai.img.dtype == torch.float16
+    # the image is exactly hi | lo
+    hi = A.to(torch.float16)
+    assert torch.equal(ai.img[:, :K], hi) and torch.equal(ai.img[:, K:], (A - hi.float()).to(torch.float16))
+    assert (bi.float() - B).abs().max().item() <= 1e-6 * B.abs().max().item()
+    stats = ops.new_stats(N, dev)
+    C = ops.gemm_split3(ai, bi, KC, M, N, K, colstats=stats)
+    ref = A.double() @ B.double().t()
+    err = ((C.double() - ref).abs().max() / ref.abs().max()).item()
+    plain = ((A.to(torch.bfloat16).float() @ B.to(torch.bfloat16).float().t()).double() - ref).abs().max() / ref.abs().max()
+    f32 = ((A @ B.t()).double() - ref).abs().max() / ref.abs().max()
+    print(f"split3 KC: rel err {err:.2e} (plain bf16 operands {plain.item():.2e}, torch fp32 matmul {f32.item():.2e})")
+    assert err <= 2e-6
+    assert torch.allclose(stats.sum(0)[0], C.double().sum(0), rtol=1e-6, atol=1e-3)
+    assert torch.allclose(stats.sum(0)[1], (C.double() ** 2).sum(0), rtol=1e-6, atol=1e-3)
+    # transposed image of a weight matrix (the dgrad's operand)
+    bt = ops.split_f16(B, transpose=True)
+    assert tuple(bt.shape) == (K, N) and (bt.float() - B.t()).abs().max().item() <= 1e-6 * B.abs().max().item()
+    # RC x RC (weight gradient: contraction over the rows), slab split-K; gradients are small numbers
+    P, co, ci = 64 * 256, 512, 256
+    dy = torch.randn(P, co, device=dev, generator=g) * 1e-5
+    a = torch.randn(P, ci, device=dev, generator=g)
+    dW = ops.gemm_slabs_split3(ops.split_f16(dy, scale=ops.SPLIT_SCALE_GRAD), ops.split_f16(a, scale=ops.SPLIT_SCALE_ACT),
+                               co, ci, P, 8)
+    refw = dy.double().t() @ a.double()
+    errw = ((dW.double() - refw).abs().max() / refw.abs().max()).item()
+    print(f"split3 RC (slab split-K): rel err {errw:.2e}")
+    assert errw <= 2e-6
+
+
+def test_split_image_producers():
+    """bn_act_fwd_split / bn_bwd_dy_fused_split / pointnet_in_apply(split) write the [hi | lo] image of what their fp32
+    forms compute"""
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(12)
+    rows, ch = 3840, 512
+    y = torch.randn(rows, ch, device=dev, generator=g)
+    scale, shift = torch.rand(ch, device=dev, generator=g) + 0.5, torch.randn(ch, device=dev, generator=g) * 0.1
+    a32 = ops.bn_act_fwd(y, scale, shift)
+    ai = ops.bn_act_fwd_split(y, scale, shift)
+    hi = a32.to(torch.float16)
+    assert torch.equal(ai.img[:, :ch], hi) and torch.equal(ai.img[:, ch:], (a32 - hi.float()).to(torch.float16))
+    coef = torch.randn(3, ch, device=dev, generator=g)
+    da = torch.randn(rows, ch, device=dev, generator=g) * 1e-4
+    dy32 = ops.bn_bwd_dy_fused(y, scale, shift, coef * 1e-4, da=da.clone())
+    dyi = ops.bn_bwd_dy_fused_split(y, scale, shift, coef * 1e-4, da=da)
+    assert (dyi.float() - dy32).abs().max().item() <= 2e-6 * dy32.abs().max().item()
+    dpool = torch.randn(rows // 128, ch, device=dev, generator=g) * 1e-3
+    dy32p = ops.bn_bwd_dy_fused(y, scale, shift, coef * 1e-4, dpool=dpool, group_rows=128, pool_scale=1 / 128)
+    dyip = ops.bn_bwd_dy_fused_split(y, scale, shift, coef * 1e-4, dpool=dpool, group_rows=128, pool_scale=1 / 128)
+    assert (dyip.float() - dy32p).abs().max().item() <= 2e-6 * dy32p.abs().max().item()
+    x = torch.randn(rows, 4, device=dev, generator=g)
+    W = torch.randn(ch, 4, device=dev, generator=g) * 0.5
+    a1 = ops.pointnet_in_apply(x, W, scale, shift, torch.float32)
+    a1i = ops.pointnet_in_apply(x, W, scale, shift, ops.SplitImage.dtype)
+    assert (a1i.float() - a1).abs().max().item() <= 1e-6 * a1.abs().max().item()
