@@ -22,6 +22,7 @@
 #include <hip/hip_ext.h>
 
 #include <cstddef>
+#include <mutex>
 #include <type_traits>
 
 #include "gemm_common.h"
@@ -1103,42 +1104,52 @@ bool launch_dma_inst(const GemmParams& p, dim3 grid, hipStream_t s) {
 // not get every CU at once -- 8 CUs held by another stream's kernel for its duration, tools/gemm_contention.py -- took
 // 0.83 ms instead of 0.49 (the late workgroups run their whole share afterwards); with tickets 0.50-0.61 ms for 8-64
 // CUs held, i.e. the ideal 256 / (256 - H).  Price: one LDS hand-off + barrier per tile, 1-5 % on an idle chip.
+static std::mutex g_sched_mutex;
+
 static unsigned persistent_grid(long ntiles) {
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-      n = 256;
-    ncu = n >= 8 ? n / 8 * 8 : 8;
+  // per device (round-3 advisor finding: the count was cached for whichever device came first)
+  static int ncu[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  std::lock_guard<std::mutex> lock(g_sched_mutex);
+  if (ncu[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    ncu[dev] = n >= 8 ? n / 8 * 8 : 8;
   }
-  return (unsigned)(ntiles < ncu ? ntiles : ncu);
+  return (unsigned)(ntiles < ncu[dev] ? ntiles : ncu[dev]);
 }
 
-// Ticket counters of the tile loop: 16 ints per stream that launches these kernels (launches of one stream run in
-// order, and the last workgroup of a launch leaves its counters at zero).  Allocated once; never during a stream
-// capture (a captured first launch walks fixed shares instead).
+// Ticket counters of the tile loop: 16 ints per (device, stream) that launches these kernels (launches of one stream
+// run in order, and the last workgroup of a launch leaves its counters at zero).  Allocated per device on first use,
+// never during a stream capture (a captured first launch walks fixed shares instead).  128 slots per device: torch
+// hands out its side streams from a pool of 32 + 32, so a process that builds trainer after trainer (bench.py's legs)
+// keeps meeting new stream handles -- with 16 slots the fifth trainer's GEMMs silently fell back to fixed shares and
+// ran 5 % slower beside the side-stream Adam (round 3).  Guarded by a mutex: the autograd engine's thread launches too.
 static int* sched_slot(hipStream_t s) {
-  constexpr int SLOTS = 16;
-  static int* base = nullptr;
-  static hipStream_t owner[SLOTS];
-  static int used = 0;
-  static bool failed = false;
-  if (failed) return nullptr;
-  if (base == nullptr) {
+  constexpr int SLOTS = 128, DEVS = 64;
+  struct Table { int* base; hipStream_t owner[SLOTS]; int used; bool failed; };
+  static Table tables[DEVS] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DEVS) return nullptr;
+  std::lock_guard<std::mutex> lock(g_sched_mutex);
+  Table& t = tables[dev];
+  if (t.failed) return nullptr;
+  if (t.base == nullptr) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&base), SLOTS * 16 * sizeof(int)) != hipSuccess ||
-        hipMemset(base, 0, SLOTS * 16 * sizeof(int)) != hipSuccess) {
-      base = nullptr;
-      failed = true;
+    if (hipMalloc(reinterpret_cast<void**>(&t.base), SLOTS * 16 * sizeof(int)) != hipSuccess ||
+        hipMemset(t.base, 0, SLOTS * 16 * sizeof(int)) != hipSuccess) {
+      t.base = nullptr;
+      t.failed = true;
       return nullptr;
     }
   }
-  for (int i = 0; i < used; ++i)
-    if (owner[i] == s) return base + 16 * i;
-  if (used == SLOTS) return nullptr;
-  owner[used] = s;
-  return base + 16 * used++;
+  for (int i = 0; i < t.used; ++i)
+    if (t.owner[i] == s) return t.base + 16 * i;
+  if (t.used == SLOTS) return nullptr;
+  t.owner[t.used] = s;
+  return t.base + 16 * t.used++;
 }
 
 template <typename TC, int ALAY, int BLAY, int EPI>

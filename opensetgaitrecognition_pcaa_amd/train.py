@@ -31,6 +31,19 @@ from .utils import sample_distant_points, save_model
 _ALIGN = 64  # floats; keeps every parameter view 256-B aligned inside the flat buffers
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device):
+    """(adam, critic, wgrad) streams of ``device``, created on first use"""
+    if device.type != "cuda":
+        return None, None, None
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = tuple(torch.cuda.Stream(device=device) for _ in range(3))
+    return _SIDE_STREAMS[key]
+
+
 class StepCount:
     """An optimizer step count on the device (int32) with the two bias-correction scalars Adam derives from it
     (``pcaa_adam_advance``), plus its host mirror."""
@@ -372,11 +385,13 @@ class PCAATrainer:
         # measured (round 1, same box, ms/step): no side stream 8.08-8.26 | beside the temporal-conv/head backward
         # 7.90 (256 blocks), 7.99 (128) | beside the PointNet backward GEMMs 8.29 (256) .. 9.03 (32): the GEMMs lose
         # more to the extra HBM stream than the update costs on its own; 256 blocks 6.63 | 128: 6.91 | 512: 6.72 | 1024: 6.76
-        self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        # second stream for the critic branch of the step (see step())
-        self._aux = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        # third stream: the small weight-gradient products of the temporal block / heads (functional._WGRAD_STREAM)
-        self._wg = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        # The three side streams are made ONCE per device and shared by every trainer of the process: HIP maps streams
+        # onto a few hardware queues round-robin, and a later trainer's fresh streams can land on the main stream's queue
+        # (or on each other's) -- the fourth trainer built in one process ran 6.0 instead of 5.7 ms/step (round 3,
+        # tools/leg_check.py).  Trainers of one process never step concurrently, so sharing is safe.
+        self._side, self._aux, self._wg = _side_streams(self.device)
+        # _side: the decoder's Adam; _aux: the critic branch of the step (see step()); _wg: the small weight-gradient
+        # products of the temporal block / heads (functional._WGRAD_STREAM)
         if self._zero:
             n = (self.flat_g.total - self._dec_start) // self._zero_chunks
             self._zero_len = n                                            # floats per chunk (divisible by world * 64)
