@@ -5,9 +5,9 @@
 tag=$1
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_${tag}_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-parity-mode --no-batcher-leg > $R/gpurun_out/pmc_${tag}_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_${tag}_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-parity-mode --no-batcher-leg --no-extra-legs --windows 1 > $R/gpurun_out/pmc_${tag}_fetch.log 2>&1
 echo fetch_exit=$?
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_${tag}_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-parity-mode --no-batcher-leg > $R/gpurun_out/pmc_${tag}_write.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_${tag}_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-parity-mode --no-batcher-leg --no-extra-legs --windows 1 > $R/gpurun_out/pmc_${tag}_write.log 2>&1
 echo write_exit=$?
 python $R/tools/pmc_summary.py $R/gpurun_out $tag $R/gpurun_out/${tag}_pmc_summary.json
 # drop the bulky raw traces from what gets merged back (summary json + logs stay)
