@@ -40,7 +40,19 @@ def _side_streams(device):
         return None, None, None
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = tuple(torch.cuda.Stream(device=device) for _ in range(3))
+        # Three streams beside the main one.  Two leaner layouts were measured on one box (round 3, ms/step single |
+        # forced 1-rank RCCL): the critic branch sharing the weight-gradient stream 5.74 | 6.50, sharing the Adam stream
+        # (both idle while the critic runs) 5.72 | 6.38, separate streams 5.67 | 6.10 -- although a data-parallel process
+        # then has five streams (RCCL brings its own) on the device's four hardware queues and rocprofv3 shows the
+        # critic on the main stream's queue.  PCAA_STREAM_LAYOUT keeps the other two selectable for re-measurement.
+        side, small = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+        layout = os.environ.get("PCAA_STREAM_LAYOUT", "separate")
+        if layout == "critic_on_wgrad":
+            _SIDE_STREAMS[key] = (side, small, small)
+        elif layout == "critic_on_side":
+            _SIDE_STREAMS[key] = (side, side, small)
+        else:
+            _SIDE_STREAMS[key] = (side, small, torch.cuda.Stream(device=device))
     return _SIDE_STREAMS[key]
 
 
