@@ -201,8 +201,9 @@ class PCAATrainer:
                  force_collectives=False, fused_decoder_update=True):
         """``fused_decoder_update`` (single process, bf16 mode): the decoder's wide weight gradients are formed and
         consumed by one kernel per layer that applies Adam in place (pcaa_skinny_linear_wgrad_adam) -- those
-        gradients never exist in ``flat_g.g``; pass False to keep them (gradient inspection, parity tests: the
-        resulting parameters are bit-identical either way).
+        gradients never exist in ``flat_g.g`` (``self.gradless_ranges`` lists the [lo, hi) element ranges the last step
+        left without one); pass False to keep them (gradient inspection, parity tests: the resulting parameters are
+        bit-identical either way).
         Data-parallel options (``process_group`` given): ``dp_zero`` True = sharded decoder optimizer
         (reduce-scatter, Adam on 1/world of the decoder, all-gather; default off); ``grad_compress="bf16"`` = the decoder's gradient buckets cross the wire as bf16 (half the
         bytes; fp32 master gradients, moments and weights; each bucket is rounded once before the sum and the sum
@@ -259,6 +260,7 @@ class PCAATrainer:
                 torch.nn.Linear(self.L * 2, self.L), torch.nn.ELU()).to(self.device).float()
         self.discriminator_means = None
         self._flat_ready = False
+        self.gradless_ranges = []      # see _step: ranges of flat_g.g the last step left without a gradient
         self._graphs = {}
         # raised on the device by a label outside [0, K) (torch's CrossEntropyLoss raises there); read by check()
         self._err = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -683,6 +685,11 @@ class PCAATrainer:
                 if F_hip._skinny(mode, B, view16.shape[0], view16.shape[1]) and view16.numel() >= self._COMPRESS_MIN:
                     dec_grads[f"dense{layer}.weight"] = view16
                     self._g16_direct.add(lo)
+        # [lo, hi) ranges of flat_g.g that hold NO gradient after this step: the fused weight-gradient + Adam kernels and
+        # the bf16-direct wire images never write the fp32 gradient there (round-2 advisor finding: a consumer of
+        # grad_views -- clipping, norm logging -- must skip them or construct the trainer with fused_decoder_update=False)
+        self.gradless_ranges = sorted(fused_ranges) + sorted(
+            (lo, lo + v.numel()) for lo, v in (self._dec_grads16.values() if self._g16_direct else ()) if lo in self._g16_direct)
         if self.decoder_projection_head is not None:
             # the head's own backward (dh -> dsup, dW, db) runs inside the heads' backward launch below
             _, dh = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=dec_grads, mode=mode,
