@@ -147,6 +147,10 @@ int pcaa_points_moments_size(void);
 int pcaa_points_moments(const float* x, int C, long P, double* mom, void* stream);
 int pcaa_pointnet_in_bwd_combine(const float* G, const float* W, const double* mom, const float* coef,
                                  float* dW, int cout, int C, void* stream);
+/* The same moments give the layer's forward BatchNorm statistics without a pass over the points (sum y = W.sum x,
+ * sum y^2 = W^T (x^T x) W per channel): arm the forward finalize on `mom` (pcaa_bn_tail_arm_fwd with stats = mom,
+ * count = P, any non-null counter), then this call writes scale / shift / mean / rstd and the running statistics. */
+int pcaa_pointnet_in_moment_stats(const double* mom, const float* W, int C, int cout, void* stream);
 int pcaa_pointnet_in_bwd_wgrad(const void* da, int dtype, const float* x, int C, const float* W,
                                const float* scale, const float* shift, const float* coef, float* dW,
                                long P, int cout, int dz_is_pre /* da already is dz (pcaa_gemm_dgrad_bn) */,

@@ -48,6 +48,35 @@ __device__ __forceinline__ double bn_tail_ld(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// the finalize of ONE channel from its two reduced sums (== bn_finalize_kernel / bn_bwd_finalize_kernel, elementwise.hip)
+__device__ __forceinline__ void bn_tail_channel(const BnTail& t, int c, double s1, double s2) {
+  const int ch = t.ch;
+  if (t.kind == 1) {
+    const double m0 = s1 * t.inv_count;
+    double var = s2 * t.inv_count - m0 * m0;
+    if (var < 0.0) var = 0.0;
+    const double mean = m0 + (t.lin_bias ? (double)t.lin_bias[c] : 0.0);
+    const double rstd = 1.0 / sqrt(var + (double)t.eps);
+    t.scale[c] = (float)((double)t.gamma[c] * rstd);
+    t.shift[c] = (float)((double)t.beta[c] - m0 * (double)t.gamma[c] * rstd);
+    t.mean[c] = (float)m0;
+    t.rstd[c] = (float)rstd;
+    if (t.running_mean != nullptr) {
+      t.running_mean[c] = (1.f - t.momentum) * t.running_mean[c] + t.momentum * (float)mean;
+      t.running_var[c] = (1.f - t.momentum) * t.running_var[c] + t.momentum * (float)(var * t.unbias);
+    }
+  } else {
+    if (t.dbeta) t.dbeta[c] = (float)s1;
+    if (t.dgamma) t.dgamma[c] = (float)s2;
+    const double c1 = s1 * t.inv_count, c2 = s2 * t.inv_count;
+    const double rs = t.rstd[c], mu = t.mean[c];
+    const double g = (double)t.gamma[c] * rs;
+    t.coef[0 * ch + c] = (float)g;
+    t.coef[1 * ch + c] = (float)(-g * c2 * rs);
+    t.coef[2 * ch + c] = (float)(-g * c1 + g * c2 * rs * mu);
+  }
+}
+
 // Call from EVERY thread of EVERY workgroup of the launch, after the thread's last statistics atomic has been issued
 // (uniform control flow).  ``flag`` is one int of LDS that nothing else uses until the call returns.
 __device__ __forceinline__ void bn_tail_run(const BnTail& t, int tid, int nthreads, unsigned nblocks, int* flag) {
@@ -90,31 +119,6 @@ __device__ __forceinline__ void bn_tail_run(const BnTail& t, int tid, int nthrea
       s1 += bn_tail_ld(t.stats + ((long)r * 2 + 0) * ch + c);
       s2 += bn_tail_ld(t.stats + ((long)r * 2 + 1) * ch + c);
     }
-    if (t.kind == 1) {
-      // == bn_finalize_kernel (elementwise.hip)
-      const double m0 = s1 * t.inv_count;
-      double var = s2 * t.inv_count - m0 * m0;
-      if (var < 0.0) var = 0.0;
-      const double mean = m0 + (t.lin_bias ? (double)t.lin_bias[c] : 0.0);
-      const double rstd = 1.0 / sqrt(var + (double)t.eps);
-      t.scale[c] = (float)((double)t.gamma[c] * rstd);
-      t.shift[c] = (float)((double)t.beta[c] - m0 * (double)t.gamma[c] * rstd);
-      t.mean[c] = (float)m0;
-      t.rstd[c] = (float)rstd;
-      if (t.running_mean != nullptr) {
-        t.running_mean[c] = (1.f - t.momentum) * t.running_mean[c] + t.momentum * (float)mean;
-        t.running_var[c] = (1.f - t.momentum) * t.running_var[c] + t.momentum * (float)(var * t.unbias);
-      }
-    } else {
-      // == bn_bwd_finalize_kernel (elementwise.hip)
-      if (t.dbeta) t.dbeta[c] = (float)s1;
-      if (t.dgamma) t.dgamma[c] = (float)s2;
-      const double c1 = s1 * t.inv_count, c2 = s2 * t.inv_count;
-      const double rs = t.rstd[c], mu = t.mean[c];
-      const double g = (double)t.gamma[c] * rs;
-      t.coef[0 * ch + c] = (float)g;
-      t.coef[1 * ch + c] = (float)(-g * c2 * rs);
-      t.coef[2 * ch + c] = (float)(-g * c1 + g * c2 * rs * mu);
-    }
+    bn_tail_channel(t, c, s1, s2);
   }
 }

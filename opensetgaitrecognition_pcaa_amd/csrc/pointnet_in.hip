@@ -232,43 +232,73 @@ __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restric
   if (MODE == 0 || MODE == 3) bn_tail_run(tail, threadIdx.x, 256, gridDim.x, &tail_flag);
 }
 
-// Second moments of the points for the one-pass backward: mom[k*MAXC + c] += sum_p x[p][k] x[p][c] (k, c < C),
-// mom[MAXC*MAXC + c] += sum_p x[p][c]; fp64 atomics, one set per workgroup.  x is 16 B per point: a 4 MB read.
+// Second moments of the points: mom[k*MAXC + c] += sum_p x[p][k] x[p][c] (k, c < C), mom[MAXC*MAXC + c] += sum_p x[p][c];
+// fp64 atomics, one set per workgroup.  x is 16 B per point: a 4 MB read.  They serve the forward (the first layer's
+// BatchNorm statistics follow from them: y = x.W^T is linear) and the one-pass backward.
+template <int CP>
 __global__ __launch_bounds__(256) void points_moments_kernel(const float* __restrict__ x, int C, long P,
                                                              double* __restrict__ mom) {
-  __shared__ double red[4][MAXC * MAXC + MAXC];
-  float a[MAXC][MAXC], sm[MAXC];
+  constexpr int NV = CP * (CP + 1) / 2 + CP;           // upper triangle + sums
+  __shared__ float red[256][NV + 1];
+  float a[NV];
 #pragma unroll
-  for (int k = 0; k < MAXC; ++k) {
-    sm[k] = 0.f;
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) a[k][c] = 0.f;
-  }
+  for (int i = 0; i < NV; ++i) a[i] = 0.f;
   for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < P; r += (long)gridDim.x * 256) {
-    float xv[MAXC];
+    float xv[CP];
+    if (CP == 4 && C == 4) {
+      const f32x4 v = load4(x + r * 4);
+      xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
+    } else {
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) xv[c] = c < C ? x[r * C + c] : 0.f;
-#pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-      sm[k] += xv[k];
-#pragma unroll
-      for (int c = 0; c < MAXC; ++c) a[k][c] = fmaf(xv[k], xv[c], a[k][c]);
+      for (int c = 0; c < CP; ++c) xv[c] = c < C ? x[r * C + c] : 0.f;
     }
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int i = 0;
 #pragma unroll
-  for (int k = 0; k < MAXC; ++k) {
+    for (int k = 0; k < CP; ++k)
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-      const double v = wave_sum_d((double)a[k][c]);
-      if (lane == 0) red[wave][k * MAXC + c] = v;
-    }
-    const double v = wave_sum_d((double)sm[k]);
-    if (lane == 0) red[wave][MAXC * MAXC + k] = v;
+      for (int c = k; c < CP; ++c) { a[i] = fmaf(xv[k], xv[c], a[i]); ++i; }
+#pragma unroll
+    for (int c = 0; c < CP; ++c) a[i + c] += xv[c];
   }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) red[threadIdx.x][i] = a[i];
   __syncthreads();
-  for (int o = threadIdx.x; o < MAXC * MAXC + MAXC; o += 256)
-    unsafeAtomicAdd(&mom[o], (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]));
+  if (threadIdx.x < NV) {
+    double v = 0.0;
+    for (int t = 0; t < 256; ++t) v += (double)red[t][threadIdx.x];
+    // scatter the triangle entry to both symmetric positions of the MAXC x MAXC layout
+    int i = threadIdx.x;
+    if (i < CP * (CP + 1) / 2) {
+      int k = 0;
+      while (i >= CP - k) { i -= CP - k; ++k; }
+      const int c = k + i;
+      unsafeAtomicAdd(&mom[k * MAXC + c], v);
+      if (c != k) unsafeAtomicAdd(&mom[c * MAXC + k], v);
+    } else {
+      unsafeAtomicAdd(&mom[MAXC * MAXC + (i - CP * (CP + 1) / 2)], v);
+    }
+  }
+}
+
+// The first layer's BatchNorm coefficients straight from the moments (round 3): y = x.W^T, so per output channel
+//   sum_p y = W[o] . sum_p x,    sum_p y^2 = W[o]^T (x^T x) W[o]
+// -- no pass over the points at all.  One thread per channel, fp64; `t` carries the finalize's arguments (bn_tail.h;
+// no arrival counter is involved: this launch is the only writer).
+__global__ void pointnet_in_moment_stats_kernel(const double* __restrict__ mom, const float* __restrict__ W, int C,
+                                                BnTail t) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o == 0 && t.kind == 1 && t.nbt != nullptr) *t.nbt += 1;
+  if (o >= t.ch) return;
+  double w[MAXC];
+  for (int k = 0; k < MAXC; ++k) w[k] = k < C ? (double)W[o * C + k] : 0.0;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < C; ++k) {
+    s1 += w[k] * mom[MAXC * MAXC + k];
+    double row = 0.0;
+    for (int c = 0; c < C; ++c) row += mom[k * MAXC + c] * w[c];
+    s2 += w[k] * row;
+  }
+  bn_tail_channel(t, o, s1, s2);
 }
 
 // dW[o][c] = c0[o] G[o][c] + c1[o] sum_k W[o][k] XtX[k][c] + c2[o] sum_p x[p][c]     (fp64 combination)
@@ -498,8 +528,22 @@ extern "C" int pcaa_points_moments(const float* x, int C, long P, double* mom, v
   PCAA_CHECK_ARG(x && mom && C >= 1 && C <= MAXC && P >= 1, "pcaa_points_moments: bad args");
   long g = cdiv(P, 256 * 4);
   if (g > 512) g = 512;
-  hipLaunchKernelGGL(points_moments_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), x, C, P, mom);
+  if (C <= 4) hipLaunchKernelGGL(points_moments_kernel<4>, dim3((unsigned)g), dim3(256), 0, as_stream(stream), x, C, P, mom);
+  else hipLaunchKernelGGL(points_moments_kernel<8>, dim3((unsigned)g), dim3(256), 0, as_stream(stream), x, C, P, mom);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_points_moments");
+}
+
+/* BatchNorm coefficients of the first layer from the points' moments: takes the finalize armed by pcaa_bn_tail_arm_fwd
+ * (its `stats` argument must be `mom`: the armed tail is matched by that pointer) and runs it on sums derived from
+ * the moments instead of a statistics pass over the points. */
+extern "C" int pcaa_pointnet_in_moment_stats(const double* mom, const float* W, int C, int cout, void* stream) {
+  PCAA_CHECK_ARG(mom && W && C >= 1 && C <= MAXC && cout >= 1, "pcaa_pointnet_in_moment_stats: bad args");
+  const BnTail t = pcaa_take_bn_tail(mom);
+  PCAA_CHECK_ARG(t.kind == 1 && t.ch == cout, "pcaa_pointnet_in_moment_stats: arm the forward finalize on `mom` first "
+                 "(pcaa_bn_tail_arm_fwd)");
+  hipLaunchKernelGGL(pointnet_in_moment_stats_kernel, dim3((unsigned)cdiv(cout, 256)), dim3(256), 0, as_stream(stream), mom,
+                     W, C, t);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_moment_stats");
 }
 
 extern "C" int pcaa_pointnet_in_bwd_combine(const float* G, const float* W, const double* mom, const float* coef,

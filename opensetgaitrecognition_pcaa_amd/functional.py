@@ -117,10 +117,11 @@ def _point_major(x):
 # TemporalConvolutionBlock models.py:108-160)
 # ======================================================================
 class _LayerSave:
-    __slots__ = ("a_in", "col", "y", "scale", "shift", "mean", "rstd", "rows", "cin", "cout", "dil", "pool_e")
+    __slots__ = ("a_in", "col", "y", "scale", "shift", "mean", "rstd", "rows", "cin", "cout", "dil", "pool_e", "mom")
 
     def __init__(self):
         self.pool_e = None
+        self.mom = None
 
 
 def _linear_bn(a_in, W2d, lin_bias, bn, training, mode, first_layer):
@@ -191,7 +192,13 @@ def pointnet_forward(xp2d, layers, training, mode, pool_rows=0):
             # raw points -> first layer: y = x.W^T costs cin FMAs per element, less than reading it back, so
             # it is never stored: statistics pass, then a = ELU(BN(y)) straight from the points
             rows = a.shape[0]
-            if training:
+            mom = None
+            if training and _MOMENT_STATS and _sync_fn() is None and ops.TAILS["enabled"]:
+                # y = x.W^T is linear in the points: the layer's batch statistics follow from the points' C x C second
+                # moments (a 4 MB read) -- no statistics pass over [P, cout]; the backward reuses the moments
+                scale, shift, mean, rstd, mom = ops.pointnet_in_moment_coeffs(a, W2d, conv.bias, bn)
+                count = rows
+            elif training:
                 stats = ops.new_stats(cout, a.device)
                 tail = ops.BnTailFwd(rows, conv.bias, bn, cout, sync=_sync_fn())
                 ops.pointnet_in_fwd(a, W2d, None, None, stats, tail=tail)
@@ -204,6 +211,7 @@ def pointnet_forward(xp2d, layers, training, mode, pool_rows=0):
             s = _LayerSave()
             s.a_in, s.col, s.y, s.scale, s.shift, s.mean, s.rstd = a, None, None, scale, shift, mean, rstd
             s.rows, s.cin, s.cout, s.dil = count, cin, cout, 0
+            s.mom = mom
             saves.append(s)
             a = ops.pointnet_in_apply(a, W2d, scale, shift, torch.bfloat16 if mode == "bf16" else
                                       (ops.SplitImage.dtype if split else torch.float32))
@@ -294,6 +302,8 @@ class _on_wgrad_stream:
 # environment switches in round 1 and are plain constants now: the product has one path per shape.
 # PointNet weight gradients on the wgrad side stream: measured no change (they fill the chip either way) -> off.
 _BIG_WGRAD_ASIDE = False
+# ... but the split-K slab reductions that follow them (12 us each, three per step, needed only by Adam) do leave it
+_REDUCE_ASIDE = os.environ.get("PCAA_REDUCE_ASIDE", "1") != "0"
 _FUSE_DGRAD_BN = True
 # the same fusion into the dgrad above the FIRST layer (y rebuilt from the points in the epilogue; the kernel and
 # ops.gemm_dgrad_bn(points=...) exist and are tested) measured slower: the layer-2 dgrad went 0.195 -> 0.361 ms
@@ -301,6 +311,8 @@ _FUSE_DGRAD_BN = True
 _FUSE_DGRAD_POINTS = False
 # first PointNet layer, bf16 mode: one pass over the incoming gradient instead of two (ops.pointnet_in_bwd_onepass)
 _ONEPASS_IN_BWD = os.environ.get("PCAA_ONEPASS_IN_BWD", "1") != "0"
+# first PointNet layer, forward: BatchNorm statistics from the points' second moments instead of a pass over [P, cout]
+_MOMENT_STATS = os.environ.get("PCAA_MOMENT_STATS", "1") != "0"
 
 
 def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool_scale=1.0,
@@ -369,7 +381,9 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
         sk = ops.pick_split_k(cout, K, rows_local, target_blocks=256, bk=64, tile=256)
         with _on_wgrad_stream(dy, lhs) if (_BIG_WGRAD_ASIDE and dW_out is not None) else contextlib.nullcontext():
             if sk > 1:
-                dW = ops.gemm_slabs(dy, RC, lhs, RC, cout, K, rows_local, sk, out=dW_out, math=PCAA_BF16)
+                # the slab sum only feeds the optimizer: off the main stream (joined before the encoder's Adam)
+                dW = ops.gemm_slabs(dy, RC, lhs, RC, cout, K, rows_local, sk, out=dW_out, math=PCAA_BF16,
+                                    reduce_ctx=_on_wgrad_stream if (_REDUCE_ASIDE and dW_out is not None) else None)
             else:
                 dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, math=PCAA_BF16)
     else:
@@ -465,7 +479,7 @@ def pointnet_backward(saves, layers, mode, d_last=None, dpool=None, pool_rows=0,
                     # combination of G with the points' second moments (exact-fp32 mode keeps the two passes: there
                     # dy is formed per element before the contraction, as the oracle's autograd does)
                     dW = ops.pointnet_in_bwd_onepass(da, s.a_in, W2d, s.scale, s.shift, s.mean, s.rstd, tail,
-                                                     out=outs[0].view(s.cout, s.cin))
+                                                     mom=s.mom, out=outs[0].view(s.cout, s.cin))
                     coef, dg, db = tail.out
                     zb = gout[f"{prefix}{li + 1}.module.0.bias"] if gout is not None else torch.zeros_like(conv.bias)
                     grads.append({"module.0.weight": dW.view_as(conv.weight), "module.0.bias": zb,

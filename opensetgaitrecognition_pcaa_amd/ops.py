@@ -154,6 +154,15 @@ class StatsPool:
             self.buf[:self.off].zero_()
         self.off = 0
 
+    def take_raw(self, n):
+        """n zeroed doubles (16-B granular) from the pool, or None when it is full"""
+        n = (n + 1) // 2 * 2
+        if self.off + n > self.buf.numel():
+            return None
+        v = self.buf[self.off:self.off + n]
+        self.off += n
+        return v
+
     def take(self, ch):
         # + 2 doubles: the arrival counter of a finalize carried by the producer (BnTailFwd / BnTailBwd below), zeroed
         # with the statistics by begin(); 16-B granularity keeps every buffer aligned
@@ -335,7 +344,7 @@ def gemm(A, a_layout, B, b_layout, M, N, K, *, lda=None, ldb=None, out=None, out
 
 
 def gemm_slabs(A, a_layout, B, b_layout, M, N, K, split_k, out=None, accumulate=False, math=PCAA_BF16,
-               colstats=None, tail=None):
+               colstats=None, tail=None, reduce_ctx=None):
     """Split-K product without atomics: every split writes its partial [M,N] slab, a second
     launch sums the slabs into ``out`` (=|+=).  Used for the long-K weight gradients, where the
     atomic epilogue (256 KB of fp32 atomics per workgroup) cost as much as the MFMA loop."""
@@ -376,6 +385,13 @@ def gemm_slabs(A, a_layout, B, b_layout, M, N, K, split_k, out=None, accumulate=
               "pcaa_splitk_reduce_stats")
         if tail is not None:
             tail.resolve(colstats)
+        return out
+    if reduce_ctx is not None:
+        # ``reduce_ctx(slabs)``: a context manager under which the slab reduction is enqueued (functional's wgrad side
+        # stream: the sum only feeds the optimizer, so it leaves the stream that carries the backward's chain)
+        with reduce_ctx(slabs):
+            check(lib.pcaa_splitk_reduce(_p(slabs), ns, stride, stride, _p(out), int(bool(accumulate)), _s()),
+                  "pcaa_splitk_reduce")
         return out
     check(lib.pcaa_splitk_reduce(_p(slabs), ns, stride, stride, _p(out), int(bool(accumulate)), _s()),
           "pcaa_splitk_reduce")
@@ -670,9 +686,33 @@ def points_moments(x2d):
     """fp64 second moments and sums of the points (pcaa_points_moments) for pointnet_in_bwd_onepass."""
     _chk(x2d, "points_moments.x", torch.float32, 2)
     lib = _lib.load()
-    mom = torch.zeros(lib.pcaa_points_moments_size(), dtype=torch.float64, device=x2d.device)
+    n = lib.pcaa_points_moments_size()
+    mom = STATS_POOL.take_raw(n) if (STATS_POOL is not None and STATS_POOL.buf.device == x2d.device) else None
+    if mom is None:
+        mom = torch.zeros(n, dtype=torch.float64, device=x2d.device)
+    else:
+        mom = mom[:n]
     check(lib.pcaa_points_moments(_p(x2d), x2d.shape[1], x2d.shape[0], _p(mom), _s()), "pcaa_points_moments")
     return mom
+
+
+def pointnet_in_moment_coeffs(x2d, W2d, lin_bias, bn, mom=None, update_running=True):
+    """Train-mode BatchNorm coefficients of the first PointNet layer from the points' moments (no pass over [P, cout]):
+    -> (scale, shift, mean, rstd, mom)."""
+    _chk(x2d, "pointnet_in_moment_coeffs.x", torch.float32, 2)
+    P, C = x2d.shape
+    cout = W2d.shape[0]
+    if mom is None:
+        mom = points_moments(x2d)
+    tail = BnTailFwd(P, lin_bias, bn, cout, update_running=update_running)
+    stats = mom                       # the armed finalize is matched by this pointer
+    stats._pcaa_counter = mom         # (no arrival counter is used by this producer; any non-null word)
+    tail.arm(stats)
+    if not tail.armed:
+        raise RuntimeError("pointnet_in_moment_coeffs: the carried finalize is switched off")
+    check(_lib.load().pcaa_pointnet_in_moment_stats(_p(mom), _p(W2d), C, cout, _s()), "pcaa_pointnet_in_moment_stats")
+    TAILS["taken"] += 1
+    return tail.out + (mom,)
 
 
 def pointnet_in_bwd_onepass(da, x2d, W2d, scale, shift, mean, rstd, tail, mom=None, out=None):
