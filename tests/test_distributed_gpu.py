@@ -425,3 +425,25 @@ def test_two_rank_step_at_bench_shape_vs_oracle(precision, compress):
     assert comm["collectives"] >= 7
     if compress == "bf16":
         assert comm["payload_bytes"] < 0.6 * 4 * 159_300_000
+
+
+@pytest.mark.timeout(900)
+def test_bench_multi_rank_branch_runs_on_two_gloo_ranks():
+    """bench.py's N>1 branch (torchrun environment, barrier, max-over-ranks windows, one JSON line on rank 0, bf16
+    gradient buckets) launched the way the driver launches it, with 2 ranks sharing this box's GPU over gloo."""
+    import json
+    import subprocess
+    env = dict(os.environ, PCAA_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--windows", "2", "--backend", "gloo", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["global_batch"] == 128
+    assert d["config"]["finite_loss"] and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["dp"]["collectives_per_step"] >= 7 and d["config"]["dp"]["grad_compress"] == "bf16"
+    assert len(d["config"]["windows_ms_per_step"]) == 2 and d["value"] > 0
+    assert "sweep" not in d and "cpu_baseline" not in d          # single-GPU legs stay out of the N>1 line

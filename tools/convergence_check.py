@@ -39,7 +39,7 @@ def make_data(n, seed):
 
 train_x, train_y = make_data(2048, 1)
 test_x, test_y = make_data(512, 2)
-for prec in ("bf16", "fp32"):
+for prec in ("bf16", "fp16x3", "fp32"):
     torch.manual_seed(0); np.random.seed(0)
     constants.NFEATURES = C
     cfg = dict(constants.CONFIG); cfg.update(NMAX=N, TRAIN_CLASSES=list(range(K)), BATCH_SIZE=B)
