@@ -1,0 +1,295 @@
+// LAB (timing only, no result written): a ping-pong K loop for the 256x256 bf16 tile -- the schedule VERDICT round 2
+// asked to be tried (the guide's "8-phase" idea: half-tile stages, the two M-groups of waves one barrier apart so that
+// one group's fragment reads + DMA requests run under the other group's MFMAs) -- against the product kernel's loop
+// (one barrier per 64-deep step, A x3 / B x2 whole-step stages, both waves of a SIMD in lock-step), same tiles, same
+// operands, same process.
+//
+//   stages : half-steps (32 deep): A half-tile [256 rows][32 k] and B half-tile [256 cols][32 k], 16 KB each, NS = 5
+//            slots per operand (all 160 KB), requested L = 3 half-steps ahead, 4 one-KB pieces per wave per half-step
+//   wave   : READ(u): 4 DMA pieces of half-step u+L, then the 12 fragment reads of half-step u  | barrier |
+//            MFMA(u): lgkmcnt(0), 32 x v_mfma_f32_16x16x32_bf16                                  | barrier |
+//   groups : wm = 1 runs one barrier behind wm = 0, so every interval has one group in READ and one in MFMA
+//   hazards: RAW  every wave waits (counted vmcnt) for its pieces of half-step v before the barrier in front of the
+//                 first READ(v); WAR  slot v mod NS is re-requested NS - L = 2 half-steps after its last reader's
+//                 lgkmcnt(0) (see DESIGN.md section 7 for the interval arithmetic)
+//   hipcc --offload-arch=gfx950 -O3 -o gemm_pp gemm_pp.hip && ./gemm_pp
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int BM = 256, BN = 256, BK = 64;
+
+// ------------------------------------------------------------------------------------------------ baseline
+// the product kernel's loop (gemm_bf16.hip, MF = 16 path), K loop only
+constexpr int D_TILE = 256 * 64;
+__device__ __forceinline__ void piece64(rsrc_t r, long ld, int row0, int k0, bf16_t* s_tile, int p, const unsigned (&vo)[2]) {
+  const unsigned soff = (unsigned)(((long)(row0 + 8 * p) * ld + k0) * 2);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(s_tile + p * 512), 16, vo[p & 1], soff, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void k_loop_base(const bf16_t* A, const bf16_t* B, float* out, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nbn = N / BN, nb = (M / BM) * nbn, nt = K / BK;
+  rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)(unsigned)((long)M * K * 2), 0x00020000);
+  rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, (int)(unsigned)((long)N * K * 2), 0x00020000);
+  unsigned vo[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int g = (lane & 7) ^ ((4 * e + (lane >> 4)) & 7);
+    vo[e] = (unsigned)((lane >> 3) * (long)K * 2 + 16 * g);
+  }
+  auto slotA = [&](int i) { return smem + (i < 2 ? i : 3) * D_TILE; };
+  auto slotB = [&](int i) { return smem + (i == 0 ? 2 : 4) * D_TILE; };
+  const int l15 = lane & 15, q = lane >> 4;
+  int offA[8], offB[4], kofs[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) offA[i] = (wm * 128 + i * 16 + l15) * 64;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) offB[j] = (wn * 64 + j * 16 + l15) * 64;
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) kofs[s2] = ((4 * s2 + q) ^ (l15 >> 1)) * 8;
+  float total = 0.f;
+  for (int vb = blockIdx.x; vb < nb; vb += gridDim.x) {
+    const int tm = vb / nbn, tn = vb % nbn;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto pc = [&](int which, int k0, bf16_t* s, int j) {
+      if (which == 0) piece64(rA, K, tm * BM, k0, s, wave * 4 + j, vo);
+      else piece64(rB, K, tn * BN, k0, s, wave * 4 + j, vo);
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pc(0, 0, slotA(0), j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pc(1, 0, slotB(0), j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pc(0, BK, slotA(1), j);
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int ia = 0;
+    for (int t = 0; t < nt; ++t) {
+      const bf16_t* sA = slotA(ia);
+      const bf16_t* sB = slotB(t & 1);
+      bf16_t* nA = slotA(ia == 0 ? 2 : ia - 1);
+      bf16_t* nB = slotB((t + 1) & 1);
+      const int k0 = (t + 1) * BK, k0A = k0 + BK;
+      const bool more = t + 1 < nt, moreA = t + 2 < nt;
+      bf16x8 af[2][4], bfr[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(sB + offB[j] + kofs[0]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(sA + offA[i] + kofs[0]);
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        const int s2 = blk >> 1, h = blk & 1, cur = blk & 1, nxt = cur ^ 1;
+        if (blk < 3) {
+          const int ns2 = (blk + 1) >> 1, nh = (blk + 1) & 1;
+          if (nh == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[ns2 & 1][j] = *reinterpret_cast<const bf16x8*>(sB + offB[j] + kofs[ns2]);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[nxt][i] = *reinterpret_cast<const bf16x8*>(sA + offA[4 * nh + i] + kofs[ns2]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          {
+            const int p = 2 * blk + g;
+            if (p < 4) { if (more) pc(1, k0, nB, p); }
+            else if (moreA) pc(0, k0A, nA, p - 4);
+          }
+#pragma unroll
+          for (int i = 2 * g; i < 2 * g + 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[4 * h + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][i], bfr[s2 & 1][j], acc[4 * h + i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (moreA) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      ia = ia == 2 ? 0 : ia + 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) total += acc[i][j].x + acc[i][j].y + acc[i][j].z + acc[i][j].w;
+  }
+  if (total == 12345.f) out[tid] = total;
+}
+
+// ------------------------------------------------------------------------------------------------ ping-pong
+constexpr int H_TILE = 256 * 32;         // elements of a half-step tile (16 KB)
+template <int NS, int L>
+__global__ __launch_bounds__(512) void k_loop_pp(const bf16_t* A, const bf16_t* B, float* out, int M, int N, int K) {
+  static_assert(NS >= L + 2, "a slot is re-requested two half-steps after its last reader");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nbn = N / BN, nb = (M / BM) * nbn, NH = K / 32;       // half-steps per tile
+  rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)(unsigned)((long)M * K * 2), 0x00020000);
+  rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, (int)(unsigned)((long)N * K * 2), 0x00020000);
+  // 64-B rows: four rows share a 256-B bank row.  Stored granule s of row r holds k-granule s ^ h((r >> 2) & 3), h =
+  // {0, 2, 3, 1}: every 16-lane group of a ds_read_b128 then touches 16 distinct 16-B slots (see the lane groups in
+  // MI355X_MICROARCH.md).
+  auto hmap = [](int j) { return (0x78 >> (2 * j)) & 3; };           // {0, 2, 3, 1}
+  // DMA piece: 16 rows x 64 B; lane -> row (lane >> 2), stored granule (lane & 3)
+  const int prow = lane >> 2;
+  const unsigned vo = (unsigned)(prow * (long)K * 2 + 16 * ((lane & 3) ^ hmap((prow >> 2) & 3)));
+  auto slotA = [&](int s) { return smem + s * H_TILE; };
+  auto slotB = [&](int s) { return smem + (NS + s) * H_TILE; };
+  // half-step v of the tile at (tm, tn): pieces (wave, j), j = 0..3: A pieces 2*wave + {0,1}, B pieces 2*wave + {0,1}
+  auto request = [&](int tm, int tn, int v) {
+    const int s = v % NS, k0 = v * 32;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int p = 2 * wave + j;
+      const unsigned soffA = (unsigned)(((long)(tm * BM + 16 * p) * K + k0) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(slotA(s) + p * 512), 16, vo, soffA, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int p = 2 * wave + j;
+      const unsigned soffB = (unsigned)(((long)(tn * BN + 16 * p) * K + k0) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(slotB(s) + p * 512), 16, vo, soffB, 0, 0);
+    }
+  };
+  const int l15 = lane & 15, q = lane >> 4;
+  const int kq = (q ^ hmap((l15 >> 2) & 3)) * 8;
+  int offA[8], offB[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) offA[i] = (wm * 128 + i * 16 + l15) * 32 + kq;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) offB[j] = (wn * 64 + j * 16 + l15) * 32 + kq;
+  float total = 0.f;
+  for (int vb = blockIdx.x; vb < nb; vb += gridDim.x) {
+    const int tm = vb / nbn, tn = vb % nbn;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // prologue: half-steps 0 .. L-1 requested, half-step 0 landed
+#pragma unroll
+    for (int v = 0; v < L; ++v) request(tm, tn, v);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (L - 1)) : "memory");
+    if (wm == 1) __builtin_amdgcn_s_barrier();                    // the second group runs one barrier behind
+    for (int u = 0; u < NH; ++u) {
+      // ---- READ(u)
+      if (u + L < NH) request(tm, tn, u + L);
+      const bf16_t* sA = slotA(u % NS);
+      const bf16_t* sB = slotB(u % NS);
+      bf16x8 af[8], bfr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sB + offB[j]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sA + offA[i]);
+      // every wave's pieces of half-step u+1 must have landed before the barrier in front of the first READ(u+1):
+      // group 0 reaches it from MFMA(u) (below), group 1 from this READ(u) -- outstanding here: u+1 .. u+L
+      if (wm == 1) {
+        if (u + L < NH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (L - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      // ---- MFMA(u)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      if (wm == 0) {
+        if (u + L < NH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (L - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();                    // the first group waits for the second to finish
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) total += acc[i][j].x + acc[i][j].y + acc[i][j].z + acc[i][j].w;
+  }
+  if (total == 12345.f) out[tid] = total;
+}
+
+template <typename Kern>
+static float time_kernel(Kern kern, int lds, const bf16_t* A, const bf16_t* B, float* out, int M, int N, int K) {
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  float best = 1e9f;
+  for (int rep = 0; rep < 6; ++rep) {
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, 0, A, B, out, M, N, K);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  return best;
+}
+
+static void report(const char* name, float ms, int M, int N, int K) {
+  const double fl = 2.0 * M * N * K, tiles = (double)(M / 256) * (N / 256) / 256;
+  printf("%-26s [%d,%d]x[%d,%d]^T  %.3f ms  %5.0f TF-equivalent  %.1f us per tile (K loop only)\n", name, M, K, N, K, ms,
+         fl / ms / 1e9, ms * 1e3 / tiles);
+}
+
+int main() {
+  const int M = 245760;
+  bf16_t *A, *B; float* out;
+  if (hipMalloc(&A, (size_t)M * 1024 * 2) != hipSuccess || hipMalloc(&B, (size_t)1024 * 1024 * 2) != hipSuccess) return 1;
+  (void)hipMalloc(&out, 4096);
+  {  // uniform random bf16 in [-1, 1): constant operands draw less power and read high
+    const size_t na = (size_t)M * 1024, nbw = (size_t)1024 * 1024;
+    unsigned short* h = (unsigned short*)malloc(na * 2);
+    unsigned long long st = 88172645463325252ULL;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    for (size_t i = 0; i < na; ++i) {
+      const float f = (float)((rnd() >> 40) & 0xffff) / 32768.f - 1.f;
+      unsigned u; memcpy(&u, &f, 4);
+      h[i] = (unsigned short)(u >> 16);
+    }
+    (void)hipMemcpy(A, h, na * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(B, h + 12345, nbw * 2, hipMemcpyHostToDevice);
+    free(h);
+  }
+  // interleaved rounds in one process, median per (kernel, K): single launches read +-10 % with the chip's clock
+  const int Ks[2] = {512, 1024};
+  const char* names[3] = {"product loop (A x3, B x2)", "ping-pong NS=5 L=3", "ping-pong NS=4 L=2"};
+  float t[2][3][9];
+  for (int round = 0; round < 9; ++round)
+    for (int ki = 0; ki < 2; ++ki) {
+      t[ki][0][round] = time_kernel(k_loop_base, 163840, A, B, out, M, 1024, Ks[ki]);
+      t[ki][1][round] = time_kernel(k_loop_pp<5, 3>, 163840, A, B, out, M, 1024, Ks[ki]);
+      t[ki][2][round] = time_kernel(k_loop_pp<4, 2>, 131072, A, B, out, M, 1024, Ks[ki]);
+    }
+  for (int ki = 0; ki < 2; ++ki)
+    for (int v = 0; v < 3; ++v) {
+      float* a = t[ki][v];
+      for (int i = 0; i < 9; ++i)
+        for (int k = i + 1; k < 9; ++k)
+          if (a[k] < a[i]) { const float x = a[i]; a[i] = a[k]; a[k] = x; }
+      printf("median of 9 (min %.3f, max %.3f): ", a[0], a[8]);
+      report(names[v], a[4], M, 1024, Ks[ki]);
+    }
+  (void)hipDeviceSynchronize();
+  printf("%s\n", hipGetErrorString(hipGetLastError()));
+  return 0;
+}
