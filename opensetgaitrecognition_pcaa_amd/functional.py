@@ -137,7 +137,7 @@ def _linear_bn(a_in, W2d, lin_bias, bn, training, mode, first_layer):
     use_bf16 = (mode == "bf16") and a_in.dtype == torch.bfloat16 and cin % 8 == 0
     out_dtype = torch.bfloat16 if (mode == "bf16" and first_layer is not None) else torch.float32
     if isinstance(a_in, ops.SplitImage):
-        # fp16x3 mode: both operands as [hi | lo] images, three bf16 MFMA passes, fp32 result
+        # fp16x3 mode: both operands as [hi | lo] images, three f16 MFMA passes, fp32 result
         w_img = ops.split_f16(W2d)
         if training:
             _WSPLIT_T_CACHE[W2d.data_ptr()] = ops.split_f16(W2d, transpose=True)      # the dgrad's operand
