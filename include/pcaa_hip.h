@@ -137,7 +137,8 @@ int pcaa_pointnet_in_bwd_stats(const void* da, int dtype, const float* x, int C,
                                double* stats, int nrep, long P, int cout, void* stream);
 /* One pass instead of the two (round 3): the weight gradient is linear in dy and y = x.W^T, so
  *   dW = c0 (.) (dz^T x) + c1 (.) (W . x^T x) + c2 (x) sum_p x.
- * pcaa_pointnet_in_bwd_onepass reduces the statistics AND G[cout,C] += dz^T.x (G zero-initialised) from one read of
+ * pcaa_pointnet_in_bwd_onepass reduces the statistics AND G[nrep][cout,C] += dz^T.x (zero-initialised; workgroup b adds
+ * into replica b % nrep: one shared image ran at the contended atomic rate) from one read of
  * da; pcaa_points_moments accumulates mom[pcaa_points_moments_size()] (zero-initialised fp64: x^T x at [k*8 + c], the
  * sums at [64 + c]); pcaa_pointnet_in_bwd_combine forms dW (=) from G, the moments and pcaa_bn_bwd_finalize's coef. */
 int pcaa_pointnet_in_bwd_onepass(const void* da, int dtype, const float* x, int C, const float* W,
@@ -145,7 +146,7 @@ int pcaa_pointnet_in_bwd_onepass(const void* da, int dtype, const float* x, int 
                                  double* stats, int nrep, float* G, long P, int cout, void* stream);
 int pcaa_points_moments_size(void);
 int pcaa_points_moments(const float* x, int C, long P, double* mom, void* stream);
-int pcaa_pointnet_in_bwd_combine(const float* G, const float* W, const double* mom, const float* coef,
+int pcaa_pointnet_in_bwd_combine(const float* G, int nrep, const float* W, const double* mom, const float* coef,
                                  float* dW, int cout, int C, void* stream);
 /* The same moments give the layer's forward BatchNorm statistics without a pass over the points (sum y = W.sum x,
  * sum y^2 = W^T (x^T x) W per channel): arm the forward finalize on `mom` (pcaa_bn_tail_arm_fwd with stats = mom,

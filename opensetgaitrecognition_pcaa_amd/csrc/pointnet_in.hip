@@ -11,7 +11,7 @@ namespace {
 constexpr int MAXC = 8;
 constexpr int FWD_ROWS = 128;    // points per workgroup (forward)
 constexpr int WG_ROWS = 256;     // points per workgroup (wgrad): 960 workgroups at P = 245760
-constexpr int BWD_ROWS = 128;   // points per workgroup of the recompute backward passes (1920 workgroups)
+constexpr int BWD_ROWS = 256;   // points per workgroup of the recompute backward passes (960 workgroups at config[1]; 128 rows: +10 % time, twice the atomics)
 
 // CP: point features padded to 4 or 8 (C <= 4 is the common case: half the multiply-adds of the padded-to-8 loop);
 // the product runs on column pairs with packed fp32 fused multiply-adds -- per element the same operations in the same
@@ -169,12 +169,17 @@ __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restric
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int c = 0; c < CP; ++c) acc[j][c] = 0.f;
-  // 4 rows per trip: four independent gradient loads in flight per lane
-  for (int r = rlane; r < nrows; r += 4 * rl) {
-    f32x4 g[4];
+  // 4 rows per trip, the NEXT trip's four gradient loads issued before this trip's arithmetic (the loop is bound by
+  // bytes in flight x latency, not by the vector ALU: at 100 registers only four waves share a SIMD)
+  auto load_trip = [&](int r, f32x4 (&g)[4]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       g[u] = (r + u * rl < nrows) ? load4(da + (r0 + r + u * rl) * cout + cq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  f32x4 g[4], gn[4];
+  load_trip(rlane, g);
+  for (int r = rlane; r < nrows; r += 4 * rl) {
+    if (r + 4 * rl < nrows) load_trip(r + 4 * rl, gn);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (r + u * rl >= nrows) break;
@@ -200,6 +205,8 @@ __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restric
         }
       }
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) g[u] = gn[u];
   }
   __syncthreads();                       // xs is reused for the row-lane combine
   if (MODE == 0 || MODE == 3) {
@@ -226,7 +233,9 @@ __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restric
       const int ch = o / C, c = o - ch * C;
       float v = 0.f;
       for (int l = 0; l < rl; ++l) v += red[(l * cout + ch) * CP + c];
-      atomicAdd(&dW[o], v);
+      // MODE 3 spreads the 1 920 workgroups' adds over nrep replicas of G (all of them into ONE [cout, C] image ran at the
+      // contended atomic rate: the pass took 0.14 ms for a 252 MB read); the combine kernel sums the replicas
+      atomicAdd(&dW[(MODE == 3 ? (long)(blockIdx.x % nrep) * cout * C : 0L) + o], v);
     }
   }
   if (MODE == 0 || MODE == 3) bn_tail_run(tail, threadIdx.x, 256, gridDim.x, &tail_flag);
@@ -302,16 +311,16 @@ __global__ void pointnet_in_moment_stats_kernel(const double* __restrict__ mom, 
 }
 
 // dW[o][c] = c0[o] G[o][c] + c1[o] sum_k W[o][k] XtX[k][c] + c2[o] sum_p x[p][c]     (fp64 combination)
-__global__ void pointnet_in_bwd_combine_kernel(const float* __restrict__ G, const float* __restrict__ W,
+__global__ void pointnet_in_bwd_combine_kernel(const float* __restrict__ G, int nrep, const float* __restrict__ W,
                                                const double* __restrict__ mom, const float* __restrict__ coef,
                                                float* __restrict__ dW, int cout, int C) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cout * C) return;
   const int o = i / C, c = i - o * C;
-  double yx = 0.0;
+  double yx = 0.0, g = 0.0;
   for (int k = 0; k < C; ++k) yx += (double)W[o * C + k] * mom[k * MAXC + c];
-  dW[i] = (float)((double)coef[o] * (double)G[i] + (double)coef[cout + o] * yx +
-                  (double)coef[2 * cout + o] * mom[MAXC * MAXC + c]);
+  for (int r = 0; r < nrep; ++r) g += (double)G[(long)r * cout * C + i];
+  dW[i] = (float)((double)coef[o] * g + (double)coef[cout + o] * yx + (double)coef[2 * cout + o] * mom[MAXC * MAXC + c]);
 }
 
 // dW[o][c] += sum_p dy[p][o] * x[p][c]
@@ -546,11 +555,12 @@ extern "C" int pcaa_pointnet_in_moment_stats(const double* mom, const float* W, 
   PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_moment_stats");
 }
 
-extern "C" int pcaa_pointnet_in_bwd_combine(const float* G, const float* W, const double* mom, const float* coef,
-                                            float* dW, int cout, int C, void* stream) {
-  PCAA_CHECK_ARG(G && W && mom && coef && dW && cout >= 1 && C >= 1 && C <= MAXC, "pcaa_pointnet_in_bwd_combine: bad args");
+extern "C" int pcaa_pointnet_in_bwd_combine(const float* G, int nrep, const float* W, const double* mom,
+                                            const float* coef, float* dW, int cout, int C, void* stream) {
+  PCAA_CHECK_ARG(G && W && mom && coef && dW && cout >= 1 && C >= 1 && C <= MAXC && nrep >= 1,
+                 "pcaa_pointnet_in_bwd_combine: bad args");
   hipLaunchKernelGGL(pointnet_in_bwd_combine_kernel, dim3((unsigned)cdiv((long)cout * C, 256)), dim3(256), 0,
-                     as_stream(stream), G, W, mom, coef, dW, cout, C);
+                     as_stream(stream), G, nrep, W, mom, coef, dW, cout, C);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_bwd_combine");
 }
 

@@ -729,14 +729,14 @@ def pointnet_in_bwd_onepass(da, x2d, W2d, scale, shift, mean, rstd, tail, mom=No
     if mom is None:
         mom = points_moments(x2d)
     stats = new_stats(cout, da.device)
-    G = torch.zeros((cout, C), dtype=torch.float32, device=da.device)
+    G = torch.zeros((NREP, cout, C), dtype=torch.float32, device=da.device)     # replica b % NREP of workgroup b
     tail.arm(stats)
     check(lib.pcaa_pointnet_in_bwd_onepass(_p(da), _dt(da), _p(x2d), C, _p(W2d), _p(scale), _p(shift), _p(mean), _p(rstd),
                                            _p(stats), NREP, _p(G), P, cout, _s()), "pcaa_pointnet_in_bwd_onepass")
     coef, _, _ = tail.resolve(stats)
     if out is None:
         out = torch.empty((cout, C), dtype=torch.float32, device=da.device)
-    check(lib.pcaa_pointnet_in_bwd_combine(_p(G), _p(W2d), _p(mom), _p(coef), _p(out), cout, C, _s()),
+    check(lib.pcaa_pointnet_in_bwd_combine(_p(G), NREP, _p(W2d), _p(mom), _p(coef), _p(out), cout, C, _s()),
           "pcaa_pointnet_in_bwd_combine")
     return out
 
