@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PCAA_ABI_VERSION 10 /* pcaa_abi_version() of a library built from this header */
+#define PCAA_ABI_VERSION 11 /* pcaa_abi_version() of a library built from this header */
 
 #define PCAA_OK 0
 #define PCAA_ERR_INVALID_ARG 1
@@ -111,6 +111,13 @@ int pcaa_timing_events_destroy(void* start, void* stop);
 int pcaa_time_next_gemm(void* start, void* stop);
 int pcaa_timing_pending(void);
 int pcaa_timing_elapsed_ms(void* start, void* stop, float* ms);
+/* A stream whose kernels run on compute units [first_cu, first_cu + n_cus) of the XCD-interleaved numbering only
+ * (multiples of 8: n_cus / 8 on every XCD), for launches that
+ * are to share the chip with the calling stream's instead of queueing behind / in front of them (csrc/streams.hip).
+ * The caller sizes such a launch for n_cus workgroups.  No counterpart in the reference (PyTorch runs its backward on
+ * one stream); the host side wraps the handle as a torch.cuda.ExternalStream. */
+int pcaa_stream_create_masked(int first_cu, int n_cus, void** stream);
+int pcaa_stream_destroy(void* stream);
 int pcaa_splitk_reduce(const float* slabs, int nsplit, long slab_stride, long n, float* out,
                        int accumulate, void* stream);
 /* same, for out[rows, ch], plus the BatchNorm column statistics of out (stats as in pcaa_gemm) */

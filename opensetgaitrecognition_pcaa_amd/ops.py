@@ -398,6 +398,55 @@ def gemm_slabs(A, a_layout, B, b_layout, M, N, K, split_k, out=None, accumulate=
     return out
 
 
+def gemm_slabs_part(A, B, M, N, K, split_k, slabs, math=PCAA_BF16):
+    """The weight-gradient form (RC x RC, contraction over the rows) over the rows the two views cover: writes the
+    partial products of its splits into ``slabs`` (a float32 view with room for them, ``M*N`` apart) and returns their
+    count.  Launch only -- the caller sums the slabs (``splitk_reduce``).  With this a long-K product can be cut in
+    two launches on different streams (functional's overlapped weight gradients)."""
+    _chk(A, "gemm_slabs_part.A", dim=2)
+    _chk(B, "gemm_slabs_part.B", dim=2)
+    if A.shape[0] != K or B.shape[0] != K or A.shape[1] != M or B.shape[1] != N:
+        raise ValueError("gemm_slabs_part: operand views must be [K, M] and [K, N]")
+    lib = _lib.load()
+    ns = lib.pcaa_gemm_num_splits(math, K, int(split_k))
+    stride = M * N
+    _chk(slabs, "gemm_slabs_part.slabs", torch.float32)
+    if slabs.numel() < ns * stride or not slabs.is_contiguous():
+        raise ValueError("gemm_slabs_part: slab view too small")
+    check(lib.pcaa_gemm_slabs(math, _p(A), _dt(A), RC, A.stride(0), _p(B), _dt(B), RC, B.stride(0),
+                              _p(slabs), stride, M, N, K, int(split_k), _s()), "pcaa_gemm_slabs")
+    return ns
+
+
+def splitk_reduce(slabs, ns, M, N, out, accumulate=False):
+    """out[M, N] (=|+=) the sum of ``ns`` slabs laid ``M*N`` apart"""
+    _chk(out, "splitk_reduce.out", torch.float32)
+    if out.numel() != M * N or slabs.numel() < ns * M * N:
+        raise ValueError("splitk_reduce: sizes")
+    check(_lib.load().pcaa_splitk_reduce(_p(slabs), int(ns), M * N, M * N, _p(out), int(bool(accumulate)), _s()),
+          "pcaa_splitk_reduce")
+    return out
+
+
+_MASKED_STREAMS = {}
+
+
+def masked_stream(n_cus, first_cu=0, device=None):
+    """A torch stream confined to compute units [first_cu, first_cu + n_cus) (n_cus / 8 on every XCD); one per
+    (device, range) and process -- HIP maps streams onto few hardware queues, so they are not created per trainer."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(first_cu), int(n_cus))
+    st = _MASKED_STREAMS.get(key)
+    if st is None:
+        with torch.cuda.device(key[0]):
+            h = ctypes.c_void_p()
+            check(_lib.load().pcaa_stream_create_masked(int(first_cu), int(n_cus), ctypes.byref(h)),
+                  "pcaa_stream_create_masked")
+            st = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", key[0]))
+        _MASKED_STREAMS[key] = st
+    return st
+
+
 def gemm_affine_elu(a, W16, scale, shift, pool_rows=0):
     """ELU(scale * (a[M,K] @ W16[N,K]^T) + shift) in one launch (eval-mode BatchNorm+ELU in the GEMM
     epilogue): bf16 [M,N], or with pool_rows in {32,64,128} its mean over groups of pool_rows consecutive

@@ -803,3 +803,35 @@ def test_split_image_producers():
     a1 = ops.pointnet_in_apply(x, W, scale, shift, torch.float32)
     a1i = ops.pointnet_in_apply(x, W, scale, shift, ops.SplitImage.dtype)
     assert (a1i.float() - a1).abs().max().item() <= 1e-6 * a1.abs().max().item()
+
+
+def test_gemm_slabs_part_on_masked_streams():
+    """A weight-gradient product cut in two launches on two CU-masked streams (pcaa_stream_create_masked: the lab hook
+    of tools/overlap_lab.py) and summed by pcaa_splitk_reduce equals the fp64 product of the same bf16 operands."""
+    M, N, K = 512, 256, 4096
+    a = _rand((K, M), 1).bfloat16().to(DEV)
+    b = _rand((K, N), 2).bfloat16().to(DEV)
+    ref = a.double().cpu().t() @ b.double().cpu()
+    lo, hi = ops.masked_stream(64), ops.masked_stream(192, first_cu=64)
+    assert ops.masked_stream(64) is lo                       # one stream per (device, range)
+    slabs = torch.empty(16 * M * N, device=DEV)
+    out = torch.empty(M, N, device=DEV)
+    main = torch.cuda.current_stream()
+    ev = torch.cuda.Event()
+    ev.record(main)
+    k0 = 1024
+    with torch.cuda.stream(lo):
+        lo.wait_event(ev)
+        na = ops.gemm_slabs_part(a[:k0], b[:k0], M, N, k0, 4, slabs)
+    with torch.cuda.stream(hi):
+        hi.wait_event(ev)
+        nb = ops.gemm_slabs_part(a[k0:], b[k0:], M, N, K - k0, 8, slabs[na * M * N:])
+    main.wait_stream(lo)
+    main.wait_stream(hi)
+    ops.splitk_reduce(slabs, na + nb, M, N, out)
+    torch.cuda.synchronize()
+    assert (na, nb) == (4, 8)
+    err = (out.double().cpu() - ref).abs().max().item()
+    assert err <= 1e-4 * ref.abs().max().item(), err          # fp32 accumulation of exact bf16 products
+    with pytest.raises(RuntimeError):
+        ops.masked_stream(12)                                 # not a multiple of 8
