@@ -101,6 +101,10 @@ def _require_gpu(x, what):
     if not isinstance(x, torch.Tensor) or not x.is_cuda:
         raise RuntimeError(f"{what}: input must live on the HIP device; this package has no CPU path "
                            "(the CPU restatement lives in oracle/ and is test infrastructure only)")
+    if x.numel() == 0:
+        # the reference's train-mode BatchNorm raises ValueError on an empty batch ("Expected more than 1 value per
+        # channel"); its eval mode would hand back empty tensors -- here both refuse (error behaviour)
+        raise ValueError(f"{what}: empty input {tuple(x.shape)}")
 
 
 def _point_major(x):

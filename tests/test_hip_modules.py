@@ -492,3 +492,32 @@ def test_checkpoints_are_compact_and_reload(tmp_path):
     enc2.load_state_dict(torch.load(tmp_path / "mdl_E.pt", map_location="cpu"))
     for (k, a), (_, b) in zip(enc2.state_dict().items(), tr.encoder.state_dict().items()):
         assert torch.equal(a, b.cpu()), k
+
+
+
+def test_empty_and_single_inputs():
+    """Edge cases of the module boundary: an empty batch is refused with ValueError in both modes (the reference's
+    train-mode BatchNorm raises ValueError too); a single sequence (B = 1: T*N rows feed the BatchNorm statistics)
+    runs the train-mode forward and matches the oracle."""
+    F_hip.set_precision("fp32")
+    K, N, C = 4, 32, 4
+    enc = make_encoder(K, N, C, True, seed=5)
+    sd = sd_clone(enc)                                  # CPU copies for the oracle
+    enc = enc.to(DEV)
+    dec = make_decoder(32, N, C, seed=6).to(DEV)
+    disc = make_disc(K, seed=7).to(DEV)
+    for mode in (True, False):
+        for mod in (enc, dec, disc):
+            mod.train(mode)
+        with pytest.raises(ValueError):
+            enc(torch.empty(0, C, T, N, device=DEV))
+        with pytest.raises(ValueError):
+            dec(torch.empty(0, 32, device=DEV))
+        with pytest.raises(ValueError):
+            disc(torch.empty(0, 32, device=DEV), torch.empty(0, K, device=DEV))
+    enc.train()
+    xpm = syn.synthetic_pcs(1, T, N, C, seed=11)
+    logits, fv = enc(xpm.to(DEV).permute(0, 3, 1, 2))
+    ref = O.cg_encoder_forward(xpm.permute(0, 3, 1, 2), sd, True, True)
+    _close(logits, ref[0], what="B=1 logits")
+    _close(fv, ref[1], what="B=1 sup_fv")

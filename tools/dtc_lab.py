@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""The temporal block's layers alone on the GPU (B=64, T=30): forward and adjoint per layer, with and without the
+im2col / statistics side outputs.   python tools/dtc_lab.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from opensetgaitrecognition_pcaa_amd import ops
+
+B, T, dev = 64, 30, "cuda"
+chans = [1024, 16, 32, 64, 128, 256, 512]
+dils = [1, 2, 4, 1, 2, 4]
+
+
+def timed(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+for li in range(6):
+    cin, cout, d = chans[li], chans[li + 1], dils[li]
+    src = torch.randn(B * T, cin, device=dev)
+    sc = torch.rand(cin, device=dev) + 0.5
+    sh = torch.randn(cin, device=dev) * 0.1
+    W = torch.randn(cout, cin * 3, device=dev) * 0.05
+    stats = torch.zeros(ops.NREP, 2, cout, dtype=torch.float64, device=dev)
+    t_full = timed(lambda: ops.dtc_conv_fwd(src, sc, sh, W, B, T, d, stats=stats, want_col=True))
+    t_nocol = timed(lambda: ops.dtc_conv_fwd(src, sc, sh, W, B, T, d, stats=stats, want_col=False))
+    t_bare = timed(lambda: ops.dtc_conv_fwd(src, sc, sh, W, B, T, d, stats=None, want_col=False))
+    t_noact = timed(lambda: ops.dtc_conv_fwd(src, None, None, W, B, T, d, stats=None, want_col=False))
+    dy = torch.randn(B * T, cout, device=dev)
+    t_dg = timed(lambda: ops.dtc_conv_dgrad(dy, W, B, T, cin, d))
+    fl = 2.0 * B * T * cin * 3 * cout
+    print(f"layer {li + 1} {cin:4d}->{cout:3d} d={d}: fwd {t_full:6.1f} us (no col {t_nocol:6.1f}, no col/stats {t_bare:6.1f}, "
+          f"no activation on load {t_noact:6.1f})  dgrad {t_dg:6.1f} us   {fl / 1e9:.2f} GFLOP")
