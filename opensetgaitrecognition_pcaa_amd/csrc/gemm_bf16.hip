@@ -304,11 +304,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_big_kernel(GemmParams p) {
 // the third stage to B -- the L2-resident weights -- and measured nothing.
 // ===========================================================================
 constexpr int D_TILE = 256 * 64;                       // elements per operand per stage (32 KB)
-constexpr int EP_PITCH = 72;                           // bf16 elements per row of a wave's epilogue image (144 B)
 constexpr int D_LDS_BYTES = 5 * D_TILE * 2;            // 163840: A in a ring of three stages, B of two -- all of the LDS
 
 // one of the 4 pieces a wave moves per tile
-template <int LAY>
+// PERM (KC, the B operand of the 16x16x32 kernels): LDS row l = 16 j + c of every 64-row group holds operand row
+// 4 c + j of that group.  The fragment reads do not change (lane c of column block j still reads LDS row 16 j + c,
+// conflict-free as before), but the accumulator a lane holds in block j is now output column 4 c + j: the four
+// blocks of a lane are four ADJACENT columns of one row, and the epilogue stores them straight from registers
+// (8 B per lane, 16 lanes = one 128-B line per row) -- no LDS transpose, no lane exchange (see epilogue_full_tile).
+__device__ __forceinline__ int perm_row(int l) { return (l & ~63) + 4 * (l & 15) + ((l >> 4) & 3); }
+
+template <int LAY, bool PERM = false>
 __device__ __forceinline__ void dma_piece(const bf16_t* __restrict__ base, long ld, int row0, int R, int k0,
                                           bf16_t* s_tile, int wave, int lane, int j) {
   const int p = wave * 4 + j;       // 1-KB piece index, 32 per tile
@@ -316,7 +322,7 @@ __device__ __forceinline__ void dma_piece(const bf16_t* __restrict__ base, long 
   if (LAY == KC) {
     const int r = 8 * p + (lane >> 3);
     const int g = (lane & 7) ^ ((r >> 1) & 7);
-    src = base + (long)min(row0 + r, R - 1) * ld + k0 + 8 * g;
+    src = base + (long)min(row0 + (PERM ? perm_row(r) : r), R - 1) * ld + k0 + 8 * g;
   } else {
     const int k = 2 * p + (lane >> 5);
     const int c = (lane & 31) ^ (4 * (k & 3));
@@ -343,13 +349,13 @@ __device__ __forceinline__ buf_rsrc_t make_rsrc(const void* base, long bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(unsigned)bytes, 0x00020000);
 }
 // per-lane byte offsets for pieces of even / odd index
-template <int LAY>
+template <int LAY, bool PERM = false>
 __device__ __forceinline__ void piece_lane_offsets(long ld, int lane, unsigned (&voff)[2]) {
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     if (LAY == KC) {
       const int g = (lane & 7) ^ ((4 * e + (lane >> 4)) & 7);            // r >> 1 = 4 p + (lane >> 4)
-      voff[e] = (unsigned)((lane >> 3) * ld * 2 + 16 * g);
+      voff[e] = (unsigned)((PERM ? 4 : 1) * (lane >> 3) * ld * 2 + 16 * g);    // PERM: rows of a piece lie 4 apart
     } else {
       const int c = (lane & 31) ^ (4 * ((2 * e + (lane >> 5)) & 3));     // k & 3 = (2 p + (lane >> 5)) & 3
       voff[e] = (unsigned)((lane >> 5) * ld * 2 + 16 * c);
@@ -357,11 +363,13 @@ __device__ __forceinline__ void piece_lane_offsets(long ld, int lane, unsigned (
   }
 }
 // wave (scalar) and j select the piece p = 4 wave + j; row0 / k0 as in dma_piece
-template <int LAY>
+template <int LAY, bool PERM = false>
 __device__ __forceinline__ void dma_piece_buf(buf_rsrc_t rsrc, long ld, int row0, int k0, bf16_t* s_tile, int wave,
                                               const unsigned (&voff)[2], int j, long extra = 0) {
   const int p = wave * 4 + j;
-  const unsigned soff = LAY == KC ? (unsigned)(((long)(row0 + 8 * p) * ld + k0 + extra) * 2)
+  // PERM: piece p = LDS rows 8p .. 8p+7 = lanes c = 8 (p & 1) + 0..7 of column block (p >> 1) & 3 of group p >> 3
+  const int prow = PERM ? 64 * (p >> 3) + 32 * (p & 1) + ((p >> 1) & 3) : 8 * p;
+  const unsigned soff = LAY == KC ? (unsigned)(((long)(row0 + prow) * ld + k0 + extra) * 2)
                                   : (unsigned)(((long)(k0 + 2 * p) * ld + row0 + extra) * 2);
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(s_tile + p * 512), 16,
                                            voff[j & 1], soff, 0, 0);
@@ -385,7 +393,8 @@ template <> struct AccLayout<16> {
   typedef f32x4 vec;
   static constexpr int MB = 8, NB = 4, NR = 4, BR = 16;
   static __device__ __forceinline__ int row(int i, int r, int lane) { return i * 16 + 4 * (lane >> 4) + r; }
-  static __device__ __forceinline__ int col(int j, int lane) { return j * 16 + (lane & 15); }
+  // (the B operand's rows are permuted on their way into the LDS, dma_piece<KC, PERM>: block j of lane c is column 4 c + j)
+  static __device__ __forceinline__ int col(int j, int lane) { return 4 * (lane & 15) + j; }
   static __device__ __forceinline__ float colreduce(float v) {
     v += __shfl_xor(v, 16, 64);
     return v + __shfl_xor(v, 32, 64);
@@ -393,48 +402,22 @@ template <> struct AccLayout<16> {
   static __device__ __forceinline__ bool col_leader(int lane) { return lane < 16; }
 };
 
-__device__ __forceinline__ float dpp_swap_neighbour(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+
+// LDS scratch of the epilogues: the column statistics' [2 stats][2 wm][256 cols] floats, in the ring's last two slots (the
+// ones the NEXT tile's first stages do not use, see the kernel).  (Rounds 1-2 also kept eight 4.5-KB wave images here:
+// the accumulators went through the LDS to become row-contiguous 16-B stores.  With the B operand's rows permuted on
+// their way in -- dma_piece<KC, PERM> -- a lane's four column blocks ARE four adjacent columns, and the tile leaves
+// straight from the registers.)
+constexpr int EP_RED_OFFSET = 0;
+// 8-B store of a piece of the OUTPUT tile with the non-temporal (streaming) cache policy: the tile is not read again by
+// this launch, and with the default policy its 128 KB per workgroup push the streamed operand's lines -- which the three
+// sibling workgroups of the row block still want -- out of the XCD's 4 MB L2.  Same-box A/B on the forward shapes
+// (tools/gemm_epi_lab.py): 512->512 0.171 -> 0.155 ms, 512->1024 0.300 -> 0.254, 1024->1024 0.494 -> 0.490.
+__device__ __forceinline__ void store_stream8(bf16_t* dst, uint2 v) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  __builtin_nontemporal_store(u32x2{v.x, v.y}, reinterpret_cast<u32x2*>(dst));
 }
 
-// A wave parks its 128 x 64 accumulator sub-tile 32 rows at a time as a row-major bf16 image [32][EP_PITCH] in its
-// own LDS region (4.5 KB; the eight regions + the statistics scratch live in the two ring slots the NEXT tile's
-// first stages do not use, see the kernel): neighbouring lanes exchange one value (DPP quad_perm [1,0,3,2]) so that
-// every lane owns two adjacent columns of one row -> v_cvt_pk_bf16_f32 + ds_write_b32; the 144-B pitch keeps the
-// writes at 2-way bank conflicts (free for ds_write_b32) and rows 16-B aligned for the row-contiguous 16-B reads that
-// follow.  Everything is wave-local (LDS operations of a wave execute in order): no workgroup barrier.
-// F(value, j) is applied to every element first.  CHUNK (compile time) selects rows [32 CHUNK, 32 CHUNK + 32).
-constexpr int EP_CHUNK_ROWS = 32;
-constexpr int EP_WAVE_ELEMS = EP_CHUNK_ROWS * EP_PITCH;            // bf16 elements of one wave's image
-constexpr int EP_RED_OFFSET = 8 * EP_WAVE_ELEMS;                   // statistics scratch behind the eight images
-static_assert(EP_RED_OFFSET * 2 + 2 * 2 * 256 * 4 + 16 <= 2 * D_TILE * 2, "the epilogue lives in the ring's last two slots");
-template <int MF, int CHUNK, typename F>
-__device__ __forceinline__ void park_chunk(typename AccLayout<MF>::vec (&acc)[AccLayout<MF>::MB][AccLayout<MF>::NB],
-                                           bf16_t* wave_img, int lane, F f) {
-  typedef AccLayout<MF> L;
-  constexpr int BPC = EP_CHUNK_ROWS / L::BR;                       // accumulator row blocks per chunk
-  uint32_t* w32 = reinterpret_cast<uint32_t*>(wave_img);
-  const bool odd = lane & 1;
-  // mine = {row R, row R+1} of my column as two bf16; theirs = the same of the neighbouring column (one DPP move).
-  // even lane stores row R: (mine.lo, theirs.lo); odd lane stores row R+1: (theirs.hi, mine.hi) -- one v_perm_b32
-  // with a per-lane byte selector
-  const uint32_t sel = odd ? 0x03020706u : 0x05040100u;       // bytes 0-3 = mine (S1), 4-7 = theirs (S0)
-#pragma unroll
-  for (int j = 0; j < L::NB; ++j) {
-    const int colw = (L::col(j, lane) & ~1) >> 1;            // 32-bit word index of the column pair
-#pragma unroll
-    for (int ii = 0; ii < BPC; ++ii)
-#pragma unroll
-      for (int r = 0; r < L::NR; r += 2) {
-        const int i = CHUNK * BPC + ii;
-        const uint32_t mine = pack2(f(acc[i][j][r], j), f(acc[i][j][r + 1], j));
-        const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, true);
-        const uint32_t packed = __builtin_amdgcn_perm(theirs, mine, sel);
-        const int row = L::row(ii, r, lane) + (odd ? 1 : 0);
-        w32[row * (EP_PITCH / 2) + colw] = packed;
-      }
-  }
-}
 // workgroup barrier that leaves vector-memory operations (the next tile's LDS-DMA pieces, this tile's C stores) alone
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -453,43 +436,54 @@ __device__ __forceinline__ void epilogue_full_tile(const GemmParams& p,
   const int wm = wave >> 2, wn = wave & 3;
   const bool add_bias = p.bias != nullptr && (!p.atomic || split == 0);
   if constexpr (sizeof(TC) == 2) {
-    bf16_t* w = smem + wave * EP_WAVE_ELEMS;              // smem: the epilogue's LDS region
-    float bv[L::NB], esc[L::NB], esh[L::NB];
+    // 16x16x32 layout: lane (c = lane & 15, q = lane >> 4) holds rows 16 i + 4 q + r of columns 4 c .. 4 c + 3 (one per
+    // column block j): two v_cvt_pk_bf16_f32 and one 8-B store per row; the 16 lanes of a q are one 128-B line
+    static_assert(MF == 16, "bf16 output leaves the 16x16x32 kernels only");
+    const int l15 = lane & 15, q = lane >> 4;
+    float bv[4], esc[4], esh[4];
 #pragma unroll
-    for (int j = 0; j < L::NB; ++j) {
-      const int gc = tn * BN + wn * 64 + L::col(j, lane);
+    for (int j = 0; j < 4; ++j) {
+      const int gc = tn * BN + wn * 64 + 4 * l15 + j;
       bv[j] = add_bias ? p.bias[gc] : 0.f;
       esc[j] = AFFINE ? p.ep_scale[gc] : 1.f;
       esh[j] = AFFINE ? p.ep_shift[gc] : 0.f;
     }
-    bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + (long)(tm * BM + wm * 128) * p.ldc + tn * BN + wn * 64;
-    const int cg = (lane & 7) * 8, r0 = lane >> 3;
-    auto chunk = [&](auto CH) {
-      constexpr int c = decltype(CH)::value;
+    bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + (long)(tm * BM + wm * 128 + 4 * q) * p.ldc + tn * BN + wn * 64 + 4 * l15;
+    auto out = [&](float v, int j) {
       if constexpr (AFFINE) {
-        park_chunk<MF, c>(acc, w, lane, [&](float v, int j) {
-          v = fmaf(v + bv[j], esc[j], esh[j]);
-          return v > 0.f ? v : __expf(v) - 1.f;
-        });
-      } else if (add_bias) {                 // (uniform) the BatchNorm layers pass no bias: keep the adds out of their way
-        park_chunk<MF, c>(acc, w, lane, [&](float v, int j) { return v + bv[j]; });
+        v = fmaf(v + bv[j], esc[j], esh[j]);
+        return v > 0.f ? v : __expf(v) - 1.f;
       } else {
-        park_chunk<MF, c>(acc, w, lane, [](float v, int) { return v; });
-      }
-#pragma unroll
-      for (int pass = 0; pass < EP_CHUNK_ROWS / 8; ++pass) {
-        const int row = pass * 8 + r0;
-        *reinterpret_cast<uint4*>(C + (long)(c * EP_CHUNK_ROWS + row) * p.ldc + cg) =
-            *reinterpret_cast<const uint4*>(&w[row * EP_PITCH + cg]);
+        return add_bias ? v + bv[j] : v;       // (uniform) the BatchNorm layers pass no bias
       }
     };
-    chunk(std::integral_constant<int, 0>{});
-    chunk(std::integral_constant<int, 1>{});
-    chunk(std::integral_constant<int, 2>{});
-    chunk(std::integral_constant<int, 3>{});
+#pragma unroll
+    for (int i = 0; i < L::MB; ++i)
+#pragma unroll
+      for (int r = 0; r < L::NR; ++r) {
+        uint2 o;
+        o.x = pack2(out(acc[i][0][r], 0), out(acc[i][1][r], 1));
+        o.y = pack2(out(acc[i][2][r], 2), out(acc[i][3][r], 3));
+        store_stream8(C + (long)(i * 16 + r) * p.ldc, o);
+      }
   } else {
     float* C = reinterpret_cast<float*>(p.C) + (long)split * p.c_split_stride +
                (long)(tm * BM + wm * 128) * p.ldc + tn * BN + wn * 64;
+    if constexpr (MF == 16) {
+      // the lane's four column blocks are four adjacent floats of a row: one 16-B store (16 lanes = 256 B of the row)
+      if (!p.atomic && (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0 && (p.c_split_stride & 3) == 0) {
+        const int l15 = lane & 15, q = lane >> 4;
+        const f32x4 bv = add_bias ? load4(p.bias + tn * BN + wn * 64 + 4 * l15) : f32x4{0.f, 0.f, 0.f, 0.f};
+        float* Cl = C + (long)(4 * q) * p.ldc + 4 * l15;
+#pragma unroll
+        for (int i = 0; i < L::MB; ++i)
+#pragma unroll
+          for (int r = 0; r < L::NR; ++r)
+            *reinterpret_cast<f32x4*>(Cl + (long)(i * 16 + r) * p.ldc) =
+                f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]} + bv;
+        return;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < L::NB; ++j) {
       const int cl = L::col(j, lane);
@@ -581,144 +575,117 @@ __device__ __forceinline__ void epilogue_affine_meanpool(const GemmParams& p,
 }
 
 // dgrad epilogue fused with the BatchNorm+ELU backward of the layer BELOW (pcaa_gemm_dgrad_bn):
-// the tile of da = dy.Wt never reaches HBM as such -- on its way out (row-contiguous, after the LDS
-// transpose) each lane loads the same 16 B of that layer's stored pre-activation y and writes
+// the tile of da = dy.Wt never reaches HBM as such -- on its way out each lane loads the 8 B of that layer's stored
+// pre-activation y that belong to its four adjacent columns of a row and writes
 //   dz = da * ELU'(y*scale + shift)
 // while accumulating the column sums {dz, dz * (y-mean)*rstd} the BatchNorm backward needs.  That
 // replaces a separate pass that re-read da and y (0.31 ms per step for PointNet layers 2-3).
-__device__ __forceinline__ void unpack8(const uint4 v, float (&f)[8]) {
-  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
-}
-
 // POINTS: the layer below is the first PointNet layer on its recompute path -- its pre-activation was
 // never stored, y[row][col] = sum_c x[row][c] * W1[col][c] (C <= 8 point features) is rebuilt here.
 template <int MF, bool POINTS>
 __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p,
                                                   typename AccLayout<MF>::vec (&acc)[AccLayout<MF>::MB][AccLayout<MF>::NB],
                                                   bf16_t* smem, int tm, int tn, int tid) {
+  static_assert(MF == 16, "built for the 16x16x32 accumulator layout (a lane = 4 adjacent columns)");
+  typedef AccLayout<MF> L;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  bf16_t* w = smem + wave * EP_WAVE_ELEMS;                // smem: the epilogue's LDS region
-  const int cg = (lane & 7) * 8, r0 = lane >> 3;
-  const long tile_off = (long)(tm * BM + wm * 128) * p.ldc + tn * BN + wn * 64;
-  bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + tile_off;
-  const bf16_t* Y = reinterpret_cast<const bf16_t*>(p.ep_y) + tile_off;       // same shape and ld as C
-  const int gcol = tn * BN + wn * 64 + cg;
-  float sc[8], sh[8], mu[8], rs[8];
+  const int l15 = lane & 15, q = lane >> 4;
+  const int c0 = tn * BN + wn * 64 + 4 * l15;                  // the lane's first column
+  const long row0 = (long)tm * BM + wm * 128 + 4 * q;          // its first row (rows 16 i + r further on)
+  bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + row0 * p.ldc + c0;
+  const bf16_t* Y = reinterpret_cast<const bf16_t*>(p.ep_y) + row0 * p.ldc + c0;       // same shape and ld as C
+  // The element-wise part runs on column PAIRS with packed fp32 instructions: ELU'(z) = exp(min(z, 0)) =
+  // exp2(min(z log2e, 0)) with log2e folded into the affine coefficients (no compare / select), yhat = y rstd - mean rstd
+  // as one fused multiply-add.
+  f32x2 sc2[2], sh2[2], rs2[2], nm2[2], s1[2], s2[2];
+  {
+    constexpr float kLog2e = 1.4426950408889634f;
+    const f32x4 a = load4(p.ep_scale + c0), b = load4(p.ep_shift + c0), c = load4(p.ep_mean + c0), d = load4(p.ep_rstd + c0);
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const f32x4 a = load4(p.ep_scale + gcol + 4 * q), b = load4(p.ep_shift + gcol + 4 * q);
-    const f32x4 c = load4(p.ep_mean + gcol + 4 * q), d = load4(p.ep_rstd + gcol + 4 * q);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { sc[4 * q + e] = a[e]; sh[4 * q + e] = b[e]; mu[4 * q + e] = c[e]; rs[4 * q + e] = d[e]; }
-  }
-  uint4 yv[2][EP_CHUNK_ROWS / 8];          // the stored pre-activations of one chunk, requested one chunk ahead
-  f32x4 xv[16][2];
-  float w1[8][8];
-  const int xc = p.ep_xc;
-  if (POINTS) {
-    const float* X = p.ep_x + (long)(tm * BM + wm * 128) * xc;
-#pragma unroll
-    for (int pass = 0; pass < 16; ++pass) {
-      const float* xr = X + (long)(pass * 8 + r0) * xc;
-      if (xc == 4) { xv[pass][0] = load4(xr); xv[pass][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      else {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) xv[pass][c >> 2][c & 3] = c < xc ? xr[c] : 0.f;
-      }
+    for (int h = 0; h < 2; ++h) {
+      sc2[h] = f32x2{a[2 * h] * kLog2e, a[2 * h + 1] * kLog2e};
+      sh2[h] = f32x2{b[2 * h] * kLog2e, b[2 * h + 1] * kLog2e};
+      rs2[h] = f32x2{d[2 * h], d[2 * h + 1]};
+      nm2[h] = f32x2{-c[2 * h] * d[2 * h], -c[2 * h + 1] * d[2 * h + 1]};
+      s1[h] = f32x2{0.f, 0.f};
+      s2[h] = f32x2{0.f, 0.f};
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) w1[j][c] = c < xc ? p.ep_w1[(long)(gcol + j) * xc + c] : 0.f;
   }
-  auto load_y = [&](int ch, int b) {
+  const int xc = p.ep_xc;
+  float w1[4][8];
+  const float* X = nullptr;
+  if (POINTS) {
+    X = p.ep_x + row0 * xc;
 #pragma unroll
-    for (int ps = 0; ps < EP_CHUNK_ROWS / 8; ++ps)
-      yv[b][ps] = *reinterpret_cast<const uint4*>(Y + (long)(ch * EP_CHUNK_ROWS + ps * 8 + r0) * p.ldc + cg);
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) w1[j][c] = c < xc ? p.ep_w1[(long)(c0 + j) * xc + c] : 0.f;
+  }
+  uint2 yv[2][4];                        // the stored pre-activations of one 16-row block, requested one block ahead
+  auto load_y = [&](int i, int b) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) yv[b][r] = *reinterpret_cast<const uint2*>(Y + (long)(i * 16 + r) * p.ldc);
   };
   if (!POINTS) load_y(0, 0);
-  // The element-wise part runs on column PAIRS with packed fp32 instructions (the epilogue is bound by vector-ALU issue):
-  // ELU'(z) = exp(min(z, 0)) = exp2(min(z log2e, 0)) with log2e folded into the affine coefficients (no compare / select),
-  // yhat = y rstd - mean rstd as one fused multiply-add.
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  f32x2 sc2[4], sh2[4], rs2[4], nm2[4], s1[4], s2[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    constexpr float kLog2e = 1.4426950408889634f;
-    sc2[q] = f32x2{sc[2 * q] * kLog2e, sc[2 * q + 1] * kLog2e};
-    sh2[q] = f32x2{sh[2 * q] * kLog2e, sh[2 * q + 1] * kLog2e};
-    rs2[q] = f32x2{rs[2 * q], rs[2 * q + 1]};
-    nm2[q] = f32x2{-mu[2 * q] * rs[2 * q], -mu[2 * q + 1] * rs[2 * q + 1]};
-    s1[q] = f32x2{0.f, 0.f};
-    s2[q] = f32x2{0.f, 0.f};
-  }
-  // 32 rows at a time through the wave's LDS image (wave-local: no workgroup barrier)
-  auto chunk = [&](auto CH) {
-    constexpr int ch = decltype(CH)::value;
-    if (!POINTS && ch < 3) load_y(ch + 1, (ch + 1) & 1);
-    park_chunk<MF, ch>(acc, w, lane, [](float v, int) { return v; });
+  for (int i = 0; i < L::MB; ++i) {
+    if (!POINTS && i + 1 < L::MB) load_y(i + 1, (i + 1) & 1);
 #pragma unroll
-    for (int ps = 0; ps < EP_CHUNK_ROWS / 8; ++ps) {
-      constexpr int per = EP_CHUNK_ROWS / 8;
-      const int pass = ch * per + ps;                      // 8-row pass of the wave's 128 rows
-      const int lrow = ps * 8 + r0, row = pass * 8 + r0;
-      float da[8], yy[8], dz[8];
-      unpack8(*reinterpret_cast<const uint4*>(&w[lrow * EP_PITCH + cg]), da);
+    for (int r = 0; r < 4; ++r) {
+      f32x2 y2[2];
       if (POINTS) {
+        const float* xr = X + (long)(i * 16 + r) * xc;
+        float xv[8];
+        if (xc == 4) {
+          const f32x4 t = load4(xr);
+          xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w; xv[4] = xv[5] = xv[6] = xv[7] = 0.f;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+          for (int c = 0; c < 8; ++c) xv[c] = c < xc ? xr[c] : 0.f;
+        }
+        float yy[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
           float a = 0.f;
 #pragma unroll
-          for (int c = 0; c < 8; ++c) a = fmaf(w1[j][c], xv[pass][c >> 2][c & 3], a);   // same order as pointnet_in.hip
+          for (int c = 0; c < 8; ++c) a = fmaf(w1[j][c], xv[c], a);             // same order as pointnet_in.hip
           yy[j] = a;
         }
+        y2[0] = f32x2{yy[0], yy[1]};
+        y2[1] = f32x2{yy[2], yy[3]};
       } else {
-        unpack8(yv[ch & 1][ps], yy);
+        const uint2 w = yv[i & 1][r];
+        y2[0] = f32x2{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u)};
+        y2[1] = f32x2{__uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u)};
       }
+      uint2 o;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x2 yv2 = {yy[2 * q], yy[2 * q + 1]}, dav = {da[2 * q], da[2 * q + 1]};
-        f32x2 z2 = __builtin_elementwise_fma(yv2, sc2[q], sh2[q]);
+      for (int h = 0; h < 2; ++h) {
+        const f32x2 dav = {acc[i][2 * h][r], acc[i][2 * h + 1][r]};
+        f32x2 z2 = __builtin_elementwise_fma(y2[h], sc2[h], sh2[h]);
         z2 = __builtin_elementwise_min(z2, f32x2{0.f, 0.f});
         const f32x2 g = {__builtin_amdgcn_exp2f(z2.x), __builtin_amdgcn_exp2f(z2.y)};
         const f32x2 d2 = dav * g;
-        s1[q] += d2;
-        s2[q] = __builtin_elementwise_fma(d2, __builtin_elementwise_fma(yv2, rs2[q], nm2[q]), s2[q]);
-        dz[2 * q] = d2.x;
-        dz[2 * q + 1] = d2.y;
+        s1[h] += d2;
+        s2[h] = __builtin_elementwise_fma(d2, __builtin_elementwise_fma(y2[h], rs2[h], nm2[h]), s2[h]);
+        (h == 0 ? o.x : o.y) = pack2(d2.x, d2.y);
       }
-      uint4 o;
-      o.x = pack2(dz[0], dz[1]); o.y = pack2(dz[2], dz[3]); o.z = pack2(dz[4], dz[5]); o.w = pack2(dz[6], dz[7]);
-      *reinterpret_cast<uint4*>(C + (long)row * p.ldc + cg) = o;
-    }
-  };
-  chunk(std::integral_constant<int, 0>{});
-  chunk(std::integral_constant<int, 1>{});
-  chunk(std::integral_constant<int, 2>{});
-  chunk(std::integral_constant<int, 3>{});
-  // lanes with equal (lane & 7) hold the same 8 columns: fold the 8 row lanes
-  float t1[8], t2[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    t1[c] = s1[c >> 1][c & 1];
-    t2[c] = s2[c >> 1][c & 1];
-#pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {
-      t1[c] += __shfl_xor(t1[c], o, 64);
-      t2[c] += __shfl_xor(t2[c], o, 64);
+      store_stream8(C + (long)(i * 16 + r) * p.ldc, o);
     }
   }
-  float* red = reinterpret_cast<float*>(smem) + EP_RED_OFFSET / 2;      // [2 stats][2 wm][256 cols], behind the images
-  if (lane < 8) {
+  // the four lanes q = 0..3 of a column quad hold partial sums over different rows: fold them (2 steps)
+  float t1[4], t2[4];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      red[(0 * 2 + wm) * 256 + wn * 64 + cg + c] = t1[c];
-      red[(1 * 2 + wm) * 256 + wn * 64 + cg + c] = t2[c];
-    }
+  for (int c = 0; c < 4; ++c) {
+    t1[c] = L::colreduce(s1[c >> 1][c & 1]);
+    t2[c] = L::colreduce(s2[c >> 1][c & 1]);
+  }
+  float* red = reinterpret_cast<float*>(smem) + EP_RED_OFFSET / 2;      // [2 stats][2 wm][256 cols]
+  if (L::col_leader(lane)) {
+    *reinterpret_cast<f32x4*>(&red[(0 * 2 + wm) * 256 + wn * 64 + 4 * l15]) = f32x4{t1[0], t1[1], t1[2], t1[3]};
+    *reinterpret_cast<f32x4*>(&red[(1 * 2 + wm) * 256 + wn * 64 + 4 * l15]) = f32x4{t2[0], t2[1], t2[2], t2[3]};
   }
   lds_barrier();
   const int stat = tid >> 8, col = tid & 255;
@@ -783,6 +750,7 @@ template <typename TC, int ALAY, int BLAY, int EPI, int MF, bool BUF, bool SPLIT
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   typedef AccLayout<MF> L;
   static_assert(MF == 32 || (ALAY == KC && BLAY == KC), "the 16x16x32 fragments are built for KC operands");
+  constexpr bool PERMB = MF == 16;     // B's rows permuted into the LDS: a lane's four column blocks are adjacent columns
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
 
@@ -811,7 +779,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
     rA = make_rsrc(A, (long)(ALAY == KC ? p.M : krows) * p.lda * 2);
     rB = make_rsrc(B, (long)(BLAY == KC ? p.N : krows) * p.ldb * 2);
     piece_lane_offsets<ALAY>(p.lda, lane, voA);
-    piece_lane_offsets<BLAY>(p.ldb, lane, voB);
+    piece_lane_offsets<BLAY, PERMB>(p.ldb, lane, voB);
   }
   // per-lane constants of the K loop are rebuilt at the top of every tile from an opaque copy of the lane id, so that
   // they do not stay in registers across the epilogue (which needs them all: accumulators + 64 of operands)
@@ -829,10 +797,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
     }
     if (BUF) {
       if (which == 0) dma_piece_buf<ALAY>(rA, p.lda, tmx * BM, k0, s_tile, wave, voA, j, extra);
-      else dma_piece_buf<BLAY>(rB, p.ldb, tnx * BN, k0, s_tile, wave, voB, j, extra);
+      else dma_piece_buf<BLAY, PERMB>(rB, p.ldb, tnx * BN, k0, s_tile, wave, voB, j, extra);
     } else {
       if (which == 0) dma_piece<ALAY>(A + extra, p.lda, tmx * BM, p.M, k0, s_tile, wave, lane, j);
-      else dma_piece<BLAY>(B + extra, p.ldb, tnx * BN, p.N, k0, s_tile, wave, lane, j);
+      else dma_piece<BLAY, PERMB>(B + extra, p.ldb, tnx * BN, p.N, k0, s_tile, wave, lane, j);
     }
   };
   auto piece = [&](int which, int k0, bf16_t* s_tile, int j) { piece_of(tm, tn, which, k0, s_tile, j); };
@@ -888,7 +856,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
     asm volatile("" : "+v"(ln));
     if (BUF) {
       piece_lane_offsets<ALAY>(p.lda, ln, voA);
-      piece_lane_offsets<BLAY>(p.ldb, ln, voB);
+      piece_lane_offsets<BLAY, PERMB>(p.ldb, ln, voB);
     }
   }
   int ia = 0;                                   // A slot of the current step (t mod 3)

@@ -215,7 +215,9 @@ def test_gemm_dgrad_bn_fused_epilogue(M, N, K):
     dz_ref, st_ref = ops.bn_act_bwd_dz(y, scale, shift, mean, rstd, da=da)
     assert (dz.float() - dz_ref.float()).abs().max().item() <= 1e-2 * max(1.0, dz_ref.float().abs().max().item())
     sa, sb = st.sum(0).cpu(), st_ref.sum(0).cpu()
-    assert (sa - sb).abs().max().item() <= 2e-3 * max(1.0, sb.abs().max().item())
+    # (the separate chain rounds da to bf16 before the statistics; the fused epilogue forms them from the fp32
+    # accumulators -- since round 3 they no longer pass through a bf16 LDS image -- so the two differ by that rounding)
+    assert (sa - sb).abs().max().item() <= 5e-3 * max(1.0, sb.abs().max().item())
     # exact fp64 check of the statistics against the dz the kernel itself wrote is not possible (they are
     # accumulated before the bf16 rounding); against fp64 of the unrounded product instead
     da64 = dy.float().cpu().double() @ Wt.float().cpu().double().t()
@@ -247,7 +249,7 @@ def test_gemm_dgrad_bn_recomputed_points_layer(C):
     dz_ref, st_ref = ops.bn_act_bwd_dz(y32, scale, shift, mean, rstd, da=da.float())
     assert (dz.float() - dz_ref).abs().max().item() <= 1e-2 * max(1.0, dz_ref.abs().max().item())
     sa, sb = st.sum(0).cpu(), st_ref.sum(0).cpu()
-    assert (sa - sb).abs().max().item() <= 2e-3 * max(1.0, sb.abs().max().item())
+    assert (sa - sb).abs().max().item() <= 5e-3 * max(1.0, sb.abs().max().item())     # (the reference chain rounds da to bf16)
     bn = _BN(N, 43)
     coef, _, _ = ops.bn_bwd_finalize(st_ref, M, bn, mean, rstd, N)
     dW_a = ops.pointnet_in_bwd_wgrad(da, x, W1, scale, shift, coef).cpu().double()
