@@ -409,15 +409,6 @@ template <> struct AccLayout<16> {
 // their way in -- dma_piece<KC, PERM> -- a lane's four column blocks ARE four adjacent columns, and the tile leaves
 // straight from the registers.)
 constexpr int EP_RED_OFFSET = 0;
-// 8-B store of a piece of the OUTPUT tile with the non-temporal (streaming) cache policy: the tile is not read again by
-// this launch, and with the default policy its 128 KB per workgroup push the streamed operand's lines -- which the three
-// sibling workgroups of the row block still want -- out of the XCD's 4 MB L2.  Same-box A/B on the forward shapes
-// (tools/gemm_epi_lab.py): 512->512 0.171 -> 0.155 ms, 512->1024 0.300 -> 0.254, 1024->1024 0.494 -> 0.490.
-__device__ __forceinline__ void store_stream8(bf16_t* dst, uint2 v) {
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  __builtin_nontemporal_store(u32x2{v.x, v.y}, reinterpret_cast<u32x2*>(dst));
-}
-
 // workgroup barrier that leaves vector-memory operations (the next tile's LDS-DMA pieces, this tile's C stores) alone
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -464,7 +455,7 @@ __device__ __forceinline__ void epilogue_full_tile(const GemmParams& p,
         uint2 o;
         o.x = pack2(out(acc[i][0][r], 0), out(acc[i][1][r], 1));
         o.y = pack2(out(acc[i][2][r], 2), out(acc[i][3][r], 3));
-        store_stream8(C + (long)(i * 16 + r) * p.ldc, o);
+        *reinterpret_cast<uint2*>(C + (long)(i * 16 + r) * p.ldc) = o;
       }
   } else {
     float* C = reinterpret_cast<float*>(p.C) + (long)split * p.c_split_stride +
@@ -672,7 +663,7 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p,
         s2[h] = __builtin_elementwise_fma(d2, __builtin_elementwise_fma(y2[h], rs2[h], nm2[h]), s2[h]);
         (h == 0 ? o.x : o.y) = pack2(d2.x, d2.y);
       }
-      store_stream8(C + (long)(i * 16 + r) * p.ldc, o);
+      *reinterpret_cast<uint2*>(C + (long)(i * 16 + r) * p.ldc) = o;
     }
   }
   // the four lanes q = 0..3 of a column quad hold partial sums over different rows: fold them (2 steps)
