@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PCAA_ABI_VERSION 11 /* pcaa_abi_version() of a library built from this header */
+#define PCAA_ABI_VERSION 12 /* pcaa_abi_version() of a library built from this header */
 
 #define PCAA_OK 0
 #define PCAA_ERR_INVALID_ARG 1
@@ -364,6 +364,16 @@ int pcaa_skinny_linear_dgrad(const float* dz, long lddz, const float* W, long ld
                              int K, int nsplit, void* stream);
 int pcaa_skinny_linear_wgrad(const float* dz, long lddz, const float* x, long ldx, float* dW, long lddw,
                              int M, int N, int K, void* stream);
+/* The same three passes with fp32 products (v_mfma_f32_32x32x2_f32 on the unrounded operands): the decoder of the parity
+ * modes ("fp32", "fp16x3"), which rounds 1-2 ran on the 128x128-tile fp32 GEMM.  Same arguments; the dgrad needs W 8-B
+ * aligned with an even leading dimension. */
+int pcaa_skinny_linear_fwd_exact(const float* x, long ldx, const float* W, long ldw, const float* bias, int act,
+                                 float* y, float* ws, long ws_floats, int M, int N, int K, int nsplit, void* stream);
+int pcaa_skinny_linear_dgrad_exact(const float* dz, long lddz, const float* W, long ldw, float* dx,
+                                   const float* a_prev, int accumulate, float* ws, long ws_floats, int M, int N,
+                                   int K, int nsplit, void* stream);
+int pcaa_skinny_linear_wgrad_exact(const float* dz, long lddz, const float* x, long ldx, float* dW, long lddw,
+                                   int M, int N, int K, void* stream);
 /* The same product written as bf16 (dW_bf16 [N, lddw] bf16, lddw even): the data-parallel step with bf16 gradient
  * buckets produces the gradient in the form it crosses the wire in (no fp32 copy, no cast pass). */
 int pcaa_skinny_linear_wgrad_bf16(const float* dz, long lddz, const float* x, long ldx, void* dW_bf16, long lddw,

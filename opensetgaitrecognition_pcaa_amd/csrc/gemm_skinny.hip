@@ -76,6 +76,28 @@ __device__ __forceinline__ bf16x8 small_frag(const bf16_t* buf, int mf, int s, i
   return *reinterpret_cast<const bf16x8*>(&buf[(mf * 32 + l31) * SP + s * 16 + h * 8]);
 }
 
+// ---- exact-fp32 variants (the parity modes: "fp32" and "fp16x3"): the same streams and the same lane maps, the operands
+// stay fp32 and one v_mfma_f32_32x32x16_bf16 becomes eight v_mfma_f32_32x32x2_f32 (lane (c, h) holds k = 8h .. 8h+7 of
+// its row / column; MFMA e contracts k = e and 8 + e): fp32 products, 1/16 of the bf16 rate -- 20 GFLOP per pass over the
+// 157 M decoder weights, about what the fp32 weight stream itself takes.  Rounds 1-2 served these modes with the
+// 128x128-tile fp32 GEMM: 64 of its 128 rows padding, and the weight gradient (contraction over the 64 batch rows) 2-3 ms.
+constexpr int SPF = 68;           // LDS pitch in floats of a 64-deep fp32 chunk row (272 B: 16 rows x b128 = all 64 banks)
+__device__ __forceinline__ void small_store_f32(const SmallStage& st, float* buf, int tid) {
+  const int m = tid >> 2, seg = (tid & 3) * 16;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(&buf[m * SPF + seg + 4 * q]) = st.v[q];
+}
+__device__ __forceinline__ void frag_f32(const float* buf, int row, int s, int h, float (&f)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(&buf[row * SPF + s * 16 + h * 8]);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(&buf[row * SPF + s * 16 + h * 8 + 4]);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+__device__ __forceinline__ f32x16 mfma8_f32(const float (&a)[8], const float (&b)[8], f32x16 acc) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+  return acc;
+}
+
 // slab store of a wave's 64(m) x 32(col) accumulators
 __device__ __forceinline__ void store_acc(const f32x16 (&acc)[2], float* __restrict__ out, long ld, int M, int col,
                                           int ncols, int h) {
@@ -146,11 +168,14 @@ __global__ __launch_bounds__(256) void skinny_dgrad_kernel(const float* __restri
 // a wave covers 64 columns with HALF the vector-memory instructions per byte.  The one-column kernel was bound
 // by those (7200 dword wave-loads per CU on the 7680x15360 layer: 3.2 TB/s against 4.5-5 of the other two).
 // grid (ceil(K/256), nsplit)
+template <bool F32 = false>
 __global__ __launch_bounds__(256) void skinny_dgrad2_kernel(const float* __restrict__ dz, long lddz,
                                                             const float* __restrict__ W, long ldw,
                                                             float* __restrict__ slabs, long slab_stride, int M,
                                                             int N, int K, int cps) {
-  __shared__ __attribute__((aligned(16))) bf16_t sbuf[2][64 * SP];
+  __shared__ __attribute__((aligned(16))) unsigned char sraw[2 * 64 * (F32 ? SPF * 4 : SP * 2)];
+  bf16_t (*sbuf)[64 * SP] = reinterpret_cast<bf16_t (*)[64 * SP]>(sraw);
+  float (*sbuf32)[64 * SPF] = reinterpret_cast<float (*)[64 * SPF]>(sraw);
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int col = blockIdx.x * 256 + wave * 64 + 2 * l31;          // this lane's column pair
@@ -167,7 +192,7 @@ __global__ __launch_bounds__(256) void skinny_dgrad2_kernel(const float* __restr
     for (int e = 0; e < 8; ++e) wr[s][e] = *reinterpret_cast<const f32x2*>(Wc + (long)(s * 16 + e) * ldw + lane_off);
   SmallStage st;
   small_load(st, dz, lddz, M, c0 * CH, tid);
-  small_store(st, sbuf[0], tid);
+  if constexpr (F32) small_store_f32(st, sbuf32[0], tid); else small_store(st, sbuf[0], tid);
   f32x16 acc[2][2];
 #pragma unroll
   for (int mf = 0; mf < 2; ++mf)
@@ -180,6 +205,7 @@ __global__ __launch_bounds__(256) void skinny_dgrad2_kernel(const float* __restr
   for (int c = 0; c < nch; ++c) {
     const bool more = c + 1 < nch;
     const bf16_t* cur = sbuf[c & 1];
+    const float* cur32 = sbuf32[c & 1];
     if (more) small_load(st, dz, lddz, M, (c0 + c + 1) * CH, tid);
     const float* Wn = Wc + (long)min(c + 1, nch - 1) * CH * ldw;     // last trip: harmless re-read
 #pragma unroll
@@ -187,16 +213,26 @@ __global__ __launch_bounds__(256) void skinny_dgrad2_kernel(const float* __restr
       float ev[8], od[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { ev[e] = wr[s][e].x; od[e] = wr[s][e].y; }
-      const bf16x8 b0 = pack8(ev), b1 = pack8(od);
 #pragma unroll
       for (int e = 0; e < 8; ++e) wr[s][e] = *reinterpret_cast<const f32x2*>(Wn + (long)(s * 16 + e) * ldw + lane_off);
-      const bf16x8 a0 = small_frag(cur, 0, s, l31, h), a1 = small_frag(cur, 1, s, l31, h);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+      if constexpr (F32) {
+        float a0[8], a1[8];
+        frag_f32(cur32, l31, s, h, a0);
+        frag_f32(cur32, 32 + l31, s, h, a1);
+        acc[0][0] = mfma8_f32(a0, ev, acc[0][0]);
+        acc[0][1] = mfma8_f32(a0, od, acc[0][1]);
+        acc[1][0] = mfma8_f32(a1, ev, acc[1][0]);
+        acc[1][1] = mfma8_f32(a1, od, acc[1][1]);
+      } else {
+        const bf16x8 b0 = pack8(ev), b1 = pack8(od);
+        const bf16x8 a0 = small_frag(cur, 0, s, l31, h), a1 = small_frag(cur, 1, s, l31, h);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+      }
     }
-    if (more) small_store(st, sbuf[(c + 1) & 1], tid);
+    if (more) { if constexpr (F32) small_store_f32(st, sbuf32[(c + 1) & 1], tid); else small_store(st, sbuf[(c + 1) & 1], tid); }
     lds_barrier();
   }
   if (col >= K) return;
@@ -212,12 +248,17 @@ __global__ __launch_bounds__(256) void skinny_dgrad2_kernel(const float* __restr
 
 // ------------------------------------------------------------------ forward: y = x . W^T
 // grid (ceil(N/128), nsplit); wave w owns output columns (rows of W) [128 bx + 32 w, +32)
+template <bool F32 = false>
 __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, long ldx,
                                                          const float* __restrict__ W, long ldw,
                                                          float* __restrict__ slabs, long slab_stride, int M,
                                                          int N, int K, int cps) {
-  __shared__ __attribute__((aligned(16))) bf16_t sbuf[2][64 * SP];
-  __shared__ __attribute__((aligned(16))) bf16_t wbuf[4][32 * SP];
+  __shared__ __attribute__((aligned(16))) unsigned char sraw[2 * 64 * (F32 ? SPF * 4 : SP * 2)];
+  __shared__ __attribute__((aligned(16))) unsigned char wraw[4 * 32 * (F32 ? SPF * 4 : SP * 2)];
+  bf16_t (*sbuf)[64 * SP] = reinterpret_cast<bf16_t (*)[64 * SP]>(sraw);
+  float (*sbuf32)[64 * SPF] = reinterpret_cast<float (*)[64 * SPF]>(sraw);
+  bf16_t (*wbuf)[32 * SP] = reinterpret_cast<bf16_t (*)[32 * SP]>(wraw);
+  float (*wbuf32)[32 * SPF] = reinterpret_cast<float (*)[32 * SPF]>(wraw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int n0 = blockIdx.x * 128 + wave * 32;
   const int c0 = blockIdx.y * cps;
@@ -229,6 +270,7 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < 8; ++i) roff[i] = min(n0 + 4 * i + lr, N - 1) * (int)ldw + kseg;   // < 2^31: host-checked
   bf16_t* wl = wbuf[wave];
+  float* wl32 = wbuf32[wave];
 
   f32x4 wr[8];
   const float* Wk = W + (long)c0 * CH;
@@ -236,7 +278,7 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
   for (int i = 0; i < 8; ++i) wr[i] = load4(Wk + roff[i]);
   SmallStage st;
   small_load(st, x, ldx, M, c0 * CH, tid);
-  small_store(st, sbuf[0], tid);
+  if constexpr (F32) small_store_f32(st, sbuf32[0], tid); else small_store(st, sbuf[0], tid);
   f32x16 acc[2];
 #pragma unroll
   for (int mf = 0; mf < 2; ++mf)
@@ -247,12 +289,17 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
   for (int c = 0; c < nch; ++c) {
     const bool more = c + 1 < nch;
     const bf16_t* cur = sbuf[c & 1];
+    const float* cur32 = sbuf32[c & 1];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      uint2 u;
-      u.x = pk2(wr[i].x, wr[i].y);
-      u.y = pk2(wr[i].z, wr[i].w);
-      *reinterpret_cast<uint2*>(&wl[(4 * i + lr) * SP + kseg]) = u;
+      if constexpr (F32) {
+        *reinterpret_cast<f32x4*>(&wl32[(4 * i + lr) * SPF + kseg]) = wr[i];
+      } else {
+        uint2 u;
+        u.x = pk2(wr[i].x, wr[i].y);
+        u.y = pk2(wr[i].z, wr[i].w);
+        *reinterpret_cast<uint2*>(&wl[(4 * i + lr) * SP + kseg]) = u;
+      }
     }
     {
       const float* Wn = Wk + (long)min(c + 1, nch - 1) * CH;      // last iteration: harmless re-read
@@ -265,12 +312,21 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const bf16x8 b = *reinterpret_cast<const bf16x8*>(&wl[l31 * SP + s * 16 + h * 8]);
-      const bf16x8 a0 = small_frag(cur, 0, s, l31, h), a1 = small_frag(cur, 1, s, l31, h);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[1], 0, 0, 0);
+      if constexpr (F32) {
+        float bq[8], a0[8], a1[8];
+        frag_f32(wl32, l31, s, h, bq);
+        frag_f32(cur32, l31, s, h, a0);
+        frag_f32(cur32, 32 + l31, s, h, a1);
+        acc[0] = mfma8_f32(a0, bq, acc[0]);
+        acc[1] = mfma8_f32(a1, bq, acc[1]);
+      } else {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(&wl[l31 * SP + s * 16 + h * 8]);
+        const bf16x8 a0 = small_frag(cur, 0, s, l31, h), a1 = small_frag(cur, 1, s, l31, h);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[1], 0, 0, 0);
+      }
     }
-    if (more) small_store(st, sbuf[(c + 1) & 1], tid);
+    if (more) { if constexpr (F32) small_store_f32(st, sbuf32[(c + 1) & 1], tid); else small_store(st, sbuf[(c + 1) & 1], tid); }
     lds_barrier();
   }
   store_acc(acc, slabs + (long)blockIdx.y * slab_stride, N, M, n0 + l31, N, h);
@@ -288,12 +344,13 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
 // in, no fp32 copy and no cast pass): neighbouring lanes exchange one packed pair (DPP) so that every lane stores two
 // adjacent columns of one row as one dword -- 64-B runs per row and half-wave, the other half of the line follows with
 // the wave's next 32 columns.
-template <int JL, bool FULLN, typename TO = float>
+template <int JL, bool FULLN, typename TO = float, bool F32 = false>
 __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restrict__ dz, long lddz,
                                                            const float* __restrict__ x, long ldx,
                                                            TO* __restrict__ dW, long lddw, int M, int N,
                                                            int K) {
-  __shared__ __attribute__((aligned(16))) bf16x8 apan[4][4][64];      // [row fragment i][k-step s][lane]
+  __shared__ __attribute__((aligned(16))) bf16x8 apan[F32 ? 1 : 4][4][64];      // [row fragment i][k-step s][lane]
+  __shared__ __attribute__((aligned(16))) f32x4 apan32[F32 ? 4 : 1][4][2][64];   // exact variant: the same, fp32 (2 x 16 B)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
   const int n0 = blockIdx.y * 128;
   const int kb = (blockIdx.x * 4 + wave) * (32 * JL);
@@ -311,7 +368,12 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restri
         const float v = dz[(unsigned)min(m, M - 1) * (unsigned)lddz + ncol];
         t[e] = m < M ? v : 0.f;
       }
-      apan[i][s][lane] = pack8(t);
+      if constexpr (F32) {
+        apan32[i][s][0][lane] = f32x4{t[0], t[1], t[2], t[3]};
+        apan32[i][s][1][lane] = f32x4{t[4], t[5], t[6], t[7]};
+      } else {
+        apan[i][s][lane] = pack8(t);
+      }
     }
   }
   unsigned xoff[4][8];
@@ -330,8 +392,16 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restri
   const unsigned row0 = (unsigned)(n0 + 4 * h);
   for (int j = 0; j < jn; ++j) {
     bf16x8 bf[4];
+    float bq[F32 ? 4 : 1][8];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) bf[s] = pack8(br[s]);
+    for (int s = 0; s < 4; ++s) {
+      if constexpr (F32) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bq[s][e] = br[s][e];
+      } else {
+        bf[s] = pack8(br[s]);
+      }
+    }
     {
       const float* xn = x + 32 * min(j + 1, jn - 1);      // last iteration: harmless re-read
 #pragma unroll
@@ -348,8 +418,15 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restri
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apan[i][s][lane], bf[s], acc[i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (F32) {
+          const f32x4 lo = apan32[i][s][0][lane], hi = apan32[i][s][1][lane];
+          const float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          acc[i] = mfma8_f32(a, bq[s], acc[i]);
+        } else {
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apan[i][s][lane], bf[s], acc[i], 0, 0, 0);
+        }
+      }
     TO* dj = dW + kb + 32 * j;                             // uniform
     unsigned o0 = row0 * (unsigned)lddw + l31;
     // opaque to the optimiser: LICM otherwise hoists all 64 store offsets (and the 16 LDS
@@ -546,9 +623,9 @@ extern "C" int pcaa_skinny_supported(int M, int N, int K) {
   return M >= 1 && M <= 64 && N >= 128 && K >= 64 && N % 64 == 0 && K % 64 == 0 && (long)N * K < (1L << 31) - (1L << 20);
 }
 
-extern "C" int pcaa_skinny_linear_fwd(const float* x, long ldx, const float* W, long ldw, const float* bias, int act,
-                                      float* y, float* ws, long ws_floats, int M, int N, int K, int nsplit,
-                                      void* stream) {
+static int skinny_fwd_impl(const float* x, long ldx, const float* W, long ldw, const float* bias, int act,
+                           float* y, float* ws, long ws_floats, int M, int N, int K, int nsplit, int exact,
+                           void* stream) {
   PCAA_CHECK_ARG(x && W && y && ws, "pcaa_skinny_linear_fwd: null pointer");
   PCAA_CHECK_ARG(pcaa_skinny_supported(M, N, K), "pcaa_skinny_linear_fwd: unsupported shape M=%d N=%d K=%d", M, N, K);
   PCAA_CHECK_ARG(ldx >= K && ldx % 4 == 0 && ldw >= K && ldw % 4 == 0 && ldw * (long)N < (1L << 31),
@@ -563,15 +640,30 @@ extern "C" int pcaa_skinny_linear_fwd(const float* x, long ldx, const float* W, 
   const long stride = (long)M * N;
   PCAA_CHECK_ARG(ws_floats >= stride * nsplit, "pcaa_skinny_linear_fwd: workspace too small");
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(skinny_fwd_kernel, dim3((unsigned)cdiv(N, 128), nsplit), dim3(256), 0, s, x, ldx, W, ldw, ws,
-                     stride, M, N, K, cps);
+  if (exact)
+    hipLaunchKernelGGL(skinny_fwd_kernel<true>, dim3((unsigned)cdiv(N, 128), nsplit), dim3(256), 0, s, x, ldx, W, ldw, ws,
+                       stride, M, N, K, cps);
+  else
+    hipLaunchKernelGGL(skinny_fwd_kernel<false>, dim3((unsigned)cdiv(N, 128), nsplit), dim3(256), 0, s, x, ldx, W, ldw, ws,
+                       stride, M, N, K, cps);
   reduce_launch(ws, nsplit, stride, y, bias, act, nullptr, 0, M, N, s);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_fwd");
 }
 
-extern "C" int pcaa_skinny_linear_dgrad(const float* dz, long lddz, const float* W, long ldw, float* dx,
-                                        const float* a_prev, int accumulate, float* ws, long ws_floats, int M, int N,
-                                        int K, int nsplit, void* stream) {
+extern "C" int pcaa_skinny_linear_fwd(const float* x, long ldx, const float* W, long ldw, const float* bias, int act,
+                                      float* y, float* ws, long ws_floats, int M, int N, int K, int nsplit,
+                                      void* stream) {
+  return skinny_fwd_impl(x, ldx, W, ldw, bias, act, y, ws, ws_floats, M, N, K, nsplit, 0, stream);
+}
+extern "C" int pcaa_skinny_linear_fwd_exact(const float* x, long ldx, const float* W, long ldw, const float* bias, int act,
+                                            float* y, float* ws, long ws_floats, int M, int N, int K, int nsplit,
+                                            void* stream) {
+  return skinny_fwd_impl(x, ldx, W, ldw, bias, act, y, ws, ws_floats, M, N, K, nsplit, 1, stream);
+}
+
+static int skinny_dgrad_impl(const float* dz, long lddz, const float* W, long ldw, float* dx,
+                             const float* a_prev, int accumulate, float* ws, long ws_floats, int M, int N,
+                             int K, int nsplit, int exact, void* stream) {
   PCAA_CHECK_ARG(dz && W && dx && ws, "pcaa_skinny_linear_dgrad: null pointer");
   PCAA_CHECK_ARG(pcaa_skinny_supported(M, N, K), "pcaa_skinny_linear_dgrad: unsupported shape M=%d N=%d K=%d", M, N, K);
   PCAA_CHECK_ARG(lddz >= N && lddz % 4 == 0 && ldw >= K && ldw * (long)N < (1L << 31),
@@ -586,8 +678,13 @@ extern "C" int pcaa_skinny_linear_dgrad(const float* dz, long lddz, const float*
   PCAA_CHECK_ARG(ws_floats >= stride * nsplit, "pcaa_skinny_linear_dgrad: workspace too small");
   hipStream_t s = as_stream(stream);
   // two columns per lane where the 8-B loads are aligned, else the one-column-per-lane kernel
-  if ((ldw % 2) == 0 && ((uintptr_t)W % 8) == 0)
-    hipLaunchKernelGGL(skinny_dgrad2_kernel, dim3((unsigned)cdiv(K, 256), nsplit), dim3(256), 0, s, dz, lddz, W, ldw,
+  const bool pairs = (ldw % 2) == 0 && ((uintptr_t)W % 8) == 0;
+  PCAA_CHECK_ARG(!exact || pairs, "pcaa_skinny_linear_dgrad_exact: W must be 8-B aligned with an even leading dimension");
+  if (exact)
+    hipLaunchKernelGGL(skinny_dgrad2_kernel<true>, dim3((unsigned)cdiv(K, 256), nsplit), dim3(256), 0, s, dz, lddz, W, ldw,
+                       ws, stride, M, N, K, cps);
+  else if (pairs)
+    hipLaunchKernelGGL(skinny_dgrad2_kernel<false>, dim3((unsigned)cdiv(K, 256), nsplit), dim3(256), 0, s, dz, lddz, W, ldw,
                        ws, stride, M, N, K, cps);
   else
     hipLaunchKernelGGL(skinny_dgrad_kernel, dim3((unsigned)cdiv(K, 128), nsplit), dim3(256), 0, s, dz, lddz, W, ldw,
@@ -596,8 +693,19 @@ extern "C" int pcaa_skinny_linear_dgrad(const float* dz, long lddz, const float*
   PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_dgrad");
 }
 
-extern "C" int pcaa_skinny_linear_wgrad(const float* dz, long lddz, const float* x, long ldx, float* dW, long lddw,
-                                        int M, int N, int K, void* stream) {
+extern "C" int pcaa_skinny_linear_dgrad(const float* dz, long lddz, const float* W, long ldw, float* dx,
+                                        const float* a_prev, int accumulate, float* ws, long ws_floats, int M, int N,
+                                        int K, int nsplit, void* stream) {
+  return skinny_dgrad_impl(dz, lddz, W, ldw, dx, a_prev, accumulate, ws, ws_floats, M, N, K, nsplit, 0, stream);
+}
+extern "C" int pcaa_skinny_linear_dgrad_exact(const float* dz, long lddz, const float* W, long ldw, float* dx,
+                                              const float* a_prev, int accumulate, float* ws, long ws_floats, int M,
+                                              int N, int K, int nsplit, void* stream) {
+  return skinny_dgrad_impl(dz, lddz, W, ldw, dx, a_prev, accumulate, ws, ws_floats, M, N, K, nsplit, 1, stream);
+}
+
+static int skinny_wgrad_impl(const float* dz, long lddz, const float* x, long ldx, float* dW, long lddw,
+                             int M, int N, int K, int exact, void* stream) {
   PCAA_CHECK_ARG(dz && x && dW, "pcaa_skinny_linear_wgrad: null pointer");
   PCAA_CHECK_ARG(M >= 1 && M <= 64 && N >= 1 && K >= 32 && K % 32 == 0,
                  "pcaa_skinny_linear_wgrad: unsupported shape M=%d N=%d K=%d", M, N, K);
@@ -606,13 +714,30 @@ extern "C" int pcaa_skinny_linear_wgrad(const float* dz, long lddz, const float*
                  "pcaa_skinny_linear_wgrad: operands beyond 32-bit element offsets");
   constexpr int JL = 4;
   const dim3 grid((unsigned)cdiv(K, 4 * 32 * JL), (unsigned)cdiv(N, 128));
-  if (N % 128 == 0)
+  if (exact) {
+    if (N % 128 == 0)
+      hipLaunchKernelGGL((skinny_wgrad_kernel<JL, true, float, true>), grid, dim3(256), 0, as_stream(stream), dz, lddz, x,
+                         ldx, dW, lddw, M, N, K);
+    else
+      hipLaunchKernelGGL((skinny_wgrad_kernel<JL, false, float, true>), grid, dim3(256), 0, as_stream(stream), dz, lddz, x,
+                         ldx, dW, lddw, M, N, K);
+  } else if (N % 128 == 0) {
     hipLaunchKernelGGL((skinny_wgrad_kernel<JL, true>), grid, dim3(256), 0, as_stream(stream), dz, lddz, x, ldx, dW,
                        lddw, M, N, K);
-  else
+  } else {
     hipLaunchKernelGGL((skinny_wgrad_kernel<JL, false>), grid, dim3(256), 0, as_stream(stream), dz, lddz, x, ldx, dW,
                        lddw, M, N, K);
+  }
   PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_wgrad");
+}
+
+extern "C" int pcaa_skinny_linear_wgrad(const float* dz, long lddz, const float* x, long ldx, float* dW, long lddw,
+                                        int M, int N, int K, void* stream) {
+  return skinny_wgrad_impl(dz, lddz, x, ldx, dW, lddw, M, N, K, 0, stream);
+}
+extern "C" int pcaa_skinny_linear_wgrad_exact(const float* dz, long lddz, const float* x, long ldx, float* dW, long lddw,
+                                              int M, int N, int K, void* stream) {
+  return skinny_wgrad_impl(dz, lddz, x, ldx, dW, lddw, M, N, K, 1, stream);
 }
 
 extern "C" int pcaa_skinny_linear_wgrad_bf16(const float* dz, long lddz, const float* x, long ldx, void* dW_bf16, long lddw,

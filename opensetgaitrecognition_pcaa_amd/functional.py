@@ -632,6 +632,12 @@ def _skinny(mode, M, N, K):
     return mode == "bf16" and ops.skinny_supported(M, N, K)
 
 
+def _skinny_exact(mode, M, N, K):
+    """The same kernels with fp32 products (the parity modes): round 3 -- before, those modes ran the decoder on the
+    128x128-tile fp32 GEMM (half of every tile padding; the weight gradient, a 64-deep contraction, 2-3 ms per step)."""
+    return mode in ("fp32", "fp16x3") and ops.skinny_supported(M, N, K)
+
+
 def linear_act_forward(x, lin, act, mode="fp32"):
     """act(x @ W^T + b); x [M,K] fp32 -> [M,N] fp32.  fp32 MFMA, or (bf16 mode,
     wide layers) bf16 MFMA with fp32 accumulation: the layer is bound by
@@ -641,6 +647,8 @@ def linear_act_forward(x, lin, act, mode="fp32"):
     N = lin.weight.shape[0]
     if _skinny(mode, M, N, K):
         return ops.skinny_linear_fwd(x, lin.weight, lin.bias, act)
+    if _skinny_exact(mode, M, N, K):
+        return ops.skinny_linear_fwd(x, lin.weight, lin.bias, act, exact=True)
     if _wide_bf16(mode, M, N, K):
         sk = ops.pick_split_k(M, N, K, target_blocks=256, bk=64, tile=256)
         y = ops.gemm(x, KC, lin.weight, KC, M, N, K, split_k=sk, accumulate=True, math=PCAA_BF16)
@@ -679,19 +687,20 @@ def linear_act_backward(x, a_out, lin, act, d_out, need_dx=True, dW_out=None, db
                                          accumulate=dx_init is not None)
         update(dz2, x)
         return None, db, dx
-    if _skinny(mode, M, N, K):
+    exact = _skinny_exact(mode, M, N, K)
+    if _skinny(mode, M, N, K) or exact:
         if dW_out is not None and db_out is not None:
             # the weight-gradient write stream (and the bias gradient) beside the dgrad read stream of the same layer
             with _on_wgrad_stream(dz2, x):
                 db = ops.colsum(dz2, out=db_out)
-                dW = ops.skinny_linear_wgrad(dz2, x, out=dW_out)
+                dW = ops.skinny_linear_wgrad(dz2, x, out=dW_out, exact=exact)
         else:
             db = ops.colsum(dz2, out=db_out)
-            dW = ops.skinny_linear_wgrad(dz2, x, out=dW_out)
+            dW = ops.skinny_linear_wgrad(dz2, x, out=dW_out, exact=exact)
         dx = None
         if need_dx:
             dx = ops.skinny_linear_dgrad(dz2, lin.weight, a_prev=x if fuse_elu_in else None, out=dx_init,
-                                         accumulate=dx_init is not None)
+                                         accumulate=dx_init is not None, exact=exact)
         return dW, db, dx
     if fuse_elu_in:
         raise RuntimeError("linear_act_backward: fuse_elu_in is only served by the skinny path")
@@ -1135,7 +1144,7 @@ def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=Non
         dW_out = grads_out[nm + ".weight"] if grads_out else None
         db_out = grads_out[nm + ".bias"] if grads_out else None
         M, K = acts[i].shape
-        fuse = i > 0 and _skinny(mode, M, lin.weight.shape[0], K)      # acts[i] is an ELU output for i >= 1
+        fuse = i > 0 and (_skinny(mode, M, lin.weight.shape[0], K) or _skinny_exact(mode, M, lin.weight.shape[0], K))    # acts[i] is an ELU output for i >= 1
         dW, db, d = linear_act_backward(acts[i], acts[i + 1], lin, ACT_ELU if i < 4 else ACT_NONE, d,
                                         need_dx=(i > 0 or need_dz), dW_out=dW_out, db_out=db_out,
                                         dx_init=dz_init if i == 0 else None, mode=mode, d_is_pre=pre,

@@ -989,8 +989,9 @@ def _skinny_timed(fn, flops, nbytes):
     timer.records.append(("gemm_skinny_kernel", flops, float(nbytes), ev))
 
 
-def skinny_linear_fwd(x, W, bias, act):
-    """act(x[M,K] @ W[N,K]^T + bias) with M <= 64: one streaming pass over W."""
+def skinny_linear_fwd(x, W, bias, act, exact=False):
+    """act(x[M,K] @ W[N,K]^T + bias) with M <= 64: one streaming pass over W.  ``exact``: fp32 products on the fp32
+    matrix pipe (the parity modes) instead of bf16-rounded operands."""
     _chk(x, "skinny_fwd.x", torch.float32, 2)
     _chk(W, "skinny_fwd.W", torch.float32, 2)
     M, K = x.shape
@@ -1001,13 +1002,14 @@ def skinny_linear_fwd(x, W, bias, act):
     ns = lib.pcaa_skinny_splits(0, M, N, K)
     ws = torch.empty(ns * M * N, dtype=torch.float32, device=x.device)
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    _skinny_timed(lambda: check(lib.pcaa_skinny_linear_fwd(_p(x), x.stride(0), _p(W), W.stride(0), _p(bias), act,
-                                                           _p(y), _p(ws), ws.numel(), M, N, K, ns, _s()),
+    fn = lib.pcaa_skinny_linear_fwd_exact if exact else lib.pcaa_skinny_linear_fwd
+    _skinny_timed(lambda: check(fn(_p(x), x.stride(0), _p(W), W.stride(0), _p(bias), act,
+                                   _p(y), _p(ws), ws.numel(), M, N, K, ns, _s()),
                                 "pcaa_skinny_linear_fwd"), 2.0 * M * N * K, 4 * (N * K + M * K + M * N))
     return y
 
 
-def skinny_linear_dgrad(dz, W, a_prev=None, out=None, accumulate=False):
+def skinny_linear_dgrad(dz, W, a_prev=None, out=None, accumulate=False, exact=False):
     """dx[M,K] (=|+=) (dz[M,N] @ W[N,K]) * ELU'(a_prev) (a_prev: ELU OUTPUT of the layer below or None)."""
     _chk(dz, "skinny_dgrad.dz", torch.float32, 2)
     _chk(W, "skinny_dgrad.W", torch.float32, 2)
@@ -1030,14 +1032,15 @@ def skinny_linear_dgrad(dz, W, a_prev=None, out=None, accumulate=False):
     lib = _lib.load()
     ns = lib.pcaa_skinny_splits(1, M, N, K)
     ws = torch.empty(ns * M * K, dtype=torch.float32, device=dz.device)
-    _skinny_timed(lambda: check(lib.pcaa_skinny_linear_dgrad(_p(dz), dz.stride(0), _p(W), W.stride(0), _p(out),
-                                                             _p(a_prev), int(bool(accumulate)), _p(ws), ws.numel(),
-                                                             M, N, K, ns, _s()),
+    fn = lib.pcaa_skinny_linear_dgrad_exact if exact else lib.pcaa_skinny_linear_dgrad
+    _skinny_timed(lambda: check(fn(_p(dz), dz.stride(0), _p(W), W.stride(0), _p(out),
+                                   _p(a_prev), int(bool(accumulate)), _p(ws), ws.numel(),
+                                   M, N, K, ns, _s()),
                                 "pcaa_skinny_linear_dgrad"), 2.0 * M * N * K, 4 * (N * K + M * K + M * N))
     return out
 
 
-def skinny_linear_wgrad(dz, x, out=None):
+def skinny_linear_wgrad(dz, x, out=None, exact=False):
     """dW[N,K] = dz[M,N]^T @ x[M,K] with M <= 64: one streaming store pass over dW."""
     _chk(dz, "skinny_wgrad.dz", torch.float32, 2)
     _chk(x, "skinny_wgrad.x", torch.float32, 2)
@@ -1053,12 +1056,14 @@ def skinny_linear_wgrad(dz, x, out=None):
             raise ValueError("skinny_linear_wgrad: out must hold N*K fp32 or bf16 elements")
     lib = _lib.load()
     if out.dtype == torch.bfloat16:       # the gradient as it crosses the wire (bf16 gradient buckets)
+        if exact:
+            raise ValueError("skinny_linear_wgrad: the exact variant writes fp32")
         _skinny_timed(lambda: check(lib.pcaa_skinny_linear_wgrad_bf16(_p(dz), dz.stride(0), _p(x), x.stride(0), _p(out), K,
                                                                       M, N, K, _s()),
                                     "pcaa_skinny_linear_wgrad_bf16"), 2.0 * M * N * K, 2 * N * K + 4 * (M * K + M * N))
         return out
-    _skinny_timed(lambda: check(lib.pcaa_skinny_linear_wgrad(_p(dz), dz.stride(0), _p(x), x.stride(0), _p(out), K,
-                                                             M, N, K, _s()),
+    fn = lib.pcaa_skinny_linear_wgrad_exact if exact else lib.pcaa_skinny_linear_wgrad
+    _skinny_timed(lambda: check(fn(_p(dz), dz.stride(0), _p(x), x.stride(0), _p(out), K, M, N, K, _s()),
                                 "pcaa_skinny_linear_wgrad"), 2.0 * M * N * K, 4 * (N * K + M * K + M * N))
     return out
 

@@ -197,6 +197,28 @@ def test_skinny_linear_layers_random_bf16_rounding():
     assert (dW - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 3840, 1920), (37, 1920, 960), (5, 256, 64)])
+def test_skinny_linear_layers_exact_variants(M, N, K):
+    """the fp32-product variants (the parity modes' decoder): fp32 accuracy against the fp64 product of the UNROUNDED
+    operands, in all three passes, with the fused bias + ELU / ELU' reductions"""
+    rng = np.random.default_rng(44)
+    x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32))
+    W = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(N).astype(np.float32))
+    dz = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32))
+    a_prev = torch.from_numpy(rng.uniform(-0.9, 2.0, (M, K)).astype(np.float32))
+    y = ops.skinny_linear_fwd(x.to(DEV), W.to(DEV), b.to(DEV), ACT_ELU, exact=True).cpu().double()
+    z = x.double() @ W.double().t() + b.double()
+    ref = torch.where(z > 0, z, torch.expm1(z))
+    assert (y - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    dx = ops.skinny_linear_dgrad(dz.to(DEV), W.to(DEV), a_prev=a_prev.to(DEV), exact=True).cpu().double()
+    ref = (dz.double() @ W.double()) * torch.where(a_prev > 0, torch.ones_like(a_prev), a_prev + 1).double()
+    assert (dx - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    dW = ops.skinny_linear_wgrad(dz.to(DEV), x.to(DEV), exact=True).cpu().double()
+    ref = dz.double().t() @ x.double()
+    assert (dW - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("M,N,K", [(512, 256, 256), (768, 512, 1024), (1024, 1024, 512)])
 def test_gemm_dgrad_bn_fused_epilogue(M, N, K):
     """dgrad fused with ELU' and the BatchNorm-backward statistics of the layer below: must agree with
