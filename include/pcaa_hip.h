@@ -100,6 +100,15 @@ int pcaa_gemm_dgrad_bn(const void* dy, long lddy, const void* Wt, long ldw, cons
                        const float* scale, const float* shift, const float* mean, const float* rstd,
                        double* stats, int nrep, int M, int N, int K,
                        const float* x, int xc, const float* W1, void* stream);
+/* dy = coef0*dz + coef1*y + coef2 (fp32 dz, y) written as its [hi | lo] fp16 image [rows, 2 ch]: the second half of the
+ * BatchNorm backward behind pcaa_gemm_dgrad_bn_split3 */
+int pcaa_bn_bwd_dy_split(const float* dz, const float* y, void* dy_img, const float* coef, long rows, int ch,
+                         float img_scale, void* stream);
+/* pcaa_gemm_dgrad_bn for the split-fp16 parity mode: dy_img [M, 2K], Wt_img [N, 2K] are [hi | lo] fp16 images, y and dz
+ * fp32 [M, ld]; out_scale = 1 / (image scales). */
+int pcaa_gemm_dgrad_bn_split3(const void* dy_img, long lddy, const void* Wt_img, long ldw, const float* y, float* dz,
+                              long ld, const float* scale, const float* shift, const float* mean, const float* rstd,
+                              double* stats, int nrep, int M, int N, int K, float out_scale, void* stream);
 /* Kernel-exact timing of one LDS-DMA GEMM launch (bench.py's roofline figure): events made by
  * pcaa_timing_events_create and armed with pcaa_time_next_gemm ride on the NEXT such launch of the
  * calling thread (hipExtLaunchKernelGGL start/stop events: the timestamps of the kernel's own dispatch

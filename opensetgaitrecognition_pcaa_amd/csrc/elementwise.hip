@@ -415,6 +415,24 @@ __global__ __launch_bounds__(256) void bn_bwd_dy_kernel(const T* __restrict__ dz
   }
 }
 
+// dy = c0*dz + c1*y + c2 written as its [hi | lo] fp16 image (split parity mode: the dgrad above already formed dz
+// and its statistics in its epilogue, pcaa_gemm_dgrad_bn_split3; dy only feeds the two products below)
+__global__ __launch_bounds__(256) void bn_bwd_dy_split_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                                                              split_t* __restrict__ dy_img,
+                                                              const float* __restrict__ coef, unsigned nquads,
+                                                              unsigned qpr, unsigned ch, float img_scale) {
+  const unsigned q0 = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+  const unsigned c = (q0 % qpr) << 2;
+  const unsigned rstep = stride / qpr;
+  unsigned rr = q0 / qpr;
+  const f32x4 k0 = load4(coef + c), k1 = load4(coef + ch + c), k2 = load4(coef + 2 * ch + c);
+  for (unsigned q = q0; q < nquads; q += stride) {
+    const f32x4 d = load4(dz + (size_t)q * 4), yv = load4(y + (size_t)q * 4);
+    store4_split(dy_img, rr, ch, c, k0 * d + k1 * yv + k2, img_scale);
+    rr += rstep;
+  }
+}
+
 // ---------------------------------------------------------------- small fp32 helpers
 __global__ void bias_act_kernel(float* y, const float* __restrict__ bias, int act, long n, int cols) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -937,6 +955,19 @@ extern "C" int pcaa_bn_bwd_dy(const void* dz, const void* y, void* dy, int dtype
                        (const bf16_t*)y, (bf16_t*)dy, coef, (unsigned)nq, (unsigned)(ch >> 2), (unsigned)ch);
   else { pcaa_set_error("pcaa_bn_bwd_dy: bad dtype"); return PCAA_ERR_INVALID_ARG; }
   PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_bwd_dy");
+}
+
+extern "C" int pcaa_bn_bwd_dy_split(const float* dz, const float* y, void* dy_img, const float* coef, long rows, int ch,
+                                    float img_scale, void* stream) {
+  PCAA_CHECK_ARG(dz && y && dy_img && coef, "pcaa_bn_bwd_dy_split: null pointer");
+  PCAA_CHECK_ARG(rows >= 1 && ch >= 4 && (ch & 3) == 0, "pcaa_bn_bwd_dy_split: ch must be a multiple of 4");
+  PCAA_CHECK_ARG((const void*)dz != dy_img && (const void*)y != dy_img, "pcaa_bn_bwd_dy_split: the image cannot alias an input");
+  const long nq = rows * (ch >> 2);
+  PCAA_CHECK_ARG(nq < (1L << 31), "pcaa_bn_bwd_dy_split: tensor too large for 32-bit quad indices");
+  const int grid = col_invariant_grid(nq, ch >> 2);
+  hipLaunchKernelGGL(bn_bwd_dy_split_kernel, dim3(grid), dim3(256), 0, as_stream(stream), dz, y, (split_t*)dy_img, coef,
+                     (unsigned)nq, (unsigned)(ch >> 2), (unsigned)ch, img_scale);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_bwd_dy_split");
 }
 
 extern "C" int pcaa_bias_act(float* y, const float* bias, int act, long rows, int cols, void* stream) {

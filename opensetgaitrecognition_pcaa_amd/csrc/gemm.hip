@@ -577,6 +577,39 @@ extern "C" int pcaa_gemm_dgrad_bn(const void* dy, long lddy, const void* Wt, lon
   PCAA_RETURN_LAUNCH_STATUS("pcaa_gemm_dgrad_bn");
 }
 
+/* The same fusion for the split-fp16 parity mode: dy and Wt are [hi | lo] fp16 images (pcaa_split_f16: dy [M, 2K],
+ * Wt [N, 2K]), y and dz fp32 [M, ld]; ELU' and the statistics in the arithmetic of pcaa_bn_act_bwd_dz on fp32 tensors. */
+extern "C" int pcaa_gemm_dgrad_bn_split3(const void* dy_img, long lddy, const void* Wt_img, long ldw, const float* y,
+                                         float* dz, long ld, const float* scale, const float* shift, const float* mean,
+                                         const float* rstd, double* stats, int nrep, int M, int N, int K,
+                                         float out_scale, void* stream) {
+  PCAA_CHECK_ARG(dy_img && Wt_img && y && dz && scale && shift && mean && rstd && stats,
+                 "pcaa_gemm_dgrad_bn_split3: null pointer");
+  PCAA_CHECK_ARG(pcaa_gemm_dgrad_bn_supported(M, N, K), "pcaa_gemm_dgrad_bn_split3: M, N must be multiples of 256 and K "
+                 "of 64 (M=%d N=%d K=%d)", M, N, K);
+  PCAA_CHECK_ARG((long)K * 3 < (1L << 31) && lddy >= 2L * K && ldw >= 2L * K && ld >= N && (lddy % 8) == 0 &&
+                 (ldw % 8) == 0 && (ld % 4) == 0 && nrep >= 1, "pcaa_gemm_dgrad_bn_split3: bad leading dimension / nrep");
+  PCAA_CHECK_ARG(((uintptr_t)dy_img % 16) == 0 && ((uintptr_t)Wt_img % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+                 ((uintptr_t)dz % 16) == 0 && ((uintptr_t)scale % 16) == 0 && ((uintptr_t)shift % 16) == 0 &&
+                 ((uintptr_t)mean % 16) == 0 && ((uintptr_t)rstd % 16) == 0, "pcaa_gemm_dgrad_bn_split3: 16-B alignment");
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = dy_img; p.B = Wt_img; p.C = dz;
+  p.lda = lddy; p.ldb = ldw; p.ldc = ld;
+  p.M = M; p.N = N; p.K = 3 * K;
+  p.colstats = stats; p.nrep = nrep;
+  p.seg_len = K;
+  p.out_scale = out_scale;
+  p.seg_off_a[0] = 0; p.seg_off_a[1] = K; p.seg_off_a[2] = 0;        // hi, lo, hi
+  p.seg_off_b[0] = 0; p.seg_off_b[1] = 0; p.seg_off_b[2] = K;        // hi, hi, lo
+  p.ep_y = y; p.ep_scale = scale; p.ep_shift = shift; p.ep_mean = mean; p.ep_rstd = rstd;
+  if (!pcaa_launch_gemm_dgrad_bn(p, as_stream(stream))) {
+    pcaa_set_error("pcaa_gemm_dgrad_bn_split3: launch configuration failed");
+    return PCAA_ERR_LAUNCH;
+  }
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_gemm_dgrad_bn_split3");
+}
+
 extern "C" int pcaa_gemm_affine_elu(const void* A, long lda, const void* W, long ldw, void* out, long ldo,
                                     const float* scale, const float* shift, int M, int N, int K, int pool_rows,
                                     void* stream) {

@@ -573,11 +573,15 @@ __device__ __forceinline__ void epilogue_affine_meanpool(const GemmParams& p,
 // replaces a separate pass that re-read da and y (0.31 ms per step for PointNet layers 2-3).
 // POINTS: the layer below is the first PointNet layer on its recompute path -- its pre-activation was
 // never stored, y[row][col] = sum_c x[row][c] * W1[col][c] (C <= 8 point features) is rebuilt here.
-template <int MF, bool POINTS>
+// TE = float (the split-fp16 parity mode, round 3): y and dz are fp32 (16 B per lane and row) and ELU' is the exact
+// expression of the separate pass (bn_act_bwd_dz_kernel<float>), not the exp2 form of the bf16 mode.
+template <int MF, bool POINTS, typename TE = bf16_t>
 __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p,
                                                   typename AccLayout<MF>::vec (&acc)[AccLayout<MF>::MB][AccLayout<MF>::NB],
                                                   bf16_t* smem, int tm, int tn, int tid) {
   static_assert(MF == 16, "built for the 16x16x32 accumulator layout (a lane = 4 adjacent columns)");
+  constexpr bool kF32 = sizeof(TE) == 4;
+  static_assert(!(kF32 && POINTS), "the recompute form exists for the bf16 mode only");
   typedef AccLayout<MF> L;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -585,14 +589,14 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p,
   const int l15 = lane & 15, q = lane >> 4;
   const int c0 = tn * BN + wn * 64 + 4 * l15;                  // the lane's first column
   const long row0 = (long)tm * BM + wm * 128 + 4 * q;          // its first row (rows 16 i + r further on)
-  bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + row0 * p.ldc + c0;
-  const bf16_t* Y = reinterpret_cast<const bf16_t*>(p.ep_y) + row0 * p.ldc + c0;       // same shape and ld as C
+  TE* C = reinterpret_cast<TE*>(p.C) + row0 * p.ldc + c0;
+  const TE* Y = reinterpret_cast<const TE*>(p.ep_y) + row0 * p.ldc + c0;               // same shape and ld as C
   // The element-wise part runs on column PAIRS with packed fp32 instructions: ELU'(z) = exp(min(z, 0)) =
   // exp2(min(z log2e, 0)) with log2e folded into the affine coefficients (no compare / select), yhat = y rstd - mean rstd
   // as one fused multiply-add.
   f32x2 sc2[2], sh2[2], rs2[2], nm2[2], s1[2], s2[2];
   {
-    constexpr float kLog2e = 1.4426950408889634f;
+    constexpr float kLog2e = kF32 ? 1.f : 1.4426950408889634f;
     const f32x4 a = load4(p.ep_scale + c0), b = load4(p.ep_shift + c0), c = load4(p.ep_mean + c0), d = load4(p.ep_rstd + c0);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -614,10 +618,11 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p,
 #pragma unroll
       for (int c = 0; c < 8; ++c) w1[j][c] = c < xc ? p.ep_w1[(long)(c0 + j) * xc + c] : 0.f;
   }
-  uint2 yv[2][4];                        // the stored pre-activations of one 16-row block, requested one block ahead
+  typedef typename std::conditional<kF32, f32x4, uint2>::type yraw_t;
+  yraw_t yv[2][4];                       // the stored pre-activations of one 16-row block, requested one block ahead
   auto load_y = [&](int i, int b) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) yv[b][r] = *reinterpret_cast<const uint2*>(Y + (long)(i * 16 + r) * p.ldc);
+    for (int r = 0; r < 4; ++r) yv[b][r] = *reinterpret_cast<const yraw_t*>(Y + (long)(i * 16 + r) * p.ldc);
   };
   if (!POINTS) load_y(0, 0);
 #pragma unroll
@@ -646,24 +651,41 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p,
         }
         y2[0] = f32x2{yy[0], yy[1]};
         y2[1] = f32x2{yy[2], yy[3]};
+      } else if constexpr (kF32) {
+        const f32x4 w = yv[i & 1][r];
+        y2[0] = f32x2{w.x, w.y};
+        y2[1] = f32x2{w.z, w.w};
       } else {
         const uint2 w = yv[i & 1][r];
         y2[0] = f32x2{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u)};
         y2[1] = f32x2{__uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u)};
       }
-      uint2 o;
+      f32x2 dq[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const f32x2 dav = {acc[i][2 * h][r], acc[i][2 * h + 1][r]};
-        f32x2 z2 = __builtin_elementwise_fma(y2[h], sc2[h], sh2[h]);
-        z2 = __builtin_elementwise_min(z2, f32x2{0.f, 0.f});
-        const f32x2 g = {__builtin_amdgcn_exp2f(z2.x), __builtin_amdgcn_exp2f(z2.y)};
+        f32x2 g;
+        if constexpr (kF32) {
+          // the separate pass's arithmetic (elementwise.hip, bn_act_bwd_dz_kernel<float>): z = y*scale + shift, yhat = (y - mean)*rstd
+          g = f32x2{elu_grad_from_pre(y2[h].x * sc2[h].x + sh2[h].x), elu_grad_from_pre(y2[h].y * sc2[h].y + sh2[h].y)};
+        } else {
+          f32x2 z2 = __builtin_elementwise_fma(y2[h], sc2[h], sh2[h]);
+          z2 = __builtin_elementwise_min(z2, f32x2{0.f, 0.f});
+          g = f32x2{__builtin_amdgcn_exp2f(z2.x), __builtin_amdgcn_exp2f(z2.y)};
+        }
         const f32x2 d2 = dav * g;
         s1[h] += d2;
         s2[h] = __builtin_elementwise_fma(d2, __builtin_elementwise_fma(y2[h], rs2[h], nm2[h]), s2[h]);
-        (h == 0 ? o.x : o.y) = pack2(d2.x, d2.y);
+        dq[h] = d2;
       }
-      *reinterpret_cast<uint2*>(C + (long)(i * 16 + r) * p.ldc) = o;
+      if constexpr (kF32) {
+        *reinterpret_cast<f32x4*>(C + (long)(i * 16 + r) * p.ldc) = f32x4{dq[0].x, dq[0].y, dq[1].x, dq[1].y};
+      } else {
+        uint2 o;
+        o.x = pack2(dq[0].x, dq[0].y);
+        o.y = pack2(dq[1].x, dq[1].y);
+        *reinterpret_cast<uint2*>(C + (long)(i * 16 + r) * p.ldc) = o;
+      }
     }
   }
   // the four lanes q = 0..3 of a column quad hold partial sums over different rows: fold them (2 steps)
@@ -1001,7 +1023,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   int te = tid;
   if (PERSIST) asm volatile("" : "+v"(te));
   if constexpr (EPI == EPI_DGRAD_BN || EPI == EPI_DGRAD_BN_POINTS) {
-    epilogue_dgrad_bn<MF, EPI == EPI_DGRAD_BN_POINTS>(p, acc, epi, tm, tn, te);
+    epilogue_dgrad_bn<MF, EPI == EPI_DGRAD_BN_POINTS, TC>(p, acc, epi, tm, tn, te);
   } else if constexpr (EPI == EPI_AFFINE) {
     epilogue_full_tile<TC, MF, true>(p, acc, epi, tm, tn, te, split);
   } else if constexpr (EPI == EPI_POOL1 || EPI == EPI_POOL2 || EPI == EPI_POOL4) {
@@ -1131,11 +1153,12 @@ bool launch_dma(const GemmParams& p_in, dim3 grid_in, hipStream_t s) {
   const int krows = p.seg_len > 0 ? p.seg_len : p.K;
   const long a_bytes = (long)(ALAY == KC ? p.M : krows) * p.lda * 2, b_bytes = (long)(BLAY == KC ? p.N : krows) * p.ldb * 2;
   const bool buf = a_bytes < (1L << 32) && b_bytes < (1L << 32);
-  if constexpr (EPI == EPI_PLAIN && sizeof(TC) == 4) {
-    // split-fp16 operands (pcaa_gemm_split3): fp32 result only
+  if constexpr ((EPI == EPI_PLAIN || (EPI == EPI_DGRAD_BN && ALAY == KC)) && sizeof(TC) == 4) {
+    // split-fp16 operands (pcaa_gemm_split3, pcaa_gemm_dgrad_bn_split3): fp32 result only
     if (p.seg_len > 0)
       return buf ? launch_dma_inst<TC, ALAY, BLAY, EPI, true, true>(p, grid, s)
                  : launch_dma_inst<TC, ALAY, BLAY, EPI, false, true>(p, grid, s);
+    if (EPI == EPI_DGRAD_BN) return false;          // fp32 dz exists for the split operands only
   }
   if (p.seg_len > 0) return false;
   if (buf) return launch_dma_inst<TC, ALAY, BLAY, EPI, true>(p, grid, s);
@@ -1169,6 +1192,12 @@ bool pcaa_launch_gemm_dgrad_bn(const GemmParams& p_in, hipStream_t stream) {
   p.c_split_stride = 0;
   const long ntiles = (long)(p.M / BM) * (p.N / BN);
   if (ntiles >= (1L << 31)) return false;
+  if (p.seg_len > 0) {
+    // split-fp16 operands: K is the contraction length of ONE pass (the kernel walks 3 K); y and dz fp32
+    if (p.ep_y == nullptr) return false;
+    p.k_per_split = p.K;
+    return launch_dma<float, KC, KC, EPI_DGRAD_BN>(p, dim3((unsigned)ntiles, 1, 1), stream);
+  }
   if (p.ep_y == nullptr) return launch_dma<bf16_t, KC, KC, EPI_DGRAD_BN_POINTS>(p, dim3((unsigned)ntiles, 1, 1), stream);
   return launch_dma<bf16_t, KC, KC, EPI_DGRAD_BN>(p, dim3((unsigned)ntiles, 1, 1), stream);
 }

@@ -347,6 +347,9 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
             # for the weight gradient: no separate elementwise pass
             d_lhs, dy = dgrad_fn(None, dz=da.dz, y=y, coef=coef)
             dgrad_done = True
+        elif isinstance(lhs, ops.SplitImage):
+            # fp16x3 mode: dz (fp32) came out of the split-operand dgrad's epilogue; dy only feeds the two products below
+            dy = ops.bn_bwd_dy_split(da.dz, y, coef)
         else:
             dy = ops.bn_bwd_dy(da.dz, y, coef, out=da.dz)
     else:
@@ -407,7 +410,20 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
         wt_img = _WSPLIT_T_CACHE.pop(W2d.data_ptr(), None)            # [K, 2 cout] image of W^T made by the forward
         if wt_img is None or tuple(wt_img.shape) != (K, cout):
             wt_img = ops.split_f16(W2d, transpose=True)
-        d_lhs = ops.gemm_split3(dy, wt_img, KC, rows_local, K, cout)
+        if (_FUSE_DGRAD_BN and below is not None and below.y is not None and below.y.dtype == torch.float32
+                and below.mean is not None and tuple(below.y.shape) == (rows_local, K)
+                and ops.gemm_dgrad_bn_split3_supported(rows_local, K, cout)):
+            # as in the bf16 mode: ELU' and the BatchNorm-backward statistics of the layer below in the dgrad's epilogue
+            # (round 3; before, this mode re-read da and y in a statistics pass of its own: 0.6 ms per step)
+            btail = None
+            if below_bn is not None:
+                btail = ops.BnTailBwd(below.rows, below_bn, below.mean, below.rstd, K,
+                                      dgamma=below_outs[1] if below_outs else None,
+                                      dbeta=below_outs[2] if below_outs else None, sync=_sync_fn())
+            d_lhs = _FusedGrad(*ops.gemm_dgrad_bn_split3(dy, wt_img, below.y, below.scale, below.shift, below.mean,
+                                                         below.rstd, tail=btail), fin=btail.out if btail else None)
+        else:
+            d_lhs = ops.gemm_split3(dy, wt_img, KC, rows_local, K, cout)
     elif need_dinput:
         if mode == "bf16" and dy.dtype == torch.bfloat16 and cout % 8 == 0:
             Wt = _W16_CACHE.pop(W2d.data_ptr(), None)      # bf16 [K, cout] made by the forward pass

@@ -644,6 +644,41 @@ def bn_bwd_dy_fused_split(y, scale, shift, coef, *, da=None, dpool=None, group_r
     return dy
 
 
+def bn_bwd_dy_split(dz, y, coef):
+    """dy = coef0*dz + coef1*y + coef2 as a SplitImage (fp32 dz, y): behind gemm_dgrad_bn_split3"""
+    _chk(dz, "bn_bwd_dy_split.dz", torch.float32, 2)
+    _chk(y, "bn_bwd_dy_split.y", torch.float32, 2)
+    rows, ch = y.shape
+    dy = split_image_empty(rows, ch, y.device, SPLIT_SCALE_GRAD)
+    check(_lib.load().pcaa_bn_bwd_dy_split(_p(dz), _p(y), _p(dy.img), _p(coef), rows, ch, dy.scale, _s()),
+          "pcaa_bn_bwd_dy_split")
+    return dy
+
+
+def gemm_dgrad_bn_split3_supported(M, N, K):
+    return bool(_lib.load().pcaa_gemm_dgrad_bn_supported(M, N, K))
+
+
+def gemm_dgrad_bn_split3(dy, wt, y, scale, shift, mean, rstd, tail=None):
+    """dgrad of a PointNet layer on split-fp16 operands (dy [M, K], wt [N, K] SplitImages) fused with the first half of
+    the BatchNorm + ELU backward of the layer below (fp32 y [M, N]): returns (dz fp32 [M, N], stats)."""
+    M, K = dy.shape
+    N = wt.shape[0]
+    if wt.shape[1] != K or tuple(y.shape) != (M, N):
+        raise ValueError("gemm_dgrad_bn_split3: operand shapes")
+    _chk(y, "gemm_dgrad_bn_split3.y", torch.float32, 2)
+    dz = torch.empty((M, N), dtype=torch.float32, device=y.device)
+    stats = new_stats(N, y.device)
+    if tail is not None:
+        tail.arm(stats)
+    check(_lib.load().pcaa_gemm_dgrad_bn_split3(_p(dy.img), dy.img.stride(0), _p(wt.img), wt.img.stride(0), _p(y), _p(dz), N,
+                                                _p(scale), _p(shift), _p(mean), _p(rstd), _p(stats), NREP, M, N, K,
+                                                1.0 / (dy.scale * wt.scale), _s()), "pcaa_gemm_dgrad_bn_split3")
+    if tail is not None:
+        tail.resolve(stats)
+    return dz, stats
+
+
 def pick_split_k(M, N, K, target_blocks=1024, bk=32, tile=128):
     tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
     if tiles >= target_blocks:

@@ -859,3 +859,33 @@ def test_gemm_slabs_part_on_masked_streams():
     assert err <= 1e-4 * ref.abs().max().item(), err          # fp32 accumulation of exact bf16 products
     with pytest.raises(RuntimeError):
         ops.masked_stream(12)                                 # not a multiple of 8
+
+
+def test_gemm_dgrad_bn_split3_vs_separate_chain():
+    """the fused dgrad of the fp16x3 mode (split operands, fp32 y / dz, statistics in the epilogue) against the separate
+    chain gemm_split3 -> bn_act_bwd_dz on the same operands, and bn_bwd_dy_split against bn_bwd_dy_fused_split"""
+    M, N, K = 768, 512, 256
+    rng = np.random.default_rng(45)
+    dy = torch.from_numpy((rng.standard_normal((M, K)) * 1e-3).astype(np.float32)).to(DEV)
+    Wt = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(DEV)
+    y = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(DEV)
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, N).astype(np.float32)).to(DEV)
+    shift = torch.from_numpy(rng.uniform(-0.5, 0.5, N).astype(np.float32)).to(DEV)
+    mean = torch.from_numpy(rng.uniform(-0.2, 0.2, N).astype(np.float32)).to(DEV)
+    rstd = torch.from_numpy(rng.uniform(0.5, 2.0, N).astype(np.float32)).to(DEV)
+    dyi, wti = ops.split_f16(dy, scale=ops.SPLIT_SCALE_GRAD), ops.split_f16(Wt, scale=ops.SPLIT_SCALE_WEIGHT)
+    dz, st = ops.gemm_dgrad_bn_split3(dyi, wti, y, scale, shift, mean, rstd)
+    da = ops.gemm_split3(dyi, wti, KC, M, N, K)
+    dz_ref, st_ref = ops.bn_act_bwd_dz(y, scale, shift, mean, rstd, da=da)
+    assert (dz - dz_ref).abs().max().item() <= 1e-6 * max(1e-30, dz_ref.abs().max().item())
+    sa, sb = st.sum(0).cpu(), st_ref.sum(0).cpu()
+    assert (sa - sb).abs().max().item() <= 1e-5 * sb.abs().max().item()
+    # fp64 of the unrounded product
+    da64 = dy.cpu().double() @ Wt.cpu().double().t()
+    z = y.cpu().double() * scale.cpu().double() + shift.cpu().double()
+    dz64 = da64 * torch.where(z > 0, torch.ones_like(z), torch.exp(z))
+    assert (dz.cpu().double() - dz64).abs().max().item() <= 2e-5 * dz64.abs().max().item()
+    coef = torch.from_numpy((rng.standard_normal((3, N)) * 1e-4).astype(np.float32)).to(DEV)   # gradient-sized: the image's 2^16 scale
+    a = ops.bn_bwd_dy_split(dz, y, coef).float()
+    b = (coef[0] * dz + coef[1] * y + coef[2])
+    assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()
