@@ -494,8 +494,9 @@ def pointnet_backward(saves, layers, mode, d_last=None, dpool=None, pool_rows=0,
             else:
                 tail = ops.BnTailBwd(s.rows, bn, s.mean, s.rstd, s.cout, dgamma=outs[1] if outs else None,
                                      dbeta=outs[2] if outs else None, sync=_sync_fn())
-                if _ONEPASS_IN_BWD and da.dtype == torch.bfloat16 and outs is not None and outs[0].is_contiguous():
-                    # bf16 throughput mode: statistics and G = dz^T.x from ONE read of da; the weight gradient is then a
+                if (_ONEPASS_IN_BWD and (da.dtype == torch.bfloat16 or (mode == "fp16x3" and da.dtype == torch.float32))
+                        and outs is not None and outs[0].is_contiguous()):
+                    # bf16 and fp16x3 modes: statistics and G = dz^T.x from ONE read of da; the weight gradient is then a
                     # combination of G with the points' second moments (exact-fp32 mode keeps the two passes: there
                     # dy is formed per element before the contraction, as the oracle's autograd does)
                     dW = ops.pointnet_in_bwd_onepass(da, s.a_in, W2d, s.scale, s.shift, s.mean, s.rstd, tail,
