@@ -287,8 +287,8 @@ class _on_wgrad_stream:
         if st is None:
             return self
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        self.ctx = torch.cuda.stream(st)
+        ev.record()                      # (on the current stream)
+        self.ctx = ops.on_stream(st)
         self.ctx.__enter__()
         st.wait_event(ev)
         for t in self.tensors:

@@ -592,10 +592,10 @@ class PCAATrainer:
 
         joined = None
         if self._aux is not None:
-            main = torch.cuda.current_stream()
+            main = ops.current_stream()
             fork = torch.cuda.Event()
             fork.record(main)
-            with torch.cuda.stream(self._aux):
+            with ops.on_stream(self._aux):
                 self._aux.wait_event(fork)
                 d_losses, loss_g, dsup = critic_branch()
                 joined = torch.cuda.Event()
@@ -608,14 +608,14 @@ class PCAATrainer:
         if self.variant == "v3":
             # no decoder, no reconstruction term: tot = loss_g (+ sup_loss) (PCAA_ablation.py:621-645)
             if joined is not None:
-                torch.cuda.current_stream().wait_event(joined)
+                ops.current_stream().wait_event(joined)
             F_hip.set_wgrad_stream(self._wg)
             try:
                 F_hip.encoder_backward(enc, st, dlogits if supervise else None, dsup, gout=self._enc_grads)
             finally:
                 F_hip.set_wgrad_stream(None)
             if self._wg is not None:
-                torch.cuda.current_stream().wait_stream(self._wg)
+                ops.current_stream().wait_stream(self._wg)
             self._allreduce(self.flat_g.g)
             self._advance_g(supervise)
             self._adam_g(0, self.flat_g.total, supervise, gs)
@@ -636,7 +636,7 @@ class PCAATrainer:
         # (5) G-step backward (the adversarial gradient w.r.t. sup_fvs seeds the accumulation)
         F_hip.set_wgrad_stream(self._wg)
         if joined is not None and self.decoder_projection_head is None:
-            torch.cuda.current_stream().wait_event(joined)
+            ops.current_stream().wait_event(joined)
             joined = None
         dh = None
         collective = self.pg is not None and (self.world > 1 or self._force_collectives)
@@ -660,8 +660,8 @@ class PCAATrainer:
                 nxt = f"G.dense{layer + 1}.weight"
                 hi = fg.offsets[fg.names.index(nxt)] if nxt in fg.names else fg.total
                 # ordered behind this layer's dW / db kernels, whichever stream the layer's path put them on
-                self._wg.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self._wg):
+                self._wg.wait_stream(ops.current_stream())
+                with ops.on_stream(self._wg):
                     early_buckets.append((lo, hi, self._allreduce(fg.g[lo:hi], async_op=True)))
 
         # Single process: the wide decoder layers' weight gradients go straight into Adam (one kernel per layer forms
@@ -695,7 +695,7 @@ class PCAATrainer:
             _, dh = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=dec_grads, mode=mode,
                                            after_layer=layer_hook, updates=updates)
             if joined is not None:
-                torch.cuda.current_stream().wait_event(joined)
+                ops.current_stream().wait_event(joined)
         else:
             _, dsup = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=dec_grads, dz_init=dsup,
                                              mode=mode, after_layer=layer_hook, updates=updates)
@@ -711,7 +711,7 @@ class PCAATrainer:
             fg, n, w = self.flat_g, self._zero_len, self.world
             rank = dist.get_rank(self.pg)
             if self._wg is not None:
-                torch.cuda.current_stream().wait_stream(self._wg)   # the decoder's dW/db were written on that stream
+                ops.current_stream().wait_stream(self._wg)   # the decoder's dW/db were written on that stream
             scatter = []
             for c in range(self._zero_chunks):
                 lo = self._dec_start + c * n
@@ -721,8 +721,8 @@ class PCAATrainer:
 
             def launch_zero_adam():
                 ready = torch.cuda.Event()
-                ready.record(torch.cuda.current_stream())
-                with torch.cuda.stream(self._side):
+                ready.record(ops.current_stream())
+                with ops.on_stream(self._side):
                     self._side.wait_event(ready)
                     for c in range(self._zero_chunks):
                         lo = self._dec_start + c * n + rank * (n // w)      # this rank's slice of chunk c
@@ -740,14 +740,14 @@ class PCAATrainer:
             # (first layer): its weight gradient was written on the wgrad stream, its bias gradient on this one
             rest_hi = min(lo for lo, _, _ in early_buckets)
             if rest_hi > self._dec_start:
-                torch.cuda.current_stream().wait_stream(self._wg)
+                ops.current_stream().wait_stream(self._wg)
                 pending.append((self._dec_start, rest_hi,
                                 self._allreduce(self.flat_g.g[self._dec_start:rest_hi], async_op=True)))
             pending = early_buckets + pending      # issue order = the order the collectives complete in
         else:
             bounds = [self._dec_start]
             if collective and self._wg is not None:
-                torch.cuda.current_stream().wait_stream(self._wg)   # the decoder's dW/db were written on that stream
+                ops.current_stream().wait_stream(self._wg)   # the decoder's dW/db were written on that stream
             nchunk = self._dp_chunks if collective else 1
             dec_n = self.flat_g.total - self._dec_start
             for i in range(1, nchunk + 1):
@@ -767,8 +767,8 @@ class PCAATrainer:
 
             def launch_side_adam():
                 ready = torch.cuda.Event()
-                ready.record(torch.cuda.current_stream())
-                with torch.cuda.stream(self._side):
+                ready.record(ops.current_stream())
+                with ops.on_stream(self._side):
                     self._side.wait_event(ready)        # everything enqueued on the main stream so far
                     if self._wg is not None:
                         self._side.wait_stream(self._wg)   # ... and the decoder weight gradients on the wgrad stream
@@ -811,7 +811,7 @@ class PCAATrainer:
         finally:
             F_hip.set_wgrad_stream(None)
         if self._wg is not None:
-            torch.cuda.current_stream().wait_stream(self._wg)       # its products feed the all-reduce / Adam below
+            ops.current_stream().wait_stream(self._wg)       # its products feed the all-reduce / Adam below
         self._allreduce(self.flat_g.g[:self._dec_start])      # encoder + projection head
         for _, _, work in pending:
             if work is not None:
@@ -822,7 +822,7 @@ class PCAATrainer:
                 work.wait()                                      # next forward reads the gathered decoder
         elif early:
             self._adam_g(0, self._dec_start, supervise, gs)
-            torch.cuda.current_stream().wait_event(done[0])      # next forward reads the updated decoder
+            ops.current_stream().wait_event(done[0])      # next forward reads the updated decoder
         else:
             self._advance_g(supervise)
             self._adam_g(0, self.flat_g.total, supervise, gs)
