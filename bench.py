@@ -212,7 +212,8 @@ def build_trainer(a, N, dev, pg, precision, fill="deterministic"):
     tr = PCAATrainer(cfg, device=dev, precision=precision, process_group=pg, sync_bn=a.sync_bn,
                      dp_zero=(a.dp_mode == "zero") and pg is not None,
                      grad_compress=None if a.grad_compress == "none" else a.grad_compress,
-                     force_collectives=a.dp_force, fused_decoder_update=a.decoder_update == "fused")
+                     force_collectives=a.dp_force,
+                     fused_decoder_update=("all" if a.decoder_update == "fused" else False))
     for i, m in enumerate((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head,
                            tr.discriminator_projection_head)):
         if fill == "deterministic":

@@ -383,6 +383,10 @@ int pcaa_skinny_linear_dgrad_exact(const float* dz, long lddz, const float* W, l
                                    int K, int nsplit, void* stream);
 int pcaa_skinny_linear_wgrad_exact(const float* dz, long lddz, const float* x, long ldx, float* dW, long lddw,
                                    int M, int N, int K, void* stream);
+int pcaa_skinny_linear_wgrad_adam_exact(const float* dz, long lddz, const float* x, long ldx, float* W,
+                                        float* exp_avg, float* exp_avg_sq, long ldw, int M, int N, int K,
+                                        float beta1, float beta2, float eps, float grad_scale,
+                                        const float* coef_dev, void* stream);   /* = pcaa_skinny_linear_wgrad_adam, fp32 products */
 /* The same product written as bf16 (dW_bf16 [N, lddw] bf16, lddw even): the data-parallel step with bf16 gradient
  * buckets produces the gradient in the form it crosses the wire in (no fp32 copy, no cast pass). */
 int pcaa_skinny_linear_wgrad_bf16(const float* dz, long lddz, const float* x, long ldx, void* dW_bf16, long lddw,

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restri
 // (common.h adam_update) and writes the three back -- 24 B per parameter instead of 4 (dW store) + 28 (Adam pass).  One 32 x 32 fragment's
 // operands (48 dwords per lane) are in flight while the previous fragment is updated.  Single-process training only:
 // a data-parallel step needs the reduced gradient before the update.
-template <int JL, bool FULLN, int NB>
+template <int JL, bool FULLN, int NB, bool F32 = false>
 __global__ __launch_bounds__(256) void skinny_wgrad_adam_kernel(const float* __restrict__ dz, long lddz,
                                                                 const float* __restrict__ x, long ldx,
                                                                 float* __restrict__ W, float* __restrict__ mo,
@@ -475,7 +475,8 @@ __global__ __launch_bounds__(256) void skinny_wgrad_adam_kernel(const float* __r
                                                                 float b1, float b2, float eps, float grad_scale,
                                                                 const float* __restrict__ coef) {
   static_assert(NB == 2 || NB == 4, "fragment buffers: a ring of 2 or 4 (index = fragment number mod NB, static)");
-  __shared__ __attribute__((aligned(16))) bf16x8 apan[4][4][64];      // [row fragment i][k-step s][lane]
+  __shared__ __attribute__((aligned(16))) bf16x8 apan[F32 ? 1 : 4][4][64];      // [row fragment i][k-step s][lane]
+  __shared__ __attribute__((aligned(16))) f32x4 apan32[F32 ? 4 : 1][4][2][64];   // exact variant: the same, fp32
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
   const float step_size = coef[0], inv_bc2_sqrt = coef[1];
   const int n0 = blockIdx.y * 128;
@@ -493,7 +494,12 @@ __global__ __launch_bounds__(256) void skinny_wgrad_adam_kernel(const float* __r
         const float v = dz[(unsigned)min(m, M - 1) * (unsigned)lddz + ncol];
         t[e] = m < M ? v : 0.f;
       }
-      apan[i][s][lane] = pack8(t);
+      if constexpr (F32) {
+        apan32[i][s][0][lane] = f32x4{t[0], t[1], t[2], t[3]};
+        apan32[i][s][1][lane] = f32x4{t[4], t[5], t[6], t[7]};
+      } else {
+        apan[i][s][lane] = pack8(t);
+      }
     }
   }
   unsigned xoff[4][8];
@@ -532,8 +538,16 @@ __global__ __launch_bounds__(256) void skinny_wgrad_adam_kernel(const float* __r
 
   for (int j = 0; j < jn; ++j) {
     bf16x8 bf[4];
+    float bq[F32 ? 4 : 1][8];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) bf[s] = pack8(br[s]);
+    for (int s = 0; s < 4; ++s) {
+      if constexpr (F32) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bq[s][e] = br[s][e];
+      } else {
+        bf[s] = pack8(br[s]);
+      }
+    }
     {
       const float* xn = x + 32 * min(j + 1, jn - 1);
 #pragma unroll
@@ -550,8 +564,15 @@ __global__ __launch_bounds__(256) void skinny_wgrad_adam_kernel(const float* __r
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apan[i][s][lane], bf[s], acc[i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (F32) {
+          const f32x4 lo = apan32[i][s][0][lane], hi = apan32[i][s][1][lane];
+          const float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          acc[i] = mfma8_f32(a, bq[s], acc[i]);
+        } else {
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apan[i][s][lane], bf[s], acc[i], 0, 0, 0);
+        }
+      }
     const unsigned base = o0 + 32u * (unsigned)j;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -761,10 +782,10 @@ extern "C" int pcaa_skinny_linear_wgrad_bf16(const float* dz, long lddz, const f
   PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_wgrad_bf16");
 }
 
-extern "C" int pcaa_skinny_linear_wgrad_adam(const float* dz, long lddz, const float* x, long ldx, float* W,
-                                             float* exp_avg, float* exp_avg_sq, long ldw, int M, int N, int K,
-                                             float beta1, float beta2, float eps, float grad_scale,
-                                             const float* coef_dev, void* stream) {
+static int skinny_wgrad_adam_impl(const float* dz, long lddz, const float* x, long ldx, float* W,
+                                  float* exp_avg, float* exp_avg_sq, long ldw, int M, int N, int K,
+                                  float beta1, float beta2, float eps, float grad_scale,
+                                  const float* coef_dev, int exact, void* stream) {
   PCAA_CHECK_ARG(dz && x && W && exp_avg && exp_avg_sq && coef_dev, "pcaa_skinny_linear_wgrad_adam: null pointer");
   PCAA_CHECK_ARG(M >= 1 && M <= 64 && N >= 1 && K >= 32 && K % 32 == 0,
                  "pcaa_skinny_linear_wgrad_adam: unsupported shape M=%d N=%d K=%d", M, N, K);
@@ -779,15 +800,35 @@ extern "C" int pcaa_skinny_linear_wgrad_adam(const float* dz, long lddz, const f
   constexpr int NB = 2;
   auto ntile = [&](int jl) { return cdiv(K, 4 * 32 * jl) * cdiv(N, 128); };
   const int jl = ntile(4) >= 1024 ? 4 : (ntile(2) >= 1024 ? 2 : 1);
-#define WA_LAUNCH(JL, FULL)                                                                                       \
-  hipLaunchKernelGGL((skinny_wgrad_adam_kernel<JL, FULL, NB>), dim3((unsigned)cdiv(K, 4 * 32 * JL), (unsigned)cdiv(N, 128)), \
+#define WA_LAUNCH(JL, FULL, EX)                                                                                   \
+  hipLaunchKernelGGL((skinny_wgrad_adam_kernel<JL, FULL, NB, EX>), dim3((unsigned)cdiv(K, 4 * 32 * JL), (unsigned)cdiv(N, 128)), \
                      dim3(256), 0, as_stream(stream), dz, lddz, x, ldx, W, exp_avg, exp_avg_sq, ldw, M, N, K, beta1,  \
                      beta2, eps, grad_scale, coef_dev)
-  if (N % 128 == 0) {
-    if (jl == 4) WA_LAUNCH(4, true); else if (jl == 2) WA_LAUNCH(2, true); else WA_LAUNCH(1, true);
-  } else {
-    if (jl == 4) WA_LAUNCH(4, false); else if (jl == 2) WA_LAUNCH(2, false); else WA_LAUNCH(1, false);
-  }
+#define WA_PICK(EX)                                                                                               \
+  do {                                                                                                            \
+    if (N % 128 == 0) {                                                                                           \
+      if (jl == 4) WA_LAUNCH(4, true, EX); else if (jl == 2) WA_LAUNCH(2, true, EX); else WA_LAUNCH(1, true, EX); \
+    } else {                                                                                                      \
+      if (jl == 4) WA_LAUNCH(4, false, EX); else if (jl == 2) WA_LAUNCH(2, false, EX); else WA_LAUNCH(1, false, EX); \
+    }                                                                                                             \
+  } while (0)
+  if (exact) WA_PICK(true); else WA_PICK(false);
+#undef WA_PICK
 #undef WA_LAUNCH
   PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_wgrad_adam");
+}
+
+extern "C" int pcaa_skinny_linear_wgrad_adam(const float* dz, long lddz, const float* x, long ldx, float* W,
+                                             float* exp_avg, float* exp_avg_sq, long ldw, int M, int N, int K,
+                                             float beta1, float beta2, float eps, float grad_scale,
+                                             const float* coef_dev, void* stream) {
+  return skinny_wgrad_adam_impl(dz, lddz, x, ldx, W, exp_avg, exp_avg_sq, ldw, M, N, K, beta1, beta2, eps, grad_scale,
+                                coef_dev, 0, stream);
+}
+extern "C" int pcaa_skinny_linear_wgrad_adam_exact(const float* dz, long lddz, const float* x, long ldx, float* W,
+                                                   float* exp_avg, float* exp_avg_sq, long ldw, int M, int N, int K,
+                                                   float beta1, float beta2, float eps, float grad_scale,
+                                                   const float* coef_dev, void* stream) {
+  return skinny_wgrad_adam_impl(dz, lddz, x, ldx, W, exp_avg, exp_avg_sq, ldw, M, N, K, beta1, beta2, eps, grad_scale,
+                                coef_dev, 1, stream);
 }

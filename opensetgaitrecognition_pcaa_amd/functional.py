@@ -694,14 +694,14 @@ def linear_act_backward(x, a_out, lin, act, d_out, need_dx=True, dW_out=None, db
     dz = ops.elu_bwd_from_out(d_out, a_out) if (act == ACT_ELU and not d_is_pre) else d_out
     dz2 = dz.view(M, N)
     if update is not None:
-        if not _skinny(mode, M, N, K):
+        if not (_skinny(mode, M, N, K) or _skinny_exact(mode, M, N, K)):
             raise RuntimeError("linear_act_backward: a fused weight update is only served by the skinny path")
         with _on_wgrad_stream(dz2):
             db = ops.colsum(dz2, out=db_out)
         dx = None
         if need_dx:
             dx = ops.skinny_linear_dgrad(dz2, lin.weight, a_prev=x if fuse_elu_in else None, out=dx_init,
-                                         accumulate=dx_init is not None)
+                                         accumulate=dx_init is not None, exact=_skinny_exact(mode, M, N, K))
         update(dz2, x)
         return None, db, dx
     exact = _skinny_exact(mode, M, N, K)

@@ -1151,7 +1151,7 @@ def skinny_linear_wgrad(dz, x, out=None, exact=False):
     return out
 
 
-def skinny_linear_wgrad_adam_(dz, x, W, exp_avg, exp_avg_sq, beta1, beta2, eps, coef_dev, grad_scale=1.0):
+def skinny_linear_wgrad_adam_(dz, x, W, exp_avg, exp_avg_sq, beta1, beta2, eps, coef_dev, grad_scale=1.0, exact=False):
     """W[N,K] <- Adam(W, dz[M,N]^T @ x[M,K]) in place, moments too (M <= 64): the weight gradient never reaches HBM.
     ``coef_dev``: the two step-dependent scalars of the optimizer step in progress (StepCount.coef_dev)."""
     _chk(dz, "skinny_wgrad_adam.dz", torch.float32, 2)
@@ -1166,7 +1166,8 @@ def skinny_linear_wgrad_adam_(dz, x, W, exp_avg, exp_avg_sq, beta1, beta2, eps, 
             raise ValueError(f"skinny_linear_wgrad_adam_: {nm} must be [{N},{K}], got {tuple(t.shape)}")
     _chk(coef_dev, "skinny_wgrad_adam.coef", torch.float32)
     lib = _lib.load()
-    _skinny_timed(lambda: check(lib.pcaa_skinny_linear_wgrad_adam(
+    fn = lib.pcaa_skinny_linear_wgrad_adam_exact if exact else lib.pcaa_skinny_linear_wgrad_adam
+    _skinny_timed(lambda: check(fn(
         _p(dz), dz.stride(0), _p(x), x.stride(0), _p(W), _p(exp_avg), _p(exp_avg_sq), K, M, N, K, float(beta1),
         float(beta2), float(eps), float(grad_scale), _p(coef_dev), _s()), "pcaa_skinny_linear_wgrad_adam"),
         2.0 * M * N * K, 4 * (6 * N * K + M * K + M * N))

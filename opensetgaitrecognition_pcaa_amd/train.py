@@ -203,7 +203,7 @@ class PCAATrainer:
         consumed by one kernel per layer that applies Adam in place (pcaa_skinny_linear_wgrad_adam) -- those
         gradients never exist in ``flat_g.g`` (``self.gradless_ranges`` lists the [lo, hi) element ranges the last step
         left without one); pass False to keep them (gradient inspection, parity tests: the resulting parameters are
-        bit-identical either way).
+        bit-identical either way); "all" extends it to the parity modes (fp32-product kernels; the bench's parity legs).
         Data-parallel options (``process_group`` given): ``dp_zero`` True = sharded decoder optimizer
         (reduce-scatter, Adam on 1/world of the decoder, all-gather; default off); ``grad_compress="bf16"`` = the decoder's gradient buckets cross the wire as bf16 (half the
         bytes; fp32 master gradients, moments and weights; each bucket is rounded once before the sum and the sum
@@ -231,6 +231,9 @@ class PCAATrainer:
         self._dp_zero_arg = bool(dp_zero)
         self._force_collectives = bool(force_collectives)
         self.fused_decoder_update = bool(fused_decoder_update)
+        # "all": the parity modes too (fp32-product kernels) -- not the default there: their tests read the decoder's weight
+        # gradients, which a fused update never writes (gradless_ranges)
+        self.fused_exact = fused_decoder_update == "all"
         if grad_compress not in (None, "bf16"):
             raise ValueError("grad_compress must be None or 'bf16'")
         self.grad_compress = grad_compress
@@ -670,9 +673,11 @@ class PCAATrainer:
         # -- whose dgrads read the weights they overwrite -- is enqueued (measured, same box, ms/step: unfused 6.27-6.30
         # | behind each layer's own dgrad 6.13-6.18, the decoder backward section 276 -> 634 us | here 6.12-6.14).
         updates, fused_ranges, deferred = None, [], []
-        if self.fused_decoder_update and not collective and self._side is not None and mode == "bf16":
+        exact_dec = mode in ("fp32", "fp16x3")      # the parity modes: the same fused kernels with fp32 products
+        if (self.fused_decoder_update and not collective and self._side is not None
+                and (mode == "bf16" or (self.fused_exact and exact_dec))):
             for layer, (lo, hi, Wv, mv, vv) in self._dec_fused.items():
-                if F_hip._skinny(mode, B, Wv.shape[0], Wv.shape[1]):
+                if F_hip._skinny(mode, B, Wv.shape[0], Wv.shape[1]) or F_hip._skinny_exact(mode, B, Wv.shape[0], Wv.shape[1]):
                     updates = updates or {}
                     updates[layer] = lambda dz2, x, t=(Wv, mv, vv): deferred.append((dz2, x) + t)
                     fused_ranges.append((lo, hi))
@@ -775,7 +780,8 @@ class PCAATrainer:
                     for dz2, x, Wv, mv, vv in deferred:
                         dz2.record_stream(self._side)
                         x.record_stream(self._side)
-                        ops.skinny_linear_wgrad_adam_(dz2, x, Wv, mv, vv, *self.betas_g(), 1e-8, self.flat_g.coef_dev, gs)
+                        ops.skinny_linear_wgrad_adam_(dz2, x, Wv, mv, vv, *self.betas_g(), 1e-8, self.flat_g.coef_dev, gs,
+                                                      exact=exact_dec)
                     for lo, hi, work in pending:
                         if hi <= self._dec_start:
                             continue                    # the projection-head slice is updated on the main stream

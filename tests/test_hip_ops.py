@@ -466,6 +466,19 @@ def test_skinny_wgrad_adam_equals_wgrad_then_adam_bitwise(M, N, K):
         ops.skinny_linear_wgrad_adam_(dz, x, Wb, mb, vb, 0.9, 0.99, 1e-8, cb.coef_dev)
         assert torch.equal(Wa, Wb) and torch.equal(ma, mb) and torch.equal(va, vb), s
     assert not torch.equal(Wa, W0)
+    # the fp32-product variants (parity modes) hold the same identity
+    Wa, Wb = W0.clone(), W0.clone()
+    ma, va, mb, vb = (torch.zeros_like(W0) for _ in range(4))
+    ca, cb = StepCount(DEV), StepCount(DEV)
+    for s in range(2):
+        dz = _rand((M, N), 321 + 2 * s, 0.3).to(DEV)
+        x = _rand((M, K), 322 + 2 * s, 1.0).to(DEV)
+        ca.advance(1e-3, 0.9, 0.99)
+        cb.advance(1e-3, 0.9, 0.99)
+        dW = ops.skinny_linear_wgrad(dz, x, exact=True)
+        ops.adam_step_dev_(Wa, dW, ma, va, 0.9, 0.99, 1e-8, ca.coef_dev)
+        ops.skinny_linear_wgrad_adam_(dz, x, Wb, mb, vb, 0.9, 0.99, 1e-8, cb.coef_dev, exact=True)
+        assert torch.equal(Wa, Wb) and torch.equal(ma, mb) and torch.equal(va, vb), ("exact", s)
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 256, 128), (37, 192, 160), (64, 960, 1920), (16, 4544, 2304)])

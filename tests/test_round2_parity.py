@@ -374,8 +374,9 @@ def test_reference_d_step_body_runs_unmodified_on_the_drop_in_critic(tag):
     opt.step()          # and the optimizer of the caller steps on those gradients
 
 
-@pytest.mark.parametrize("B,N", [(6, 32), (16, 150), (64, 128)])
-def test_fused_decoder_update_performs_the_unfused_step(B, N):
+@pytest.mark.parametrize("B,N,precision", [(6, 32, "bf16"), (16, 150, "bf16"), (64, 128, "bf16"), (6, 32, "fp32"),
+                                           (8, 64, "fp16x3")])
+def test_fused_decoder_update_performs_the_unfused_step(B, N, precision):
     """bf16 mode, single process: the decoder's wide layers take their Adam update inside the weight-gradient
     kernel (pcaa_skinny_linear_wgrad_adam; bit-identical to wgrad -> Adam at the op level, tests/test_hip_ops.py).
     At the trainer level two runs of the SAME step already differ by the order of the fp64 statistics atomics
@@ -387,8 +388,9 @@ def test_fused_decoder_update_performs_the_unfused_step(B, N):
     means = O.sample_distant_points(32, K, 10, 10).float()
     states = []
     try:
-        for fused, graphed in ((False, False), (True, False)) + (((True, True),) if N == 32 else ()):
-            tr, _ = _v4_trainer(B, N, C, K, [0, 1, 2, 3, 4], "bf16", fused=fused)
+        # (the parity modes take the fused update only on request: fused_decoder_update="all", fp32-product kernels)
+        for fused, graphed in ((False, False), ("all", False)) + ((("all", True),) if N == 32 else ()):
+            tr, _ = _v4_trainer(B, N, C, K, [0, 1, 2, 3, 4], precision, fused=fused)
             tr.set_prior_means(means)
             tr.finalize()
             tr.train()

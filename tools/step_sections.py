@@ -29,7 +29,7 @@ B, N, C, K, T = a.batch, a.points, 4, 8, constants.NSTEPS
 constants.NFEATURES = C
 cfg = dict(constants.CONFIG); cfg.update(NMAX=N, TRAIN_CLASSES=list(range(K)), BATCH_SIZE=B)
 F_hip.set_precision(a.precision)
-tr = PCAATrainer(cfg, device="cuda", precision=a.precision, fused_decoder_update=a.fused != "off", process_group=pg,
+tr = PCAATrainer(cfg, device="cuda", precision=a.precision, fused_decoder_update=("all" if a.fused != "off" else False), process_group=pg,
                  force_collectives=a.dp_force, grad_compress=None if a.grad_compress == "none" else a.grad_compress,
                  dp_zero=a.dp_mode == "zero" and pg is not None)
 for i, m in enumerate((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head, tr.discriminator_projection_head)):
