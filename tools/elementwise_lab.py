@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The HBM-bound passes of the PointNet block alone on the GPU: ms and TB/s of the bytes each moves, at the bench
-shape.  python tools/elementwise_lab.py        (PCAA_EW_UNROLL=1|2|4|8: quads per thread and trip of the
-column-invariant kernels, for A/B runs in separate processes)"""
+shape.  python tools/elementwise_lab.py        (profiles/r03_elementwise_unroll_lab.txt is this lab on a scratch build
+whose column-invariant kernels took 1 / 2 / 4 / 8 quads per thread and trip; the switch was not kept)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
