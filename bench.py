@@ -92,11 +92,48 @@ def parse():
 # ---------------------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (plain-PyTorch restatement of the reference, kind="port") on this host's cores
 # ---------------------------------------------------------------------------------------------------------------
-def cpu_baseline(B, N, C, K, T, budget_s=75.0):
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _conv2d_vs_einsum(threads, b=8, T=30, N=128, cin=1024, cout=1024):
+    """The oracle writes the per-point layers as einsum contractions, the reference as nn.Conv2d(1x1): the same layer
+    (PointNet 4, the largest) timed both ways on this host, so that "the port is on par with ATen's conv2d" is a number
+    in the line.  Best of 2 after a warm-up each, seconds."""
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(b, cin, T, N, generator=g)
+    w = torch.randn(cout, cin, generator=g) * 0.03
+    w4 = w.view(cout, cin, 1, 1)
+
+    def best(fn):
+        fn()
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return min(ts)
+    with torch.no_grad():
+        t_conv = best(lambda: torch.nn.functional.conv2d(x, w4))
+        t_ein = best(lambda: torch.einsum("bctn,oc->botn", x, w))
+    return {"shape": f"[{b},{cin},{T},{N}] -> {cout} channels, 1x1", "aten_conv2d_s": t_conv, "oracle_einsum_s": t_ein,
+            "einsum_over_conv2d": t_ein / t_conv}
+
+
+def cpu_baseline(B, N, C, K, T, budget_s=150.0):
     """BASELINE.md section 3 / SURVEY 8d protocol: identical synthetic tensors, 1 warm-up + 3 timed full V4 train
     steps (loop body PCAA_ablation.py:882-1021), median, with the per-phase breakdown.  The thread count is picked
-    on a small calibration batch first (torch's CPU kernels do not scale to every core of a big host).  The sample is
-    bounded to ~``budget_s`` seconds of CPU work: the batch is cut to B/2 or B/4 when 4 full-batch steps do not fit."""
+    on a small calibration batch first (torch's CPU kernels do not scale to every core of a big host).  The budget
+    (round 4: 150 s, was 75) lets the WORKLOAD'S OWN batch run (4 steps of ~20 s at B=64 on the GPU box's host); only if
+    even that does not fit is the batch halved -- ``batch`` says what ran, ``batch_is_workload`` whether it is B."""
     from opensetgaitrecognition_pcaa_amd import constants, models, synthetic as syn
     from oracle import pcaa_oracle as O
     ncpu = os.cpu_count() or 1
@@ -142,6 +179,9 @@ def cpu_baseline(B, N, C, K, T, budget_s=75.0):
     med = statistics.median(times)
     pmed = {k: statistics.median(p[k] for p in phases) for k in phases[0]}
     return {"value": sample_b / med, "unit": "sequences/s", "cores": threads, "kind": "port",
+            "batch": sample_b, "batch_is_workload": sample_b == B, "threads": threads, "threads_tried": cands,
+            "host_cpus": ncpu, "cpu_model": _cpu_model(), "torch": torch.__version__,
+            "conv2d_vs_einsum": _conv2d_vs_einsum(threads),
             "protocol": "1 warm-up + 3 timed full V4 train steps, median",
             "seconds_per_step": times, "median_s": med,
             "phases_s": pmed,
@@ -256,14 +296,21 @@ def spread(ms_list):
 # ---------------------------------------------------------------------------------------------------------------
 # extra legs of the default line (single GPU)
 # ---------------------------------------------------------------------------------------------------------------
-def leg_train_shape(a, dev, N, C, steps, windows, warmup=3):
-    """The bf16 train step at another shape (sweep points, C=5): ms per step (median window) + whole-step fractions."""
-    from opensetgaitrecognition_pcaa_amd import constants
-    B, K, T = a.batch, a.classes, constants.NSTEPS
-    c_saved = constants.NFEATURES
+def leg_train_shape(a, dev, N, C, steps, windows, warmup=3, B=None, precision=None):
+    """The train step at another shape (sweep points, C=5, the reference's default B=16 / N=150): ms per step (median
+    window) + whole-step fractions."""
+    from opensetgaitrecognition_pcaa_amd import constants, functional as F_hip
+    import copy
+    B = a.batch if B is None else B
+    K, T = a.classes, constants.NSTEPS
+    precision = precision or a.precision
+    c_saved, p_saved = constants.NFEATURES, F_hip.get_precision()
     constants.NFEATURES = C
+    F_hip.set_precision(precision)
+    a = copy.copy(a)
+    a.batch = B
     try:
-        tr, _ = build_trainer(a, N, dev, None, a.precision, fill="device")
+        tr, _ = build_trainer(a, N, dev, None, precision, fill="device")
         pcs, gt, z0, al = make_inputs(B, T, N, C, K, dev)
         graph = a.graph == "on" or (a.graph == "auto" and tr.prefers_graph(B, N))
         run = (lambda: tr.step_graphed(pcs, gt, z0, al, warmup=0)) if graph else (lambda: tr.step(pcs, gt, z0, al))
@@ -272,7 +319,7 @@ def leg_train_shape(a, dev, N, C, steps, windows, warmup=3):
         run()
         ms_list, out = time_single_gpu(run, steps, windows)
         ms = statistics.median(ms_list)
-        ent = {"N": N, "C": C, "B": B, "ms_per_step": ms, "value": B / ms * 1e3, "unit": "sequences/s",
+        ent = {"N": N, "C": C, "B": B, "precision": precision, "ms_per_step": ms, "value": B / ms * 1e3, "unit": "sequences/s",
                "windows_ms_per_step": ms_list, "steps": steps, "hip_graph": bool(graph),
                "finite_loss": bool(torch.isfinite(out["tot_loss"]).item())}
         ent.update(step_fracs(tr, B, T, N, ms))
@@ -282,6 +329,7 @@ def leg_train_shape(a, dev, N, C, steps, windows, warmup=3):
         return ent
     finally:
         constants.NFEATURES = c_saved
+        F_hip.set_precision(p_saved)
 
 
 def leg_infer(a, dev, steps, windows, with_cpu=False):
@@ -562,7 +610,45 @@ def main():
         parity_leg["exact_fp32"] = legs["fp32"]
         F_hip.set_precision(a.precision)
 
-    sweep = infer = c5 = None
+    # Data-parallel legs (round 4): the driver runs `bench.py --gpus N` ONCE per N, so that one
+    # invocation also times every exchange scheme the trainer has -- (all-reduce | ZeRO-1 reduce-scatter + sharded Adam +
+    # all-gather) x (fp32 | bf16 gradient buckets), and SyncBN -- each with the communication time the step could not
+    # hide.  ``value`` stays the documented default (all-reduce, bf16 buckets in the bf16 mode, per-rank BatchNorm).
+    dp_legs = None
+    if (world > 1 or a.dp_force) and not a.no_extra_legs:
+        import copy
+        dp_legs = []
+        combos = [("allreduce", "bf16", False), ("allreduce", "none", False), ("zero", "bf16", False),
+                  ("zero", "none", False), ("allreduce", "bf16", True)]
+        if a.precision != "bf16":
+            combos = [("allreduce", "none", False), ("zero", "none", False), ("allreduce", "none", True)]
+        lsteps = max(1, min(a.steps, 10))
+        for mode_, comp, sbn in combos:
+            aa = copy.copy(a)
+            aa.dp_mode, aa.grad_compress, aa.sync_bn = mode_, comp, sbn
+            trl, _ = build_trainer(aa, N, dev, pg, a.precision, fill="device")
+            trl.time_comm = True
+            for _ in range(3):
+                trl.step(pcs, gt, z0, al)
+            trl.comm_events.clear()
+            barrier()
+            t_0 = time.perf_counter()
+            for _ in range(lsteps):
+                trl.step(pcs, gt, z0, al)
+            barrier()
+            d = max_over_ranks(time.perf_counter() - t_0)
+            exposed = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in trl.comm_events)
+            exp_us = max_over_ranks(statistics.median(exposed)) if exposed else None
+            dp_legs.append({"dp_mode": mode_, "grad_buckets": "bf16" if comp == "bf16" else "fp32", "sync_bn": sbn,
+                            "ms_per_step": d / lsteps * 1e3, "value": world * B * lsteps / d, "steps": lsteps,
+                            "exposed_comm_us": exp_us,
+                            "collectives_per_step": trl.comm["collectives"],
+                            "payload_bytes_per_step": trl.comm["payload_bytes"],
+                            "is_default": (mode_, comp, sbn) == (a.dp_mode, a.grad_compress, bool(a.sync_bn))})
+            del trl
+            torch.cuda.empty_cache()
+
+    sweep = infer = c5 = ref_default = None
     if single and not a.no_extra_legs and a.precision == "bf16":
         esteps = max(1, min(a.steps, 10))
         # BASELINE config[3]: the point-subsampling sweep (train_pointsubsampling.py:19-71), 10 steps x 3 windows each
@@ -571,6 +657,12 @@ def main():
         infer = leg_infer(a, dev, max(1, min(a.steps, 5)), 3)
         # config[1] with the five features its wording names (x, y, z, doppler, power dB)
         c5 = leg_train_shape(a, dev, N, 5, esteps, 3)
+        # the reference's own operating point (constants.py:29,55: BATCH_SIZE = 16, NMAX = 150; what a drop-in user of
+        # train_variant4(CONFIG) runs; BASELINE.md section 2, first row), throughput mode and parity-grade mode
+        ref_default = {"workload": "the reference's default config: V4 train step at B=16 N=150 C=4 (constants.py:29,55)",
+                       "bf16": leg_train_shape(a, dev, 150, 4, esteps, 3, B=16, precision="bf16"),
+                       "fp16x3": leg_train_shape(a, dev, 150, 4, max(1, min(a.steps, 5)), 3, B=16, precision="fp16x3"),
+                       "parity": "tests/test_round3_parity.py::test_reference_default_shape_step_vs_oracle"}
 
     if rank == 0:
         ms = dt / a.steps * 1e3
@@ -603,6 +695,13 @@ def main():
                        # time the host spends enqueueing one step (no synchronisation inside step())
                        "host_enqueue_ms_per_step": host_s / (a.steps * a.windows) * 1e3},
         }
+        if dp_legs is not None:
+            line["dp_legs"] = {"note": "every exchange scheme of the data-parallel step, timed in this run (3 warm-up + "
+                                       "`steps` steps, barrier + synchronize on both sides, max over ranks); exposed_comm_us = "
+                                       "median over the steps (max over ranks) of the main stream's time between the point "
+                                       "where it needs the encoder gradients reduced and the point where every decoder "
+                                       "bucket is back (HIP events, train.PCAATrainer.time_comm); the line's `value` is the "
+                                       "leg marked is_default", "legs": dp_legs}
         if parity_leg is not None:
             line["parity_mode"] = parity_leg
         if batcher_leg is not None:
@@ -616,6 +715,8 @@ def main():
         if c5 is not None:
             c5["workload"] = f"BASELINE config[1] at C=5 (x, y, z, doppler, power): B={B} N={N} bf16"
             line["c5"] = c5
+        if ref_default is not None:
+            line["ref_default"] = ref_default
         if sections is not None:
             line["gpu_sections"] = sections
         if agg:

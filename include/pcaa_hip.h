@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PCAA_ABI_VERSION 12 /* pcaa_abi_version() of a library built from this header */
+#define PCAA_ABI_VERSION 13 /* pcaa_abi_version() of a library built from this header */
 
 #define PCAA_OK 0
 #define PCAA_ERR_INVALID_ARG 1
@@ -120,13 +120,6 @@ int pcaa_timing_events_destroy(void* start, void* stop);
 int pcaa_time_next_gemm(void* start, void* stop);
 int pcaa_timing_pending(void);
 int pcaa_timing_elapsed_ms(void* start, void* stop, float* ms);
-/* A stream whose kernels run on compute units [first_cu, first_cu + n_cus) of the XCD-interleaved numbering only
- * (multiples of 8: n_cus / 8 on every XCD), for launches that
- * are to share the chip with the calling stream's instead of queueing behind / in front of them (csrc/streams.hip).
- * The caller sizes such a launch for n_cus workgroups.  No counterpart in the reference (PyTorch runs its backward on
- * one stream); the host side wraps the handle as a torch.cuda.ExternalStream. */
-int pcaa_stream_create_masked(int first_cu, int n_cus, void** stream);
-int pcaa_stream_destroy(void* stream);
 int pcaa_splitk_reduce(const float* slabs, int nsplit, long slab_stride, long n, float* out,
                        int accumulate, void* stream);
 /* same, for out[rows, ch], plus the BatchNorm column statistics of out (stats as in pcaa_gemm) */
@@ -159,11 +152,17 @@ int pcaa_pointnet_in_bwd_stats(const void* da, int dtype, const float* x, int C,
  * sums at [64 + c]); pcaa_pointnet_in_bwd_combine forms dW (=) from G, the moments and pcaa_bn_bwd_finalize's coef. */
 int pcaa_pointnet_in_bwd_onepass(const void* da, int dtype, const float* x, int C, const float* W,
                                  const float* scale, const float* shift, const float* mean, const float* rstd,
-                                 double* stats, int nrep, float* G, long P, int cout, void* stream);
+                                 double* stats, int nrep, float* G, long P, int cout, const double* pivot_mom,
+                                 double pivot_inv_count, void* stream);
 int pcaa_points_moments_size(void);
 int pcaa_points_moments(const float* x, int C, long P, double* mom, void* stream);
+/* Round 4: G is accumulated against the points centred on a pivot, pivot[c] = (float)(pivot_mom[64 + c] *
+ * pivot_inv_count) (pivot_mom NULL: no centring) -- normally the points' own moments and 1 / P; under SyncBN the
+ * all-reduced moments and 1 / (global count), so that every rank uses the same pivot.  The combine takes the LOCAL
+ * moments and point count P plus the same pivot source, and drops pivot (x) sum_p dy (zero per channel). */
 int pcaa_pointnet_in_bwd_combine(const float* G, int nrep, const float* W, const double* mom, const float* coef,
-                                 float* dW, int cout, int C, void* stream);
+                                 float* dW, int cout, int C, long P, const double* pivot_mom, double pivot_inv_count,
+                                 void* stream);
 /* The same moments give the layer's forward BatchNorm statistics without a pass over the points (sum y = W.sum x,
  * sum y^2 = W^T (x^T x) W per channel): arm the forward finalize on `mom` (pcaa_bn_tail_arm_fwd with stats = mom,
  * count = P, any non-null counter), then this call writes scale / shift / mean / rstd and the running statistics. */
@@ -472,6 +471,11 @@ int pcaa_gemm_split3_num_splits(int K, int split_k);
 int pcaa_gemm_slabs_split3(const void* A, const void* B, int layout, long lda, long ldb, float* slabs,
                            long slab_stride, int M, int N, int K, int split_k, float out_scale, void* stream);
 int pcaa_split_f16(const float* src, void* dst_img, long rows, int ch, int transpose, float img_scale, void* stream);
+/* Range guard of the images (round 4): fp16 holds |x| <= 65504 while the fp32 tensors of the reference have no limit.
+ * Every image producer saturates a scaled value that leaves that range (finite hi, lo = 0) and sets *dev_flag
+ * (device int32, registered per calling thread; NULL = no flag) to 1; NaN inputs set it too.  The caller reads the
+ * flag when it next synchronises (PCAATrainer.check()) and must not trust that step's products. */
+int pcaa_set_range_flag(int* dev_flag);
 int pcaa_bn_act_fwd_split(const float* y, void* a_img, const float* scale, const float* shift, long rows,
                           int ch, float img_scale, void* stream);
 int pcaa_bn_bwd_dy_fused_split(const float* da, const float* dpool, int group_rows, float pool_scale,

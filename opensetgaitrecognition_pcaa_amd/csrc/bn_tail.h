@@ -43,6 +43,7 @@ struct BnTail {
 
 // armed by pcaa_bn_tail_arm_fwd / _bwd, taken (and disarmed) by the next launcher that can carry it
 BnTail pcaa_take_bn_tail(const double* stats);
+void pcaa_rearm_bn_tail(const BnTail& t);      // give a taken tail back when the launch did not happen
 
 __device__ __forceinline__ double bn_tail_ld(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

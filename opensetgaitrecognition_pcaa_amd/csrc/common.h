@@ -78,8 +78,30 @@ __device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
 // gradients 2^16): hi + lo then carries 22 mantissa bits, against 16 for a bf16 pair.
 typedef _Float16 split_t;
 typedef _Float16 split_x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store4_split(split_t* img, size_t row, unsigned ch, unsigned c, f32x4 v, float s) {
+// Range guard of the images (round 4, advisor finding): fp16 holds |x| <= 65504, the fp32 tensors the images stand for
+// have no such limit (ELU is unbounded above, a gradient spike can pass 2^-16 ... 1).  A value whose scaled magnitude
+// leaves fp16's range is SATURATED (hi = +-65504, lo = 0: finite, so one outlier does not turn the whole product into
+// inf - inf = NaN) and the caller's device flag is raised: pcaa_set_range_flag registers it, the producers' launchers
+// hand it to their kernels, PCAATrainer.check() reads it and refuses the step's result (the exact-fp32 mode has no
+// limit).  NaN inputs raise the flag too and stay NaN.
+constexpr float SPLIT_MAX = 65504.f;
+int* pcaa_range_flag_ptr();      // host: the registered device flag of the calling thread (may be null)
+__device__ __forceinline__ float split_guard(float v, int* oflow) {
+  if (!(fabsf(v) <= SPLIT_MAX)) {
+    if (oflow) *oflow = 1;
+    v = fminf(fmaxf(v, -SPLIT_MAX), SPLIT_MAX);      // (fminf / fmaxf drop a NaN operand: a NaN saturates too, flagged)
+  }
+  return v;
+}
+__device__ __forceinline__ void store4_split(split_t* img, size_t row, unsigned ch, unsigned c, f32x4 v, float s,
+                                             int* oflow) {
   v *= s;
+  const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+  if (!(m <= SPLIT_MAX) || v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w) {
+    v.x = split_guard(v.x, oflow); v.y = split_guard(v.y, oflow);
+    v.z = split_guard(v.z, oflow); v.w = split_guard(v.w, oflow);
+    if (oflow) *oflow = 1;
+  }
   split_x4 hi, lo;
   hi.x = (split_t)v.x; hi.y = (split_t)v.y; hi.z = (split_t)v.z; hi.w = (split_t)v.w;
   lo.x = (split_t)(v.x - (float)hi.x); lo.y = (split_t)(v.y - (float)hi.y);

@@ -17,6 +17,10 @@ void pcaa_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* pcaa_last_error(void) { return g_err; }
+// the device flag the split-image producers raise when a value leaves fp16's range (common.h, split_guard)
+static thread_local int* g_range_flag = nullptr;
+int* pcaa_range_flag_ptr() { return g_range_flag; }
+extern "C" int pcaa_set_range_flag(int* dev_flag) { g_range_flag = dev_flag; return PCAA_OK; }
 extern "C" int pcaa_abi_version(void) { return PCAA_ABI_VERSION; }
 
 namespace {
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
 __global__ __launch_bounds__(256) void bn_act_fwd_split_kernel(const float* __restrict__ y, split_t* __restrict__ a,
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ shift, unsigned nquads,
-                                                               unsigned qpr, float img_scale) {
+                                                               unsigned qpr, float img_scale, int* oflow) {
   const unsigned q0 = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
   const unsigned c = (q0 % qpr) << 2, ch = qpr << 2, rstep = stride / qpr;
   unsigned r = q0 / qpr;
@@ -130,19 +134,19 @@ __global__ __launch_bounds__(256) void bn_act_fwd_split_kernel(const float* __re
   for (unsigned q = q0; q < nquads; q += stride, r += rstep) {
     const f32x4 v = load4(y + (size_t)q * 4);
     store4_split(a, r, ch, c, f32x4{elu_f(v.x * sc.x + sh.x), elu_f(v.y * sc.y + sh.y), elu_f(v.z * sc.z + sh.z),
-                                     elu_f(v.w * sc.w + sh.w)}, img_scale);
+                                     elu_f(v.w * sc.w + sh.w)}, img_scale, oflow);
   }
 }
 
 // fp32 [rows, ch] -> its [hi | lo] fp16 image [rows, 2 ch] (of value * img_scale); transpose != 0: the image of the TRANSPOSED matrix, [ch, 2 rows]
 // (weights: a few MB)
 __global__ void split_f16_kernel(const float* __restrict__ src, split_t* __restrict__ dst, long rows, int ch,
-                                  int transpose, float img_scale) {
+                                  int transpose, float img_scale, int* oflow) {
   const long n = rows * ch;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const long r = i / ch;
     const int c = (int)(i - r * ch);
-    const float v = src[i] * img_scale;
+    const float v = split_guard(src[i] * img_scale, oflow);
     const split_t hi = (split_t)v, lo = (split_t)(v - (float)hi);
     if (transpose) {
       dst[(long)c * 2 * rows + r] = hi;
@@ -420,7 +424,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dy_kernel(const T* __restrict__ dz
 __global__ __launch_bounds__(256) void bn_bwd_dy_split_kernel(const float* __restrict__ dz, const float* __restrict__ y,
                                                               split_t* __restrict__ dy_img,
                                                               const float* __restrict__ coef, unsigned nquads,
-                                                              unsigned qpr, unsigned ch, float img_scale) {
+                                                              unsigned qpr, unsigned ch, float img_scale, int* oflow) {
   const unsigned q0 = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
   const unsigned c = (q0 % qpr) << 2;
   const unsigned rstep = stride / qpr;
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dy_split_kernel(const float* __res
   const f32x4 k0 = load4(coef + c), k1 = load4(coef + ch + c), k2 = load4(coef + 2 * ch + c);
   for (unsigned q = q0; q < nquads; q += stride) {
     const f32x4 d = load4(dz + (size_t)q * 4), yv = load4(y + (size_t)q * 4);
-    store4_split(dy_img, rr, ch, c, k0 * d + k1 * yv + k2, img_scale);
+    store4_split(dy_img, rr, ch, c, k0 * d + k1 * yv + k2, img_scale, oflow);
     rr += rstep;
   }
 }
@@ -695,7 +699,7 @@ extern "C" int pcaa_bn_act_fwd_split(const float* y, void* a_img, const float* s
   PCAA_CHECK_ARG(nq < (1L << 31), "pcaa_bn_act_fwd_split: tensor too large for 32-bit quad indices");
   const int grid = col_invariant_grid(nq, ch >> 2);
   hipLaunchKernelGGL(bn_act_fwd_split_kernel, dim3(grid), dim3(256), 0, as_stream(stream), y, (split_t*)a_img, scale, shift,
-                     (unsigned)nq, (unsigned)(ch >> 2), img_scale);
+                     (unsigned)nq, (unsigned)(ch >> 2), img_scale, pcaa_range_flag_ptr());
   PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_act_fwd_split");
 }
 
@@ -705,7 +709,7 @@ extern "C" int pcaa_split_f16(const float* src, void* dst_img, long rows, int ch
   long g = cdiv(rows * ch, 256);
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), src, (split_t*)dst_img, rows, ch,
-                     transpose, img_scale);
+                     transpose, img_scale, pcaa_range_flag_ptr());
   PCAA_RETURN_LAUNCH_STATUS("pcaa_split_f16");
 }
 
@@ -780,7 +784,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dy_fused_kernel(const T* __restric
                                                               T* __restrict__ dy, const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
                                                               const float* __restrict__ coef, unsigned nquads,
-                                                              unsigned qpr, unsigned ch, float img_scale = 1.f) {
+                                                              unsigned qpr, unsigned ch, float img_scale = 1.f,
+                                                              int* oflow = nullptr) {
   // column-invariant grid (see bn_act_fwd_kernel): coefficients in registers, rows advance by a
   // constant; the pooled variant's group index is one 32-bit division per quad
   const unsigned q0 = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
@@ -826,7 +831,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dy_fused_kernel(const T* __restric
     }
     if constexpr (SPLIT) {
       // dy as the [hi | lo] bf16 image (its only readers are the split-fp16 GEMMs); dy points at the image
-      store4_split(reinterpret_cast<split_t*>(dy), rr, ch, c, k0 * (g * e) + k1 * yv + k2, img_scale);
+      store4_split(reinterpret_cast<split_t*>(dy), rr, ch, c, k0 * (g * e) + k1 * yv + k2, img_scale, oflow);
       rr += rstep;
     } else {
       store4(dy + (size_t)q * 4, k0 * (g * e) + k1 * yv + k2);
@@ -873,11 +878,11 @@ extern "C" int pcaa_bn_bwd_dy_fused_split(const float* da, const float* dpool, i
   if (dpool)
     hipLaunchKernelGGL((bn_bwd_dy_fused_kernel<float, true, true>), dim3(grid), dim3(256), 0, s, da, dpool,
                        (unsigned)group_rows, pool_scale, y, (float*)dy_img, scale, shift, coef, (unsigned)nq,
-                       (unsigned)(ch >> 2), (unsigned)ch, img_scale);
+                       (unsigned)(ch >> 2), (unsigned)ch, img_scale, pcaa_range_flag_ptr());
   else
     hipLaunchKernelGGL((bn_bwd_dy_fused_kernel<float, false, true>), dim3(grid), dim3(256), 0, s, da, dpool,
                        (unsigned)group_rows, pool_scale, y, (float*)dy_img, scale, shift, coef, (unsigned)nq,
-                       (unsigned)(ch >> 2), (unsigned)ch, img_scale);
+                       (unsigned)(ch >> 2), (unsigned)ch, img_scale, pcaa_range_flag_ptr());
   PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_bwd_dy_fused_split");
 }
 
@@ -934,6 +939,11 @@ extern "C" int pcaa_bn_tail_arm_bwd(const double* stats, int nrep, long count, c
   g_tail = t;
   return PCAA_OK;
 }
+// a launcher that took the tail and then could NOT launch hands it back: the stand-alone finalize then runs
+// (ops.BnTailFwd/Bwd.resolve sees it pending) instead of coefficient tensors nobody ever wrote
+void pcaa_rearm_bn_tail(const BnTail& t) {
+  if (t.kind != 0) g_tail = t;
+}
 extern "C" int pcaa_bn_tail_pending(void) { return g_tail.kind != 0 ? 1 : 0; }
 extern "C" int pcaa_bn_tail_disarm(void) {
   g_tail.kind = 0;
@@ -966,7 +976,7 @@ extern "C" int pcaa_bn_bwd_dy_split(const float* dz, const float* y, void* dy_im
   PCAA_CHECK_ARG(nq < (1L << 31), "pcaa_bn_bwd_dy_split: tensor too large for 32-bit quad indices");
   const int grid = col_invariant_grid(nq, ch >> 2);
   hipLaunchKernelGGL(bn_bwd_dy_split_kernel, dim3(grid), dim3(256), 0, as_stream(stream), dz, y, (split_t*)dy_img, coef,
-                     (unsigned)nq, (unsigned)(ch >> 2), (unsigned)ch, img_scale);
+                     (unsigned)nq, (unsigned)(ch >> 2), (unsigned)ch, img_scale, pcaa_range_flag_ptr());
   PCAA_RETURN_LAUNCH_STATUS("pcaa_bn_bwd_dy_split");
 }
 

@@ -1153,16 +1153,26 @@ bool launch_dma(const GemmParams& p_in, dim3 grid_in, hipStream_t s) {
   const int krows = p.seg_len > 0 ? p.seg_len : p.K;
   const long a_bytes = (long)(ALAY == KC ? p.M : krows) * p.lda * 2, b_bytes = (long)(BLAY == KC ? p.N : krows) * p.ldb * 2;
   const bool buf = a_bytes < (1L << 32) && b_bytes < (1L << 32);
+  // (advisor, round 3) every path that does not launch hands the tail back: resolve() then runs the stand-alone finalize
+  bool ok = false;
+  bool decided = false;
   if constexpr ((EPI == EPI_PLAIN || (EPI == EPI_DGRAD_BN && ALAY == KC)) && sizeof(TC) == 4) {
     // split-fp16 operands (pcaa_gemm_split3, pcaa_gemm_dgrad_bn_split3): fp32 result only
-    if (p.seg_len > 0)
-      return buf ? launch_dma_inst<TC, ALAY, BLAY, EPI, true, true>(p, grid, s)
-                 : launch_dma_inst<TC, ALAY, BLAY, EPI, false, true>(p, grid, s);
-    if (EPI == EPI_DGRAD_BN) return false;          // fp32 dz exists for the split operands only
+    if (p.seg_len > 0) {
+      ok = buf ? launch_dma_inst<TC, ALAY, BLAY, EPI, true, true>(p, grid, s)
+               : launch_dma_inst<TC, ALAY, BLAY, EPI, false, true>(p, grid, s);
+      decided = true;
+    } else if (EPI == EPI_DGRAD_BN) {
+      decided = true;                                // fp32 dz exists for the split operands only
+    }
   }
-  if (p.seg_len > 0) return false;
-  if (buf) return launch_dma_inst<TC, ALAY, BLAY, EPI, true>(p, grid, s);
-  return launch_dma_inst<TC, ALAY, BLAY, EPI, false>(p, grid, s);
+  if (!decided) {
+    if (p.seg_len > 0) ok = false;
+    else ok = buf ? launch_dma_inst<TC, ALAY, BLAY, EPI, true>(p, grid, s)
+                  : launch_dma_inst<TC, ALAY, BLAY, EPI, false>(p, grid, s);
+  }
+  if (!ok) pcaa_rearm_bn_tail(p.tail);
+  return ok;
 }
 
 template <typename TA, typename TB, typename TC, int ALAY, int BLAY>

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void pointnet_in_apply_kernel(const float* __r
                                                                 const float* __restrict__ W,
                                                                 const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, T* __restrict__ a,
-                                                                long P, int cout) {
+                                                                long P, int cout, int* oflow = nullptr) {
   __shared__ float xs[FWD_ROWS * CP];
   const int qpr = cout >> 2, rl = 256 / qpr;
   const int cq = threadIdx.x % qpr, rlane = threadIdx.x / qpr;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void pointnet_in_apply_kernel(const float* __r
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = elu_t<T>(acc[e] * sc[e] + sh[e]);
-    if constexpr (SPLIT) store4_split(reinterpret_cast<split_t*>(a), (size_t)(r0 + r), cout, cq * 4, o, 1.f);   // [hi | lo] image
+    if constexpr (SPLIT) store4_split(reinterpret_cast<split_t*>(a), (size_t)(r0 + r), cout, cq * 4, o, 1.f, oflow);   // [hi | lo] image
     else store4(a + (r0 + r) * cout + cq * 4, o);
   }
 }
@@ -148,7 +148,9 @@ __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restric
                                                               const float* __restrict__ rstd,     // MODE 0
                                                               const float* __restrict__ coef,     // MODE 1: [3][cout]
                                                               double* __restrict__ stats, int nrep,
-                                                              float* __restrict__ dW, long P, int cout, BnTail tail) {
+                                                              float* __restrict__ dW, long P, int cout, BnTail tail,
+                                                              const double* __restrict__ pivot_mom = nullptr,
+                                                              double pivot_inv_count = 0.0) {
   __shared__ int tail_flag;
   __shared__ float xs[1024 * CP];     // points [WG_ROWS][CP], later the [rl][cout][CP] row-lane combine (rl*cout = 1024)
   const int qpr = cout >> 2, rl = 256 / qpr;
@@ -156,6 +158,18 @@ __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restric
   const long r0 = (long)blockIdx.x * BWD_ROWS;
   const int nrows = (int)min((long)BWD_ROWS, P - r0);
   stage_points<CP>(xs, x, C, r0, nrows, BWD_ROWS);
+  // MODE 3 (round 4, advisor finding): G is accumulated against the points CENTRED on a pivot (their mean, from the
+  // moments): dW = sum dy x has the three terms c0 G, c1 W.x^T x, c2 sum x cancel to the part that comes from the
+  // points' spread, and for un-centred features (range, power in dB: mean >> deviation) fp32 partial sums of dz.x lose
+  // exactly those digits.  y itself (ELU', y-hat) is still formed from the raw points.  xc: [BWD_ROWS][CP] behind xs.
+  float* xc = xs + BWD_ROWS * CP;
+  if constexpr (MODE == 3) {
+    for (int e = threadIdx.x; e < BWD_ROWS * CP; e += 256) {
+      const int r = e / CP, c = e - r * CP;
+      const float piv = (pivot_mom != nullptr && c < C) ? (float)(pivot_mom[MAXC * MAXC + c] * pivot_inv_count) : 0.f;
+      xc[e] = (r < nrows && c < C) ? x[(r0 + r) * C + c] - piv : 0.f;
+    }
+  }
   float w[4][CP];
   load_weights<CP>(w, W, C, cq);
   const f32x4 sc = load4(scale + cq * 4), sh = load4(shift + cq * 4);
@@ -244,6 +258,12 @@ __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restric
         s1hi += dhi;
         s2lo = __builtin_elementwise_fma(dlo, __builtin_elementwise_fma(ylo, rslo, nmlo), s2lo);
         s2hi = __builtin_elementwise_fma(dhi, __builtin_elementwise_fma(yhi, rshi, nmhi), s2hi);
+        const f32x4 cq0 = *reinterpret_cast<const f32x4*>(xc + (r + u * rl) * CP);      // centred points for G
+        xr[0] = cq0.x; xr[1] = cq0.y; xr[2] = cq0.z; xr[3] = cq0.w;
+        if constexpr (CP > 4) {
+          const f32x4 cq1 = *reinterpret_cast<const f32x4*>(xc + (r + u * rl) * CP + 4);
+          xr[4] = cq1.x; xr[5] = cq1.y; xr[6] = cq1.z; xr[7] = cq1.w;
+        }
 #pragma unroll
         for (int c = 0; c < CP; ++c) {
           const f32x2 xv = {xr[c], xr[c]};
@@ -280,9 +300,10 @@ __global__ __launch_bounds__(256) void pointnet_in_bwd_kernel(const T* __restric
       }
       if (MODE != 0) {
         const f32x4 dy = MODE == 3 ? d : p0 * d + p1 * yv + p2;
+        const float* xg = MODE == 3 ? xc + (r + u * rl) * CP : xr;      // MODE 3: the centred points (see the top)
 #pragma unroll
         for (int c = 0; c < CP; ++c) {
-          const float xv = xr[c];
+          const float xv = xg[c];
           acc[0][c] = fmaf(dy.x, xv, acc[0][c]);
           acc[1][c] = fmaf(dy.y, xv, acc[1][c]);
           acc[2][c] = fmaf(dy.z, xv, acc[2][c]);
@@ -334,33 +355,38 @@ template <int CP>
 __global__ __launch_bounds__(256) void points_moments_kernel(const float* __restrict__ x, int C, long P,
                                                              double* __restrict__ mom) {
   constexpr int NV = CP * (CP + 1) / 2 + CP;           // upper triangle + sums
-  __shared__ float red[256][NV + 1];
-  float a[NV];
+  // fp64 partial sums (round 4, advisor finding: they were fp32): a product of two fp32 values is exact in fp64, so
+  // the moments carry ~1e-16 relative error and var = w^T (x^T x / P) w - (w.m)^2 survives features whose mean is
+  // 1e3..1e5 times their deviation.  14 (44) fp64 FMAs per point on a 4 MB read: still a few microseconds.
+  __shared__ double red[4][NV];
+  double a[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) a[i] = 0.f;
+  for (int i = 0; i < NV; ++i) a[i] = 0.0;
   for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < P; r += (long)gridDim.x * 256) {
-    float xv[CP];
+    double xv[CP];
     if (CP == 4 && C == 4) {
       const f32x4 v = load4(x + r * 4);
       xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
     } else {
 #pragma unroll
-      for (int c = 0; c < CP; ++c) xv[c] = c < C ? x[r * C + c] : 0.f;
+      for (int c = 0; c < CP; ++c) xv[c] = c < C ? (double)x[r * C + c] : 0.0;
     }
     int i = 0;
 #pragma unroll
     for (int k = 0; k < CP; ++k)
 #pragma unroll
-      for (int c = k; c < CP; ++c) { a[i] = fmaf(xv[k], xv[c], a[i]); ++i; }
+      for (int c = k; c < CP; ++c) { a[i] = fma(xv[k], xv[c], a[i]); ++i; }
 #pragma unroll
     for (int c = 0; c < CP; ++c) a[i + c] += xv[c];
   }
 #pragma unroll
-  for (int i = 0; i < NV; ++i) red[threadIdx.x][i] = a[i];
+  for (int i = 0; i < NV; ++i) {
+    const double v = wave_sum_d(a[i]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+  }
   __syncthreads();
   if (threadIdx.x < NV) {
-    double v = 0.0;
-    for (int t = 0; t < 256; ++t) v += (double)red[t][threadIdx.x];
+    const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     // scatter the triangle entry to both symmetric positions of the MAXC x MAXC layout
     int i = threadIdx.x;
     if (i < CP * (CP + 1) / 2) {
@@ -396,17 +422,25 @@ __global__ void pointnet_in_moment_stats_kernel(const double* __restrict__ mom, 
   bn_tail_channel(t, o, s1, s2);
 }
 
-// dW[o][c] = c0[o] G[o][c] + c1[o] sum_k W[o][k] XtX[k][c] + c2[o] sum_p x[p][c]     (fp64 combination)
+// dW[o][c] = c0[o] G'[o][c] + c1[o] sum_k W[o][k] XtX'[k][c] + c2[o] sum_p x'[p][c]     (fp64 combination)
+// with x' = x - pivot (the pivot the one-pass kernel centred G on: pivot_mom's sums * pivot_inv_count; null: 0):
+//   XtX'[k][c] = sum_p x_k x'_c = XtX[k][c] - pivot_c sum_p x_k,      sum_p x'_c = sum_p x_c - P pivot_c.
+// The term pivot_c * sum_p dy[p][o] that completes sum dy x is dropped: sum_p dy = 0 for every channel (BatchNorm's
+// backward removes the mean; under SyncBN the pivot is the GLOBAL mean, the same on every rank, so the ranks' terms
+// cancel in the gradient all-reduce) -- it only ever held rounding noise times the pivot.
 __global__ void pointnet_in_bwd_combine_kernel(const float* __restrict__ G, int nrep, const float* __restrict__ W,
                                                const double* __restrict__ mom, const float* __restrict__ coef,
-                                               float* __restrict__ dW, int cout, int C) {
+                                               float* __restrict__ dW, int cout, int C, double P,
+                                               const double* __restrict__ pivot_mom, double pivot_inv_count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cout * C) return;
   const int o = i / C, c = i - o * C;
+  const double piv = pivot_mom ? (double)(float)(pivot_mom[MAXC * MAXC + c] * pivot_inv_count) : 0.0;
   double yx = 0.0, g = 0.0;
-  for (int k = 0; k < C; ++k) yx += (double)W[o * C + k] * mom[k * MAXC + c];
+  for (int k = 0; k < C; ++k) yx += (double)W[o * C + k] * (mom[k * MAXC + c] - piv * mom[MAXC * MAXC + k]);
   for (int r = 0; r < nrep; ++r) g += (double)G[(long)r * cout * C + i];
-  dW[i] = (float)((double)coef[o] * g + (double)coef[cout + o] * yx + (double)coef[2 * cout + o] * mom[MAXC * MAXC + c]);
+  dW[i] = (float)((double)coef[o] * g + (double)coef[cout + o] * yx +
+                  (double)coef[2 * cout + o] * (mom[MAXC * MAXC + c] - P * piv));
 }
 
 // dW[o][c] += sum_p dy[p][o] * x[p][c]
@@ -554,10 +588,10 @@ extern "C" int pcaa_pointnet_in_apply(const float* x, int C, const float* W, con
     // fp32 arithmetic, the activation written as its [hi | lo] bf16 image [P, 2 cout]
     if (C <= 4)
       hipLaunchKernelGGL((pointnet_in_apply_kernel<float, 4, true>), dim3(grid), dim3(256), 0, as_stream(stream), x, C, W,
-                         scale, shift, (float*)a, P, cout);
+                         scale, shift, (float*)a, P, cout, pcaa_range_flag_ptr());
     else
       hipLaunchKernelGGL((pointnet_in_apply_kernel<float, 8, true>), dim3(grid), dim3(256), 0, as_stream(stream), x, C, W,
-                         scale, shift, (float*)a, P, cout);
+                         scale, shift, (float*)a, P, cout, pcaa_range_flag_ptr());
   }
   else { pcaa_set_error("pcaa_pointnet_in_apply: bad dtype"); return PCAA_ERR_INVALID_ARG; }
   PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_apply");
@@ -603,16 +637,18 @@ extern "C" int pcaa_pointnet_in_bwd_wgrad(const void* da, int dtype, const float
 extern "C" int pcaa_pointnet_in_bwd_onepass(const void* da, int dtype, const float* x, int C, const float* W,
                                             const float* scale, const float* shift, const float* mean,
                                             const float* rstd, double* stats, int nrep, float* G, long P, int cout,
-                                            void* stream) {
+                                            const double* pivot_mom, double pivot_inv_count, void* stream) {
   PCAA_CHECK_ARG(da && x && W && scale && shift && mean && rstd && stats && G && P >= 1 && nrep >= 1,
                  "pcaa_pointnet_in_bwd_onepass: bad args");
   PCAA_CHECK_ARG(shape_ok(C, cout), "pcaa_pointnet_in_bwd_onepass: need C<=%d and cout/4 dividing 256 (C=%d cout=%d)", MAXC, C, cout);
   const unsigned grid = (unsigned)cdiv(P, BWD_ROWS);
   const BnTail tail = pcaa_take_bn_tail(stats);
   if (dtype == PCAA_F32)
-    LAUNCH_BWD(float, 3, (const float*)da, x, C, W, scale, shift, mean, rstd, nullptr, stats, nrep, G, P, cout, tail);
+    LAUNCH_BWD(float, 3, (const float*)da, x, C, W, scale, shift, mean, rstd, nullptr, stats, nrep, G, P, cout, tail,
+               pivot_mom, pivot_inv_count);
   else if (dtype == PCAA_BF16)
-    LAUNCH_BWD(bf16_t, 3, (const bf16_t*)da, x, C, W, scale, shift, mean, rstd, nullptr, stats, nrep, G, P, cout, tail);
+    LAUNCH_BWD(bf16_t, 3, (const bf16_t*)da, x, C, W, scale, shift, mean, rstd, nullptr, stats, nrep, G, P, cout, tail,
+               pivot_mom, pivot_inv_count);
   else { pcaa_set_error("pcaa_pointnet_in_bwd_onepass: bad dtype"); return PCAA_ERR_INVALID_ARG; }
   PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_bwd_onepass");
 }
@@ -642,11 +678,12 @@ extern "C" int pcaa_pointnet_in_moment_stats(const double* mom, const float* W, 
 }
 
 extern "C" int pcaa_pointnet_in_bwd_combine(const float* G, int nrep, const float* W, const double* mom,
-                                            const float* coef, float* dW, int cout, int C, void* stream) {
+                                            const float* coef, float* dW, int cout, int C, long P,
+                                            const double* pivot_mom, double pivot_inv_count, void* stream) {
   PCAA_CHECK_ARG(G && W && mom && coef && dW && cout >= 1 && C >= 1 && C <= MAXC && nrep >= 1,
                  "pcaa_pointnet_in_bwd_combine: bad args");
   hipLaunchKernelGGL(pointnet_in_bwd_combine_kernel, dim3((unsigned)cdiv((long)cout * C, 256)), dim3(256), 0,
-                     as_stream(stream), G, nrep, W, mom, coef, dW, cout, C);
+                     as_stream(stream), G, nrep, W, mom, coef, dW, cout, C, (double)P, pivot_mom, pivot_inv_count);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_pointnet_in_bwd_combine");
 }
 

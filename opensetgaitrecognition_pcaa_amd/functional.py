@@ -88,6 +88,8 @@ def _sync_stats(stats, count):
         return count
     import torch.distributed as dist
     dist.all_reduce(stats, group=g)
+    _SYNC_BN["collectives"] = _SYNC_BN.get("collectives", 0) + 1          # PCAATrainer folds these into its comm record
+    _SYNC_BN["payload_bytes"] = _SYNC_BN.get("payload_bytes", 0) + stats.numel() * stats.element_size()
     return count * dist.get_world_size(g)
 
 
@@ -1004,16 +1006,18 @@ class _KlFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mu, logvar, mu_k):
         mu, logvar, mu_k = mu.contiguous().float(), logvar.contiguous().float(), mu_k.contiguous().float()
-        ctx.save_for_backward(mu, logvar, mu_k)
-        return ops.orced_kl(mu, logvar, mu_k)[0]
+        # loss and the three UNSCALED gradients from the one launch (as _CeFn): the backward multiplies by the upstream
+        # gradient on the device -- no host read of a device scalar (round-3 advisor finding: float(g) synchronised
+        # every step and cannot be captured into a hipGraph)
+        loss, grads = ops.orced_kl(mu, logvar, mu_k, want_loss=True, gscale=1.0)
+        ctx.save_for_backward(*grads)
+        return loss
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        mu, logvar, mu_k = ctx.saved_tensors
-        # the upstream gradient is a device scalar: read it here (OR-CED's loop synchronises on .item() every step anyway)
-        _, (dm, dl, dk) = ops.orced_kl(mu, logvar, mu_k, want_loss=False, gscale=float(g))
-        return dm, dl, dk
+        dm, dl, dk = ctx.saved_tensors
+        return dm * g, dl * g, dk * g
 
 
 def cg_kl_divergence(mu, logvar, mu_k):

@@ -58,7 +58,12 @@ class on_stream:
         self.prev = None
 
     def __enter__(self):
-        if _set_cur_stream is None or _get_cur_stream is None or _raw_device is None:
+        # torch._C._cuda_getCurrentStream / _cuda_setStream / _cuda_getDevice are PRIVATE torch entry points (present in
+        # the 2.x series this image ships): when any is missing, or the stream belongs to another device than the
+        # current one (the raw path saves and restores the current device's stream only -- round-3 advisor finding),
+        # the public context manager runs instead
+        if (_set_cur_stream is None or _get_cur_stream is None or _raw_device is None
+                or self.st.device_index != _raw_device()):
             self.prev = torch.cuda.stream(self.st)
             self.prev.__enter__()
             return self
@@ -476,25 +481,6 @@ def splitk_reduce(slabs, ns, M, N, out, accumulate=False):
     return out
 
 
-_MASKED_STREAMS = {}
-
-
-def masked_stream(n_cus, first_cu=0, device=None):
-    """A torch stream confined to compute units [first_cu, first_cu + n_cus) (n_cus / 8 on every XCD); one per
-    (device, range) and process -- HIP maps streams onto few hardware queues, so they are not created per trainer."""
-    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(first_cu), int(n_cus))
-    st = _MASKED_STREAMS.get(key)
-    if st is None:
-        with torch.cuda.device(key[0]):
-            h = ctypes.c_void_p()
-            check(_lib.load().pcaa_stream_create_masked(int(first_cu), int(n_cus), ctypes.byref(h)),
-                  "pcaa_stream_create_masked")
-            st = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", key[0]))
-        _MASKED_STREAMS[key] = st
-    return st
-
-
 def gemm_affine_elu(a, W16, scale, shift, pool_rows=0):
     """ELU(scale * (a[M,K] @ W16[N,K]^T) + shift) in one launch (eval-mode BatchNorm+ELU in the GEMM
     epilogue): bf16 [M,N], or with pool_rows in {32,64,128} its mean over groups of pool_rows consecutive
@@ -604,7 +590,39 @@ class SplitImage:
         return (self.img[:, :self.ch].float() + self.img[:, self.ch:].float()) / self.scale
 
 
+# Range guard (round 4, advisor finding): fp16 images hold |scale * v| <= 65504 while the reference's fp32 tensors have no
+# limit.  The producers saturate what leaves the range and raise a per-device flag (csrc/common.h, split_guard); the
+# flag is registered right before every producer launch (split_image_empty is on each producer's path) and read by
+# range_check() -- PCAATrainer.check() calls it -- which raises: the caller reruns in "fp32" (exact, no range limit).
+_RANGE_FLAGS = {}
+
+
+def _range_flag(device):
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = _RANGE_FLAGS.get(idx)
+    if t is None:
+        t = _RANGE_FLAGS[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+    return t
+
+
+def range_check(device=None, reset=True):
+    """Raise FloatingPointError if an fp16x3-mode operand image saturated on ``device`` since the last check (one
+    host sync).  The products of such a step are wrong; rerun it with precision "fp32"."""
+    idxs = list(_RANGE_FLAGS) if device is None else [torch.device(device).index or 0]
+    for idx in idxs:
+        t = _RANGE_FLAGS.get(idx)
+        if t is not None and int(t.item()):
+            if reset:
+                t.zero_()
+            raise FloatingPointError(
+                "fp16x3 mode: a value left the fp16 range of its [hi | lo] operand image (|scale * v| > 65504 or NaN; "
+                f"scales: activations {SPLIT_SCALE_ACT:g}, weights {SPLIT_SCALE_WEIGHT:g}, gradients {SPLIT_SCALE_GRAD:g}); "
+                "the image was saturated and this step's products are not fp32-grade -- use precision='fp32'")
+
+
 def split_image_empty(rows, ch, device, scale):
+    check(_lib.load().pcaa_set_range_flag(_p(_range_flag(device))), "pcaa_set_range_flag")
     return SplitImage(torch.empty((rows, 2 * ch), dtype=torch.float16, device=device), rows, ch, scale)
 
 
@@ -860,16 +878,23 @@ def pointnet_in_bwd_onepass(da, x2d, W2d, scale, shift, mean, rstd, tail, mom=No
     lib = _lib.load()
     if mom is None:
         mom = points_moments(x2d)
+    # G is accumulated against the points centred on their mean (csrc/pointnet_in.hip, MODE 3); under SyncBN the pivot is
+    # the GLOBAL mean -- the same on every rank, so that the dropped term pivot (x) sum dy cancels in the all-reduce
+    pivot_mom, pivot_count = mom, P
+    if tail.sync is not None:
+        pivot_mom = mom.clone()
+        pivot_count = tail.sync(pivot_mom, P)
     stats = new_stats(cout, da.device)
     G = torch.zeros((NREP, cout, C), dtype=torch.float32, device=da.device)     # replica b % NREP of workgroup b
     tail.arm(stats)
     check(lib.pcaa_pointnet_in_bwd_onepass(_p(da), _dt(da), _p(x2d), C, _p(W2d), _p(scale), _p(shift), _p(mean), _p(rstd),
-                                           _p(stats), NREP, _p(G), P, cout, _s()), "pcaa_pointnet_in_bwd_onepass")
+                                           _p(stats), NREP, _p(G), P, cout, _p(pivot_mom), 1.0 / pivot_count, _s()),
+          "pcaa_pointnet_in_bwd_onepass")
     coef, _, _ = tail.resolve(stats)
     if out is None:
         out = torch.empty((cout, C), dtype=torch.float32, device=da.device)
-    check(lib.pcaa_pointnet_in_bwd_combine(_p(G), NREP, _p(W2d), _p(mom), _p(coef), _p(out), cout, C, _s()),
-          "pcaa_pointnet_in_bwd_combine")
+    check(lib.pcaa_pointnet_in_bwd_combine(_p(G), NREP, _p(W2d), _p(mom), _p(coef), _p(out), cout, C, P, _p(pivot_mom),
+                                           1.0 / pivot_count, _s()), "pcaa_pointnet_in_bwd_combine")
     return out
 
 

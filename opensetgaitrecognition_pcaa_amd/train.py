@@ -238,6 +238,12 @@ class PCAATrainer:
             raise ValueError("grad_compress must be None or 'bf16'")
         self.grad_compress = grad_compress
         self.comm = {"collectives": 0, "payload_bytes": 0}     # of the LAST step (gradient / parameter exchanges)
+        # bench.py's data-parallel legs: with ``time_comm`` set, every step appends a pair of timing events on the main
+        # stream around the place where it must have the gradients back -- from just before the (synchronous) all-reduce
+        # of the encoder + head gradients to just after the waits for the decoder buckets: what the step pays for
+        # communication it could not hide ("exposed"), measured where it is paid
+        self.time_comm = False
+        self.comm_events = []
         if variant not in ("v4", "base", "v1", "v3"):
             raise ValueError(f"PCAATrainer: unknown variant {variant!r}")
         head = variant in ("v4", "v1")
@@ -416,6 +422,9 @@ class PCAATrainer:
                             for _ in range(self._zero_chunks)]            # this rank's reduced gradient slice
             self._zero_p = [torch.empty(n // self.world, dtype=torch.float32, device=self.device)
                             for _ in range(self._zero_chunks)]            # staging of the updated slice for the gather
+            if self.grad_compress == "bf16":
+                self._zero_g16 = [torch.empty(n // self.world, dtype=torch.bfloat16, device=self.device)
+                                  for _ in range(self._zero_chunks)]      # this rank's slice of the bf16 sum
         self._g16_direct = set()
         if self.grad_compress == "bf16" and self.pg is not None:
             self._g16 = torch.zeros(self.flat_g.total, dtype=torch.bfloat16, device=self.device)
@@ -462,6 +471,8 @@ class PCAATrainer:
         call it once per epoch)."""
         if int(self._err.item()):
             raise IndexError(f"PCAATrainer: a ground-truth label was outside [0, {self.K})")
+        # fp16x3 mode: an operand image that left fp16's range (saturated, flagged on the device) voids the step
+        ops.range_check(self.device)
 
     def train(self):
         for m in self.modules().values():
@@ -549,6 +560,7 @@ class PCAATrainer:
         self._stats_pool.begin()
         self._enc_region.zero_()
         self.comm = {"collectives": 0, "payload_bytes": 0}
+        F_hip._SYNC_BN["collectives"] = F_hip._SYNC_BN["payload_bytes"] = 0
 
         # (1) encoder forward (train-mode BatchNorm)
         # (the decoder projection head rides in the launch of the MLP heads)
@@ -718,10 +730,20 @@ class PCAATrainer:
             if self._wg is not None:
                 ops.current_stream().wait_stream(self._wg)   # the decoder's dW/db were written on that stream
             scatter = []
+            z16 = self.grad_compress == "bf16"
             for c in range(self._zero_chunks):
                 lo = self._dec_start + c * n
-                self._count(4 * n)
-                scatter.append(dist.reduce_scatter_tensor(self._zero_g[c], fg.g[lo:lo + n], group=self.pg, async_op=True))
+                if z16:
+                    # bf16 buckets (round 4): the chunk is rounded once, summed on the wire in bf16, and this rank's
+                    # reduced slice goes to Adam as it came off the wire (adam_step_dev_g16_) -- the gradient half of
+                    # the exchange moves half the bytes; the updated parameters are gathered in fp32 as before
+                    g16 = self._g16[lo:lo + n]
+                    g16.copy_(fg.g[lo:lo + n])
+                    self._count(2 * n)
+                    scatter.append(dist.reduce_scatter_tensor(self._zero_g16[c], g16, group=self.pg, async_op=True))
+                else:
+                    self._count(4 * n)
+                    scatter.append(dist.reduce_scatter_tensor(self._zero_g[c], fg.g[lo:lo + n], group=self.pg, async_op=True))
             self._advance_g(supervise)
 
             def launch_zero_adam():
@@ -733,8 +755,12 @@ class PCAATrainer:
                         lo = self._dec_start + c * n + rank * (n // w)      # this rank's slice of chunk c
                         hi = lo + n // w
                         scatter[c].wait()
-                        ops.adam_step_dev_(fg.p[lo:hi], self._zero_g[c], fg.m[lo:hi], fg.v[lo:hi], cfg["B1"], cfg["B2"],
-                                           1e-8, fg.coef_dev, gs, self._side_adam_blocks)
+                        if z16:
+                            ops.adam_step_dev_g16_(fg.p[lo:hi], self._zero_g16[c], fg.m[lo:hi], fg.v[lo:hi], cfg["B1"],
+                                                   cfg["B2"], 1e-8, fg.coef_dev, gs, self._side_adam_blocks)
+                        else:
+                            ops.adam_step_dev_(fg.p[lo:hi], self._zero_g[c], fg.m[lo:hi], fg.v[lo:hi], cfg["B1"], cfg["B2"],
+                                               1e-8, fg.coef_dev, gs, self._side_adam_blocks)
                         self._zero_p[c].copy_(fg.p[lo:hi])
                         self._count(4 * n)
                         zero_gather.append(dist.all_gather_into_tensor(
@@ -818,10 +844,18 @@ class PCAATrainer:
             F_hip.set_wgrad_stream(None)
         if self._wg is not None:
             ops.current_stream().wait_stream(self._wg)       # its products feed the all-reduce / Adam below
+        ev_c0 = None
+        if self.time_comm and collective:
+            ev_c0 = torch.cuda.Event(enable_timing=True)
+            ev_c0.record()
         self._allreduce(self.flat_g.g[:self._dec_start])      # encoder + projection head
         for _, _, work in pending:
             if work is not None:
                 work.wait()         # stream-side wait, no host block
+        if ev_c0 is not None:
+            ev_c1 = torch.cuda.Event(enable_timing=True)
+            ev_c1.record()
+            self.comm_events.append((ev_c0, ev_c1))
         if zero:
             self._adam_g(0, self._dec_start, supervise, gs)
             for work in zero_gather:
@@ -834,6 +868,9 @@ class PCAATrainer:
             self._adam_g(0, self.flat_g.total, supervise, gs)
 
         F_hip.mark("adam+join")
+        # SyncBN's statistics all-reduces (functional._sync_stats) belong to the step's exchanges too
+        self.comm["collectives"] += F_hip._SYNC_BN.get("collectives", 0)
+        self.comm["payload_bytes"] += F_hip._SYNC_BN.get("payload_bytes", 0)
         tot = rec_loss + loss_g + (sup_loss if supervise else 0.0)
         return {"d_loss": d_losses[0], "gp": d_losses[1], "rec_loss": rec_loss, "loss_g": loss_g,
                 "sup_loss": sup_loss, "tot_loss": tot, "preds": preds, "out_labels": logits, "sup_fvs": sup_fv}

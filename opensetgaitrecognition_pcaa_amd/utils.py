@@ -68,8 +68,5 @@ def openness(n_train_classes, n_test_classes):
 def CG_kl_divergence(mu, logvar, mu_k):
     """KL( N(mu, exp(logvar)) || N(mu_k, I) ) averaged over the batch (reference utils.py:72-85, equation (6) of
     "Conditional Gaussian Distribution Learning for Open Set Recognition"): [B,32] device tensors -> scalar."""
-    if mu.is_cuda:
-        from . import functional as F_hip
-        return F_hip.cg_kl_divergence(mu, logvar, mu_k)        # pcaa_orced_kl (forward + its three gradients)
-    batch_kl_div = -0.5 * torch.sum(1 + logvar - (mu - mu_k) ** 2 - torch.exp(logvar), axis=1)
-    return torch.mean(batch_kl_div)
+    from . import functional as F_hip
+    return F_hip.cg_kl_divergence(mu, logvar, mu_k)        # pcaa_orced_kl (forward + its three gradients); raises on CPU tensors

@@ -203,3 +203,49 @@ def test_first_layer_coefficients_from_moments(C):
     y = xd @ W.double().t()
     assert torch.allclose(mean.double(), y.mean(0), rtol=1e-5, atol=1e-6)
     assert torch.allclose(rstd.double(), 1.0 / torch.sqrt(y.var(0, unbiased=False) + bn_a.eps), rtol=1e-5)
+
+
+@pytest.mark.parametrize("C", [4, 5])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_first_layer_with_offcentre_features(C, dtype):
+    """Round-3 advisor finding: features whose mean is far larger than their deviation (range in metres, power in dB).
+    The moment form of the statistics (var = w^T (x^T x / P) w - (w.m)^2) and the one-pass weight gradient
+    (dW = c0 G + c1 W.x^T x + c2 sum x) both cancel leading digits there.  Round 4: the moments are accumulated in fp64
+    from exact products and G against the points centred on their mean; both must match an fp64 evaluation as well as
+    the two-pass kernels do on the same inputs."""
+    P, cout = 64 * 30 * 64, 512
+    g = torch.Generator(device=DEV).manual_seed(11)
+    offs = torch.tensor([40.0, -25.0, 3.0, 0.5, 900.0][:C], device=DEV)          # mean / deviation up to 3 000
+    devs = torch.tensor([0.3, 0.2, 0.5, 1.0, 0.3][:C], device=DEV)
+    x = torch.randn(P, C, device=DEV, generator=g) * devs + offs
+    W = torch.randn(cout, C, device=DEV, generator=g) * 0.5
+    bias = torch.randn(cout, device=DEV, generator=g) * 0.1
+    bn = _bn(cout, 5)
+    xd, Wd = x.double(), W.double()
+    y = xd @ Wd.t()
+    # forward coefficients from the moments against fp64
+    scale, shift, mean, rstd, mom = ops.pointnet_in_moment_coeffs(x, W, bias, bn, update_running=False)
+    var_ref = y.var(0, unbiased=False)
+    rstd_ref = 1.0 / torch.sqrt(var_ref + bn.eps)
+    e_mean = ((mean.double() - y.mean(0)).abs() / (y.std(0) + 1e-12)).max().item()     # (`mean` is that of the bias-free y)
+    e_rstd = ((rstd.double() - rstd_ref).abs() / rstd_ref).max().item()
+    print(f"C={C}: moment-form mean error {e_mean:.2e} of a deviation, rstd rel {e_rstd:.2e}")
+    assert e_mean <= 2e-3 and e_rstd <= 1e-5        # (fp32 storage of `mean` itself: ~6e-8 |mean| / deviation)
+    da = (torch.randn(P, cout, device=DEV, generator=g) * 0.1).to(dtype)
+    tail = ops.BnTailBwd(P, bn, mean, rstd, cout)
+    dW1 = ops.pointnet_in_bwd_onepass(da, x, W, scale, shift, mean, rstd, tail, mom=mom)
+    coef, dg, db = tail.out
+    # fp64 evaluation of the layer's backward from the same da, with the fp64 statistics
+    z = (y - y.mean(0)) * rstd_ref * bn.weight.double() + bn.bias.double()
+    dz = da.double() * torch.where(z > 0, torch.ones_like(z), torch.exp(z))
+    yhat = (y - y.mean(0)) * rstd_ref
+    dy = bn.weight.double() * rstd_ref * (dz - dz.mean(0) - yhat * (dz * yhat).mean(0))
+    ref = dy.t() @ xd
+    e1 = (dW1.double() - ref).norm().item() / ref.norm().item()
+    # the two-pass form on the same inputs (dy rounded per element, contracted with the raw points)
+    st = ops.pointnet_in_bwd_stats(da, x, W, scale, shift, mean, rstd)
+    coef2, _, _ = ops.bn_bwd_finalize(st, P, bn, mean, rstd, cout)
+    dW2 = ops.pointnet_in_bwd_wgrad(da, x, W, scale, shift, coef2)
+    e2 = (dW2.double() - ref).norm().item() / ref.norm().item()
+    print(f"C={C} {dtype}: off-centre one-pass rel-l2 {e1:.2e}, two-pass {e2:.2e}")
+    assert e1 <= 2e-3, e1

@@ -447,3 +447,16 @@ def test_bench_multi_rank_branch_runs_on_two_gloo_ranks():
     assert d["config"]["dp"]["collectives_per_step"] >= 7 and d["config"]["dp"]["grad_compress"] == "bf16"
     assert len(d["config"]["windows_ms_per_step"]) == 2 and d["value"] > 0
     assert "sweep" not in d and "cpu_baseline" not in d          # single-GPU legs stay out of the N>1 line
+    # round 4: the one N>1 invocation times every exchange scheme, each with its exposed communication time
+    legs = d["dp_legs"]["legs"]
+    kinds = {(l["dp_mode"], l["grad_buckets"], l["sync_bn"]) for l in legs}
+    assert kinds == {("allreduce", "bf16", False), ("allreduce", "fp32", False), ("zero", "bf16", False),
+                     ("zero", "fp32", False), ("allreduce", "bf16", True)}
+    assert sum(l["is_default"] for l in legs) == 1
+    for l in legs:
+        assert l["ms_per_step"] > 0 and l["exposed_comm_us"] is not None and l["exposed_comm_us"] >= 0, l
+        assert l["collectives_per_step"] >= 7, l
+    by = {(l["dp_mode"], l["grad_buckets"], l["sync_bn"]): l for l in legs}
+    assert by[("allreduce", "bf16", False)]["payload_bytes_per_step"] < 0.6 * by[("allreduce", "fp32", False)]["payload_bytes_per_step"]
+    assert by[("zero", "bf16", False)]["payload_bytes_per_step"] < 0.8 * by[("zero", "fp32", False)]["payload_bytes_per_step"]
+    assert by[("allreduce", "bf16", True)]["collectives_per_step"] > by[("allreduce", "bf16", False)]["collectives_per_step"]

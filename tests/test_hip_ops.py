@@ -842,38 +842,6 @@ def test_split_image_producers():
     assert (a1i.float() - a1).abs().max().item() <= 1e-6 * a1.abs().max().item()
 
 
-def test_gemm_slabs_part_on_masked_streams():
-    """A weight-gradient product cut in two launches on two CU-masked streams (pcaa_stream_create_masked: the lab hook
-    of tools/overlap_lab.py) and summed by pcaa_splitk_reduce equals the fp64 product of the same bf16 operands."""
-    M, N, K = 512, 256, 4096
-    a = _rand((K, M), 1).bfloat16().to(DEV)
-    b = _rand((K, N), 2).bfloat16().to(DEV)
-    ref = a.double().cpu().t() @ b.double().cpu()
-    lo, hi = ops.masked_stream(64), ops.masked_stream(192, first_cu=64)
-    assert ops.masked_stream(64) is lo                       # one stream per (device, range)
-    slabs = torch.empty(16 * M * N, device=DEV)
-    out = torch.empty(M, N, device=DEV)
-    main = torch.cuda.current_stream()
-    ev = torch.cuda.Event()
-    ev.record(main)
-    k0 = 1024
-    with torch.cuda.stream(lo):
-        lo.wait_event(ev)
-        na = ops.gemm_slabs_part(a[:k0], b[:k0], M, N, k0, 4, slabs)
-    with torch.cuda.stream(hi):
-        hi.wait_event(ev)
-        nb = ops.gemm_slabs_part(a[k0:], b[k0:], M, N, K - k0, 8, slabs[na * M * N:])
-    main.wait_stream(lo)
-    main.wait_stream(hi)
-    ops.splitk_reduce(slabs, na + nb, M, N, out)
-    torch.cuda.synchronize()
-    assert (na, nb) == (4, 8)
-    err = (out.double().cpu() - ref).abs().max().item()
-    assert err <= 1e-4 * ref.abs().max().item(), err          # fp32 accumulation of exact bf16 products
-    with pytest.raises(RuntimeError):
-        ops.masked_stream(12)                                 # not a multiple of 8
-
-
 def test_gemm_dgrad_bn_split3_vs_separate_chain():
     """the fused dgrad of the fp16x3 mode (split operands, fp32 y / dz, statistics in the epilogue) against the separate
     chain gemm_split3 -> bn_act_bwd_dz on the same operands, and bn_bwd_dy_split against bn_bwd_dy_fused_split"""
@@ -902,3 +870,48 @@ def test_gemm_dgrad_bn_split3_vs_separate_chain():
     a = ops.bn_bwd_dy_split(dz, y, coef).float()
     b = (coef[0] * dz + coef[1] * y + coef[2])
     assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()
+
+
+def test_split_image_range_guard_saturates_and_flags():
+    """Round-3 advisor finding: the fp16x3 mode's [hi | lo] images hold |scale * v| <= 65504 only.  A value beyond that
+    is saturated (finite image: no inf - inf = NaN in the product) and the device flag is raised; ops.range_check()
+    -- called by PCAATrainer.check() -- then raises.  In-range tensors leave the flag alone."""
+    ops.range_check()                                        # clear anything an earlier test left
+    y = torch.randn(256, 64, device=DEV) * 0.1
+    scale, shift = torch.ones(64, device=DEV), torch.zeros(64, device=DEV)
+    a = ops.bn_act_fwd_split(y, scale, shift)
+    torch.cuda.synchronize()
+    ops.range_check()                                        # in range: no complaint
+    # a gradient spike: |dy| * 2^16 > 65504  <=>  |dy| >= ~1.0
+    dz = torch.randn(256, 64, device=DEV) * 1e-3
+    dz[17, 5] = 3.0
+    coef = torch.stack([torch.ones(64), torch.zeros(64), torch.zeros(64)]).to(DEV).contiguous()
+    dy = ops.bn_bwd_dy_split(dz, y, coef)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dy.img.float()).all()
+    assert abs(dy.float()[17, 5].item() - 65504.0 / ops.SPLIT_SCALE_GRAD) < 1e-6      # saturated, not inf
+    ok = torch.ones_like(dz, dtype=torch.bool); ok[17, 5] = False
+    assert torch.allclose(dy.float()[ok], dz[ok], rtol=2e-6, atol=1e-12)
+    with pytest.raises(FloatingPointError):
+        ops.range_check()
+    ops.range_check()                                        # the check reset the flag
+    # an activation beyond fp16's range (ELU is unbounded above), a weight beyond 65504 / 2^8, and a NaN
+    big = torch.full((256, 64), 7.0e4, device=DEV)
+    a = ops.bn_act_fwd_split(big, scale, shift)
+    assert torch.isfinite(a.img.float()).all()
+    with pytest.raises(FloatingPointError):
+        ops.range_check()
+    w = torch.randn(64, 64, device=DEV); w[3, 3] = 300.0
+    ops.split_f16(w)
+    with pytest.raises(FloatingPointError):
+        ops.range_check()
+    y2 = y.clone(); y2[0, 0] = float("nan")
+    ops.bn_act_fwd_split(y2, scale, shift)
+    with pytest.raises(FloatingPointError):
+        ops.range_check()
+    # the first layer's producer
+    x = torch.randn(512, 4, device=DEV) * 1e3
+    Wp = torch.randn(512, 4, device=DEV) * 100.0
+    ops.pointnet_in_apply(x, Wp, torch.ones(512, device=DEV), torch.zeros(512, device=DEV), ops.SplitImage.dtype)
+    with pytest.raises(FloatingPointError):
+        ops.range_check()

@@ -17,8 +17,19 @@ G, META = load_golden("orced")
 T = constants.NSTEPS
 
 
-def test_kl_divergence_vs_reference():
-    got = CG_kl_divergence(torch.from_numpy(G["kl.mu"]), torch.from_numpy(G["kl.logvar"]), torch.from_numpy(G["kl.mu_k"]))
+def test_kl_divergence_oracle_vs_reference():
+    from oracle import pcaa_oracle as O
+    got = O.cg_kl_divergence(torch.from_numpy(G["kl.mu"]), torch.from_numpy(G["kl.logvar"]), torch.from_numpy(G["kl.mu_k"]))
+    assert abs(got.item() - float(G["kl.value"])) <= 1e-6 * abs(float(G["kl.value"]))
+    with pytest.raises(RuntimeError):          # the product has no CPU path (round 4: the torch branch is gone)
+        CG_kl_divergence(torch.from_numpy(G["kl.mu"]), torch.from_numpy(G["kl.logvar"]), torch.from_numpy(G["kl.mu_k"]))
+
+
+@pytest.mark.gpu
+def test_kl_divergence_hip_vs_reference():
+    dev = "cuda:0"
+    got = CG_kl_divergence(torch.from_numpy(G["kl.mu"]).to(dev), torch.from_numpy(G["kl.logvar"]).to(dev),
+                           torch.from_numpy(G["kl.mu_k"]).to(dev))
     assert abs(got.item() - float(G["kl.value"])) <= 1e-6 * abs(float(G["kl.value"]))
 
 

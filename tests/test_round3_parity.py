@@ -33,56 +33,73 @@ def _cfg(B, N, K):
     return cfg
 
 
-def _trainer(N, precision):
+def _trainer(N, precision, B=B_BENCH):
     constants.NFEATURES = C_BENCH
-    tr = PCAATrainer(_cfg(B_BENCH, N, K_BENCH), precision=precision, fused_decoder_update=False)
+    tr = PCAATrainer(_cfg(B, N, K_BENCH), precision=precision, fused_decoder_update=False)
     mods = (tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head, tr.discriminator_projection_head)
     for mod, seed in zip(mods, SEEDS):
         syn.deterministic_fill_(mod, seed)
     return tr, mods
 
 
-def _inputs(N):
-    return (syn.synthetic_pcs(B_BENCH, T, N, C_BENCH, seed=1234), syn.synthetic_labels(B_BENCH, K_BENCH, seed=1235),
-            syn.synthetic_z0(B_BENCH, 32, seed=1236), syn.synthetic_alphas(B_BENCH, seed=1237))
+def _inputs(N, B=B_BENCH):
+    return (syn.synthetic_pcs(B, T, N, C_BENCH, seed=1234), syn.synthetic_labels(B, K_BENCH, seed=1235),
+            syn.synthetic_z0(B, 32, seed=1236), syn.synthetic_alphas(B, seed=1237))
 
 
 _ORACLE_CACHE = {}
 
 
-def _oracle_step(N):
+def _oracle_step(N, B=B_BENCH):
     """One oracle V4 step at B=64 (N=64: ~10 s, N=256: ~1 min of host CPU and ~35 GB of host memory), shared by the
     fp32 and bf16 tests of that N; only what the tests compare is kept."""
-    if N in _ORACLE_CACHE:
-        return _ORACLE_CACHE[N]
+    if (N, B) in _ORACLE_CACHE:
+        return _ORACLE_CACHE[(N, B)]
     _ORACLE_CACHE.clear()                                  # one shape resident at a time
     saved = constants.NFEATURES
-    tr, mods = _trainer(N, "fp32")
+    tr, mods = _trainer(N, "fp32", B)
     constants.NFEATURES = saved
     means = O.sample_distant_points(32, K_BENCH, 10, 10).float()
     st = O.V4State(*({k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for m in mods),
                    means, C_BENCH, T, N, K_BENCH)
     del tr
     torch.cuda.empty_cache()
-    pcs, gt, z0, al = _inputs(N)
-    ref = O.v4_train_step(st, pcs.permute(0, 3, 1, 2), gt, z0, al, _cfg(B_BENCH, N, K_BENCH))
+    pcs, gt, z0, al = _inputs(N, B)
+    ref = O.v4_train_step(st, pcs.permute(0, 3, 1, 2), gt, z0, al, _cfg(B, N, K_BENCH))
     keep = {k: ref[k] for k in LOSS_KEYS + ("preds", "sup_fvs", "out_labels")}
     # encoder / head gradients in full, the decoder's as (l2, 64 strided samples): dense5 alone is 1.9 GB at N=256
     keep["g_small"] = {k: v for k, v in ref["g_grads"].items() if v is not None and not k.startswith("G.")}
     keep["g_dec"] = {k: syn.checksum(v, 64) for k, v in ref["g_grads"].items() if v is not None and k.startswith("G.")}
     keep["d_grads"] = ref["d_grads"]
     del ref, st
-    _ORACLE_CACHE[N] = (keep, means)
+    _ORACLE_CACHE[(N, B)] = (keep, means)
     return keep, means
 
 
-def _hip_step(N, precision, means):
-    tr, _ = _trainer(N, precision)
+def _hip_step(N, precision, means, B=B_BENCH, graphed=False):
+    """One HIP step from the filled state.  ``graphed``: through PCAATrainer.step_graphed -- the captured hipGraph,
+    replayed -- which is the path bench.py's sweep leg TIMES at N=32 (``prefers_graph``).  A throw-away trainer runs
+    one eager step first (the library's one-time initialisation must not fall into a capture), then the trainer under
+    test captures on its very first call (warmup=0): the replay IS its first step, from the oracle's state."""
+    pcs, gt, z0, al = _inputs(N, B)
+    args = (pcs.to(DEV).permute(0, 3, 1, 2), gt.to(DEV), z0.to(DEV), al.to(DEV))
+    if graphed:
+        warm, _ = _trainer(N, precision, B)
+        warm.set_prior_means(means)
+        warm.finalize()
+        warm.train()
+        warm.step(*args)
+        torch.cuda.synchronize()
+        del warm
+    tr, _ = _trainer(N, precision, B)
     tr.set_prior_means(means)
     tr.finalize()
     tr.train()
-    pcs, gt, z0, al = _inputs(N)
-    out = tr.step(pcs.to(DEV).permute(0, 3, 1, 2), gt.to(DEV), z0.to(DEV), al.to(DEV))
+    if graphed:
+        out = tr.step_graphed(*args, warmup=0)
+        assert len(tr._graphs) == 1 and next(iter(tr._graphs.values()))["graph"] is not None, "the step was not captured"
+    else:
+        out = tr.step(*args)
     torch.cuda.synchronize()
     return tr, out
 
@@ -92,6 +109,11 @@ def _hip_step(N, precision, means):
 def test_sweep_shape_fp32_step_vs_oracle_at_bench_batch(N):
     ref, means = _oracle_step(N)
     tr, out = _hip_step(N, "fp32", means)
+    _check_parity_grade(tr, out, ref, f"config[3] N={N} B=64 fp32")
+
+
+def _check_parity_grade(tr, out, ref, what):
+    """the fp32-grade gates: losses / embeddings / logits 1e-4, labels bit-exact, gradients 5e-4 relative l2"""
     for k in LOSS_KEYS:
         assert abs(out[k].item() - ref[k].item()) <= 1e-4 * abs(ref[k].item()) + 1e-5, (k, out[k].item(), ref[k].item())
     # argmax labels bit-exact; a sample whose fp32 top-2 margin is below the 1e-4 tolerance is flagged, not waved through
@@ -101,7 +123,7 @@ def test_sweep_shape_fp32_step_vs_oracle_at_bench_batch(N):
     same = out["preds"].cpu() == ref["preds"]
     assert bool(same[~tied].all()), "argmax labels must be bit-exact"
     if bool(tied.any()):
-        print(f"N={N}: {int(tied.sum())} samples with a top-2 logit margin below 1e-4 of scale; "
+        print(f"{what}: {int(tied.sum())} samples with a top-2 logit margin below 1e-4 of scale; "
               f"{int((~same & tied).sum())} of them differ")
     scale = ref["sup_fvs"].abs().max().item()
     assert (out["sup_fvs"].cpu() - ref["sup_fvs"]).abs().max().item() <= 1e-4 * scale
@@ -130,7 +152,7 @@ def test_sweep_shape_fp32_step_vs_oracle_at_bench_batch(N):
             continue
         rel = float((mine.double() - gref.double()).norm() / (gref.double().norm() + 1e-30))
         assert rel <= 5e-4, (name, rel)
-    print(f"config[3] N={N} B=64 fp32 vs oracle: worst encoder gradient rel-l2 {worst[1]:.2e} ({worst[0]})")
+    print(f"{what} vs oracle: worst encoder gradient rel-l2 {worst[1]:.2e} ({worst[0]})")
 
 
 @pytest.mark.timeout(1500)
@@ -140,6 +162,10 @@ def test_sweep_shape_bf16_step_vs_oracle_at_bench_batch(N):
     gradients 5e-2 relative l2, argmax agreement reported and gated at 0.9."""
     ref, means = _oracle_step(N)
     tr, out = _hip_step(N, "bf16", means)
+    _check_bf16_grade(tr, out, ref, f"config[3] N={N} B=64 bf16")
+
+
+def _check_bf16_grade(tr, out, ref, what):
     for k in LOSS_KEYS:
         assert np.isfinite(out[k].item())
         assert abs(out[k].item() - ref[k].item()) <= 2e-2 * abs(ref[k].item()) + 2e-2, (k, out[k].item(), ref[k].item())
@@ -157,10 +183,33 @@ def test_sweep_shape_bf16_step_vs_oracle_at_bench_batch(N):
         if name.endswith("weight"):
             l2 = syn.checksum(tr.flat_g.grad_views[name], 64)["l2"]
             assert abs(l2 - cs["l2"]) <= 5e-2 * cs["l2"], (name, l2, cs["l2"])
-    print(f"config[3] N={N} B=64 bf16 vs oracle: argmax agreement {agree:.4f}, sup_fv err {err / scale:.2e} of scale, "
+    print(f"{what} vs oracle: argmax agreement {agree:.4f}, sup_fv err {err / scale:.2e} of scale, "
           f"worst weight-gradient rel-l2 {max(rels.values()):.2e} ({max(rels, key=rels.get)})")
     assert agree >= 0.9
     assert max(rels.values()) <= 5e-2, rels
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_sweep_shape_n32_graphed_step_vs_oracle_at_bench_batch(precision):
+    """bench.py's sweep point N=32 is timed through hipGraph replay at B=64; this is that path
+    (capture + replay of the 4-stream step) at that shape against the ORACLE, fp32 at the parity gates and bf16 -- the
+    mode the sweep leg runs -- at the bf16 gates."""
+    ref, means = _oracle_step(32)
+    tr, out = _hip_step(32, precision, means, graphed=True)
+    (_check_parity_grade if precision == "fp32" else _check_bf16_grade)(tr, out, ref, f"config[3] N=32 B=64 {precision} hipGraph replay")
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3", "bf16"])
+def test_reference_default_shape_step_vs_oracle(precision):
+    """the reference's own operating point -- constants.py:29,55: BATCH_SIZE = 16, NMAX = 150,
+    4 features (what train_variant4(CONFIG) runs and bench.py's ``ref_default`` leg times) -- one step against the
+    oracle: the parity-grade modes at the fp32 gates, bf16 at the bf16 gates.  N = 150 is the shape whose decoder
+    widths (1125 ... 18000) are stored zero-padded to multiples of 64 inside the flat buffers."""
+    ref, means = _oracle_step(150, 16)
+    tr, out = _hip_step(150, precision, means, B=16)
+    (_check_bf16_grade if precision == "bf16" else _check_parity_grade)(tr, out, ref, f"reference default B=16 N=150 {precision}")
 
 
 def _oracle_eval(enc, x_cpu):

@@ -10,6 +10,26 @@ from opensetgaitrecognition_pcaa_amd.ops import RC, PCAA_BF16
 
 P, dev = 245760, "cuda"
 
+# CU-masked streams are a lab hook (tools/microbench/streams_lab.hip), not part of the product ABI
+import ctypes, subprocess
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LAB = os.path.join(_HERE, "microbench", "libstreams_lab.so")
+if not os.path.exists(_LAB):
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-o", _LAB,
+                           os.path.join(_HERE, "microbench", "streams_lab.hip")])
+_lab = ctypes.CDLL(_LAB)
+_MASKED = {}
+
+
+def masked_stream(n_cus, first_cu=0):
+    key = (int(first_cu), int(n_cus))
+    if key not in _MASKED:
+        h = ctypes.c_void_p()
+        if _lab.lab_stream_create_masked(int(first_cu), int(n_cus), ctypes.byref(h)) != 0:
+            raise RuntimeError("lab_stream_create_masked failed")
+        _MASKED[key] = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", torch.cuda.current_device()))
+    return _MASKED[key]
+
 
 def timed(fn, reps=12):
     for _ in range(3):
@@ -68,8 +88,8 @@ def case(cout, cin, ew_ch):
             ops.splitk_reduce(slabs, na + nb, cout, cin, out)
         print(f"    product cut 1/4 + 3/4, first part on the {name}: {timed(cut):.3f} ms")
     for ncu in (96, 128, 160, 192):
-        W = ops.masked_stream(ncu)
-        E = ops.masked_stream(256 - ncu, first_cu=ncu)
+        W = masked_stream(ncu)
+        E = masked_stream(256 - ncu, first_cu=ncu)
         sk_a = max(8, ncu // ntiles // 8 * 8)
         if sk_a * ntiles > ncu:
             continue
