@@ -82,3 +82,25 @@ def check_against_record(g, prefix, name, value, tol, scale_floor=0.0):
 # (BN removes the mean), the reference's value is rounding noise.
 def is_pre_bn_bias(name):
     return name.endswith("module.0.bias") or name.endswith("conv1d.bias")
+
+
+def ring_allreduce_bf16(grads):
+    """What a ring all-reduce of bf16 gradient buckets computes, element for element: every rank rounds its fp32
+    bucket to bf16 once; the buffer is cut into W chunks and chunk c is accumulated hop by hop along the ring,
+    starting at rank (c + 1) % W -- each hop adds the local bf16 value to the incoming partial sum in fp32 and rounds
+    the result to bf16 for the next hop (RCCL's bf16 sum) -- W - 1 roundings of the partial sum in a fixed, per-chunk
+    order; the all-gather phase then copies the finished chunk.  ``grads``: list of W equally sized fp32 tensors
+    (one per rank).  Returns the reduced tensor as fp32 (every rank ends with the same bits)."""
+    W = len(grads)
+    flat = [g.reshape(-1) for g in grads]
+    n = flat[0].numel()
+    out = torch.empty(n, dtype=torch.float32, device=flat[0].device)
+    bounds = [n * c // W for c in range(W + 1)]
+    for c in range(W):
+        lo, hi = bounds[c], bounds[c + 1]
+        order = [(c + 1 + i) % W for i in range(W)]
+        acc = flat[order[0]][lo:hi].bfloat16()
+        for r in order[1:]:
+            acc = (acc.float() + flat[r][lo:hi].bfloat16().float()).bfloat16()
+        out[lo:hi] = acc.float()
+    return out.view_as(grads[0])

@@ -74,3 +74,47 @@ def test_two_rank_gloo_sharding_syncbn_and_gradient_allreduce():
         assert p.exitcode == 0
     for rank, out in results:
         assert all(out.values()), (rank, out)
+
+
+def test_eight_rank_bf16_ring_sum_of_real_decoder_gradients_is_within_the_bf16_gate():
+    """bench.py's data-parallel default sends the decoder's gradient buckets as bf16 and lets the
+    collective accumulate in bf16; that was validated on 2 ranks only, while an 8-rank ring rounds the partial sum 7
+    times.  Here: 8 "ranks" each run one oracle V4 step (same state, different batch) and their REAL decoder / head
+    gradients are summed (a) in fp32 and (b) the way the bf16 ring does (helpers.ring_allreduce_bf16: per-chunk hop
+    order, one rounding per hop).  Gate: the bf16 throughput mode's own weight-gradient tolerance (5e-2 relative l2,
+    tests/test_round2_parity.py) with a wide margin -- the ring must stay below 1e-2 -- and no element off by more than
+    2 % of the tensor's largest.  The config[1]-sized version of this test runs on the GPU
+    (tests/test_distributed_gpu.py::test_eight_rank_bf16_ring_sum_at_config1)."""
+    import torch
+    from helpers import T, make_decoder, make_disc, make_encoder, make_head, ring_allreduce_bf16, sd_clone
+    from opensetgaitrecognition_pcaa_amd import synthetic as syn
+    from oracle import pcaa_oracle as O
+    W, B, N, C, K = 8, 2, 32, 4, 4
+    mods = (make_encoder(K, N, C, True, 0), make_decoder(64, N, C, 1), make_disc(K, 2), make_head(32, 64, 3), make_head(64, 32, 4))
+    means = O.sample_distant_points(32, K, 10, 10).float()
+    cfg = dict(LR=1e-4, B1=0.9, B2=0.99, GP_WEIGHT=15, ADV_WEIGHT=1)
+    per_rank = []
+    for r in range(W):
+        st = O.V4State(*(sd_clone(m) for m in mods), means, C, T, N, K)
+        ref = O.v4_train_step(st, syn.synthetic_pcs(B, T, N, C, seed=100 + r).permute(0, 3, 1, 2),
+                              syn.synthetic_labels(B, K, seed=200 + r), syn.synthetic_z0(B, 32, seed=300 + r),
+                              syn.synthetic_alphas(B, seed=400 + r), cfg)
+        per_rank.append({k: v.detach().clone() for k, v in ref["g_grads"].items() if k.startswith("G.") and v is not None})
+    worst = ("", 0.0, 0.0)
+    for name in per_rank[0]:
+        gs = [p[name] for p in per_rank]
+        exact = torch.stack([g.double() for g in gs]).sum(0)
+        ring = ring_allreduce_bf16(gs).double()
+        rel = float((ring - exact).norm() / exact.norm())
+        mx = float((ring - exact).abs().max() / exact.abs().max())
+        if rel > worst[1]:
+            worst = (name, rel, mx)
+        assert rel <= 1e-2, (name, rel)
+        assert mx <= 2e-2, (name, mx)
+        # the fp32 buckets' own order dependence, for scale: any fp32 summation order agrees to ~1e-7
+        f32 = gs[0].clone()
+        for g in gs[1:]:
+            f32 += g
+        assert float((f32.double() - exact).norm() / exact.norm()) <= 1e-6
+    print(f"8-rank bf16 ring sum of decoder gradients: worst rel-l2 {worst[1]:.2e}, max elementwise {worst[2]:.2e} of the "
+          f"tensor's largest ({worst[0]})")

@@ -460,3 +460,62 @@ def test_bench_multi_rank_branch_runs_on_two_gloo_ranks():
     assert by[("allreduce", "bf16", False)]["payload_bytes_per_step"] < 0.6 * by[("allreduce", "fp32", False)]["payload_bytes_per_step"]
     assert by[("zero", "bf16", False)]["payload_bytes_per_step"] < 0.8 * by[("zero", "fp32", False)]["payload_bytes_per_step"]
     assert by[("allreduce", "bf16", True)]["collectives_per_step"] > by[("allreduce", "bf16", False)]["collectives_per_step"]
+
+
+@pytest.mark.timeout(900)
+def test_eight_rank_bf16_ring_sum_at_config1():
+    """The 8-GPU run's bf16 gradient buckets at BASELINE config[1]'s size: eight "ranks" = eight
+    different B=64 batches through the bf16-mode HIP step from the SAME state (LR = 0: Adam leaves the parameters where
+    they are), the decoder's 157 M real gradients of each kept; per all-reduce bucket (one per decoder layer, as
+    train.PCAATrainer issues them) the bf16 ring sum -- per-chunk hop order, one rounding per hop,
+    helpers.ring_allreduce_bf16 -- against the fp64 sum of the fp32 gradients.  Gate: 1e-2 relative l2 (the bf16 mode's
+    weight-gradient tolerance is 5e-2) and 2 % of the bucket's largest element; the measured figures are printed and
+    recorded in DESIGN.md section 6 -- they decide whether bf16 buckets stay the default at N >= 4."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import T, ring_allreduce_bf16
+    from opensetgaitrecognition_pcaa_amd import constants, synthetic as syn
+    from opensetgaitrecognition_pcaa_amd.train import PCAATrainer
+    from oracle import pcaa_oracle as O
+    DEV = "cuda:0"
+    W, B, N, C, K = 8, 64, 128, 4, 8
+    constants.NFEATURES = C
+    cfg = dict(constants.CONFIG)
+    cfg.update(NMAX=N, TRAIN_CLASSES=list(range(K)), BATCH_SIZE=B, LR=0.0)
+    tr = PCAATrainer(cfg, precision="bf16", fused_decoder_update=False)
+    for i, m in enumerate((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head,
+                           tr.discriminator_projection_head)):
+        syn.deterministic_fill_(m, i)
+    tr.set_prior_means(O.sample_distant_points(32, K, 10, 10).float())
+    tr.finalize()
+    tr.train()
+    p0 = tr.flat_g.p.clone()
+    fg = tr.flat_g
+    grads = []
+    for r in range(W):
+        tr.step(syn.synthetic_pcs(B, T, N, C, seed=1234 + r).to(DEV).permute(0, 3, 1, 2),
+                syn.synthetic_labels(B, K, seed=1235 + r).to(DEV), syn.synthetic_z0(B, 32, seed=1236 + r).to(DEV),
+                syn.synthetic_alphas(B, seed=1237 + r).to(DEV))
+        torch.cuda.synchronize()
+        grads.append(fg.g[tr._dec_start:].clone())
+    assert torch.equal(tr.flat_g.p, p0), "LR = 0 must leave the replica's parameters untouched"
+    report = []
+    for layer in range(2, 6):
+        lo = fg.offsets[fg.names.index(f"G.dense{layer}.weight")] - tr._dec_start
+        nxt = f"G.dense{layer + 1}.weight"
+        hi = (fg.offsets[fg.names.index(nxt)] if nxt in fg.names else fg.total) - tr._dec_start
+        gs = [g[lo:hi] for g in grads]
+        exact = torch.zeros(hi - lo, dtype=torch.float64, device=DEV)
+        for g in gs:
+            exact += g.double()
+        ring = ring_allreduce_bf16(gs).double()
+        rel = float((ring - exact).norm() / exact.norm())
+        mx = float((ring - exact).abs().max() / exact.abs().max())
+        # one rank's own bf16 rounding, for scale (what a 1-rank "sum" already costs)
+        one = float((gs[0].bfloat16().double() - gs[0].double()).norm() / gs[0].double().norm())
+        report.append((layer, hi - lo, rel, mx, one))
+        assert rel <= 1e-2, (layer, rel)
+        assert mx <= 2e-2, (layer, mx)
+        del exact, ring
+    for layer, n, rel, mx, one in report:
+        print(f"8-rank bf16 ring sum, decoder layer {layer} bucket ({n / 1e6:.1f} M elements): rel-l2 {rel:.2e}, max "
+              f"elementwise {mx:.2e} of the largest; a single rank's bf16 rounding alone {one:.2e}")

@@ -1,0 +1,299 @@
+// LAB: the 256x256x64 bf16 tile loop restructured after hipBLASLt's hand-written gfx950 kernel
+// (Custom_Cijk_Alik_Bljk_BBS_BH_..._MT256x256x64_MI16x16x1; disassembled in round 4):
+//   * FOUR waves (2 x 2), one per SIMD, 128 x 128 accumulators each (256 accumulator registers): every fragment read
+//     from the LDS feeds 8 MFMAs (the product kernel's 128 x 64 wave tiles: 4 or 8) -- 128 KB of fragment reads per
+//     K step instead of 192 KB;
+//   * the fragments of the NEXT k-half are read into a second register set while the MFMAs of the current one run,
+//     so an LDS stage is dead as soon as its second half has been read -- its refill for K step t + 2 is issued in
+//     the MIDDLE of step t (a barrier per operand releases the region).  Two LDS stages (128 KB) then carry a
+//     prefetch distance of TWO steps for BOTH operands: a piece has a whole step (>= 1.2 us) to land, up to
+//     ~116 KB in flight per CU (the product ring: A two steps ahead, B one; <= 96 KB);
+//   * the load stream does not stop at tile boundaries: steps t + 1, t + 2 of the last steps of a tile are the next
+//     tile's first stages (the product kernel requests them in a burst before its epilogue);
+//   * a third barrier per step (counted vmcnt: only this step's own requests may still be in flight) publishes
+//     stage t + 1, whose first-half fragments are then read under the second half's MFMAs.
+// Output: bf16 C straight from the accumulators (B rows permuted into the LDS, as the product's 16x16x32 kernels).
+//   hipcc --offload-arch=gfx950 -O3 -o gemm_v2 gemm_v2.hip && ./gemm_v2 [check]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int OP_TILE = 256 * 64;            // elements of one operand's stage image (32 KB)
+constexpr int STAGE = 2 * OP_TILE;           // A image then B image (64 KB)
+constexpr int LDS_BYTES = 2 * STAGE * 2;     // two stages: 128 KB
+
+#ifndef SCHED
+#define SCHED 1
+#endif
+#define SB() __builtin_amdgcn_sched_barrier(0)
+// The accumulators are pinned to the ACCUMULATOR register file ("a" constraint): left to the register allocator (the
+// builtin), a wave with 256 accumulator + 128 fragment registers got accumulators in both files, ~1 200
+// v_accvgpr_* copies in the loop and 165 spilled registers.  The asm statements keep their order; hazards: an
+// accumulator is next touched 64 MFMAs later, fragments come from ds_reads (the compiler's own s_waitcnt).
+// fragment reads as asm too: a plain LDS load whose value is only consumed in the NEXT loop iteration gets sunk to the
+// loop latch (behind all the MFMAs it was meant to hide under).  The compiler then does not know these registers are
+// pending: every use is behind an explicit s_waitcnt lgkmcnt(0) placed in this file (before the two release barriers
+// and at the very end of the loop body -- ahead of any copy the back edge may need).
+__device__ __forceinline__ void lds_read(bf16x8& d, unsigned addr, int off) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(off));
+}
+__device__ __forceinline__ void mfma(f32x4& c, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 b;
+  b.x = (bf16_t)lo;
+  b.y = (bf16_t)hi;
+  return *reinterpret_cast<uint32_t*>(&b);
+}
+
+// one 1-KB piece (8 LDS rows x 128 B) of an operand's stage image: p = 0..31
+template <bool PERM>
+__device__ __forceinline__ void piece(rsrc_t r, long ld, int row0, int k0, bf16_t* s_img, int p, const unsigned (&vo)[2]) {
+  const int prow = PERM ? 64 * (p >> 3) + 32 * (p & 1) + ((p >> 1) & 3) : 8 * p;
+  const unsigned soff = (unsigned)(((long)(row0 + prow) * ld + k0) * 2);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(s_img + p * 512), 16, vo[p & 1], soff, 0, 0);
+}
+
+template <bool STORE>
+__global__ __launch_bounds__(256) void gemm_v2(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                               bf16_t* __restrict__ C, int M, int N, int K, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = N / BN, ntiles = (M / BM) * nbn, nt = K / BK;
+  rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)(unsigned)((long)M * K * 2), 0x00020000);
+  rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, (int)(unsigned)((long)N * K * 2), 0x00020000);
+  // per-lane constants are rebuilt from an opaque copy of the lane id at the top of every tile: kept live across the
+  // epilogue (which wants every VGPR for the accumulators on their way out) they were spilled, and their reload in
+  // front of the loop made the compiler put a drain-everything s_waitcnt vmcnt in the loop header
+  unsigned voA[2], voB[2];
+  int l15, q, kof0, kof1, fA, fB;
+  auto lane_consts = [&](int ln) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int g = (ln & 7) ^ ((4 * e + (ln >> 4)) & 7);
+      voA[e] = (unsigned)((ln >> 3) * (long)K * 2 + 16 * g);
+      voB[e] = (unsigned)(4 * (ln >> 3) * (long)K * 2 + 16 * g);      // PERM: the rows of a piece lie 4 apart
+    }
+    l15 = ln & 15;
+    q = ln >> 4;
+    // fragment addresses (elements): row (block * 16 + l15), k-granule (4 * half + q) ^ swizzle
+    kof0 = ((q) ^ (l15 >> 1)) * 8;
+    kof1 = ((4 + q) ^ (l15 >> 1)) * 8;
+    fA = (wm * 128 + l15) * 64;                 // + i * 1024 per row block
+    fB = OP_TILE + (wn * 128 + l15) * 64;       // + j * 1024
+  };
+  int ln = lane;
+  lane_consts(ln);
+
+  // load cursor: (tile, k step) of the next stage to request -- runs two steps ahead of the compute cursor and
+  // straight across tile boundaries
+  // past the last tile it wraps to this workgroup's first one: the loop stays branch-free (the two surplus stages per
+  // launch land in dead LDS; the kernel drains them before it ends)
+  const int gstride_l = gridDim.x;
+  int lvb = blockIdx.x, lkt = 0;
+  int ltm = lvb / nbn, ltn = lvb % nbn;
+  auto advance = [&]() {
+    if (++lkt == nt) {
+      lkt = 0;
+      lvb += gstride_l;
+      if (lvb >= ntiles) lvb = blockIdx.x;
+      ltm = lvb / nbn;
+      ltn = lvb % nbn;
+    }
+  };
+  auto reqA = [&](bf16_t* st, int jj) { piece<false>(rA, K, ltm * BM, lkt * BK, st, wave * 8 + jj, voA); };
+  auto reqB = [&](bf16_t* st, int jj) { piece<true>(rB, K, ltn * BN, lkt * BK, st + OP_TILE, wave * 8 + jj, voB); };
+
+  f32x4 acc[8][8];
+  bf16x8 af[2][8], bfr[2][8];
+
+  int vb = blockIdx.x;
+  if (vb >= ntiles) return;
+  // prologue: stages 0 and 1
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) reqB(smem, jj);
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) reqA(smem, jj);
+  advance();
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) reqB(smem + STAGE, jj);
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) reqA(smem + STAGE, jj);
+  advance();
+  asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(smem + fB + j * 1024 + kof0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(smem + fA + i * 1024 + kof0);
+
+  int s = 0;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+  const int gstride = gridDim.x;
+  for (;;) {
+    const int tm = vb / nbn, tn = vb % nbn;
+    asm volatile("" : "+v"(ln));
+    lane_consts(ln);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nt; ++kt) {
+      bf16_t* cur = smem + s * STAGE;              // stage of this step (and destination of the requests for step t + 2)
+      // LDS byte addresses of the fragment reads: second half of this stage, first half of the next
+      const unsigned cb = lds0 + (unsigned)s * (STAGE * 2), nb = lds0 + (unsigned)(s ^ 1) * (STAGE * 2);
+      const unsigned aB1 = cb + (unsigned)(fB + kof1) * 2, aA1 = cb + (unsigned)(fA + kof1) * 2;
+      const unsigned aB0 = nb + (unsigned)(fB + kof0) * 2, aA0 = nb + (unsigned)(fA + kof0) * 2;
+      // ---------------- k-half 0: MFMAs on af[0] / bfr[0]
+#pragma unroll
+      for (int m = 0; m < 64; ++m) {
+        const int i = m >> 3, j = m & 7;
+        // second-half fragments of B, then of A, from the current stage
+        if ((m & 1) == 1 && m < 16) lds_read(bfr[1][m >> 1], aB1, (m >> 1) * 2048);
+        if (m == 21) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // B image of this stage: dead
+        if (m >= 24 && m < 40 && (m & 1) == 0) lds_read(af[1][(m - 24) >> 1], aA1, ((m - 24) >> 1) * 2048);
+        if (m >= 23 && m < 39 && (m & 1) == 1) reqB(cur, (m - 23) >> 1);                  // 8 pieces of B(t + 2)
+        if (m == 46) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // A image: dead
+        if (m >= 48 && (m & 3) == 0) reqA(cur, (m - 48) >> 2);                             // pieces 0..3 of A(t + 2)
+        mfma(acc[i][j], af[0][i], bfr[0][j]);
+#if SCHED
+        SB();
+#endif
+      }
+      // ---------------- k-half 1: MFMAs on af[1] / bfr[1]
+#pragma unroll
+      for (int m = 0; m < 64; ++m) {
+        const int i = m >> 3, j = m & 7;
+        if (m < 16 && (m & 3) == 0) reqA(cur, 4 + (m >> 2));                               // pieces 4..7 of A(t + 2)
+        // stage t + 1 has landed: everything but this step's own 16 requests (loads retire in order, so "at most 16
+        // outstanding" means the older stage is complete whatever the previous tile's C stores -- which share the
+        // counter -- are doing; they can only make the wait longer)
+        if (m == 20) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+        if (m >= 22 && m < 38 && (m & 1) == 0) lds_read(bfr[0][(m - 22) >> 1], aB0, ((m - 22) >> 1) * 2048);
+        if (m >= 38 && m < 54 && (m & 1) == 0) lds_read(af[0][(m - 38) >> 1], aA0, ((m - 38) >> 1) * 2048);
+        mfma(acc[i][j], af[1][i], bfr[1][j]);
+#if SCHED
+        SB();
+#endif
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next step's first-half fragments are in their registers
+      advance();
+      s ^= 1;
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results (the asm hides the hazard from the compiler)
+    // ---------------- tile done: C leaves from the registers (block j of lane c = column 64 (j >> 2) + 4 c + (j & 3))
+    if (STORE) {
+      int le = lane;
+      asm volatile("" : "+v"(le));
+      bf16_t* c0 = C + (long)(tm * BM + wm * 128 + 4 * (le >> 4)) * N + tn * BN + wn * 128 + 4 * (le & 15);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int jg = 0; jg < 2; ++jg) {
+            uint2 o;
+            o.x = pack2(acc[i][4 * jg][r], acc[i][4 * jg + 1][r]);
+            o.y = pack2(acc[i][4 * jg + 2][r], acc[i][4 * jg + 3][r]);
+            *reinterpret_cast<uint2*>(c0 + (long)(i * 16 + r) * N + 64 * jg) = o;
+          }
+    } else {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += acc[i][j].x + acc[i][j].y + acc[i][j].z + acc[i][j].w;
+      if (t == 12345.f) sink[tid] = t;
+    }
+    vb += gstride;
+    if (vb >= ntiles) break;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the surplus stages must have landed before the LDS is released
+}
+
+template <bool STORE>
+static float run(const bf16_t* A, const bf16_t* B, bf16_t* C, float* sink, int M, int N, int K, int reps = 8) {
+  auto kern = gemm_v2<STORE>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  float best = 1e9f;
+  for (int rep = 0; rep < reps; ++rep) {
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(256), dim3(256), LDS_BYTES, 0, A, B, C, M, N, K, sink);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  const double fl = 2.0 * M * N * K, tiles = (double)(M / 256) * (N / 256) / 256;
+  printf("gemm_v2 %s [%d,%d]x[%d,%d]^T  %.3f ms  %.0f TF  %.1f us per tile\n", STORE ? "with bf16 C stores" : "K loop only     ", M, K,
+         N, K, best, fl / best / 1e9, best * 1e3 / tiles);
+  return best;
+}
+
+static float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+int main(int argc, char** argv) {
+  const bool check = argc > 1 && !strcmp(argv[1], "check");
+  const int M = check ? 1024 : 245760, NMAX = 1024, KMAX = 1024;
+  bf16_t *A, *B, *C; float* sink;
+  if (hipMalloc(&A, (size_t)M * KMAX * 2) != hipSuccess || hipMalloc(&B, (size_t)NMAX * KMAX * 2) != hipSuccess ||
+      hipMalloc(&C, (size_t)M * NMAX * 2) != hipSuccess) return 1;
+  (void)hipMalloc(&sink, 4096);
+  const size_t na = (size_t)M * KMAX, nbw = (size_t)NMAX * KMAX;
+  unsigned short* h = (unsigned short*)malloc((na + nbw) * 2);
+  unsigned long long st = 88172645463325252ULL;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+  for (size_t i = 0; i < na + nbw; ++i) {
+    const float f = (float)((rnd() >> 40) & 0xffff) / 32768.f - 1.f;
+    unsigned u; memcpy(&u, &f, 4);
+    h[i] = (unsigned short)(u >> 16);
+  }
+  (void)hipMemcpy(A, h, na * 2, hipMemcpyHostToDevice);
+  (void)hipMemcpy(B, h + na, nbw * 2, hipMemcpyHostToDevice);
+  if (check) {
+    int bad = 0;
+    for (int K : {128, 512, 1024})
+      for (int N : {256, 512}) {
+        (void)hipMemset(C, 0, (size_t)M * NMAX * 2);
+        (void)hipFuncSetAttribute((const void*)gemm_v2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipLaunchKernelGGL(gemm_v2<true>, dim3(3), dim3(256), LDS_BYTES, 0, A, B, C, M, N, K, sink);
+        (void)hipDeviceSynchronize();
+        unsigned short* hc = (unsigned short*)malloc((size_t)M * N * 2);
+        (void)hipMemcpy(hc, C, (size_t)M * N * 2, hipMemcpyDeviceToHost);
+        double worst = 0;
+        for (int t = 0; t < 4000; ++t) {
+          const int r = (int)(rnd() % M), c = (int)(rnd() % N);
+          double ref = 0;
+          for (int k = 0; k < K; ++k) ref += (double)bf2f(h[(size_t)r * K + k]) * (double)bf2f(h[na + (size_t)c * K + k]);
+          const double err = fabs(ref - (double)bf2f(hc[(size_t)r * N + c])) / (fabs(ref) + 1.0);
+          if (err > worst) worst = err;
+        }
+        printf("check K=%d N=%d: worst relative error of 4000 samples %.3e %s\n", K, N, worst, worst < 1e-2 ? "ok" : "BAD");
+        if (!(worst < 1e-2)) bad = 1;
+        free(hc);
+      }
+    printf("%s\n", hipGetErrorString(hipGetLastError()));
+    return bad;
+  }
+  for (int K : {512, 1024})
+    for (int N : {512, 1024}) {
+      run<false>(A, B, C, sink, M, N, K);
+      run<true>(A, B, C, sink, M, N, K);
+    }
+  (void)hipDeviceSynchronize();
+  printf("%s\n", hipGetErrorString(hipGetLastError()));
+  return 0;
+}
