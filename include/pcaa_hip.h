@@ -75,6 +75,12 @@ int pcaa_gemm(int math,
  * out (=|+=).  pcaa_gemm_num_splits tells how many splits pcaa_gemm / pcaa_gemm_slabs will
  * actually run for a requested split_k (K is cut into multiples of the kernel's K step). */
 int pcaa_gemm_num_splits(int math, int K, int split_k);
+/* Which tile loop serves the bf16 / split-fp16 KC x KC products without K splits (whole 256 x 256 tiles, contraction
+ * >= 320 deep): 1 (default; environment PCAA_GEMM_V2=0 to start with 0) = the 4-wave loop of round 4 (csrc/gemm_v2.h:
+ * 128 x 128 wave tiles, both operands requested two K steps ahead, the request stream continuous across tiles), 0 = the
+ * 8-wave loop of rounds 1-3.  Same operands, same epilogues, same results up to the summation order inside a
+ * 64-deep step (none: both accumulate k in the same order); kept switchable for same-process A/B (tools/gemm_lab.py). */
+int pcaa_gemm_v2_enable(int on);
 int pcaa_gemm_slabs(int math,
                     const void* A, int a_dtype, int a_layout, long lda,
                     const void* B, int b_dtype, int b_layout, long ldb,

@@ -759,6 +759,8 @@ __device__ __forceinline__ void step_barrier(bool keep_far) {
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+#include "gemm_v2.h"      // round 4: the 4-wave KC x KC tile loop (namespace v2)
+
 template <typename TC, int ALAY, int BLAY, int EPI, int MF, bool BUF, bool SPLIT = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
   typedef AccLayout<MF> L;
@@ -1079,6 +1081,34 @@ bool launch_dma_inst(const GemmParams& p, dim3 grid, hipStream_t s) {
   return true;
 }
 
+// The 4-wave tile loop (gemm_v2.h) serves every KC x KC launch without K splits whose contraction is at least five
+// 64-deep steps long (its ticket hand-off needs them); pcaa_gemm_v2_enable(0) routes them back to the 8-wave loop (A/B).
+static int g_v2_enabled = -1;
+static bool v2_enabled() {
+  if (g_v2_enabled < 0) {
+    const char* e = getenv("PCAA_GEMM_V2");
+    g_v2_enabled = (e != nullptr && e[0] == '0') ? 0 : 1;
+  }
+  return g_v2_enabled != 0;
+}
+template <typename TC, int EPI, bool SPLIT>
+bool launch_v2_inst(const GemmParams& p, dim3 grid, hipStream_t s) {
+  static bool configured = false;
+  auto kern = v2::gemm_bf16_v2_kernel<TC, EPI, SPLIT>;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            v2::LDS_BYTES) != hipSuccess)
+      return false;
+    configured = true;
+  }
+  const PcaaLaunchEvents ev = pcaa_take_launch_events();
+  if (ev.start != nullptr)
+    hipExtLaunchKernelGGL(kern, grid, dim3(v2::NT), v2::LDS_BYTES, s, ev.start, ev.stop, 0, p);
+  else
+    hipLaunchKernelGGL(kern, grid, dim3(v2::NT), v2::LDS_BYTES, s, p);
+  return true;
+}
+
 // Launches without K splits start one workgroup per CU (a multiple of 8: the XCD-aware tile order) and let them draw
 // their tiles: no dispatch gap between a CU's tiles, and the next tile's first stages are requested before the
 // epilogue (see the kernel).  The draw is dynamic (ticket counters, sched_slot): with FIXED shares a launch that does
@@ -1156,6 +1186,27 @@ bool launch_dma(const GemmParams& p_in, dim3 grid_in, hipStream_t s) {
   // (advisor, round 3) every path that does not launch hands the tail back: resolve() then runs the stand-alone finalize
   bool ok = false;
   bool decided = false;
+  if constexpr (ALAY == KC && BLAY == KC && EPI != EPI_DGRAD_BN_POINTS) {
+    const int steps = (p.seg_len > 0 ? 3 * p.seg_len : p.K) / BK;
+    constexpr bool kSplitOk = sizeof(TC) == 4 && (EPI == EPI_PLAIN || EPI == EPI_DGRAD_BN);
+    constexpr bool kPlainOk = !(EPI == EPI_DGRAD_BN && sizeof(TC) == 4);      // fp32 dz exists for the split operands only
+    if (v2_enabled() && grid.z == 1 && grid.y == 1 && !p.split_fast && !p.atomic && p.nsplit <= 1 && p.c_split_stride == 0 &&
+        steps >= 5 && (p.seg_len > 0 ? p.k_per_split == p.K : (p.k_per_split >= p.K)) && (p.ldc % 8) == 0 &&
+        ((uintptr_t)p.C % 16) == 0) {
+      if (p.seg_len > 0) {
+        if constexpr (kSplitOk) {
+          ok = launch_v2_inst<TC, EPI, true>(p, grid, s);
+          decided = true;
+        }
+      } else {
+        if constexpr (kPlainOk) {
+          ok = launch_v2_inst<TC, EPI, false>(p, grid, s);
+          decided = true;
+        }
+      }
+    }
+  }
+  if (!decided) {
   if constexpr ((EPI == EPI_PLAIN || (EPI == EPI_DGRAD_BN && ALAY == KC)) && sizeof(TC) == 4) {
     // split-fp16 operands (pcaa_gemm_split3, pcaa_gemm_dgrad_bn_split3): fp32 result only
     if (p.seg_len > 0) {
@@ -1170,6 +1221,7 @@ bool launch_dma(const GemmParams& p_in, dim3 grid_in, hipStream_t s) {
     if (p.seg_len > 0) ok = false;
     else ok = buf ? launch_dma_inst<TC, ALAY, BLAY, EPI, true>(p, grid, s)
                   : launch_dma_inst<TC, ALAY, BLAY, EPI, false>(p, grid, s);
+  }
   }
   if (!ok) pcaa_rearm_bn_tail(p.tail);
   return ok;
@@ -1284,6 +1336,11 @@ bool pcaa_launch_gemm_bf16_big(const GemmParams& p_in, int a_dtype, int a_layout
     return false;
   }
   return false;
+}
+
+extern "C" int pcaa_gemm_v2_enable(int on) {
+  g_v2_enabled = on ? 1 : 0;
+  return PCAA_OK;
 }
 
 // ------------------------------------------------------------------ kernel-exact launch timing

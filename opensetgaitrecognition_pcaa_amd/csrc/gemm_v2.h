@@ -1,0 +1,507 @@
+// The KC x KC bf16 (and split-fp16) tile loop of round 4 -- included by gemm_bf16.hip inside its anonymous namespace.
+//
+// Restructured after hipBLASLt's hand-written gfx950 kernel (Custom_Cijk_Alik_Bljk_BBS_BH_..._MT256x256x64_MI16x16x1,
+// disassembled from torch's TensileLibrary_BB_BB_HA_Bias_SAV_UA_..._gfx950.co; DESIGN.md section 7 has the side-by-side):
+//   * FOUR waves (2 x 2), one per SIMD, 128 x 128 accumulators each (256 accumulator registers, pinned to the
+//     accumulator file): every fragment read from the LDS feeds 8 MFMAs -- 128 KB of fragment reads per K step
+//     instead of the 8-wave kernel's 192 KB;
+//   * the fragments of the NEXT k-half are read into a second register set under the MFMAs of the current one, so an
+//     operand's stage image is dead as soon as its second half has been read: its refill for K step t + 2 is issued in
+//     the MIDDLE of step t, behind a barrier per operand.  Two LDS stages (128 KB) then carry a prefetch distance of
+//     TWO steps for BOTH operands (the 8-wave ring: A two steps ahead in three stages, B one step in two);
+//   * the request stream does not stop at tile boundaries: the cursor runs two steps ahead of the MFMAs straight into
+//     the workgroup's next tile (the 8-wave kernel requests the next tile's first stages in a burst before its epilogue);
+//   * a third barrier per step (counted vmcnt: only this step's own 16 requests may still be in flight) publishes
+//     stage t + 1, whose first-half fragments are then read under the second half's MFMAs;
+//   * the B operand's rows are permuted on their way into the LDS so that a lane's EIGHT column blocks are eight
+//     adjacent output columns: a row leaves as one 16-B store per lane (fp32: two), 16 lanes = 256 contiguous bytes --
+//     half the store instructions of the 8-wave kernel's 8-B stores.
+// Lab history (tools/microbench/gemm_v2.hip, profiles/r04_gemm_v2_lab.txt), same box, [245760, K] x [N, K]^T with bf16
+// C stores: 512->512 0.139 ms (8-wave kernel with statistics 0.168), 512->1024 0.276 (0.315), 1024->1024 0.440 (0.490;
+// hipBLASLt 0.437).
+//
+// MFMAs and fragment reads are inline asm: (1) left to the register allocator, a wave with 256 accumulator + 128
+// fragment registers got accumulators in both register files, ~1 200 v_accvgpr copies in the loop and 165 spills;
+// the "a" constraint pins them; (2) a plain LDS load whose value is consumed in the NEXT loop iteration is sunk to the
+// loop latch, behind the MFMAs it was meant to hide under.  The compiler therefore does not know the fragment
+// registers are pending: every use sits behind an explicit s_waitcnt lgkmcnt(0) in this file.
+#pragma once
+
+namespace v2 {
+
+constexpr int NT = 256;                       // threads: 4 waves
+constexpr int OP_TILE = 256 * 64;             // elements of one operand's stage image (32 KB)
+constexpr int STAGE = 2 * OP_TILE;            // A image, then B image (64 KB)
+constexpr int SCRATCH_OFF = 2 * STAGE * 2;    // bytes: behind the two stages
+constexpr int LDS_BYTES = SCRATCH_OFF + 8192; // statistics scratch [2][2][256] floats + ticket / flag words
+
+template <bool F16>
+__device__ __forceinline__ void mfma(f32x4& c, const bf16x8& a, const bf16x8& b) {
+  if constexpr (F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void lds_read(bf16x8& d, unsigned addr, int off) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(off));
+}
+
+// one 1-KB piece (8 LDS rows x 128 B) of an operand's stage image, p = 0..31.  PERM (the B operand): LDS row 16 j + c
+// of a 128-row group holds operand row 8 c + j -- the fragment reads do not change (lane c of column block j reads LDS
+// row 16 j + c), but block j of lane c is then output column 8 c + j: eight adjacent columns per lane.
+template <bool PERM>
+__device__ __forceinline__ void piece(buf_rsrc_t r, long ld, int row0, int koff, bf16_t* s_img, int p, const unsigned (&vo)[2]) {
+  const int prow = PERM ? 128 * (p >> 4) + 64 * (p & 1) + ((p >> 1) & 7) : 8 * p;
+  // (wave-uniform by construction; the readfirstlane keeps the compiler from wrapping the request in a waterfall loop
+  // when its divergence analysis cannot see that -- it could not for the split operands' segment offsets)
+  const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(((long)(row0 + prow) * ld + koff) * 2));
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(s_img + p * 512), 16, vo[p & 1], soff, 0, 0);
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------------------------------- epilogues
+// accumulator geometry: wave (wm, wn) owns rows wm * 128 .. + 127, columns wn * 128 .. + 127 of the tile; block (i, j),
+// register r of lane (c = lane & 15, q = lane >> 4) is row 16 i + 4 q + r, column 8 c + j.
+
+// C (=) acc (+ bias) [AFFINE: ELU(scale * (acc + bias) + shift), eval-mode BatchNorm + ELU]; bf16 or fp32 rows
+template <typename TC, bool AFFINE, bool SC>
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, f32x4 (&acc)[8][8], int tm, int tn, int wm, int wn, int le) {
+  const float os = SC ? p.out_scale : 1.f;
+  const int l15 = le & 15, q = le >> 4;
+  const int c0 = tn * BN + wn * 128 + 8 * l15;
+  const long row0 = (long)tm * BM + wm * 128 + 4 * q;
+  float bv[8], esc[8], esh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    bv[j] = p.bias != nullptr ? p.bias[c0 + j] : 0.f;
+    esc[j] = AFFINE ? p.ep_scale[c0 + j] : 1.f;
+    esh[j] = AFFINE ? p.ep_shift[c0 + j] : 0.f;
+  }
+  auto out = [&](float v, int j) __attribute__((always_inline)) {
+    if constexpr (AFFINE) {
+      v = fmaf(v + bv[j], esc[j], esh[j]);
+      return v > 0.f ? v : __expf(v) - 1.f;
+    } else {
+      return (SC ? v * os : v) + bv[j];
+    }
+  };
+  static_assert(!(AFFINE && SC), "the eval epilogues take bf16 operands");
+  TC* C = reinterpret_cast<TC*>(p.C) + row0 * p.ldc + c0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if constexpr (sizeof(TC) == 2) {
+        uint4 o;
+        o.x = pack2(out(acc[i][0][r], 0), out(acc[i][1][r], 1));
+        o.y = pack2(out(acc[i][2][r], 2), out(acc[i][3][r], 3));
+        o.z = pack2(out(acc[i][4][r], 4), out(acc[i][5][r], 5));
+        o.w = pack2(out(acc[i][6][r], 6), out(acc[i][7][r], 7));
+        *reinterpret_cast<uint4*>(C + (long)(i * 16 + r) * p.ldc) = o;
+      } else {
+        float* d = reinterpret_cast<float*>(C) + (long)(i * 16 + r) * p.ldc;
+        *reinterpret_cast<f32x4*>(d) = f32x4{out(acc[i][0][r], 0), out(acc[i][1][r], 1), out(acc[i][2][r], 2), out(acc[i][3][r], 3)};
+        *reinterpret_cast<f32x4*>(d + 4) = f32x4{out(acc[i][4][r], 4), out(acc[i][5][r], 5), out(acc[i][6][r], 6), out(acc[i][7][r], 7)};
+      }
+    }
+}
+
+// fold the four lanes (q = 0..3) that share a column, then hand the wave's 128 column sums of both statistics to the
+// workgroup's scratch; after the barrier thread t adds column t of both statistics to the fp64 replicas
+__device__ __forceinline__ void colstats_finish(const GemmParams& p, float (&t1)[8], float (&t2)[8], float* red, int tm, int tn,
+                                                int wm, int wn, int le, int tid) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    t1[j] += __shfl_xor(t1[j], 16, 64);
+    t1[j] += __shfl_xor(t1[j], 32, 64);
+    t2[j] += __shfl_xor(t2[j], 16, 64);
+    t2[j] += __shfl_xor(t2[j], 32, 64);
+  }
+  if (le < 16) {
+    float* d1 = &red[(0 * 2 + wm) * 256 + wn * 128 + 8 * le];
+    float* d2 = &red[(1 * 2 + wm) * 256 + wn * 128 + 8 * le];
+    *reinterpret_cast<f32x4*>(d1) = f32x4{t1[0], t1[1], t1[2], t1[3]};
+    *reinterpret_cast<f32x4*>(d1 + 4) = f32x4{t1[4], t1[5], t1[6], t1[7]};
+    *reinterpret_cast<f32x4*>(d2) = f32x4{t2[0], t2[1], t2[2], t2[3]};
+    *reinterpret_cast<f32x4*>(d2 + 4) = f32x4{t2[4], t2[5], t2[6], t2[7]};
+  }
+  lds_barrier();
+  const long base = ((long)(tm % p.nrep) * 2) * p.N + tn * BN + tid;
+  unsafeAtomicAdd(&p.colstats[base], (double)red[(0 * 2 + 0) * 256 + tid] + (double)red[(0 * 2 + 1) * 256 + tid]);
+  unsafeAtomicAdd(&p.colstats[base + p.N], (double)red[(1 * 2 + 0) * 256 + tid] + (double)red[(1 * 2 + 1) * 256 + tid]);
+  lds_barrier();      // the scratch is free again (the next tile's epilogue, or the finalize's flag word)
+}
+
+// BatchNorm column statistics (sum, sum of squares) of the bias-free accumulator
+template <bool SC>
+__device__ __forceinline__ void epilogue_colstats(const GemmParams& p, f32x4 (&acc)[8][8], float* red, int tm, int tn, int wm,
+                                                  int wn, int le, int tid) {
+  const float os = SC ? p.out_scale : 1.f;
+  float t1[8], t2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    f32x2 a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        const f32x2 v = {acc[i][j][r], acc[i][j][r + 1]};
+        a1 += v;
+        a2 = __builtin_elementwise_fma(v, v, a2);
+      }
+    t1[j] = (a1.x + a1.y) * os;                  // sums of (acc * os), (acc * os)^2: os is a power of two, exact
+    t2[j] = (a2.x + a2.y) * (os * os);
+  }
+  colstats_finish(p, t1, t2, red, tm, tn, wm, wn, le, tid);
+}
+
+// dgrad fused with the first half of the BatchNorm + ELU backward of the layer below (gemm_bf16.hip, epilogue_dgrad_bn):
+// dz = da * ELU'(y * scale + shift) leaves instead of da, with the column sums {dz, dz * yhat}.  TE = bf16 (bf16 mode:
+// ELU' = exp2(min(z log2e, 0))) or float (split-fp16 parity mode: the separate pass's exact expression).
+template <typename TE, bool SC>
+__device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p, f32x4 (&acc)[8][8], float* red, int tm, int tn, int wm,
+                                                  int wn, int le, int tid) {
+  constexpr bool kF32 = sizeof(TE) == 4;
+  const float os = SC ? p.out_scale : 1.f;
+  const int l15 = le & 15, q = le >> 4;
+  const int c0 = tn * BN + wn * 128 + 8 * l15;
+  const long row0 = (long)tm * BM + wm * 128 + 4 * q;
+  TE* C = reinterpret_cast<TE*>(p.C) + row0 * p.ldc + c0;
+  const TE* Y = reinterpret_cast<const TE*>(p.ep_y) + row0 * p.ldc + c0;
+  f32x2 sc2[4], sh2[4], rs2[4], nm2[4], s1[4], s2[4];
+  {
+    constexpr float kLog2e = kF32 ? 1.f : 1.4426950408889634f;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const float a0 = p.ep_scale[c0 + 2 * h], a1 = p.ep_scale[c0 + 2 * h + 1];
+      const float b0 = p.ep_shift[c0 + 2 * h], b1 = p.ep_shift[c0 + 2 * h + 1];
+      const float m0 = p.ep_mean[c0 + 2 * h], m1 = p.ep_mean[c0 + 2 * h + 1];
+      const float d0 = p.ep_rstd[c0 + 2 * h], d1 = p.ep_rstd[c0 + 2 * h + 1];
+      sc2[h] = f32x2{a0 * kLog2e, a1 * kLog2e};
+      sh2[h] = f32x2{b0 * kLog2e, b1 * kLog2e};
+      rs2[h] = f32x2{d0, d1};
+      nm2[h] = f32x2{-m0 * d0, -m1 * d1};
+      s1[h] = f32x2{0.f, 0.f};
+      s2[h] = f32x2{0.f, 0.f};
+    }
+  }
+  // the stored pre-activations of one 16-row block (4 rows per lane), requested one block ahead
+  typedef typename std::conditional<kF32, f32x4, uint4>::type yraw_t;
+  constexpr int YW = kF32 ? 2 : 1;                 // raw words of that type per row (8 columns)
+  yraw_t yv[2][4][YW];
+  auto load_y = [&](int i, int b) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int w = 0; w < YW; ++w)
+        yv[b][r][w] = *reinterpret_cast<const yraw_t*>(Y + (long)(i * 16 + r) * p.ldc + (kF32 ? 4 * w : 0));
+  };
+  load_y(0, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i + 1 < 8) load_y(i + 1, (i + 1) & 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      f32x2 y2[4];
+      if constexpr (kF32) {
+        const f32x4 w0 = yv[i & 1][r][0], w1 = yv[i & 1][r][YW - 1];
+        y2[0] = f32x2{w0.x, w0.y}; y2[1] = f32x2{w0.z, w0.w}; y2[2] = f32x2{w1.x, w1.y}; y2[3] = f32x2{w1.z, w1.w};
+      } else {
+        const uint4 w = yv[i & 1][r][0];
+        y2[0] = f32x2{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u)};
+        y2[1] = f32x2{__uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u)};
+        y2[2] = f32x2{__uint_as_float(w.z << 16), __uint_as_float(w.z & 0xffff0000u)};
+        y2[3] = f32x2{__uint_as_float(w.w << 16), __uint_as_float(w.w & 0xffff0000u)};
+      }
+      f32x2 dq[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        f32x2 dav = {acc[i][2 * h][r], acc[i][2 * h + 1][r]};
+        if (SC) dav *= os;
+        f32x2 g;
+        if constexpr (kF32) {
+          g = f32x2{elu_grad_from_pre(y2[h].x * sc2[h].x + sh2[h].x), elu_grad_from_pre(y2[h].y * sc2[h].y + sh2[h].y)};
+        } else {
+          f32x2 z2 = __builtin_elementwise_fma(y2[h], sc2[h], sh2[h]);
+          z2 = __builtin_elementwise_min(z2, f32x2{0.f, 0.f});
+          g = f32x2{__builtin_amdgcn_exp2f(z2.x), __builtin_amdgcn_exp2f(z2.y)};
+        }
+        const f32x2 d2 = dav * g;
+        s1[h] += d2;
+        s2[h] = __builtin_elementwise_fma(d2, __builtin_elementwise_fma(y2[h], rs2[h], nm2[h]), s2[h]);
+        dq[h] = d2;
+      }
+      if constexpr (kF32) {
+        float* d = reinterpret_cast<float*>(C) + (long)(i * 16 + r) * p.ldc;
+        *reinterpret_cast<f32x4*>(d) = f32x4{dq[0].x, dq[0].y, dq[1].x, dq[1].y};
+        *reinterpret_cast<f32x4*>(d + 4) = f32x4{dq[2].x, dq[2].y, dq[3].x, dq[3].y};
+      } else {
+        uint4 o;
+        o.x = pack2(dq[0].x, dq[0].y);
+        o.y = pack2(dq[1].x, dq[1].y);
+        o.z = pack2(dq[2].x, dq[2].y);
+        o.w = pack2(dq[3].x, dq[3].y);
+        *reinterpret_cast<uint4*>(C + (long)(i * 16 + r) * p.ldc) = o;
+      }
+    }
+  }
+  float t1[8], t2[8];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    t1[2 * h] = s1[h].x; t1[2 * h + 1] = s1[h].y;
+    t2[2 * h] = s2[h].x; t2[2 * h + 1] = s2[h].y;
+  }
+  colstats_finish(p, t1, t2, red, tm, tn, wm, wn, le, tid);
+}
+
+// Eval-mode LAST PointNet layer: BatchNorm (affine) + ELU + the mean over the N points of a frame, N = 32 IPG
+// (gemm_bf16.hip, epilogue_affine_meanpool): a wave's 128 rows are whole groups; out fp32 [P / N, ch]
+template <int IPG>
+__device__ __forceinline__ void epilogue_affine_meanpool(const GemmParams& p, f32x4 (&acc)[8][8], int tm, int tn, int wm, int wn,
+                                                         int le) {
+  constexpr int BPG = 2 * IPG;                    // 16-row accumulator blocks per group
+  const int l15 = le & 15;
+  float* out = reinterpret_cast<float*>(p.C);
+  const float inv_n = 1.f / (32 * IPG);
+  const int c0 = tn * BN + wn * 128 + 8 * l15;
+#pragma unroll
+  for (int g0 = 0; g0 < 8; g0 += BPG) {
+    float sum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float esc = p.ep_scale[c0 + j], esh = p.ep_shift[c0 + j];
+      float s = 0.f;
+#pragma unroll
+      for (int i = g0; i < g0 + BPG; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float z = fmaf(acc[i][j][r], esc, esh);
+          s += z > 0.f ? z : __expf(z) - 1.f;
+        }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      sum[j] = s * inv_n;
+    }
+    const long grp = ((long)tm * BM + wm * 128 + g0 * 16) / (32 * IPG);
+    if (le < 16) {
+      float* d = out + grp * p.ldc + c0;
+      *reinterpret_cast<f32x4*>(d) = f32x4{sum[0], sum[1], sum[2], sum[3]};
+      *reinterpret_cast<f32x4*>(d + 4) = f32x4{sum[4], sum[5], sum[6], sum[7]};
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- the kernel
+// TC: bf16 or float output (EPI_DGRAD_BN: the type of y and dz).  SPLIT: operands are [hi | lo] fp16 images
+// (pcaa_gemm_split3): the contraction walks three segments of p.seg_len at the offsets p.seg_off_a / _b.
+// Tiles: p.sched == NULL: workgroup b walks the tiles b, b + gridDim.x, ... of the XCD-aware order; else the
+// workgroups of an XCD draw the tiles behind their first one as tickets from that XCD's counter (see gemm_bf16.hip:
+// a workgroup that gets its CU late simply does fewer tiles) -- here one tile AHEAD, because the request cursor enters
+// the next tile three K steps before the MFMAs do.
+template <typename TC, int EPI, bool SPLIT>
+__global__ __launch_bounds__(NT) void gemm_bf16_v2_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  float* red = reinterpret_cast<float*>(smem_raw + SCRATCH_OFF);            // [2 stats][2 wm][256 cols]
+  int* words = reinterpret_cast<int*>(smem_raw + SCRATCH_OFF + 4096);      // [0]: next-tile hand-off, [1]: finalize flag
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbm = p.M / BM, nbn = p.N / BN, ntiles = nbm * nbn;
+  const int seg_steps = (SPLIT ? p.seg_len : p.K) / BK;                  // K steps per segment
+  const int nt = SPLIT ? 3 * seg_steps : seg_steps;                       // K steps per tile
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+  const long lda = p.lda, ldb = p.ldb;
+  const int gstride = gridDim.x;
+  int* const sched = p.sched;
+
+  // per-lane constants, rebuilt from an opaque copy of the lane id at the top of every tile (kept live across the
+  // epilogue they were spilled, and their reload in front of the loop drew a drain-everything s_waitcnt vmcnt into it)
+  unsigned voA[2], voB[2];
+  int kof0, kof1, fA, fB;
+  auto lane_consts = [&](int ln) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int g = (ln & 7) ^ ((4 * e + (ln >> 4)) & 7);
+      voA[e] = (unsigned)((ln >> 3) * lda * 2 + 16 * g);
+      voB[e] = (unsigned)(8 * (ln >> 3) * ldb * 2 + 16 * g);            // PERM: the rows of a piece lie 8 apart
+    }
+    const int l15 = ln & 15, q = ln >> 4;
+    kof0 = ((q) ^ (l15 >> 1)) * 8;                                       // k-granule (4 half + q) ^ row swizzle
+    kof1 = ((4 + q) ^ (l15 >> 1)) * 8;
+    fA = (wm * 128 + l15) * 64;                                          // + 1024 i per row block
+    fB = OP_TILE + (wn * 128 + l15) * 64;                                // + 1024 j
+  };
+  int ln = lane;
+  lane_consts(ln);
+
+  // request cursor: (tile, segment, k within the segment); two K steps ahead of the MFMAs, across tile boundaries.
+  // The buffer resources are re-based on the cursor's tile rows, so any operand size is addressable.
+  int vb = blockIdx.x;                 // tile of the MFMAs
+  if (vb >= ntiles) return;
+  int nvb = vb + gstride;              // the tile after it (fixed shares; tickets: drawn below)
+  // (kernel arguments read once: an s_load inside the loop would share lgkmcnt with the fragment reads; the element
+  // offsets of the hi / lo halves inside an image row are < 2^31)
+  const int seg_len = SPLIT ? p.seg_len : p.K;
+  const int soA0 = SPLIT ? (int)p.seg_off_a[0] : 0, soA1 = SPLIT ? (int)p.seg_off_a[1] : 0, soA2 = SPLIT ? (int)p.seg_off_a[2] : 0;
+  const int soB0 = SPLIT ? (int)p.seg_off_b[0] : 0, soB1 = SPLIT ? (int)p.seg_off_b[1] : 0, soB2 = SPLIT ? (int)p.seg_off_b[2] : 0;
+  int lvb = vb, lseg = 0, lk = 0;      // cursor
+  int lkA = soA0, lkB = soB0;          // its element offset inside a row of A / B: segment offset + k
+  buf_rsrc_t rA, rB;
+  {
+    int ltm, ltn;
+    xcd_tile_coords(nbm, nbn, lvb, ltm, ltn);
+    rA = make_rsrc(A + (long)ltm * BM * lda, (long)BM * lda * 2);
+    rB = make_rsrc(B + (long)ltn * BN * ldb, (long)BN * ldb * 2);
+  }
+  // (macros, not lambdas: with nested by-reference closures the split instantiation kept the captured variables in a
+  // stack frame and reached them through flat pointers -- 400 B of scratch traffic inside the loop)
+#define V2_REQ_A(st, jj) piece<false>(rA, lda, 0, lkA, (st), wave * 8 + (jj), voA)
+#define V2_REQ_B(st, jj) piece<true>(rB, ldb, 0, lkB, (st) + OP_TILE, wave * 8 + (jj), voB)
+  // into the next K step; behind a tile's last step into the next tile -- past the last one the cursor wraps to this
+  // workgroup's first tile: the loop stays branch-free, the two surplus stages land in dead LDS and are drained
+  // before the kernel ends
+#define V2_ADVANCE()                                                                       \
+  do {                                                                                     \
+    lk += BK;                                                                              \
+    lkA += BK;                                                                             \
+    lkB += BK;                                                                             \
+    if (lk == seg_len) {                                                                   \
+      lk = 0;                                                                              \
+      if (SPLIT) lseg = lseg == 2 ? 0 : lseg + 1;                                          \
+      lkA = lseg == 0 ? soA0 : (lseg == 1 ? soA1 : soA2);                                  \
+      lkB = lseg == 0 ? soB0 : (lseg == 1 ? soB1 : soB2);                                  \
+      if (lseg == 0) {                                                                     \
+        lvb = nvb < ntiles ? nvb : (int)blockIdx.x;                                        \
+        int ltm_, ltn_;                                                                    \
+        xcd_tile_coords(nbm, nbn, lvb, ltm_, ltn_);                                        \
+        rA = make_rsrc(A + (long)ltm_ * BM * lda, (long)BM * lda * 2);                     \
+        rB = make_rsrc(B + (long)ltn_ * BN * ldb, (long)BN * ldb * 2);                     \
+      }                                                                                    \
+    }                                                                                      \
+  } while (0)
+
+  f32x4 acc[8][8];
+  bf16x8 af[2][8], bfr[2][8];
+  // prologue: stages 0 and 1 of the first tile
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) V2_REQ_B(smem, jj);
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) V2_REQ_A(smem, jj);
+  V2_ADVANCE();
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) V2_REQ_B(smem + STAGE, jj);
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) V2_REQ_A(smem + STAGE, jj);
+  V2_ADVANCE();
+  asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(smem + fB + j * 1024 + kof0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(smem + fA + i * 1024 + kof0);
+
+  int s = 0;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+  for (;;) {
+    int tm, tn;
+    xcd_tile_coords(nbm, nbn, vb, tm, tn);
+    asm volatile("" : "+v"(ln));
+    lane_consts(ln);
+    // tickets: thread 0 draws the tile AFTER the next one's predecessor, i.e. this workgroup's next tile, now; the
+    // value returns under the first K steps and is handed to the other waves through LDS behind step 1's publish
+    // barrier (its request is older than that step's counted wait, and loads retire in order)
+    // (`ticket` deliberately has no initial value: a merge with one would be a copy out of the asm's destination register
+    // right behind the request, i.e. before the value has returned)
+    int ticket;
+    if (sched != nullptr && tid == 0)
+      asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(sched + (vb & 7)), "v"(1) : "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_nop 4" ::: "memory");
+    for (int kt = 0; kt < nt; ++kt) {
+      bf16_t* cur = smem + s * STAGE;              // this step's stage = destination of the requests for step t + 2
+      // LDS byte addresses of the fragment reads: second half of this stage, first half of the next
+      const unsigned cb = lds0 + (unsigned)s * (STAGE * 2), nb = lds0 + (unsigned)(s ^ 1) * (STAGE * 2);
+      const unsigned aB1 = cb + (unsigned)(fB + kof1) * 2, aA1 = cb + (unsigned)(fA + kof1) * 2;
+      const unsigned aB0 = nb + (unsigned)(fB + kof0) * 2, aA0 = nb + (unsigned)(fA + kof0) * 2;
+      // ---------------- k-half 0: MFMAs on af[0] / bfr[0]
+#pragma unroll
+      for (int m = 0; m < 64; ++m) {
+        const int i = m >> 3, j = m & 7;
+        if ((m & 1) == 1 && m < 16) lds_read(bfr[1][m >> 1], aB1, (m >> 1) * 2048);
+        if (m == 21) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // B image of this stage: dead
+        if (m >= 24 && m < 40 && (m & 1) == 0) lds_read(af[1][(m - 24) >> 1], aA1, ((m - 24) >> 1) * 2048);
+        if (m >= 23 && m < 39 && (m & 1) == 1) V2_REQ_B(cur, (m - 23) >> 1);                  // 8 pieces of B(t + 2)
+        if (m == 46) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // A image: dead
+        if (m >= 48 && (m & 3) == 0) V2_REQ_A(cur, (m - 48) >> 2);                             // pieces 0..3 of A(t + 2)
+        mfma<SPLIT>(acc[i][j], af[0][i], bfr[0][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---------------- k-half 1: MFMAs on af[1] / bfr[1]
+#pragma unroll
+      for (int m = 0; m < 64; ++m) {
+        const int i = m >> 3, j = m & 7;
+        if (m < 16 && (m & 3) == 0) V2_REQ_A(cur, 4 + (m >> 2));                               // pieces 4..7 of A(t + 2)
+        // stage t + 1 has landed: everything but this step's own 16 requests (loads retire in order, so "at most 16
+        // outstanding" means the older stage is complete whatever the previous tile's stores -- which share the counter
+        // -- are doing: they can only make the wait longer)
+        if (m == 20) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+        if (m >= 22 && m < 38 && (m & 1) == 0) lds_read(bfr[0][(m - 22) >> 1], aB0, ((m - 22) >> 1) * 2048);
+        if (m >= 38 && m < 54 && (m & 1) == 0) lds_read(af[0][(m - 38) >> 1], aA0, ((m - 38) >> 1) * 2048);
+        mfma<SPLIT>(acc[i][j], af[1][i], bfr[1][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next step's first-half fragments are in their registers
+      if (sched != nullptr) {
+        // kt == 1: the ticket has returned (older than step 1's counted wait); kt == 2: every wave reads it
+        if (kt == 1 && tid == 0) words[0] = ticket;
+        if (kt == 2) {
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          nvb = (vb & 7) + 8 * ((gstride >> 3) + __builtin_amdgcn_readfirstlane(words[0]));
+        }
+      }
+      V2_ADVANCE();
+      s ^= 1;
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results (the asm hides the hazard from the compiler)
+    // (split operands: the images hold value * 2^k; the epilogues multiply by p.out_scale -- an exact power of two -- as
+    // they read the accumulators: rescaling them in place would move all 256 through the vector registers and back)
+    int le = lane, te = tid;
+    asm volatile("" : "+v"(le));
+    asm volatile("" : "+v"(te));
+    if constexpr (EPI == EPI_DGRAD_BN) {
+      epilogue_dgrad_bn<TC, SPLIT>(p, acc, red, tm, tn, wm, wn, le, te);
+    } else if constexpr (EPI == EPI_AFFINE) {
+      epilogue_store<TC, true, false>(p, acc, tm, tn, wm, wn, le);
+    } else if constexpr (EPI == EPI_POOL1 || EPI == EPI_POOL2 || EPI == EPI_POOL4) {
+      epilogue_affine_meanpool<EPI == EPI_POOL1 ? 1 : (EPI == EPI_POOL2 ? 2 : 4)>(p, acc, tm, tn, wm, wn, le);
+    } else {
+      epilogue_store<TC, false, SPLIT>(p, acc, tm, tn, wm, wn, le);
+      if (p.colstats != nullptr) epilogue_colstats<SPLIT>(p, acc, red, tm, tn, wm, wn, le, te);
+    }
+    if (nvb >= ntiles) break;
+    vb = nvb;
+    nvb = vb + gstride;                  // (tickets: replaced at kt == 2 of the tile that starts now)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the surplus stages have landed before the LDS is released
+  if (sched != nullptr && tid == 0 && atomicAdd(&sched[8], 1) == gstride - 1) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) atomicExch(&sched[i], 0);
+  }
+  if constexpr (EPI == EPI_PLAIN || EPI == EPI_DGRAD_BN) {
+    // (read from the kernel-argument segment here, through a pointer the compiler cannot see through: referenced as
+    // p.tail its 20 fields sit in SGPRs through the whole tile loop)
+    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    const BnTail tail = *reinterpret_cast<const BnTail*>(ka + offsetof(GemmParams, tail));
+    bn_tail_run(tail, tid, NT, gridDim.x, words + 1);
+  }
+}
+
+#undef V2_REQ_A
+#undef V2_REQ_B
+#undef V2_ADVANCE
+
+}  // namespace v2

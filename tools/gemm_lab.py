@@ -23,14 +23,9 @@ from opensetgaitrecognition_pcaa_amd._lib import KC, PCAA_BF16, RC  # noqa: E402
 
 
 def lab_set(v, *_):
-    """temporary lab builds export pcaa_lab_set (0 = shipped kernel); without it only variant 0 is meaningful"""
-    from opensetgaitrecognition_pcaa_amd import _lib
-    import ctypes
-    fn = getattr(_lib.load(), "pcaa_lab_set", None)
-    if fn is not None:
-        fn.argtypes = [ctypes.c_int]
-        fn.restype = None
-        fn(int(v))
+    """variant 0 = the shipped default (round 4: the 4-wave tile loop, csrc/gemm_v2.h); variant 1 = the 8-wave loop of
+    rounds 1-3 (pcaa_gemm_v2_enable(0)): `--variants 0:0,1:0` A/Bs them in interleaved rounds of one process"""
+    _lib.load().pcaa_gemm_v2_enable(0 if int(v) == 1 else 1)
 
 
 def timeit(fn, iters):
@@ -135,7 +130,7 @@ def main():
                 med = t[len(t) // 2]
                 print(f"[{cin}->{cout}] {c:10s} mf={v[0]:2d} pf={v[1]}  median {med:.3f} ms  {fl / med / 1e9:7.1f} TF   "
                       f"min {t[0]:.3f}", flush=True)
-    lab_set(1, 0)
+    lab_set(0, 0)
 
 
 if __name__ == "__main__":

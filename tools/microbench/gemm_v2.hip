@@ -58,9 +58,19 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
 // one 1-KB piece (8 LDS rows x 128 B) of an operand's stage image: p = 0..31
 template <bool PERM>
 __device__ __forceinline__ void piece(rsrc_t r, long ld, int row0, int k0, bf16_t* s_img, int p, const unsigned (&vo)[2]) {
-  const int prow = PERM ? 64 * (p >> 3) + 32 * (p & 1) + ((p >> 1) & 3) : 8 * p;
+  const int prow = PERM ? 128 * (p >> 4) + 64 * (p & 1) + ((p >> 1) & 7) : 8 * p;      // PERM: LDS row 16 j + c of a 128-row group <- operand row 8 c + j
   const unsigned soff = (unsigned)(((long)(row0 + prow) * ld + k0) * 2);
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(s_img + p * 512), 16, vo[p & 1], soff, 0, 0);
+}
+
+// XCD-aware, bijective block -> tile map (the product's gemm_common.h): the 8 XCDs (blocks b, b + 8, ... share one) each
+// walk a contiguous range of tiles with the N tiles of one M panel adjacent: an A panel is re-read from that XCD's L2
+__device__ __forceinline__ void tile_coords(int nb, int nbn, int bid, int& tm, int& tn) {
+  const int q = nb >> 3, r = nb & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  tm = v / nbn;
+  tn = v - tm * nbn;
 }
 
 template <bool STORE>
@@ -84,7 +94,7 @@ __global__ __launch_bounds__(256) void gemm_v2(const bf16_t* __restrict__ A, con
     for (int e = 0; e < 2; ++e) {
       const int g = (ln & 7) ^ ((4 * e + (ln >> 4)) & 7);
       voA[e] = (unsigned)((ln >> 3) * (long)K * 2 + 16 * g);
-      voB[e] = (unsigned)(4 * (ln >> 3) * (long)K * 2 + 16 * g);      // PERM: the rows of a piece lie 4 apart
+      voB[e] = (unsigned)(8 * (ln >> 3) * (long)K * 2 + 16 * g);      // PERM: the rows of a piece lie 8 apart
     }
     l15 = ln & 15;
     q = ln >> 4;
@@ -103,14 +113,14 @@ __global__ __launch_bounds__(256) void gemm_v2(const bf16_t* __restrict__ A, con
   // launch land in dead LDS; the kernel drains them before it ends)
   const int gstride_l = gridDim.x;
   int lvb = blockIdx.x, lkt = 0;
-  int ltm = lvb / nbn, ltn = lvb % nbn;
+  int ltm, ltn;
+  tile_coords(ntiles, nbn, lvb, ltm, ltn);
   auto advance = [&]() {
     if (++lkt == nt) {
       lkt = 0;
       lvb += gstride_l;
       if (lvb >= ntiles) lvb = blockIdx.x;
-      ltm = lvb / nbn;
-      ltn = lvb % nbn;
+      tile_coords(ntiles, nbn, lvb, ltm, ltn);
     }
   };
   auto reqA = [&](bf16_t* st, int jj) { piece<false>(rA, K, ltm * BM, lkt * BK, st, wave * 8 + jj, voA); };
@@ -142,7 +152,8 @@ __global__ __launch_bounds__(256) void gemm_v2(const bf16_t* __restrict__ A, con
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
   const int gstride = gridDim.x;
   for (;;) {
-    const int tm = vb / nbn, tn = vb % nbn;
+    int tm, tn;
+    tile_coords(ntiles, nbn, vb, tm, tn);
     asm volatile("" : "+v"(ln));
     lane_consts(ln);
 #pragma unroll
@@ -196,18 +207,18 @@ __global__ __launch_bounds__(256) void gemm_v2(const bf16_t* __restrict__ A, con
     if (STORE) {
       int le = lane;
       asm volatile("" : "+v"(le));
-      bf16_t* c0 = C + (long)(tm * BM + wm * 128 + 4 * (le >> 4)) * N + tn * BN + wn * 128 + 4 * (le & 15);
+      bf16_t* c0 = C + (long)(tm * BM + wm * 128 + 4 * (le >> 4)) * N + tn * BN + wn * 128 + 8 * (le & 15);
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int jg = 0; jg < 2; ++jg) {
-            uint2 o;
-            o.x = pack2(acc[i][4 * jg][r], acc[i][4 * jg + 1][r]);
-            o.y = pack2(acc[i][4 * jg + 2][r], acc[i][4 * jg + 3][r]);
-            *reinterpret_cast<uint2*>(c0 + (long)(i * 16 + r) * N + 64 * jg) = o;
-          }
+        for (int r = 0; r < 4; ++r) {
+          uint4 o;
+          o.x = pack2(acc[i][0][r], acc[i][1][r]);
+          o.y = pack2(acc[i][2][r], acc[i][3][r]);
+          o.z = pack2(acc[i][4][r], acc[i][5][r]);
+          o.w = pack2(acc[i][6][r], acc[i][7][r]);
+          *reinterpret_cast<uint4*>(c0 + (long)(i * 16 + r) * N) = o;      // 16 B per lane, 16 lanes = 256 contiguous bytes
+        }
     } else {
       float t = 0.f;
 #pragma unroll
