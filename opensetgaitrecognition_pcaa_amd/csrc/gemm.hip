@@ -486,8 +486,12 @@ extern "C" int pcaa_gemm_slabs(int math,
 // MFMA.  (A bf16 pair carries 16 mantissa bits: 4.5e-6 per product, and the first PointNet layer's weight gradient
 // missed the 5e-4 gate at 5.7e-4; the fp16 pair carries 22.)  out_scale = 1 / (s_A s_B).  KC operands: [rows, 2K] (lo at column K + k); RC operands: [K, 2 rows] (lo at column rows + r).
 // ---------------------------------------------------------------------------------------------------------------
+bool pcaa_gemm_v2_is_enabled();      // gemm_bf16.hip
+// M need not be a multiple of 256 where the 4-wave tile loop serves the launch (round 4: it reads the rows past M as
+// zeros and skips them on the way out): contraction >= 320 deep, KC operands
+static bool ragged_m_ok(int K) { return pcaa_gemm_v2_is_enabled() && K >= 320; }
 extern "C" int pcaa_gemm_split3_supported(int M, int N, int K) {
-  return M > 0 && N > 0 && K > 0 && (M % 256) == 0 && (N % 256) == 0 && (K % 64) == 0;
+  return M > 0 && N > 0 && K > 0 && ((M % 256) == 0 || ragged_m_ok(K)) && (N % 256) == 0 && (K % 64) == 0;
 }
 
 static int gemm_split3_impl(const void* A, const void* B, int layout, long lda, long ldb, void* C, long ldc, int M, int N,
@@ -495,8 +499,11 @@ static int gemm_split3_impl(const void* A, const void* B, int layout, long lda, 
                             void* stream) {
   PCAA_CHECK_ARG(A && B && C, "pcaa_gemm_split3: null operand");
   PCAA_CHECK_ARG(layout == KC || layout == RC, "pcaa_gemm_split3: bad layout");
-  PCAA_CHECK_ARG(pcaa_gemm_split3_supported(M, N, K), "pcaa_gemm_split3: M, N must be multiples of 256 and K of 64 "
-                 "(M=%d N=%d K=%d)", M, N, K);
+  PCAA_CHECK_ARG(pcaa_gemm_split3_supported(M, N, K) && (layout == KC || (M % 256) == 0),
+                 "pcaa_gemm_split3: N must be a multiple of 256, K of 64, and M of 256 unless the 4-wave loop takes the "
+                 "launch (KC operands, K >= 320, no K split) (M=%d N=%d K=%d)", M, N, K);
+  PCAA_CHECK_ARG((M % 256) == 0 || (split_k <= 1 && c_split_stride == 0), "pcaa_gemm_split3: a partial last row tile needs a "
+                 "single K pass");
   PCAA_CHECK_ARG((long)K * 3 < (1L << 31), "pcaa_gemm_split3: K too large");
   const long a_cols = layout == KC ? 2L * K : 2L * M, b_cols = layout == KC ? 2L * K : 2L * N;
   PCAA_CHECK_ARG(lda >= a_cols && ldb >= b_cols && ldc >= N && (lda % 8) == 0 && (ldb % 8) == 0,
@@ -544,7 +551,7 @@ extern "C" int pcaa_gemm_slabs_split3(const void* A, const void* B, int layout, 
 }
 
 extern "C" int pcaa_gemm_dgrad_bn_supported(int M, int N, int K) {
-  return M > 0 && N > 0 && K > 0 && (M % 256) == 0 && (N % 256) == 0 && (K % 64) == 0;
+  return M > 0 && N > 0 && K > 0 && ((M % 256) == 0 || ragged_m_ok(K)) && (N % 256) == 0 && (K % 64) == 0;
 }
 
 extern "C" int pcaa_gemm_dgrad_bn(const void* dy, long lddy, const void* Wt, long ldw, const void* y, void* dz,

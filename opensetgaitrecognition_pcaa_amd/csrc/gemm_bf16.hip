@@ -1082,8 +1082,9 @@ bool launch_dma_inst(const GemmParams& p, dim3 grid, hipStream_t s) {
 }
 
 // The 4-wave tile loop (gemm_v2.h) serves every KC x KC launch without K splits whose contraction is at least five
-// 64-deep steps long (its ticket hand-off needs them); pcaa_gemm_v2_enable(0) routes them back to the 8-wave loop (A/B).
+// 64-deep steps long (its ticket hand-off needs four of them); pcaa_gemm_v2_enable(0) routes them back to the 8-wave loop (A/B).
 static int g_v2_enabled = -1;
+bool pcaa_gemm_v2_is_enabled();
 static bool v2_enabled() {
   if (g_v2_enabled < 0) {
     const char* e = getenv("PCAA_GEMM_V2");
@@ -1091,10 +1092,10 @@ static bool v2_enabled() {
   }
   return g_v2_enabled != 0;
 }
-template <typename TC, int EPI, bool SPLIT>
-bool launch_v2_inst(const GemmParams& p, dim3 grid, hipStream_t s) {
+template <typename TC, int EPI, bool SPLIT, bool RAG>
+bool launch_v2_rag(const GemmParams& p, dim3 grid, hipStream_t s) {
   static bool configured = false;
-  auto kern = v2::gemm_bf16_v2_kernel<TC, EPI, SPLIT>;
+  auto kern = v2::gemm_bf16_v2_kernel<TC, EPI, SPLIT, RAG>;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             v2::LDS_BYTES) != hipSuccess)
@@ -1107,6 +1108,11 @@ bool launch_v2_inst(const GemmParams& p, dim3 grid, hipStream_t s) {
   else
     hipLaunchKernelGGL(kern, grid, dim3(v2::NT), v2::LDS_BYTES, s, p);
   return true;
+}
+
+template <typename TC, int EPI, bool SPLIT>
+bool launch_v2_inst(const GemmParams& p, dim3 grid, hipStream_t s) {
+  return (p.M % BM) != 0 ? launch_v2_rag<TC, EPI, SPLIT, true>(p, grid, s) : launch_v2_rag<TC, EPI, SPLIT, false>(p, grid, s);
 }
 
 // Launches without K splits start one workgroup per CU (a multiple of 8: the XCD-aware tile order) and let them draw
@@ -1206,6 +1212,7 @@ bool launch_dma(const GemmParams& p_in, dim3 grid_in, hipStream_t s) {
       }
     }
   }
+  if (!decided && (p.M % BM) != 0) decided = true;      // a partial last row tile: the 4-wave loop only (ok stays false)
   if (!decided) {
   if constexpr ((EPI == EPI_PLAIN || (EPI == EPI_DGRAD_BN && ALAY == KC)) && sizeof(TC) == 4) {
     // split-fp16 operands (pcaa_gemm_split3, pcaa_gemm_dgrad_bn_split3): fp32 result only
@@ -1246,13 +1253,13 @@ bool launch(const GemmParams& p, dim3 grid, hipStream_t s) {
 // dgrad + BatchNorm/ELU backward of the layer below (pcaa_gemm_dgrad_bn): whole 256x256 tiles, bf16 KC x KC
 bool pcaa_launch_gemm_dgrad_bn(const GemmParams& p_in, hipStream_t stream) {
   GemmParams p = p_in;
-  if ((p.M % BM) || (p.N % BN) || (p.K % BK)) return false;
+  if ((p.N % BN) || (p.K % BK)) return false;      // (M: a partial last row tile is the 4-wave loop's; launch_dma refuses it otherwise)
   p.nsplit = 1;
   p.split_fast = 0;
   p.k_per_split = p.K;
   p.atomic = 0;
   p.c_split_stride = 0;
-  const long ntiles = (long)(p.M / BM) * (p.N / BN);
+  const long ntiles = cdiv(p.M, BM) * (p.N / BN);
   if (ntiles >= (1L << 31)) return false;
   if (p.seg_len > 0) {
     // split-fp16 operands: K is the contraction length of ONE pass (the kernel walks 3 K); y and dz fp32
@@ -1267,14 +1274,14 @@ bool pcaa_launch_gemm_dgrad_bn(const GemmParams& p_in, hipStream_t stream) {
 // product + eval-mode BatchNorm + ELU (pcaa_gemm_affine_elu): whole 256x256 tiles, bf16 KC x KC -> bf16
 bool pcaa_launch_gemm_affine_elu(const GemmParams& p_in, hipStream_t stream) {
   GemmParams p = p_in;
-  if ((p.M % BM) || (p.N % BN) || (p.K % BK)) return false;
+  if ((p.N % BN) || (p.K % BK)) return false;
   p.nsplit = 1;
   p.split_fast = 0;
   p.k_per_split = p.K;
   p.atomic = 0;
   p.c_split_stride = 0;
   p.colstats = nullptr;
-  const long ntiles = (long)(p.M / BM) * (p.N / BN);
+  const long ntiles = cdiv(p.M, BM) * (p.N / BN);
   if (ntiles >= (1L << 31)) return false;
   // p.ep_xc: rows per mean-pool group (0: plain activation output)
   switch (p.ep_xc) {
@@ -1308,7 +1315,11 @@ bool pcaa_launch_gemm_bf16_big(const GemmParams& p_in, int a_dtype, int a_layout
   if (p.split_fast) grid = dim3((unsigned)(ntiles * nsplit), 1, 1);
   const bool af = a_dtype == PCAA_F32, bf = b_dtype == PCAA_F32, cf = c_dtype == PCAA_F32;
   // LDS-DMA kernel: bf16 x bf16, whole tiles only
-  if (!af && !bf && (p.M % BM) == 0 && (p.N % BN) == 0 && (p.K % BK) == 0 && (p.k_per_split % BK) == 0 &&
+  // (a partial last row tile: KC x KC without K splits through the 4-wave loop; launch_dma returns false otherwise and
+  // the register-staged kernels below take the shape as before)
+  const bool m_ok = (p.M % BM) == 0 || (a_layout == KC && nsplit == 1 && v2_enabled() && p.K / BK >= 5 && !p.atomic &&
+                                        p.c_split_stride == 0);
+  if (!af && !bf && m_ok && (p.N % BN) == 0 && (p.K % BK) == 0 && (p.k_per_split % BK) == 0 &&
       a_layout == b_layout) {
     if (a_layout == KC)
       return cf ? launch_dma<float, KC, KC, EPI_PLAIN>(p, grid, stream) : launch_dma<bf16_t, KC, KC, EPI_PLAIN>(p, grid, stream);
@@ -1338,6 +1349,7 @@ bool pcaa_launch_gemm_bf16_big(const GemmParams& p_in, int a_dtype, int a_layout
   return false;
 }
 
+bool pcaa_gemm_v2_is_enabled() { return v2_enabled(); }
 extern "C" int pcaa_gemm_v2_enable(int on) {
   g_v2_enabled = on ? 1 : 0;
   return PCAA_OK;

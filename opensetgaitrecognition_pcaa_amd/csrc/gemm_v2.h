@@ -47,8 +47,17 @@ __device__ __forceinline__ void lds_read(bf16x8& d, unsigned addr, int off) {
 // one 1-KB piece (8 LDS rows x 128 B) of an operand's stage image, p = 0..31.  PERM (the B operand): LDS row 16 j + c
 // of a 128-row group holds operand row 8 c + j -- the fragment reads do not change (lane c of column block j reads LDS
 // row 16 j + c), but block j of lane c is then output column 8 c + j: eight adjacent columns per lane.
+// The A operand (PERM false) carries the piece's row offset in the per-lane (vector) offset: the buffer range check
+// covers vector + immediate offsets only -- a row offset in the SCALAR offset is not checked, and the rows past M of a
+// partial last row tile would be read for real (garbage in the column statistics) instead of as zeros.
 template <bool PERM>
 __device__ __forceinline__ void piece(buf_rsrc_t r, long ld, int row0, int koff, bf16_t* s_img, int p, const unsigned (&vo)[2]) {
+  if constexpr (!PERM) {
+    const unsigned voff = vo[p & 1] + (unsigned)((long)(row0 + 8 * p) * ld * 2);
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(koff * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(s_img + p * 512), 16, voff, soff, 0, 0);
+    return;
+  }
   const int prow = PERM ? 128 * (p >> 4) + 64 * (p & 1) + ((p >> 1) & 7) : 8 * p;
   // (wave-uniform by construction; the readfirstlane keeps the compiler from wrapping the request in a waterfall loop
   // when its divergence analysis cannot see that -- it could not for the split operands' segment offsets)
@@ -63,12 +72,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // register r of lane (c = lane & 15, q = lane >> 4) is row 16 i + 4 q + r, column 8 c + j.
 
 // C (=) acc (+ bias) [AFFINE: ELU(scale * (acc + bias) + shift), eval-mode BatchNorm + ELU]; bf16 or fp32 rows
-template <typename TC, bool AFFINE, bool SC>
+// RAG (every epilogue): the tile hangs over the last row of a matrix whose row count is not a multiple of 256 -- the
+// rows past M were requested out of the operand's buffer range (they read as zeros, so their accumulators and their
+// share of the column statistics are zero) and are neither loaded from y nor stored.
+template <typename TC, bool AFFINE, bool SC, bool RAG>
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, f32x4 (&acc)[8][8], int tm, int tn, int wm, int wn, int le) {
   const float os = SC ? p.out_scale : 1.f;
   const int l15 = le & 15, q = le >> 4;
   const int c0 = tn * BN + wn * 128 + 8 * l15;
   const long row0 = (long)tm * BM + wm * 128 + 4 * q;
+  const int mrows = (int)min((long)BM, (long)p.M - row0);          // valid rows from this lane's first one on
   float bv[8], esc[8], esh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -90,6 +103,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, f32x4 (&acc)
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+      if (RAG && i * 16 + r >= mrows) continue;
       if constexpr (sizeof(TC) == 2) {
         uint4 o;
         o.x = pack2(out(acc[i][0][r], 0), out(acc[i][1][r], 1));
@@ -132,10 +146,13 @@ __device__ __forceinline__ void colstats_finish(const GemmParams& p, float (&t1)
 }
 
 // BatchNorm column statistics (sum, sum of squares) of the bias-free accumulator
-template <bool SC>
+template <bool SC, bool RAG>
 __device__ __forceinline__ void epilogue_colstats(const GemmParams& p, f32x4 (&acc)[8][8], float* red, int tm, int tn, int wm,
                                                   int wn, int le, int tid) {
   const float os = SC ? p.out_scale : 1.f;
+  // RAG: rows past M are left out by a select -- an out-of-range LDS-DMA request writes NOTHING to the LDS (it does
+  // not zero-fill), so those rows of the A image hold whatever the stage held before, possibly NaN bit patterns
+  const int mrows = (int)min((long)BM, (long)p.M - ((long)tm * BM + wm * 128 + 4 * (le >> 4)));
   float t1[8], t2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -144,7 +161,11 @@ __device__ __forceinline__ void epilogue_colstats(const GemmParams& p, f32x4 (&a
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int r = 0; r < 4; r += 2) {
-        const f32x2 v = {acc[i][j][r], acc[i][j][r + 1]};
+        f32x2 v = {acc[i][j][r], acc[i][j][r + 1]};
+        if (RAG) {
+          if (i * 16 + r >= mrows) v.x = 0.f;
+          if (i * 16 + r + 1 >= mrows) v.y = 0.f;
+        }
         a1 += v;
         a2 = __builtin_elementwise_fma(v, v, a2);
       }
@@ -157,7 +178,7 @@ __device__ __forceinline__ void epilogue_colstats(const GemmParams& p, f32x4 (&a
 // dgrad fused with the first half of the BatchNorm + ELU backward of the layer below (gemm_bf16.hip, epilogue_dgrad_bn):
 // dz = da * ELU'(y * scale + shift) leaves instead of da, with the column sums {dz, dz * yhat}.  TE = bf16 (bf16 mode:
 // ELU' = exp2(min(z log2e, 0))) or float (split-fp16 parity mode: the separate pass's exact expression).
-template <typename TE, bool SC>
+template <typename TE, bool SC, bool RAG>
 __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p, f32x4 (&acc)[8][8], float* red, int tm, int tn, int wm,
                                                   int wn, int le, int tid) {
   constexpr bool kF32 = sizeof(TE) == 4;
@@ -167,6 +188,7 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p, f32x4 (&a
   const long row0 = (long)tm * BM + wm * 128 + 4 * q;
   TE* C = reinterpret_cast<TE*>(p.C) + row0 * p.ldc + c0;
   const TE* Y = reinterpret_cast<const TE*>(p.ep_y) + row0 * p.ldc + c0;
+  const int mrows = (int)min((long)BM, (long)p.M - row0);
   f32x2 sc2[4], sh2[4], rs2[4], nm2[4], s1[4], s2[4];
   {
     constexpr float kLog2e = kF32 ? 1.f : 1.4426950408889634f;
@@ -192,8 +214,13 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p, f32x4 (&a
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int w = 0; w < YW; ++w)
-        yv[b][r][w] = *reinterpret_cast<const yraw_t*>(Y + (long)(i * 16 + r) * p.ldc + (kF32 ? 4 * w : 0));
+      for (int w = 0; w < YW; ++w) {
+        // (a row past M: its gradient is forced to zero below; its y is read from row 0 of the matrix -- any FINITE
+        // values: 0 * ELU'(NaN) would still be NaN in the column sums, and this lane's own first row may itself lie
+        // past M)
+        const TE* yp = (RAG && i * 16 + r >= mrows) ? reinterpret_cast<const TE*>(p.ep_y) + c0 : Y + (long)(i * 16 + r) * p.ldc;
+        yv[b][r][w] = *reinterpret_cast<const yraw_t*>(yp + (kF32 ? 4 * w : 0));
+      }
   };
   load_y(0, 0);
 #pragma unroll
@@ -216,6 +243,7 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p, f32x4 (&a
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         f32x2 dav = {acc[i][2 * h][r], acc[i][2 * h + 1][r]};
+        if (RAG && i * 16 + r >= mrows) dav = f32x2{0.f, 0.f};      // (a select: the stale LDS rows may hold NaN patterns)
         if (SC) dav *= os;
         f32x2 g;
         if constexpr (kF32) {
@@ -230,6 +258,7 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p, f32x4 (&a
         s2[h] = __builtin_elementwise_fma(d2, __builtin_elementwise_fma(y2[h], rs2[h], nm2[h]), s2[h]);
         dq[h] = d2;
       }
+      if (RAG && i * 16 + r >= mrows) continue;
       if constexpr (kF32) {
         float* d = reinterpret_cast<float*>(C) + (long)(i * 16 + r) * p.ldc;
         *reinterpret_cast<f32x4*>(d) = f32x4{dq[0].x, dq[0].y, dq[1].x, dq[1].y};
@@ -255,7 +284,7 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p, f32x4 (&a
 
 // Eval-mode LAST PointNet layer: BatchNorm (affine) + ELU + the mean over the N points of a frame, N = 32 IPG
 // (gemm_bf16.hip, epilogue_affine_meanpool): a wave's 128 rows are whole groups; out fp32 [P / N, ch]
-template <int IPG>
+template <int IPG, bool RAG>
 __device__ __forceinline__ void epilogue_affine_meanpool(const GemmParams& p, f32x4 (&acc)[8][8], int tm, int tn, int wm, int wn,
                                                          int le) {
   constexpr int BPG = 2 * IPG;                    // 16-row accumulator blocks per group
@@ -282,6 +311,7 @@ __device__ __forceinline__ void epilogue_affine_meanpool(const GemmParams& p, f3
       sum[j] = s * inv_n;
     }
     const long grp = ((long)tm * BM + wm * 128 + g0 * 16) / (32 * IPG);
+    if (RAG && (long)tm * BM + wm * 128 + g0 * 16 >= p.M) continue;      // (M is a whole number of groups)
     if (le < 16) {
       float* d = out + grp * p.ldc + c0;
       *reinterpret_cast<f32x4*>(d) = f32x4{sum[0], sum[1], sum[2], sum[3]};
@@ -297,7 +327,9 @@ __device__ __forceinline__ void epilogue_affine_meanpool(const GemmParams& p, f3
 // workgroups of an XCD draw the tiles behind their first one as tickets from that XCD's counter (see gemm_bf16.hip:
 // a workgroup that gets its CU late simply does fewer tiles) -- here one tile AHEAD, because the request cursor enters
 // the next tile three K steps before the MFMAs do.
-template <typename TC, int EPI, bool SPLIT>
+// RAG: M is not a multiple of 256 -- its own instantiation (guarded epilogues on every tile; a runtime choice per tile
+// inside one kernel doubled the epilogue code and pushed the fused dgrad's epilogue into 600-1000 B of scratch).
+template <typename TC, int EPI, bool SPLIT, bool RAG>
 __global__ __launch_bounds__(NT) void gemm_bf16_v2_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
@@ -306,7 +338,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_v2_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int nbm = p.M / BM, nbn = p.N / BN, ntiles = nbm * nbn;
+  const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN, ntiles = nbm * nbn;      // (the last row tile may be partial)
   const int seg_steps = (SPLIT ? p.seg_len : p.K) / BK;                  // K steps per segment
   const int nt = SPLIT ? 3 * seg_steps : seg_steps;                       // K steps per tile
   const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
@@ -351,9 +383,10 @@ __global__ __launch_bounds__(NT) void gemm_bf16_v2_kernel(GemmParams p) {
   {
     int ltm, ltn;
     xcd_tile_coords(nbm, nbn, lvb, ltm, ltn);
-    rA = make_rsrc(A + (long)ltm * BM * lda, (long)BM * lda * 2);
+    rA = make_rsrc(A + (long)ltm * BM * lda, (long)min(BM, p.M - ltm * BM) * lda * 2);      // rows past M read as zeros
     rB = make_rsrc(B + (long)ltn * BN * ldb, (long)BN * ldb * 2);
   }
+  const int Mrows = p.M;
   // (macros, not lambdas: with nested by-reference closures the split instantiation kept the captured variables in a
   // stack frame and reached them through flat pointers -- 400 B of scratch traffic inside the loop)
 #define V2_REQ_A(st, jj) piece<false>(rA, lda, 0, lkA, (st), wave * 8 + (jj), voA)
@@ -375,7 +408,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_v2_kernel(GemmParams p) {
         lvb = nvb < ntiles ? nvb : (int)blockIdx.x;                                        \
         int ltm_, ltn_;                                                                    \
         xcd_tile_coords(nbm, nbn, lvb, ltm_, ltn_);                                        \
-        rA = make_rsrc(A + (long)ltm_ * BM * lda, (long)BM * lda * 2);                     \
+        rA = make_rsrc(A + (long)ltm_ * BM * lda, (long)min(BM, Mrows - ltm_ * BM) * lda * 2); \
         rB = make_rsrc(B + (long)ltn_ * BN * ldb, (long)BN * ldb * 2);                     \
       }                                                                                    \
     }                                                                                      \
@@ -407,14 +440,6 @@ __global__ __launch_bounds__(NT) void gemm_bf16_v2_kernel(GemmParams p) {
     xcd_tile_coords(nbm, nbn, vb, tm, tn);
     asm volatile("" : "+v"(ln));
     lane_consts(ln);
-    // tickets: thread 0 draws the tile AFTER the next one's predecessor, i.e. this workgroup's next tile, now; the
-    // value returns under the first K steps and is handed to the other waves through LDS behind step 1's publish
-    // barrier (its request is older than that step's counted wait, and loads retire in order)
-    // (`ticket` deliberately has no initial value: a merge with one would be a copy out of the asm's destination register
-    // right behind the request, i.e. before the value has returned)
-    int ticket;
-    if (sched != nullptr && tid == 0)
-      asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(sched + (vb & 7)), "v"(1) : "memory");
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -432,6 +457,18 @@ __global__ __launch_bounds__(NT) void gemm_bf16_v2_kernel(GemmParams p) {
         const int i = m >> 3, j = m & 7;
         if ((m & 1) == 1 && m < 16) lds_read(bfr[1][m >> 1], aB1, (m >> 1) * 2048);
         if (m == 21) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // B image of this stage: dead
+        if (m == 22 && sched != nullptr && kt == 1 && tid == 0) {
+          // tickets: thread 0 draws this workgroup's NEXT tile (one tile ahead: the request cursor enters it three K
+          // steps before the MFMAs do) and hands it over through LDS -- request, wait and hand-off in ONE asm statement,
+          // so that the compiler never sees a register whose value is still on its way (a first version let the
+          // returned value "rest" in an asm output for two K steps: an instantiation that spilled that register right
+          // behind the asm handed out garbage tiles -- a memory access fault in the bf16 N = 32 step; a compiler-visible
+          // atomic instead dragged a spill slot and an s_waitcnt vmcnt(0) into the loop).  The wait drains this wave's
+          // 16 requests of the previous step, which are at least half a step old here: ~0.5 us once per tile.
+          int tk;
+          asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)\n\tds_write_b32 %3, %0\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(tk) : "v"(sched + (vb & 7)), "v"(1), "v"(lds0 + SCRATCH_OFF + 4096) : "memory");
+        }
         if (m >= 24 && m < 40 && (m & 1) == 0) lds_read(af[1][(m - 24) >> 1], aA1, ((m - 24) >> 1) * 2048);
         if (m >= 23 && m < 39 && (m & 1) == 1) V2_REQ_B(cur, (m - 23) >> 1);                  // 8 pieces of B(t + 2)
         if (m == 46) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // A image: dead
@@ -454,14 +491,8 @@ __global__ __launch_bounds__(NT) void gemm_bf16_v2_kernel(GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next step's first-half fragments are in their registers
-      if (sched != nullptr) {
-        // kt == 1: the ticket has returned (older than step 1's counted wait); kt == 2: every wave reads it
-        if (kt == 1 && tid == 0) words[0] = ticket;
-        if (kt == 2) {
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-          nvb = (vb & 7) + 8 * ((gstride >> 3) + __builtin_amdgcn_readfirstlane(words[0]));
-        }
-      }
+      // the ticket was handed over in the first half of step 1 (two barriers ago): every wave reads it
+      if (sched != nullptr && kt == 1) nvb = (vb & 7) + 8 * ((gstride >> 3) + __builtin_amdgcn_readfirstlane(words[0]));
       V2_ADVANCE();
       s ^= 1;
     }
@@ -472,14 +503,14 @@ __global__ __launch_bounds__(NT) void gemm_bf16_v2_kernel(GemmParams p) {
     asm volatile("" : "+v"(le));
     asm volatile("" : "+v"(te));
     if constexpr (EPI == EPI_DGRAD_BN) {
-      epilogue_dgrad_bn<TC, SPLIT>(p, acc, red, tm, tn, wm, wn, le, te);
+      epilogue_dgrad_bn<TC, SPLIT, RAG>(p, acc, red, tm, tn, wm, wn, le, te);
     } else if constexpr (EPI == EPI_AFFINE) {
-      epilogue_store<TC, true, false>(p, acc, tm, tn, wm, wn, le);
+      epilogue_store<TC, true, false, RAG>(p, acc, tm, tn, wm, wn, le);
     } else if constexpr (EPI == EPI_POOL1 || EPI == EPI_POOL2 || EPI == EPI_POOL4) {
-      epilogue_affine_meanpool<EPI == EPI_POOL1 ? 1 : (EPI == EPI_POOL2 ? 2 : 4)>(p, acc, tm, tn, wm, wn, le);
+      epilogue_affine_meanpool<EPI == EPI_POOL1 ? 1 : (EPI == EPI_POOL2 ? 2 : 4), RAG>(p, acc, tm, tn, wm, wn, le);
     } else {
-      epilogue_store<TC, false, SPLIT>(p, acc, tm, tn, wm, wn, le);
-      if (p.colstats != nullptr) epilogue_colstats<SPLIT>(p, acc, red, tm, tn, wm, wn, le, te);
+      epilogue_store<TC, false, SPLIT, RAG>(p, acc, tm, tn, wm, wn, le);
+      if (p.colstats != nullptr) epilogue_colstats<SPLIT, RAG>(p, acc, red, tm, tn, wm, wn, le, te);
     }
     if (nvb >= ntiles) break;
     vb = nvb;

@@ -183,7 +183,7 @@ class _KernelEvents:
 
 
 def _begin_timing(key):
-    return _KernelEvents() if key.startswith("gemm_bf16_dma_kernel") else _TorchEvents()
+    return _KernelEvents() if key.startswith(("gemm_bf16_dma_kernel", "gemm_bf16_v2_kernel")) else _TorchEvents()
 
 
 TIMER = None
@@ -330,11 +330,31 @@ class BnTailBwd:
 
 
 # ------------------------------------------------------------------ GEMM
-def _dma_key(out_dtype, layout):
-    """LaunchTimer / PMC key of one gemm_bf16_dma_kernel instantiation (rocprofv3 lists them as
-    separate kernels: <__bf16, 0, 0, 0> = PointNet forward/dgrad, <float, 1, 1, 0> = wgrad)."""
+_GEMM_V2 = {"on": os.environ.get("PCAA_GEMM_V2", "1") != "0"}
+
+
+def gemm_v2_enable(on=True):
+    """Route the KC x KC bf16 / split-fp16 products without K splits through the 4-wave tile loop (csrc/gemm_v2.h;
+    default) or the 8-wave loop of rounds 1-3 (A/B, fallback): pcaa_gemm_v2_enable."""
+    _GEMM_V2["on"] = bool(on)
+    check(_lib.load().pcaa_gemm_v2_enable(int(bool(on))), "pcaa_gemm_v2_enable")
+
+
+def _v2_takes(K, split_k=1, accumulate=False):
+    """the dispatch rule of csrc/gemm_bf16.hip (launch_dma): the 4-wave loop takes a KC x KC launch without K splits whose
+    contraction is at least five 64-deep steps long"""
+    return _GEMM_V2["on"] and K // 64 >= 5 and int(split_k) <= 1 and not accumulate
+
+
+def _dma_key(out_dtype, layout, v2=False):
+    """LaunchTimer / PMC key of one LDS-DMA GEMM instantiation (rocprofv3 lists them as separate kernels): the 4-wave
+    loop's v2::gemm_bf16_v2_kernel<__bf16, 0, false> = PointNet forward / plain dgrad, the 8-wave
+    gemm_bf16_dma_kernel<float, 1, 1, 0> = wgrad."""
+    dt = 'bf16' if out_dtype == torch.bfloat16 else 'f32'
+    if v2 and layout == KC:
+        return f"gemm_bf16_v2_kernel<{dt},plain>"
     lay = "KC" if layout == KC else "RC"
-    return f"gemm_bf16_dma_kernel<{'bf16' if out_dtype == torch.bfloat16 else 'f32'},{lay},{lay}>"
+    return f"gemm_bf16_dma_kernel<{dt},{lay},{lay}>"
 
 
 def gemm(A, a_layout, B, b_layout, M, N, K, *, lda=None, ldb=None, out=None, out_dtype=torch.float32,
@@ -375,8 +395,8 @@ def gemm(A, a_layout, B, b_layout, M, N, K, *, lda=None, ldb=None, out=None, out
         if math != PCAA_BF16:
             key = "gemm_f32_kernel"
         elif (A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and a_layout == b_layout
-              and M % 256 == 0 and N % 256 == 0 and K % 64 == 0):
-            key = _dma_key(out.dtype, a_layout)   # same dispatch rule as pcaa_launch_gemm_bf16_big
+              and (M % 256 == 0 or (a_layout == KC and _v2_takes(K, split_k, accumulate))) and N % 256 == 0 and K % 64 == 0):
+            key = _dma_key(out.dtype, a_layout, _v2_takes(K, split_k, accumulate))   # same dispatch rule as pcaa_launch_gemm_bf16_big
         else:
             key = "gemm_bf16_big_kernel"
         timer = timer if timer.wants(key) else None
@@ -499,7 +519,8 @@ def gemm_affine_elu(a, W16, scale, shift, pool_rows=0):
     else:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     timer = TIMER
-    key = "gemm_bf16_dma_kernel<bf16,KC,KC,affine_elu>"     # eval-mode epilogues (BatchNorm affine + ELU [+ mean-pool])
+    # eval-mode epilogues (BatchNorm affine + ELU [+ mean-pool])
+    key = "gemm_bf16_v2_kernel<bf16,affine_elu>" if _v2_takes(K) else "gemm_bf16_dma_kernel<bf16,KC,KC,affine_elu>"
     timer = timer if (timer is not None and timer.wants(key)) else None
     if timer is not None:
         ev = _begin_timing(key)
@@ -542,7 +563,8 @@ def gemm_dgrad_bn(dy, Wt, y, scale, shift, mean, rstd, points=None, W1=None, tai
         dz = torch.empty_like(y)
     stats = new_stats(N, dy.device)
     timer = TIMER
-    key = "gemm_bf16_dma_kernel<bf16,KC,KC,dgrad_bn>"       # its own instantiation (epilogue carries ELU' + statistics)
+    # its own instantiation (epilogue carries ELU' + statistics)
+    key = "gemm_bf16_v2_kernel<bf16,dgrad_bn>" if (_v2_takes(K) and points is None) else "gemm_bf16_dma_kernel<bf16,KC,KC,dgrad_bn>"
     timer = timer if (timer is not None and timer.wants(key)) else None
     if timer is not None:
         ev = _begin_timing(key)
@@ -650,7 +672,7 @@ def gemm_split3(A, B, layout, M, N, K, colstats=None, tail=None, out=None):
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     timer = TIMER
-    key = "gemm_bf16_dma_kernel<f32,split3>"
+    key = "gemm_bf16_v2_kernel<f32,split3>" if (layout == KC and _v2_takes(3 * K)) else "gemm_bf16_dma_kernel<f32,split3>"
     timer = timer if (timer is not None and timer.wants(key)) else None
     if timer is not None:
         ev = _begin_timing(key)

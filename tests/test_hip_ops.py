@@ -219,7 +219,7 @@ def test_skinny_linear_layers_exact_variants(M, N, K):
     assert (dW - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("M,N,K", [(512, 256, 256), (768, 512, 1024), (1024, 1024, 512)])
+@pytest.mark.parametrize("M,N,K", [(512, 256, 256), (768, 512, 1024), (1024, 1024, 512), (1320, 512, 512), (200, 256, 1024)])
 def test_gemm_dgrad_bn_fused_epilogue(M, N, K):
     """dgrad fused with ELU' and the BatchNorm-backward statistics of the layer below: must agree with
     the separate chain  da = dy.Wt^T (bf16) ; stats = bn_act_bwd_stats(y, da) ; dz = da*ELU'(z)."""
@@ -227,12 +227,21 @@ def test_gemm_dgrad_bn_fused_epilogue(M, N, K):
     rng = np.random.default_rng(41)
     dy = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(DEV).bfloat16()
     Wt = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(DEV).bfloat16()
-    y = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(DEV).bfloat16()
+    # (y and dy sit in front of NaN-filled memory: a partial last row tile must neither read the rows past M into its
+    # statistics -- round 4: a wave whose 128 rows all lay past M read y there and 0 * ELU'(NaN) poisoned the column sums,
+    # a NaN step or a memory access fault depending on what the allocator had left behind -- nor write them)
+    ybig = torch.full((M + 300, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ybig[:M] = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(DEV).bfloat16()
+    y = ybig[:M]
+    dybig = torch.full((M + 300, K), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dybig[:M] = dy
+    dy = dybig[:M]
     scale = torch.from_numpy(rng.uniform(0.5, 1.5, N).astype(np.float32)).to(DEV)
     shift = torch.from_numpy(rng.uniform(-0.5, 0.5, N).astype(np.float32)).to(DEV)
     mean = torch.from_numpy(rng.uniform(-0.2, 0.2, N).astype(np.float32)).to(DEV)
     rstd = torch.from_numpy(rng.uniform(0.5, 2.0, N).astype(np.float32)).to(DEV)
     dz, st = ops.gemm_dgrad_bn(dy, Wt, y, scale, shift, mean, rstd)
+    assert bool(torch.isfinite(dz.float()).all()) and bool(torch.isfinite(st).all())
     da = ops.gemm(dy, KC, Wt, KC, M, N, K, out_dtype=torch.bfloat16, math=PCAA_BF16)
     dz_ref, st_ref = ops.bn_act_bwd_dz(y, scale, shift, mean, rstd, da=da)
     assert (dz.float() - dz_ref.float()).abs().max().item() <= 1e-2 * max(1.0, dz_ref.float().abs().max().item())
@@ -674,7 +683,7 @@ def test_dtc_conv_fwd_vs_fp64_conv1d(B, T, cin, cout, d, act):
     assert (col - col_ref).abs().max().item() <= 1e-6 * max(a.abs().max().item(), 1.0)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 1024, 512), (3840, 512, 512)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 1024, 512), (3840, 512, 512), (1320, 512, 512)])
 def test_gemm_affine_elu_epilogue(M, N, K):
     """Eval-mode PointNet layer in one launch: ELU(scale * (a @ W^T) + shift), bf16 in/out, fp32 accumulate."""
     a = _rand((M, K), 61).to(DEV).to(torch.bfloat16)
@@ -692,7 +701,8 @@ def test_gemm_affine_elu_epilogue(M, N, K):
     assert (out.float() - two.float()).abs().max().item() <= 2 ** -6 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("M,N,K,pool", [(512, 256, 64, 32), (1024, 1024, 512, 64), (3840, 1024, 1024, 128)])
+@pytest.mark.parametrize("M,N,K,pool", [(512, 256, 64, 32), (1024, 1024, 512, 64), (3840, 1024, 1024, 128), (960, 512, 512, 64),
+                                         (1440, 256, 1024, 32)])
 def test_gemm_affine_elu_meanpool_epilogue(M, N, K, pool):
     """Last eval-mode PointNet layer: BN (affine) + ELU + mean over the frame's points in the GEMM epilogue."""
     a = _rand((M, K), 71).to(DEV).to(torch.bfloat16)
@@ -915,3 +925,52 @@ def test_split_image_range_guard_saturates_and_flags():
     ops.pointnet_in_apply(x, Wp, torch.ones(512, device=DEV), torch.zeros(512, device=DEV), ops.SplitImage.dtype)
     with pytest.raises(FloatingPointError):
         ops.range_check()
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 512, 512), (1320, 512, 1024), (72000 // 8, 1024, 512), (130, 256, 320)])
+@pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32])
+def test_gemm_v2_tile_loop_vs_8_wave_loop_and_fp64(M, N, K, cdt):
+    """Round 4: the 4-wave tile loop (csrc/gemm_v2.h) against an fp64 product of the same bf16 operands, with the
+    BatchNorm column statistics, for whole and PARTIAL last row tiles (M % 256 != 0: rows past M are requested out of
+    the buffer range, read as zeros and are not stored) -- and, where M is a multiple of 256, bitwise against the 8-wave
+    loop of rounds 1-3 (both accumulate k in ascending 32-deep MFMA steps in fp32)."""
+    a = _rand((M, K), 71).to(DEV).to(torch.bfloat16)
+    w = (_rand((N, K), 72, K ** -0.5)).to(DEV).to(torch.bfloat16)
+    ref = a.double().cpu() @ w.double().cpu().t()
+    guard = torch.full((M + 64, N), 7.0, dtype=cdt, device=DEV)            # the rows behind M must stay untouched
+    out = guard[:M]
+    stats = ops.new_stats(N, DEV)
+    ops.gemm_v2_enable(True)
+    try:
+        ops.gemm(a, KC, w, KC, M, N, K, colstats=stats, out=out, out_dtype=cdt, math=PCAA_BF16)
+        torch.cuda.synchronize()
+        tol = (2 ** -7 if cdt == torch.bfloat16 else 1e-5) * ref.abs().max().item()
+        assert (out.double().cpu() - ref).abs().max().item() <= tol
+        assert bool((guard[M:] == 7.0).all()), "a partial tile wrote past the last row"
+        ssum = stats.sum(0).cpu()
+        assert (ssum[0] - ref.sum(0)).abs().max().item() <= 1e-4 * ref.abs().sum(0).max().item()
+        assert (ssum[1] - (ref * ref).sum(0)).abs().max().item() <= 1e-4 * (ref * ref).sum(0).max().item()
+        if M % 256 == 0:
+            ops.gemm_v2_enable(False)
+            old = torch.empty_like(out)
+            stats_old = ops.new_stats(N, DEV)
+            ops.gemm(a, KC, w, KC, M, N, K, colstats=stats_old, out=old, out_dtype=cdt, math=PCAA_BF16)
+            torch.cuda.synchronize()
+            assert torch.equal(old, out), "the two tile loops must agree bitwise"
+    finally:
+        ops.gemm_v2_enable(True)
+
+
+def test_gemm_split3_partial_row_tile():
+    """the fp16x3 mode's product and fused dgrad on a row count that is not a multiple of 256 (the reference's default
+    shape: B = 16, N = 150 -> 72 000 rows): against the fp64 product / the separate chain"""
+    M, N, K = 1320, 512, 512
+    a = _rand((M, K), 81).to(DEV)
+    w = _rand((N, K), 82, K ** -0.5).to(DEV)
+    assert ops.gemm_split3_supported(M, N, K)
+    ai, wi = ops.split_f16(a, scale=ops.SPLIT_SCALE_ACT), ops.split_f16(w)
+    stats = ops.new_stats(N, DEV)
+    y = ops.gemm_split3(ai, wi, KC, M, N, K, colstats=stats)
+    ref = a.double().cpu() @ w.double().cpu().t()
+    assert (y.double().cpu() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
+    assert (stats.sum(0).cpu()[0] - ref.sum(0)).abs().max().item() <= 1e-5 * ref.abs().sum(0).max().item()

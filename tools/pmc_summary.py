@@ -15,7 +15,25 @@ _EPI_TAIL = {"1": ",dgrad_bn", "2": ",dgrad_bn", "3": ",affine_elu", "4": ",affi
              "6": ",affine_elu"}
 
 
+_V2_EPI = {"0": "plain", "1": "dgrad_bn", "3": "affine_elu", "4": "affine_elu", "5": "affine_elu", "6": "affine_elu"}
+
+
 def key_of(name):
+    # round 4: the 4-wave tile loop, (anonymous namespace)::v2::gemm_bf16_v2_kernel<TC, EPI, SPLIT> -> ops.py's keys
+    m = re.match(r"_ZN12_GLOBAL__N_12v219gemm_bf16_v2_kernelI(DF16b|f)Li(\d)ELb(\d)E", name)
+    if m is None:
+        n2 = name.replace("(anonymous namespace)::", "").replace("void ", "")
+        m2 = re.match(r"v2::gemm_bf16_v2_kernel<(__bf16|float), (\d), (false|true)>", n2)
+        if m2:
+            m = (m2.group(1) == "__bf16" and "DF16b" or "f", m2.group(2), "1" if m2.group(3) == "true" else "0")
+    else:
+        m = m.groups()
+    if m:
+        epi = _V2_EPI.get(m[1], "plain")
+        if m[2] == "1":
+            return "gemm_bf16_v2_kernel<f32,split3>" if epi == "plain" else "gemm_bf16_v2_kernel<f32,split3," + epi + ">"
+        dt = "bf16" if (m[0] == "DF16b" or epi == "affine_elu") else "f32"
+        return f"gemm_bf16_v2_kernel<{dt},{epi}>"
     m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
     if m:                                   # rocprofv3 leaves some template instantiations mangled
         ln = int(m.group(1))
