@@ -66,7 +66,7 @@ def parse():
                          "calls and measures their fixed cost on one GPU)")
     ap.add_argument("--grad-compress", default="auto", choices=["auto", "none", "bf16"],
                     help="decoder gradient buckets cross the wire as bf16 (fp32 master gradients, moments and weights); auto "
-                         "= bf16 in the bf16 throughput mode, none in the fp32 parity mode (DESIGN.md section 6)")
+                         "= bf16 in the bf16 throughput mode, none in the fp32 parity mode (docs/LAB_LOG.md section 6)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--decoder-update", default="fused", choices=["fused", "plain"],
                     help="single process, bf16: decoder weight gradient + Adam in one kernel (default) or as two passes")

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_big_kernel(GemmParams p) {
 // pieces, A(t+2).  See the kernel for why the depth goes to A, and tools/microbench/cu_load_bw.hip for the
 // bytes-in-flight curve of a CU that motivates it.
 //
-// Measured and rejected (tools/gemm_lab.py history): touching the streamed operand's lines in L2
+// Measured and rejected (tools/gemm_lab.py history, docs/LAB_LOG.md section 4): touching the streamed operand's lines in L2
 // a few K steps ahead with one plain global_load_dword per lane and step (a software L2 prefetch behind a counted
 // vmcnt(1)) made every shape 3-10 % SLOWER (those loads queue in front of the pieces); round 1's five-slot ring gave
 // the third stage to B -- the L2-resident weights -- and measured nothing.
@@ -1193,6 +1193,9 @@ bool launch_dma(const GemmParams& p_in, dim3 grid_in, hipStream_t s) {
   bool ok = false;
   bool decided = false;
   if constexpr (ALAY == KC && BLAY == KC && EPI != EPI_DGRAD_BN_POINTS) {
+    // PCAA_GEMM_TICKETS=0: fixed tile shares in the 4-wave loop (A/B of the ticket draw's once-per-tile drain)
+    static const bool tickets = [] { const char* e = getenv("PCAA_GEMM_TICKETS"); return !(e != nullptr && e[0] == '0'); }();
+    if (!tickets) p.sched = nullptr;
     const int steps = (p.seg_len > 0 ? 3 * p.seg_len : p.K) / BK;
     constexpr bool kSplitOk = sizeof(TC) == 4 && (EPI == EPI_PLAIN || EPI == EPI_DGRAD_BN);
     constexpr bool kPlainOk = !(EPI == EPI_DGRAD_BN && sizeof(TC) == 4);      // fp32 dz exists for the split operands only

@@ -305,7 +305,7 @@ class _on_wgrad_stream:
 
 
 # Fusions that have an unfused fallback for the shapes their kernels do not take.  They were A/B-ed through
-# environment switches in round 1 and are plain constants now: the product has one path per shape.
+# environment switches in round 1 (docs/LAB_LOG.md section 4) and are plain constants now: the product has one path per shape.
 # PointNet weight gradients on the wgrad side stream: measured no change (they fill the chip either way) -> off.
 _BIG_WGRAD_ASIDE = False
 # ... but the split-K slab reductions that follow them (12 us each, three per step, needed only by Adam) do leave it

@@ -143,8 +143,55 @@ def CGAAE_inference_setup(model_name, loaders_batch_size=1, variation=False, gen
     return enc.eval(), means
 
 
-def naive_sequential_procedure(k, encoder, discriminator_means, known_pcs, known_labels, unseen_pcs,
-                               unseen_labels, seed=0, unseen_valid_ratio=0.2, batch_size=1024):
+def naive_sequential_procedure(k, encoder, discriminator_means, *args, **kwargs):
+    """Two call forms.
+
+    The REFERENCE's (inference_PCAA.py:117-125), taken when the fourth argument is a path:
+    ``naive_sequential_procedure(k, encoder, discriminator_means, figures_folder, model_folder,
+    scenarios_list=constants.TRAIN_SCENARIOS, seed=0, unseen_valid_ratio=0.2, force_pc_subsampling=0)``
+    -> ``(out_log, final_preds, final_labels)``: the sequentially ordered TEST / UNSEEN splits are read from the generated
+    dataset (packed once into an HBM-resident store), the procedure runs on the device, and ``naive_seq_log_{k}*.json`` is
+    written into ``model_folder`` under the reference's three file names.  Not reproduced: the confusion-matrix PNG in
+    ``figures_folder`` (plotting is out of scope; the folder is only created).
+
+    The in-memory form the drivers and tests use: ``naive_sequential_procedure_tensors`` below (crops already on the device)
+    -> ``(final_preds, final_labels, threshold)``."""
+    if args and isinstance(args[0], (str, os.PathLike)) or "figures_folder" in kwargs:
+        return _naive_sequential_procedure_files(k, encoder, discriminator_means, *args, **kwargs)
+    return naive_sequential_procedure_tensors(k, encoder, discriminator_means, *args, **kwargs)
+
+
+def _naive_sequential_procedure_files(k, encoder, discriminator_means, figures_folder, model_folder,
+                                      scenarios_list=None, seed=0, unseen_valid_ratio=0.2, force_pc_subsampling=0):
+    import json
+    from sklearn.metrics import f1_score
+    from .constants import SPLIT
+    scenarios_list = constants.TRAIN_SCENARIOS if scenarios_list is None else scenarios_list
+    default_scen = list(scenarios_list) == list(constants.TRAIN_SCENARIOS)
+    dev = next(encoder.parameters()).device
+    os.makedirs(figures_folder, exist_ok=True)
+    known_pcs, known_labels = _sequential_split_on_device(SPLIT.TEST, scenarios_list, dev)
+    unseen_pcs, unseen_labels = _sequential_split_on_device(SPLIT.UNSEEN, scenarios_list, dev)
+    preds, labels, _ = naive_sequential_procedure_tensors(k, encoder, discriminator_means, known_pcs, known_labels, unseen_pcs,
+                                                          unseen_labels, seed=seed, unseen_valid_ratio=unseen_valid_ratio)
+    labels = labels.astype(int)
+    out_log = {"n_steps": k, "accuracy": float(np.equal(labels, preds).sum() / max(len(labels), 1)),
+               "f1_micro": float(f1_score(labels, preds, average="micro")),
+               "f1_macro": float(f1_score(labels, preds, average="macro")),
+               "f1_weighted": float(f1_score(labels, preds, average="weighted"))}
+    if force_pc_subsampling and default_scen:
+        name = f"naive_seq_log_{k}_subsampled{force_pc_subsampling}.json"
+    elif not force_pc_subsampling and not default_scen:
+        name = f"naive_seq_log_{k}_scenarios" + "_".join(sc.value for sc in scenarios_list) + ".json"
+    else:
+        name = f"naive_seq_log_{k}.json"
+    with open(os.path.join(model_folder, name), "w") as f:
+        json.dump(out_log, f)
+    return out_log, preds, labels
+
+
+def naive_sequential_procedure_tensors(k, encoder, discriminator_means, known_pcs, known_labels, unseen_pcs,
+                                       unseen_labels, seed=0, unseen_valid_ratio=0.2, batch_size=1024):
     """The reference's procedure on in-memory, temporally ordered crops: (1) likelihoods of
     known-test and unseen crops, 20 % of the unseen SUBJECTS (rng seed 0) held out to pick the
     threshold; (2) k-window votes on the known test set and on the remaining unseen subjects.

@@ -470,7 +470,7 @@ def test_eight_rank_bf16_ring_sum_at_config1():
     train.PCAATrainer issues them) the bf16 ring sum -- per-chunk hop order, one rounding per hop,
     helpers.ring_allreduce_bf16 -- against the fp64 sum of the fp32 gradients.  Gate: 1e-2 relative l2 (the bf16 mode's
     weight-gradient tolerance is 5e-2) and 2 % of the bucket's largest element; the measured figures are printed and
-    recorded in DESIGN.md section 6 -- they decide whether bf16 buckets stay the default at N >= 4."""
+    recorded in docs/LAB_LOG.md section 6 -- they decide whether bf16 buckets stay the default at N >= 4."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import T, ring_allreduce_bf16
     from opensetgaitrecognition_pcaa_amd import constants, synthetic as syn

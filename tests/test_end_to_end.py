@@ -67,6 +67,13 @@ def _flow(classes):
         assert set(np.unique(labels)) <= set(range(len(classes) + 1)) and len(classes) in labels   # unknown class present
         assert preds.min() >= 0 and preds.max() <= len(classes)
         assert set(out[k]) == {"f1_micro", "f1_macro", "f1_weighted"}
+    # the reference's own call form of the procedure (inference_PCAA.py:117-125: folders in, (out_log, preds, labels) out)
+    enc, means = inference.CGAAE_inference_setup("e2e_V4", 32, False, generate_dataset=False, device=torch.device("cuda"))
+    log2, p2, l2 = inference.naive_sequential_procedure(2, enc, means, "figures/e2e_V4", "models/e2e_V4",
+                                                         scenarios_list=constants.TRAIN_SCENARIOS, seed=0,
+                                                         unseen_valid_ratio=0.2, force_pc_subsampling=0)
+    assert np.array_equal(p2, np.load("models/e2e_V4/final_preds_2.npy")) and np.array_equal(l2, np.load("models/e2e_V4/final_labels_2.npy"))
+    assert log2["n_steps"] == 2 and os.path.isdir("figures/e2e_V4")
     # variant 1 through its loop: learner checkpoint and the train-mode centroids file
     cfg1 = dict(cfg); cfg1["MODEL_NAME"] = "e2e_V1"
     trainer1, hist1 = train_variant1(cfg1, wandb_mode="disabled")

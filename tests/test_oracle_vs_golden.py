@@ -233,7 +233,7 @@ def test_v3_train_steps():
                 check_against_record(g, "s0.ggrad.", name, gr, 3e-4)
         if s in (0, steps - 1):
             # post-Adam parameters: with tot = loss_g + sup_loss only, many gradient elements are within ~10x of
-            # Adam's eps, where the +-lr first steps depend on the gradient's last bits:
+            # Adam's eps, where the +-lr first steps depend on the gradient's last bits (docs/LAB_LOG.md section 2):
             # worst element within 0.5*lr per step, mean error at rounding level
             for nm, sd in (("E", st.enc), ("D", st.disc)):
                 for name, v in sd.items():
@@ -244,7 +244,7 @@ def test_v3_train_steps():
                     err = np.abs(v.numpy().astype(np.float64) - ref)
                     scale = max(float(np.abs(ref).max()), 5.0 if name.endswith("running_mean") else 0.0)
                     assert err.max() <= 2e-5 * scale + 0.5e-4 * (s + 1), (name, err.max())
-                    if not name.endswith("running_mean"):      # inherits the pre-BN bias's +-lr walk
+                    if not name.endswith("running_mean"):      # inherits the pre-BN bias's +-lr walk (docs/LAB_LOG.md section 2)
                         assert err.mean() <= 2e-6 * max(scale, 1.0), (name, err.mean())
 
 

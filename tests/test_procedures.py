@@ -75,7 +75,7 @@ def test_train_variant4_two_epochs_vs_reference(tmp_path, monkeypatch):
             else:
                 # epoch 0 starts from the SAME initial weights (same draws from torch's RNG, same construction order)
                 # and sees the same batches and host draws; per-step differences are Adam's rounding-noise-signed
-                # steps, so the epoch means agree far inside 1e-2; the gate widens with the epoch
+                # steps (docs/LAB_LOG.md section 2), so the epoch means agree far inside 1e-2; the gate widens with the epoch
                 tol = 1e-2 * (e + 1)
                 assert abs(got - want) <= tol * abs(want), (e, k, got, want)
     # best-valid rule (:1073-1076): a checkpoint after an epoch iff its valid accuracy beats the best so far
@@ -98,7 +98,7 @@ def test_train_variant4_two_epochs_vs_reference(tmp_path, monkeypatch):
                     assert float(v) == s_ref
                     continue
                 if is_pre_bn_bias(name) or name.endswith("running_mean"):
-                    continue      # the reference random-walks these by +-lr on a rounding-noise gradient
+                    continue      # the reference random-walks these by +-lr on a rounding-noise gradient (docs/LAB_LOG.md section 2)
                 assert abs(float(v.norm()) - n_ref) <= 2e-3 * max(n_ref, 1e-3), (sfx, name, float(v.norm()), n_ref)
     means = torch.load("models/proc_V4/discriminator_means.pt", map_location="cpu")
     assert np.array_equal(means.numpy(), G["train.means"])

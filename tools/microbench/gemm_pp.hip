@@ -11,7 +11,7 @@
 //   groups : wm = 1 runs one barrier behind wm = 0, so every interval has one group in READ and one in MFMA
 //   hazards: RAW  every wave waits (counted vmcnt) for its pieces of half-step v before the barrier in front of the
 //                 first READ(v); WAR  slot v mod NS is re-requested NS - L = 2 half-steps after its last reader's
-//                 lgkmcnt(0) (see DESIGN.md section 7 for the interval arithmetic)
+//                 lgkmcnt(0) (see docs/LAB_LOG.md section 7 for the interval arithmetic)
 //   hipcc --offload-arch=gfx950 -O3 -o gemm_pp gemm_pp.hip && ./gemm_pp
 #include <hip/hip_runtime.h>
 #include <stdio.h>

@@ -22,7 +22,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for f in glob.glob("$R/gpurun_out/pmcg_${tag}_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = key_of(r["Kernel_Name"])
-        if not k.startswith("gemm_bf16_dma"):
+        if not k.startswith(("gemm_bf16_dma", "gemm_bf16_v2")):
             continue
         a = agg[k][r["Counter_Name"]]
         a[0] += 1; a[1] += float(r["Counter_Value"])

@@ -21,6 +21,10 @@ _V2_EPI = {"0": "plain", "1": "dgrad_bn", "3": "affine_elu", "4": "affine_elu", 
 def key_of(name):
     # round 4: the 4-wave tile loop, (anonymous namespace)::v2::gemm_bf16_v2_kernel<TC, EPI, SPLIT> -> ops.py's keys
     m = re.match(r"_ZN12_GLOBAL__N_12v219gemm_bf16_v2_kernelI(DF16b|f)Li(\d)ELb(\d)E", name)
+    if m is None and "gemm_bf16_v2_kernel<bool _Accum, int, E, false, false>" in name:
+        # rocprofv3's demangler garbles this one instantiation's argument list; in the train step it is the fused dgrad
+        # (<__bf16, EPI_DGRAD_BN, false, false>: the only v2 instantiation besides the forward's, which stays mangled)
+        return "gemm_bf16_v2_kernel<bf16,dgrad_bn>"
     if m is None:
         n2 = name.replace("(anonymous namespace)::", "").replace("void ", "")
         m2 = re.match(r"v2::gemm_bf16_v2_kernel<(__bf16|float), (\d), (false|true)>", n2)
