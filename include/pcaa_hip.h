@@ -422,6 +422,11 @@ int pcaa_dtc_conv_ksplit(int B, int cin, int cout);   /* the ksplit to pass: >= 
 int pcaa_dtc_conv_fwd(const float* src, const float* scale, const float* shift, const float* W, float* y,
                       float* col, double* stats, int nrep, int B, int T, int cin, int cout, int dilation,
                       int ksplit, long slab_stride, void* stream);
+/* the bf16 throughput mode's variant (round 4): same arguments, same results up to bf16 rounding of the operands -- the
+ * contraction on v_mfma_f32_32x32x16_bf16 (fp32 accumulate), 128 output channels per workgroup; y, col, statistics fp32 */
+int pcaa_dtc_conv_fwd_bf16(const float* src, const float* scale, const float* shift, const float* W, float* y,
+                      float* col, double* stats, int nrep, int B, int T, int cin, int cout, int dilation,
+                      int ksplit, long slab_stride, void* stream);
 
 /* The adjoint w.r.t. the layer input in one launch (replaces dcol = dy . W on the im2col layout followed by
  * pcaa_dtc_col2im): da[(b,t)][ci] = sum_{co,tap} dy[b][t+(2-tap)*d][co] * W[co][ci][tap].
@@ -438,6 +443,11 @@ int pcaa_dtc_conv_dgrad(const float* dy, const float* dz, const float* y, const 
                         const float* ep_shift, const float* ep_mean, const float* ep_rstd, double* ep_stats,
                         int nrep, int B, int T, int cin, int cout, int dilation, int ksplit, long slab_stride,
                         void* stream);
+int pcaa_dtc_conv_dgrad_bf16(const float* dy, const float* dz, const float* y, const float* coef, float* dy_out,
+                        const float* W, float* out, const float* ep_y, const float* ep_scale,
+                        const float* ep_shift, const float* ep_mean, const float* ep_rstd, double* ep_stats,
+                        int nrep, int B, int T, int cin, int cout, int dilation, int ksplit, long slab_stride,
+                        void* stream);      /* likewise, the adjoint */
 
 /* ------------------------------------------------------------------ MLP heads, fused
  * CGEncoder's MLP_sup1 / MLP_head / MLP_sup2 (models.py:252-277, applied at :285-292) and the

@@ -191,6 +191,139 @@ __global__ __launch_bounds__(256) void dtc_fwd_kernel(DtcFwdParams p) {
   bn_tail_run(p.tail, tid, 256, gridDim.x * gridDim.y * gridDim.z, &tail_flag);
 }
 
+
+// ------------------------------------------------------------------ round 4: the bf16 throughput mode's variant
+// Same staging, same implicit im2col, same statistics -- but the contraction runs on v_mfma_f32_32x32x16_bf16 (the
+// operands are rounded to bf16 as the fragments are built: the activated tile stays fp32 in the LDS, so the im2col
+// matrix for the weight gradient is unchanged; the weight chunk is stored as bf16), and a workgroup owns 128 output
+// channels -- one 32-column block per wave, the whole contraction in that wave, no cross-wave reduction -- so a
+// sequence's tile is staged and activated by 4 workgroups instead of 16 (256 -> 512 layer).  A 96-deep chunk is 6 MFMAs
+// of 32 cycles per wave instead of 12 of 64: the contraction leaves the kernel's critical path (layer 6: 22 us of 45).
+constexpr int NCT = 128;            // output channels per workgroup
+constexpr int WPH = 3 * CC + 8;     // bf16 pitch of a weight-tile row (208 B)
+
+__device__ __forceinline__ bf16x8 cvt8(const float* p) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  bf16x8 r;
+  r[0] = (bf16_t)a.x; r[1] = (bf16_t)a.y; r[2] = (bf16_t)a.z; r[3] = (bf16_t)a.w;
+  r[4] = (bf16_t)b.x; r[5] = (bf16_t)b.y; r[6] = (bf16_t)b.z; r[7] = (bf16_t)b.w;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void dtc_fwd_bf16_kernel(DtcFwdParams p) {
+  __shared__ __attribute__((aligned(16))) float a_lds[(ROWS + 1) * (MAX_CR + 4)];
+  __shared__ __attribute__((aligned(16))) bf16_t Ws[NCT * WPH];
+  __shared__ int tail_flag;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x, n0 = blockIdx.y * NCT;
+  const int T = p.T, cin = p.cin, K = cin * 3, d = p.dil;
+  const bool split = gridDim.z > 1;
+  float* yout = p.y + (long)blockIdx.z * p.slab_stride;
+  const int per_z = ((cin + CC - 1) / CC + (int)gridDim.z - 1) / (int)gridDim.z * CC;
+  const int cz0 = blockIdx.z * per_z;
+  const int cr = max(0, min(cin, cz0 + per_z) - cz0);
+  const int AP = cr + 4;
+  {
+    const int q4 = cr >> 2;
+    const bool act = p.scale != nullptr;
+    for (int q = tid; q < T * q4; q += 256) {
+      const int r = q / q4, c4 = (q - r * q4) << 2;
+      f32x4 v = load4(p.src + ((long)b * T + r) * cin + cz0 + c4);
+      if (act) {
+        const f32x4 sc = load4(p.scale + cz0 + c4), sh = load4(p.shift + cz0 + c4);
+        v.x = elu_stage(fmaf(sc.x, v.x, sh.x));
+        v.y = elu_stage(fmaf(sc.y, v.y, sh.y));
+        v.z = elu_stage(fmaf(sc.z, v.z, sh.z));
+        v.w = elu_stage(fmaf(sc.w, v.w, sh.w));
+      }
+      *reinterpret_cast<f32x4*>(&a_lds[r * AP + c4]) = v;
+    }
+    for (int q = tid; q < (ROWS + 1 - T) * AP; q += 256) a_lds[T * AP + q] = 0.f;
+  }
+  // weight chunk: 128 columns x 96 contiguous floats W[n0 + c][(cz0 + c0) * 3 ...], 12 float4 per thread
+  f32x4 rw[12];
+  auto load_w = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const int q = tid + j * 256;
+      const int c = q / 24, f = (q - c * 24) << 2;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n0 + c < p.cout && c0 * 3 + f < cr * 3) v = load4(p.W + (long)(n0 + c) * K + (long)(cz0 + c0) * 3 + f);
+      rw[j] = v;
+    }
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const int q = tid + j * 256;
+      const int c = q / 24, f = (q - c * 24) << 2;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int kk = f + m, ci_l = kk / 3, tap = kk - ci_l * 3;
+        Ws[c * WPH + tap * CC + ci_l] = (bf16_t)rw[j][m];
+      }
+    }
+  };
+  if (cr > 0) load_w(0);
+  __syncthreads();
+  if (p.col != nullptr && blockIdx.y == 0) {
+    const int run = cr * 3;
+    for (int q = tid; q < T * run; q += 256) {
+      const int r = q / run, kk = q - r * run;
+      const int ci = kk / 3, tap = kk - ci * 3;
+      const int ts = r - (2 - tap) * d;
+      p.col[((long)b * T + r) * K + (long)cz0 * 3 + kk] = ts >= 0 ? a_lds[ts * AP + ci] : 0.f;
+    }
+  }
+  const bool active = n0 + wave * 32 < p.cout;      // (wave-uniform) this wave's 32 columns exist
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int c0 = 0; c0 < cr; c0 += CC) {
+    if (c0 > 0) __syncthreads();
+    store_w();
+    __syncthreads();
+    if (c0 + CC < cr) load_w(c0 + CC);
+    if (active) {
+#pragma unroll
+      for (int st = 0; st < 6; ++st) {
+        // k' = tap * 32 + ci_l: step st covers k' = 16 st .. 16 st + 15, this lane's eight are 16 st + 8 half ...
+        const int tap = st >> 1, ci_l = ((st & 1) << 4) + (half << 3);
+        const int rs = l31 - (2 - tap) * d;
+        const float* ap = (rs >= 0 && c0 + ci_l < cr) ? &a_lds[rs * AP + c0 + ci_l] : &a_lds[ZROW * AP];
+        const bf16x8 av = cvt8(ap);
+        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(&Ws[(wave * 32 + l31) * WPH + tap * CC + ci_l]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wv, acc, 0, 0, 0);
+      }
+    }
+  }
+  // accumulator i of lane (l31, half) is row (i & 3) + 8 (i >> 2) + 4 half, column l31 of the wave's block
+  const int gn = n0 + wave * 32 + l31;
+  float s1 = 0.f, s2 = 0.f;
+  if (active && gn < p.cout) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = (i & 3) + 8 * (i >> 2) + 4 * half;
+      if (r < T) {
+        const float v = acc[i];
+        yout[((long)b * T + r) * p.cout + gn] = v;
+        s1 += v;
+        s2 += v * v;
+      }
+    }
+  }
+  if (p.stats != nullptr && !split) {
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (active && half == 0 && gn < p.cout) {
+      unsafeAtomicAdd(&p.stats[((long)(b % p.nrep) * 2 + 0) * p.cout + gn], (double)s1);
+      unsafeAtomicAdd(&p.stats[((long)(b % p.nrep) * 2 + 1) * p.cout + gn], (double)s2);
+    }
+  }
+  bn_tail_run(p.tail, tid, 256, gridDim.x * gridDim.y * gridDim.z, &tail_flag);
+}
+
 // ------------------------------------------------------------------ backward w.r.t. the layer input
 //   da[(b,t)][ci] = sum_{co,tap} dy[b][t+(2-tap)*d][co] * W[co][ci][tap]        (rows past the sequence end: zero)
 // The adjoint of the forward as the same kernel shape: the gradient sequence tile dy[T][cout range] is staged in
@@ -344,6 +477,124 @@ __global__ __launch_bounds__(256) void dtc_dgrad_kernel(DtcDgradParams p, int ti
   bn_tail_run(p.tail, tid, 256, gridDim.x * gridDim.y * gridDim.z, reinterpret_cast<int*>(red + 2 * 8 * 32));
 }
 
+// the bf16 throughput mode's adjoint (round 4): 128 input channels per workgroup, one 32-column block per wave,
+// v_mfma_f32_32x32x16_bf16 on fragments rounded as they are built (see dtc_fwd_bf16_kernel)
+__global__ __launch_bounds__(256) void dtc_dgrad_bf16_kernel(DtcDgradParams p, int tile_floats) {
+  extern __shared__ __attribute__((aligned(16))) float dg_smem[];
+  float* a_lds = dg_smem;                                            // [(ROWS+1)][cr+4]
+  bf16_t* Ws = reinterpret_cast<bf16_t*>(dg_smem + tile_floats);     // [NCT][WPH]
+  int* flag = reinterpret_cast<int*>(Ws + NCT * WPH);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x, n0 = blockIdx.y * NCT;                 // n0: first input channel (output column)
+  const int T = p.T, cin = p.cin, cout = p.cout, d = p.dil;
+  const long wrow = (long)cin * 3;
+  float* out = p.out + (long)blockIdx.z * p.slab_stride;
+  const int per_z = ((cout + CC - 1) / CC + (int)gridDim.z - 1) / (int)gridDim.z * CC;
+  const int cz0 = blockIdx.z * per_z;
+  const int cr = max(0, min(cout, cz0 + per_z) - cz0);
+  const int AP = cr + 4;
+  {
+    const int q4 = cr >> 2;
+    const bool form = p.dy == nullptr;
+    const bool keep = p.dy_out != nullptr && blockIdx.y == 0;
+    for (int q = tid; q < T * q4; q += 256) {
+      const int r = q / q4, c4 = (q - r * q4) << 2;
+      const long g = ((long)b * T + r) * cout + cz0 + c4;
+      f32x4 v;
+      if (form) {
+        const f32x4 k0 = load4(p.coef + cz0 + c4), k1 = load4(p.coef + cout + cz0 + c4),
+                    k2 = load4(p.coef + 2 * cout + cz0 + c4);
+        v = k0 * load4(p.dz + g) + k1 * load4(p.y + g) + k2;
+      } else {
+        v = load4(p.dy + g);
+      }
+      *reinterpret_cast<f32x4*>(&a_lds[r * AP + c4]) = v;
+      if (keep) store4(p.dy_out + g, v);
+    }
+    for (int q = tid; q < (ROWS + 1 - T) * AP; q += 256) a_lds[T * AP + q] = 0.f;
+  }
+  // weight chunk: 32 contraction channels co x (128 input channels x 3 taps = 384 contiguous floats)
+  // W[cz0 + c0 + co_l][(n0 ...) * 3 ...]: 12 float4 per thread, scattered transposed: Ws[ci_l][tap * 32 + co_l]
+  f32x4 rw[12];
+  auto load_w = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const int q = tid + j * 256;
+      const int co_l = q / 96, f = (q - co_l * 96) << 2;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c0 + co_l < cr && (long)n0 * 3 + f < wrow) v = load4(p.W + (long)(cz0 + c0 + co_l) * wrow + (long)n0 * 3 + f);
+      rw[j] = v;
+    }
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const int q = tid + j * 256;
+      const int co_l = q / 96, f = (q - co_l * 96) << 2;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int kk = f + m, ci_l = kk / 3, tap = kk - ci_l * 3;
+        Ws[ci_l * WPH + tap * CC + co_l] = (bf16_t)rw[j][m];
+      }
+    }
+  };
+  if (cr > 0) load_w(0);
+  __syncthreads();
+  const bool active = n0 + wave * 32 < cin;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int c0 = 0; c0 < cr; c0 += CC) {
+    if (c0 > 0) __syncthreads();
+    store_w();
+    __syncthreads();
+    if (c0 + CC < cr) load_w(c0 + CC);
+    if (active) {
+#pragma unroll
+      for (int st = 0; st < 6; ++st) {
+        const int tap = st >> 1, co_l = ((st & 1) << 4) + (half << 3);
+        const int rs = l31 + (2 - tap) * d;
+        const float* ap = (rs < T && c0 + co_l < cr) ? &a_lds[rs * AP + c0 + co_l] : &a_lds[ZROW * AP];
+        const bf16x8 av = cvt8(ap);
+        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(&Ws[(wave * 32 + l31) * WPH + tap * CC + co_l]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wv, acc, 0, 0, 0);
+      }
+    }
+  }
+  const int gn = n0 + wave * 32 + l31;
+  const bool ep = p.ep_stats != nullptr;
+  float esc = 0.f, esh = 0.f, emu = 0.f, ers = 0.f;
+  if (ep && gn < cin) { esc = p.ep_scale[gn]; esh = p.ep_shift[gn]; emu = p.ep_mean[gn]; ers = p.ep_rstd[gn]; }
+  float s1 = 0.f, s2 = 0.f;
+  if (active && gn < cin) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = (i & 3) + 8 * (i >> 2) + 4 * half;
+      if (r < T) {
+        float v = acc[i];
+        const long g = ((long)b * T + r) * cin + gn;
+        if (ep) {
+          const float yb = p.ep_y[g];
+          v *= elu_grad_from_pre(fmaf(yb, esc, esh));
+          s1 += v;
+          s2 += v * ((yb - emu) * ers);
+        }
+        out[g] = v;
+      }
+    }
+  }
+  if (ep) {
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (active && half == 0 && gn < cin) {
+      unsafeAtomicAdd(&p.ep_stats[((long)(b % p.nrep) * 2 + 0) * cin + gn], (double)s1);
+      unsafeAtomicAdd(&p.ep_stats[((long)(b % p.nrep) * 2 + 1) * cin + gn], (double)s2);
+    }
+  }
+  bn_tail_run(p.tail, tid, 256, gridDim.x * gridDim.y * gridDim.z, flag);
+}
+
 }  // namespace
 
 extern "C" int pcaa_dtc_conv_supported(int T, int cin, int cout) {
@@ -359,9 +610,9 @@ extern "C" int pcaa_dtc_conv_ksplit(int B, int cin, int cout) {
   return ks < chunks ? ks : chunks;
 }
 
-extern "C" int pcaa_dtc_conv_fwd(const float* src, const float* scale, const float* shift, const float* W, float* y,
-                                 float* col, double* stats, int nrep, int B, int T, int cin, int cout, int dilation,
-                                 int ksplit, long slab_stride, void* stream) {
+static int dtc_conv_fwd_impl(bool bf16, const float* src, const float* scale, const float* shift, const float* W, float* y,
+                             float* col, double* stats, int nrep, int B, int T, int cin, int cout, int dilation,
+                             int ksplit, long slab_stride, void* stream) {
   PCAA_CHECK_ARG(src && W && y && B >= 1 && dilation >= 1 && ksplit >= 1, "pcaa_dtc_conv_fwd: bad args");
   PCAA_CHECK_ARG(pcaa_dtc_conv_supported(T, cin, cout), "pcaa_dtc_conv_fwd: needs T <= %d, cin %% 4 == 0, cout %% 16 == 0",
                  ROWS);
@@ -377,8 +628,19 @@ extern "C" int pcaa_dtc_conv_fwd(const float* src, const float* scale, const flo
                  "pcaa_dtc_conv_fwd: ksplit > 1 writes slabs (no statistics): slab_stride >= B*T*cout");
   DtcFwdParams p{src, scale, shift, W, y, col, stats, B, T, cin, cout, dilation, nrep, ksplit > 1 ? slab_stride : 0,
                  (stats != nullptr && ksplit == 1) ? pcaa_take_bn_tail(stats) : BnTail{}};
-  hipLaunchKernelGGL(dtc_fwd_kernel, dim3(B, (cout + 31) / 32, ksplit), dim3(256), 0, as_stream(stream), p);
+  if (bf16) hipLaunchKernelGGL(dtc_fwd_bf16_kernel, dim3(B, (cout + NCT - 1) / NCT, ksplit), dim3(256), 0, as_stream(stream), p);
+  else hipLaunchKernelGGL(dtc_fwd_kernel, dim3(B, (cout + 31) / 32, ksplit), dim3(256), 0, as_stream(stream), p);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_dtc_conv_fwd");
+}
+extern "C" int pcaa_dtc_conv_fwd(const float* src, const float* scale, const float* shift, const float* W, float* y,
+                                 float* col, double* stats, int nrep, int B, int T, int cin, int cout, int dilation,
+                                 int ksplit, long slab_stride, void* stream) {
+  return dtc_conv_fwd_impl(false, src, scale, shift, W, y, col, stats, nrep, B, T, cin, cout, dilation, ksplit, slab_stride, stream);
+}
+extern "C" int pcaa_dtc_conv_fwd_bf16(const float* src, const float* scale, const float* shift, const float* W, float* y,
+                                      float* col, double* stats, int nrep, int B, int T, int cin, int cout, int dilation,
+                                      int ksplit, long slab_stride, void* stream) {
+  return dtc_conv_fwd_impl(true, src, scale, shift, W, y, col, stats, nrep, B, T, cin, cout, dilation, ksplit, slab_stride, stream);
 }
 
 /* channel split for the dgrad (its contraction runs over the OUTPUT channels of the convolution; a workgroup
@@ -389,11 +651,11 @@ extern "C" int pcaa_dtc_conv_dgrad_ksplit(int B, int cin, int cout) {
   return ks < 1 ? 1 : ks;
 }
 
-extern "C" int pcaa_dtc_conv_dgrad(const float* dy, const float* dz, const float* y, const float* coef, float* dy_out,
-                                   const float* W, float* out, const float* ep_y, const float* ep_scale,
-                                   const float* ep_shift, const float* ep_mean, const float* ep_rstd,
-                                   double* ep_stats, int nrep, int B, int T, int cin, int cout, int dilation,
-                                   int ksplit, long slab_stride, void* stream) {
+static int dtc_conv_dgrad_impl(bool bf16, const float* dy, const float* dz, const float* y, const float* coef, float* dy_out,
+                               const float* W, float* out, const float* ep_y, const float* ep_scale,
+                               const float* ep_shift, const float* ep_mean, const float* ep_rstd,
+                               double* ep_stats, int nrep, int B, int T, int cin, int cout, int dilation,
+                               int ksplit, long slab_stride, void* stream) {
   PCAA_CHECK_ARG(W && out && B >= 1 && dilation >= 1 && ksplit >= 1, "pcaa_dtc_conv_dgrad: bad args");
   PCAA_CHECK_ARG((dy != nullptr) != (dz != nullptr && y != nullptr && coef != nullptr),
                  "pcaa_dtc_conv_dgrad: either dy, or dz + y + coef");
@@ -411,21 +673,53 @@ extern "C" int pcaa_dtc_conv_dgrad(const float* dy, const float* dz, const float
   PCAA_CHECK_ARG(!ep || (ksplit == 1 && ep_y && ep_scale && ep_shift && ep_mean && ep_rstd && nrep >= 1),
                  "pcaa_dtc_conv_dgrad: the epilogue needs ksplit == 1 and ep_y, ep_scale, ep_shift, ep_mean, ep_rstd");
   const int tile = dg_tile_floats(per_z);
+  DtcDgradParams p{dy, dz, y, coef, dy_out, W, out, ep_y, ep_scale, ep_shift, ep_mean, ep_rstd, ep_stats, nrep,
+                   B, T, cin, cout, dilation, ksplit > 1 ? slab_stride : 0,
+                   ep ? pcaa_take_bn_tail(ep_stats) : BnTail{}};
+  if (bf16) {
+    const size_t lds16 = (size_t)tile * sizeof(float) + (size_t)NCT * WPH * sizeof(bf16_t) + 16;
+    static bool configured16 = false;
+    if (!configured16) {
+      const size_t cap = (size_t)dg_tile_floats(DG_MAX_CR) * sizeof(float) + (size_t)NCT * WPH * sizeof(bf16_t) + 16;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(dtc_dgrad_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)cap) != hipSuccess) {
+        pcaa_rearm_bn_tail(p.tail);
+        pcaa_set_error("pcaa_dtc_conv_dgrad_bf16: cannot raise the dynamic LDS limit");
+        return PCAA_ERR_LAUNCH;
+      }
+      configured16 = true;
+    }
+    hipLaunchKernelGGL(dtc_dgrad_bf16_kernel, dim3(B, (cin + NCT - 1) / NCT, ksplit), dim3(256), lds16, as_stream(stream), p, tile);
+    PCAA_RETURN_LAUNCH_STATUS("pcaa_dtc_conv_dgrad_bf16");
+  }
   const size_t lds = (size_t)(tile + 32 * WP + 2 * 8 * 32 + 4) * sizeof(float);     // + the finalize flag
   static bool configured = false;
   if (!configured) {
     const size_t cap = (size_t)(dg_tile_floats(DG_MAX_CR) + 32 * WP + 2 * 8 * 32 + 4) * sizeof(float);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(dtc_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)cap) != hipSuccess) {
+      pcaa_rearm_bn_tail(p.tail);
       pcaa_set_error("pcaa_dtc_conv_dgrad: cannot raise the dynamic LDS limit");
       return PCAA_ERR_LAUNCH;
     }
     configured = true;
   }
-  DtcDgradParams p{dy, dz, y, coef, dy_out, W, out, ep_y, ep_scale, ep_shift, ep_mean, ep_rstd, ep_stats, nrep,
-                   B, T, cin, cout, dilation, ksplit > 1 ? slab_stride : 0,
-                   ep ? pcaa_take_bn_tail(ep_stats) : BnTail{}};
   hipLaunchKernelGGL(dtc_dgrad_kernel, dim3(B, (cin + 31) / 32, ksplit), dim3(256), lds, as_stream(stream), p, tile);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_dtc_conv_dgrad");
 }
-
+extern "C" int pcaa_dtc_conv_dgrad(const float* dy, const float* dz, const float* y, const float* coef, float* dy_out,
+                                   const float* W, float* out, const float* ep_y, const float* ep_scale,
+                                   const float* ep_shift, const float* ep_mean, const float* ep_rstd,
+                                   double* ep_stats, int nrep, int B, int T, int cin, int cout, int dilation,
+                                   int ksplit, long slab_stride, void* stream) {
+  return dtc_conv_dgrad_impl(false, dy, dz, y, coef, dy_out, W, out, ep_y, ep_scale, ep_shift, ep_mean, ep_rstd, ep_stats, nrep,
+                             B, T, cin, cout, dilation, ksplit, slab_stride, stream);
+}
+extern "C" int pcaa_dtc_conv_dgrad_bf16(const float* dy, const float* dz, const float* y, const float* coef, float* dy_out,
+                                        const float* W, float* out, const float* ep_y, const float* ep_scale,
+                                        const float* ep_shift, const float* ep_mean, const float* ep_rstd,
+                                        double* ep_stats, int nrep, int B, int T, int cin, int cout, int dilation,
+                                        int ksplit, long slab_stride, void* stream) {
+  return dtc_conv_dgrad_impl(true, dy, dz, y, coef, dy_out, W, out, ep_y, ep_scale, ep_shift, ep_mean, ep_rstd, ep_stats, nrep,
+                             B, T, cin, cout, dilation, ksplit, slab_stride, stream);
+}

@@ -1110,6 +1110,24 @@ bool launch_v2_rag(const GemmParams& p, dim3 grid, hipStream_t s) {
   return true;
 }
 
+template <bool SPLIT>
+bool launch_v2rc(const GemmParams& p, dim3 grid, hipStream_t s) {
+  static bool configured = false;
+  auto kern = v2::gemm_bf16_v2rc_kernel<SPLIT>;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            v2::LDS_BYTES) != hipSuccess)
+      return false;
+    configured = true;
+  }
+  const PcaaLaunchEvents ev = pcaa_take_launch_events();
+  if (ev.start != nullptr)
+    hipExtLaunchKernelGGL(kern, grid, dim3(v2::NT), v2::LDS_BYTES, s, ev.start, ev.stop, 0, p);
+  else
+    hipLaunchKernelGGL(kern, grid, dim3(v2::NT), v2::LDS_BYTES, s, p);
+  return true;
+}
+
 template <typename TC, int EPI, bool SPLIT>
 bool launch_v2_inst(const GemmParams& p, dim3 grid, hipStream_t s) {
   return (p.M % BM) != 0 ? launch_v2_rag<TC, EPI, SPLIT, true>(p, grid, s) : launch_v2_rag<TC, EPI, SPLIT, false>(p, grid, s);
@@ -1213,6 +1231,15 @@ bool launch_dma(const GemmParams& p_in, dim3 grid_in, hipStream_t s) {
           decided = true;
         }
       }
+    }
+  }
+  if constexpr (ALAY == RC && BLAY == RC && EPI == EPI_PLAIN && sizeof(TC) == 4) {
+    // the weight gradients (slab split-K or a single K pass, no atomics): the 4-wave loop on the RC images
+    static const bool rc_on = [] { const char* e = getenv("PCAA_GEMM_V2_RC"); return !(e != nullptr && e[0] == '0'); }();
+    if (v2_enabled() && rc_on && !p.atomic && (p.M % BM) == 0 && (p.N % BN) == 0 && (p.k_per_split % BK) == 0 && buf &&
+        (p.ldc % 1) == 0 && p.colstats == nullptr && p.bias == nullptr) {
+      ok = p.seg_len > 0 ? launch_v2rc<true>(p, grid, s) : launch_v2rc<false>(p, grid, s);
+      decided = true;
     }
   }
   if (!decided && (p.M % BM) != 0) decided = true;      // a partial last row tile: the 4-wave loop only (ok stays false)

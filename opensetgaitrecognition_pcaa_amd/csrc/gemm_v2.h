@@ -535,4 +535,173 @@ __global__ __launch_bounds__(NT) void gemm_bf16_v2_kernel(GemmParams p) {
 #undef V2_REQ_B
 #undef V2_ADVANCE
 
+// ---------------------------------------------------------------------------------------------------- RC x RC (wgrad)
+// The weight gradients dW[cout, cin] = dy[P, cout]^T . a[P, cin]: both operands row-contiguous, the contraction runs
+// over the P rows (split into K ranges, one 256 x 256 tile of one range per workgroup, fp32 slabs out).  Same pipeline
+// as the KC x KC loop above -- 4 waves x 128 x 128, both operands requested two K steps ahead into two LDS stages, the
+// fragments of the next half-step in a second register set -- on the 8-wave kernel's RC images: a stage is [64 k][256
+// rows] as it lies in HBM (source-side XOR swizzle of the 16-B granules, dma_frag_offset<RC>), an MFMA fragment (8
+// consecutive k of one row) is two ds_read_b64_tr_b16 transpose reads, the MFMA shape is 32x32x16 (4 x 4 blocks per wave).
+// Counters of the 8-wave kernel on dW[1024,1024] (profiles/r04_gemm_counters.json): waves parked at s_waitcnt / the
+// step barrier 47 % of their cycles (the 4-wave KC loop: 16 %), 17 % more GPU cycles than the KC product of the same size.
+template <bool F16>
+__device__ __forceinline__ void mfma32(f32x16& c, const bf16x8& a, const bf16x8& b) {
+  if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// one fragment = two transpose reads 4 k-rows (2 KB) apart; both halves land in one 4-register tuple
+__device__ __forceinline__ void lds_read_tr(bf16x8& d, unsigned addr, int off) {
+  s16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+               : "=&v"(lo), "=&v"(hi) : "v"(addr), "n"(off), "n"(off + 2048));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo;
+  u.s.b = hi;
+  d = u.v;
+}
+// one 1-KB piece (2 k-rows x 512 B) of an RC stage image, p = 0..31
+__device__ __forceinline__ void piece_rc(buf_rsrc_t r, long ld, long krow, int col0, bf16_t* s_img, int p, const unsigned (&vo)[2]) {
+  const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(((krow + 2 * p) * ld + col0) * 2));
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(s_img + p * 512), 16, vo[p & 1], soff, 0, 0);
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(NT) void gemm_bf16_v2rc_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbm = p.M / BM, nbn = p.N / BN;
+  int tm, tn;
+  const int split = block_coords(p, nbm, nbn, tm, tn);
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nt = max(0, (kend - kbeg) / BK);
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+  const long lda = p.lda, ldb = p.ldb;
+  const int seg_len = SPLIT ? p.seg_len : p.K;                       // rows of the operands as they lie in memory
+  const buf_rsrc_t rA = make_rsrc(A, (long)seg_len * lda * 2), rB = make_rsrc(B, (long)seg_len * ldb * 2);
+  const int soA0 = SPLIT ? (int)p.seg_off_a[0] : 0, soA1 = SPLIT ? (int)p.seg_off_a[1] : 0, soA2 = SPLIT ? (int)p.seg_off_a[2] : 0;
+  const int soB0 = SPLIT ? (int)p.seg_off_b[0] : 0, soB1 = SPLIT ? (int)p.seg_off_b[1] : 0, soB2 = SPLIT ? (int)p.seg_off_b[2] : 0;
+  unsigned voA[2], voB[2];
+  piece_lane_offsets<RC>(lda, lane, voA);
+  piece_lane_offsets<RC>(ldb, lane, voB);
+  // fragment offsets (elements inside an operand image) of the wave's four 32-row blocks per operand
+  int offA[4], offB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    offA[i] = dma_frag_offset<RC>(wm * 128 + i * 32, lane);
+    offB[i] = dma_frag_offset<RC>(wn * 128 + i * 32, lane);
+  }
+  // request cursor over this workgroup's K range [kbeg, kend) of the (SPLIT: three-segment) contraction; behind the
+  // last step it wraps to the first one: the loop stays branch-free, the two surplus stages land in dead LDS
+  const int seg0 = SPLIT ? kbeg / seg_len : 0, lk0 = SPLIT ? kbeg - seg0 * seg_len : kbeg;
+  int lseg = seg0, lk = lk0, lcount = 0;
+#define V2RC_COLA() (tm * BM + (SPLIT ? (lseg == 0 ? soA0 : (lseg == 1 ? soA1 : soA2)) : 0))
+#define V2RC_COLB() (tn * BN + (SPLIT ? (lseg == 0 ? soB0 : (lseg == 1 ? soB1 : soB2)) : 0))
+#define V2RC_REQ_A(st, jj) piece_rc(rA, lda, lk, V2RC_COLA(), (st), wave * 8 + (jj), voA)
+#define V2RC_REQ_B(st, jj) piece_rc(rB, ldb, lk, V2RC_COLB(), (st) + OP_TILE, wave * 8 + (jj), voB)
+#define V2RC_ADVANCE()                                 \
+  do {                                                 \
+    lk += BK;                                          \
+    if (SPLIT && lk == seg_len) { lk = 0; ++lseg; }    \
+    if (++lcount >= nt) { lcount = 0; lseg = seg0; lk = lk0; } \
+  } while (0)
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  bf16x8 af[2][2][4], bfr[2][2][4];            // [register set][k-step inside the half][block]
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+  if (nt > 0) {
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) V2RC_REQ_B(smem, jj);
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) V2RC_REQ_A(smem, jj);
+    V2RC_ADVANCE();
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) V2RC_REQ_B(smem + STAGE, jj);
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) V2RC_REQ_A(smem + STAGE, jj);
+    V2RC_ADVANCE();
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lds_read_tr(bfr[0][ks][j], lds0 + (unsigned)offB[j] * 2, 32768 + ks * 8192);
+        lds_read_tr(af[0][ks][j], lds0 + (unsigned)offA[j] * 2, ks * 8192);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  int s = 0;
+  for (int kt = 0; kt < nt; ++kt) {
+    bf16_t* cur = smem + s * STAGE;
+    const unsigned cb = lds0 + (unsigned)s * (STAGE * 2), nb = lds0 + (unsigned)(s ^ 1) * (STAGE * 2);
+    unsigned aA[4], aB[4], nA[4], nB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      aA[i] = cb + (unsigned)offA[i] * 2;
+      aB[i] = cb + (unsigned)offB[i] * 2;
+      nA[i] = nb + (unsigned)offA[i] * 2;
+      nB[i] = nb + (unsigned)offB[i] * 2;
+    }
+    // ---------------- first half (k-steps 0, 1 of the stage): MFMAs on register set 0; k-steps 2, 3 are read into set 1
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+      const int ks = m >> 4, i = (m >> 2) & 3, j = m & 3;
+      if (m < 8) lds_read_tr(bfr[1][m >> 2][m & 3], aB[m & 3], 32768 + (2 + (m >> 2)) * 8192);
+      if (m == 10) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // B image of this stage: dead
+      if (m >= 11 && m < 19) V2RC_REQ_B(cur, m - 11);
+      if (m >= 12 && m < 20) lds_read_tr(af[1][(m - 12) >> 2][(m - 12) & 3], aA[(m - 12) & 3], (2 + ((m - 12) >> 2)) * 8192);
+      if (m == 23) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // A image: dead
+      if (m >= 24 && (m & 1) == 0) V2RC_REQ_A(cur, (m - 24) >> 1);
+      mfma32<SPLIT>(acc[i][j], af[0][ks][i], bfr[0][ks][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---------------- second half: MFMAs on set 1; the next stage's k-steps 0, 1 are read into set 0
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+      const int ks = m >> 4, i = (m >> 2) & 3, j = m & 3;
+      if (m < 8 && (m & 1) == 0) V2RC_REQ_A(cur, 4 + (m >> 1));
+      if (m == 10) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");        // stage t + 1 has landed
+      if (m >= 11 && m < 19) lds_read_tr(bfr[0][(m - 11) >> 2][(m - 11) & 3], nB[(m - 11) & 3], 32768 + ((m - 11) >> 2) * 8192);
+      if (m >= 19 && m < 27) lds_read_tr(af[0][(m - 19) >> 2][(m - 19) & 3], nA[(m - 19) & 3], ((m - 19) >> 2) * 8192);
+      mfma32<SPLIT>(acc[i][j], af[1][ks][i], bfr[1][ks][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    V2RC_ADVANCE();
+    s ^= 1;
+  }
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  // fp32 slab out: accumulator r of lane (c = lane & 31, half = lane >> 5) of block (i, j) is row 32 i + (r & 3) + 8 (r >> 2)
+  // + 4 half, column 32 j + c (32 lanes = 128 contiguous bytes of a row)
+  {
+    const float os = SPLIT ? p.out_scale : 1.f;
+    const int l31 = lane & 31, half = lane >> 5;
+    float* C = reinterpret_cast<float*>(p.C) + (long)split * p.c_split_stride + (long)(tm * BM + wm * 128 + 4 * half) * p.ldc +
+               tn * BN + wn * 128 + l31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          C[(long)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldc + j * 32] = SPLIT ? acc[i][j][r] * os : acc[i][j][r];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef V2RC_COLA
+#undef V2RC_COLB
+#undef V2RC_REQ_A
+#undef V2RC_REQ_B
+#undef V2RC_ADVANCE
+}
+
 }  // namespace v2

@@ -323,7 +323,7 @@ _MOMENT_STATS = os.environ.get("PCAA_MOMENT_STATS", "1") != "0"
 
 def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool_scale=1.0,
                        need_dinput=True, lhs=None, outs=None, below=None, below_W=None, dgrad_fn=None,
-                       below_bn=None, below_outs=None):
+                       below_bn=None, below_outs=None, wgrad_math=PCAA_F32):
     """Backward of one (linear, BN, ELU) layer.  ``lhs`` is the GEMM's left
     operand ([rows, K]: the input activation or the im2col matrix).  ``outs`` =
     (dW, dgamma, dbeta) destination views (dW PRE-ZEROED: the trainer's flat
@@ -396,12 +396,16 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
             else:
                 dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, math=PCAA_BF16)
     else:
-        sk = ops.pick_split_k(cout, K, rows_local)
+        # (wgrad_math = PCAA_BF16: the temporal block's weight gradients in the bf16 throughput mode -- the fp32 operands
+        # are rounded to bf16 on their way into the fragments of the 256x256-tile kernel; fp32 accumulate)
+        big = wgrad_math == PCAA_BF16 and cout >= 128 and K >= 128 and cout % 8 == 0
+        sk = ops.pick_split_k(cout, K, rows_local, target_blocks=256, bk=64, tile=256) if big else ops.pick_split_k(cout, K, rows_local)
+        wm = PCAA_BF16 if big else PCAA_F32
         if dW_out is not None:
             with _on_wgrad_stream(dy, lhs):
-                dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, split_k=sk, accumulate=True)
+                dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, split_k=sk, accumulate=True, math=wm)
         else:
-            dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, split_k=sk, accumulate=sk > 1)
+            dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, split_k=sk, accumulate=sk > 1, math=wm)
     if dgrad_done:
         pass
     elif need_dinput and dgrad_fn is not None:
@@ -539,7 +543,11 @@ _FUSE_DTC = True
 _FUSE_DTC_BWD = True
 
 
-def dtc_forward(a2d, B, T, layers, training, pool_time):
+# the temporal block's products on the bf16 MFMA pipe in the bf16 throughput mode (round 4; PCAA_DTC_BF16=0: exact fp32 as before)
+_DTC_BF16 = os.environ.get("PCAA_DTC_BF16", "1") != "0"
+
+
+def dtc_forward(a2d, B, T, layers, training, pool_time, mode="fp32"):
     """a2d: [B*T, Cin] fp32 rows (b,t).  Causal dilated conv = (implicit) im2col + contraction."""
     saves = []
     a = a2d
@@ -556,7 +564,8 @@ def dtc_forward(a2d, B, T, layers, training, pool_time):
             stats = ops.new_stats(cout, a.device) if training else None
             tail = ops.BnTailFwd(a.shape[0], conv.bias, bn, cout, sync=_sync_fn()) if training else None
             y, col = ops.dtc_conv_fwd(a, prev[0] if prev else None, prev[1] if prev else None, W2d, B, T,
-                                      layer.dilation, stats=stats, want_col=training, tail=tail)
+                                      layer.dilation, stats=stats, want_col=training, tail=tail,
+                                      bf16=(mode == "bf16" and _DTC_BF16))
             if training:
                 scale, shift, mean, rstd = tail.out
                 count = tail.count_out
@@ -585,8 +594,14 @@ def dtc_forward(a2d, B, T, layers, training, pool_time):
     return a, saves
 
 
-def dtc_backward(saves, layers, B, T, d_last=None, dpool=None, need_dx=True, gout=None, prefix="tc_block.dtc"):
+# measured (round 4, same box, 2 x 3 windows of 20 steps): N=128 5.64 / 5.56 on, 5.57 / 5.58 off; N=32 2.16 / 2.16 on, 2.13 / 2.09 off -- the
+# 256x256-tile kernel with an atomic epilogue is no better than the exact-fp32 128x128 one on these small products: off
+_DTC_WGRAD_BF16 = os.environ.get("PCAA_DTC_WGRAD_BF16", "0") != "0"
+
+
+def dtc_backward(saves, layers, B, T, d_last=None, dpool=None, need_dx=True, gout=None, prefix="tc_block.dtc", mode="fp32"):
     grads = []
+    wmath = PCAA_BF16 if (mode == "bf16" and _DTC_WGRAD_BF16) else PCAA_F32
     da = d_last
     for li in range(len(layers) - 1, -1, -1):
         layer, s = layers[li], saves[li]
@@ -613,17 +628,18 @@ def dtc_backward(saves, layers, B, T, d_last=None, dpool=None, need_dx=True, gou
                                           sync=_sync_fn())
                 out, stats, dy_used = ops.dtc_conv_dgrad(
                     dy, W2d, B, T, s.cin, s.dil, dz=dz, y=y, coef=coef, want_dy=dy is None,
-                    below=(sb.y, sb.scale, sb.shift, sb.mean, sb.rstd) if sb else None, tail=btail)
+                    below=(sb.y, sb.scale, sb.shift, sb.mean, sb.rstd) if sb else None, tail=btail,
+                    bf16=(mode == "bf16" and _DTC_BF16))
                 return (_FusedGrad(out, stats, fin=btail.out) if sb else out), dy_used
 
             dgrad_fn.forms_dy = s.cout <= 512
         if li == len(layers) - 1 and dpool is not None:
             dW, dg, db, dcol = _bn_layer_backward(s, bn, W2d, "fp32", dpool=dpool, group_rows=T,
                                                   pool_scale=1.0 / T, need_dinput=need_in, lhs=s.col, outs=outs,
-                                                  dgrad_fn=dgrad_fn)
+                                                  dgrad_fn=dgrad_fn, wgrad_math=wmath)
         else:
             dW, dg, db, dcol = _bn_layer_backward(s, bn, W2d, "fp32", da=da, need_dinput=need_in, lhs=s.col,
-                                                  outs=outs, dgrad_fn=dgrad_fn)
+                                                  outs=outs, dgrad_fn=dgrad_fn, wgrad_math=wmath)
         zb = gout[f"{prefix}{li + 1}.conv1d.bias"] if gout is not None else torch.zeros_like(conv.bias)
         grads.append({"conv1d.weight": dW.view_as(conv.weight), "conv1d.bias": zb,
                       "batch_norm.weight": dg, "batch_norm.bias": db})
@@ -798,7 +814,7 @@ def encoder_forward(enc, x, training, mode=None, gph=None):
     x2, st.pn = pointnet_forward(xp, enc.pc_block.layers(), training, mode, pool_rows=N)   # [B*T, 1024]
     st.x2 = x2
     mark("enc_fwd.pointnet")
-    x4, st.dtc = dtc_forward(x2, B, T, enc.tc_block.layers(), training, pool_time=True)     # [B, 512]
+    x4, st.dtc = dtc_forward(x2, B, T, enc.tc_block.layers(), training, pool_time=True, mode=mode)     # [B, 512]
     st.x4 = x4
     mark("enc_fwd.dtc")
     st.h = st.hproj = None
@@ -893,7 +909,7 @@ def encoder_backward(enc, st, d_logits, d_supfv, need_dx=False, gout=None, befor
     mark("enc_bwd.heads")
     if after_heads is not None:
         after_heads()            # trainer hook: the heads' backward is enqueued, the temporal block follows
-    dg, dx2 = dtc_backward(st.dtc, enc.tc_block.layers(), B, T, dpool=dx4, need_dx=True, gout=gout)
+    dg, dx2 = dtc_backward(st.dtc, enc.tc_block.layers(), B, T, dpool=dx4, need_dx=True, gout=gout, mode=st.mode)
     mark("enc_bwd.dtc")
     for i, d in enumerate(dg, start=1):
         for k, v in d.items():

@@ -1605,7 +1605,7 @@ def dtc_conv_supported(T, cin, cout):
     return bool(_lib.load().pcaa_dtc_conv_supported(int(T), int(cin), int(cout)))
 
 
-def dtc_conv_fwd(src, scale, shift, W2d, B, T, dilation, stats=None, want_col=False, tail=None):
+def dtc_conv_fwd(src, scale, shift, W2d, B, T, dilation, stats=None, want_col=False, tail=None, bf16=False):
     """One DilTempConv1d layer forward in one launch (see pcaa_dtc_conv_fwd): returns (y, col or None)."""
     _chk(src, "dtc_conv_fwd.src", torch.float32, 2)
     _chk(W2d, "dtc_conv_fwd.W", torch.float32, 2)
@@ -1625,11 +1625,12 @@ def dtc_conv_fwd(src, scale, shift, W2d, B, T, dilation, stats=None, want_col=Fa
     y = torch.empty((rows, cout), dtype=torch.float32, device=src.device)
     col = torch.empty((rows, cin * 3), dtype=torch.float32, device=src.device) if want_col else None
     lib = _lib.load()
+    fwd = lib.pcaa_dtc_conv_fwd_bf16 if bf16 else lib.pcaa_dtc_conv_fwd       # bf16: the throughput mode's MFMA variant
     ksplit = lib.pcaa_dtc_conv_ksplit(B, cin, cout)
     if ksplit > 1:
         stride = rows * cout
         slabs = torch.empty(ksplit * stride, dtype=torch.float32, device=src.device)
-        check(lib.pcaa_dtc_conv_fwd(_p(src), _p(scale), _p(shift), _p(W2d), _p(slabs), _p(col), None, NREP,
+        check(fwd(_p(src), _p(scale), _p(shift), _p(W2d), _p(slabs), _p(col), None, NREP,
                                     B, T, cin, cout, int(dilation), ksplit, stride, _s()), "pcaa_dtc_conv_fwd")
         if stats is not None:
             check(lib.pcaa_splitk_reduce_stats(_p(slabs), ksplit, stride, _p(y), _p(stats), NREP, rows, cout, _s()),
@@ -1641,14 +1642,15 @@ def dtc_conv_fwd(src, scale, shift, W2d, B, T, dilation, stats=None, want_col=Fa
         return y, col
     if tail is not None and stats is not None:
         tail.arm(stats)
-    check(lib.pcaa_dtc_conv_fwd(_p(src), _p(scale), _p(shift), _p(W2d), _p(y), _p(col), _p(stats), NREP,
-                                B, T, cin, cout, int(dilation), 1, 0, _s()), "pcaa_dtc_conv_fwd")
+    check(fwd(_p(src), _p(scale), _p(shift), _p(W2d), _p(y), _p(col), _p(stats), NREP,
+              B, T, cin, cout, int(dilation), 1, 0, _s()), "pcaa_dtc_conv_fwd")
     if tail is not None and stats is not None:
         tail.resolve(stats)
     return y, col
 
 
-def dtc_conv_dgrad(dy, W2d, B, T, cin, dilation, dz=None, y=None, coef=None, want_dy=False, below=None, tail=None):
+def dtc_conv_dgrad(dy, W2d, B, T, cin, dilation, dz=None, y=None, coef=None, want_dy=False, below=None, tail=None,
+                   bf16=False):
     """Adjoint of the causal dilated convolution w.r.t. its input in one launch (pcaa_dtc_conv_dgrad).
     ``dy`` [B*T,cout], or None with ``dz``, ``y``, ``coef``: dy is formed on load (``want_dy``: also returned).
     ``below`` = (y, scale, shift, mean, rstd) of the layer below: the result is that layer's dz and its
@@ -1670,6 +1672,7 @@ def dtc_conv_dgrad(dy, W2d, B, T, cin, dilation, dz=None, y=None, coef=None, wan
     out = torch.empty((rows, cin), dtype=torch.float32, device=dev)
     dy_out = torch.empty((rows, cout), dtype=torch.float32, device=dev) if (want_dy and dy is None) else None
     ks = lib.pcaa_dtc_conv_dgrad_ksplit(B, cin, cout)
+    dgrad = lib.pcaa_dtc_conv_dgrad_bf16 if bf16 else lib.pcaa_dtc_conv_dgrad
     stats = None
     ep = [None] * 5
     if below is not None:
@@ -1684,14 +1687,14 @@ def dtc_conv_dgrad(dy, W2d, B, T, cin, dilation, dz=None, y=None, coef=None, wan
     if ks > 1:
         stride = rows * cin
         slabs = torch.empty(ks * stride, dtype=torch.float32, device=dev)
-        check(lib.pcaa_dtc_conv_dgrad(_p(dy), _p(dz), _p(y), _p(coef), _p(dy_out), _p(W2d), _p(slabs), None, None, None,
+        check(dgrad(_p(dy), _p(dz), _p(y), _p(coef), _p(dy_out), _p(W2d), _p(slabs), None, None, None,
                                       None, None, None, NREP, B, T, cin, cout, int(dilation), ks, stride, _s()),
               "pcaa_dtc_conv_dgrad")
         check(lib.pcaa_splitk_reduce(_p(slabs), ks, stride, stride, _p(out), 0, _s()), "pcaa_splitk_reduce")
     else:
         if tail is not None and stats is not None:
             tail.arm(stats)
-        check(lib.pcaa_dtc_conv_dgrad(_p(dy), _p(dz), _p(y), _p(coef), _p(dy_out), _p(W2d), _p(out), *[_p(t) for t in ep],
+        check(dgrad(_p(dy), _p(dz), _p(y), _p(coef), _p(dy_out), _p(W2d), _p(out), *[_p(t) for t in ep],
                                       _p(stats), NREP, B, T, cin, cout, int(dilation), 1, 0, _s()),
               "pcaa_dtc_conv_dgrad")
         if tail is not None and stats is not None:

@@ -974,3 +974,69 @@ def test_gemm_split3_partial_row_tile():
     ref = a.double().cpu() @ w.double().cpu().t()
     assert (y.double().cpu() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
     assert (stats.sum(0).cpu()[0] - ref.sum(0)).abs().max().item() <= 1e-5 * ref.abs().sum(0).max().item()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# temporal block on the bf16 MFMA pipe (round 4: the bf16 throughput mode's variants of the two kernels)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,T,cin,cout,d,act", [(3, 30, 16, 32, 2, True), (2, 30, 1024, 16, 1, False), (5, 30, 256, 512, 4, True),
+                                                (64, 30, 128, 256, 2, True), (4, 30, 32, 64, 4, True), (2, 17, 64, 128, 1, True)])
+def test_dtc_conv_fwd_bf16_variant(B, T, cin, cout, d, act):
+    """pcaa_dtc_conv_fwd_bf16 against fp64 conv1d of the bf16-ROUNDED operands (the kernel rounds the activated input
+    and the weights as it builds the fragments; products exact, fp32 accumulate) and against the exact-fp32 kernel at
+    the bf16 tolerance; statistics of its own output; the im2col matrix is the fp32 one, unchanged."""
+    src = _rand((B * T, cin), 31)
+    W = _rand((cout, cin, 3), 32, (3 * cin) ** -0.5)
+    scale = (_rand((cin,), 33, 0.3) + 1.0) if act else None
+    shift = _rand((cin,), 34, 0.3) if act else None
+    args = (src.to(DEV), scale.to(DEV) if act else None, shift.to(DEV) if act else None, W.view(cout, cin * 3).to(DEV), B, T, d)
+    stats = torch.zeros((ops.NREP, 2, cout), dtype=torch.float64, device=DEV)
+    y16, col16 = ops.dtc_conv_fwd(*args, stats=stats, want_col=True, bf16=True)
+    y32, col32 = ops.dtc_conv_fwd(*args, want_col=True)
+    assert torch.equal(col16, col32)
+    # reference on the rounded operands: the activation as the kernel stages it (fp32 ELU of the fp32 affine), rounded
+    a = src.to(DEV)
+    if act:
+        a = ops.bn_act_fwd(a, scale.to(DEV), shift.to(DEV))
+    a16 = a.bfloat16().double().cpu().view(B, T, cin).permute(0, 2, 1)
+    ref = torch.nn.functional.conv1d(a16, W.bfloat16().double(), padding=2 * d, dilation=d)[:, :, :-2 * d]
+    ref = ref.permute(0, 2, 1).reshape(B * T, cout)
+    scl = ref.abs().max().item()
+    assert (y16.cpu().double() - ref).abs().max().item() <= 3e-5 * scl + 1e-6, "fp32 accumulation of exact bf16 products"
+    assert (y16 - y32).abs().max().item() <= 2e-2 * y32.abs().max().item()
+    st = stats.sum(0).cpu()
+    assert torch.allclose(st[0], y16.double().cpu().sum(0), rtol=1e-5, atol=1e-5 * scl * (B * T) ** 0.5)
+    assert torch.allclose(st[1], (y16.double().cpu() ** 2).sum(0), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,T,cin,cout,d", [(3, 30, 16, 32, 2), (2, 30, 1024, 16, 1), (5, 30, 256, 512, 4), (64, 30, 32, 64, 4),
+                                            (4, 30, 128, 256, 2)])
+def test_dtc_conv_dgrad_bf16_variant(B, T, cin, cout, d):
+    """pcaa_dtc_conv_dgrad_bf16 with the fused BatchNorm halves (dy formed on load, ELU' + statistics of the layer below)
+    against the exact-fp32 kernel: dy identical (formed in fp32 before the rounding), dz_below and the statistics at the
+    bf16 tolerance, and exact on bf16-representable operands."""
+    W2d = _rand((cout, cin * 3), 101, (3 * cin) ** -0.5).to(DEV)
+    dz, y = _rand((B * T, cout), 102).to(DEV), _rand((B * T, cout), 103).to(DEV)
+    coef = torch.stack([_rand((cout,), 104, 0.3) + 1.0, _rand((cout,), 105, 0.1), _rand((cout,), 106, 0.1)]).to(DEV).contiguous()
+    yb = _rand((B * T, cin), 107).to(DEV)
+    scale, shift = (_rand((cin,), 108, 0.3) + 1.0).to(DEV), _rand((cin,), 109, 0.3).to(DEV)
+    mean, rstd = _rand((cin,), 110, 0.2).to(DEV), (_rand((cin,), 111, 0.1).abs() + 0.8).to(DEV)
+    fused = cout <= 512
+    kw = dict(dz=dz, y=y, coef=coef, want_dy=True, below=(yb, scale, shift, mean, rstd)) if fused else {}
+    dy_in = None if fused else ops.bn_bwd_dy(dz, y, coef)
+    o32 = ops.dtc_conv_dgrad(dy_in, W2d, B, T, cin, d, **kw)
+    o16 = ops.dtc_conv_dgrad(dy_in, W2d, B, T, cin, d, bf16=True, **kw)
+    if fused:
+        assert torch.equal(o16[2], o32[2])
+        scl = o32[0].abs().max().item()
+        assert (o16[0] - o32[0]).abs().max().item() <= 2e-2 * scl
+        s16, s32 = o16[1].sum(0), o32[1].sum(0)
+        assert (s16 - s32).abs().max().item() <= 2e-2 * s32.abs().max().item() + 1e-3 * scl * (B * T) ** 0.5
+    else:
+        assert (o16[0] - o32[0]).abs().max().item() <= 2e-2 * o32[0].abs().max().item()
+    # exact on bf16-representable operands (small integers): the two kernels then agree to fp32 summation order
+    Wi = torch.randint(-3, 4, (cout, cin * 3), device=DEV).float()
+    dyi = torch.randint(-4, 5, (B * T, cout), device=DEV).float()
+    a32, _, _ = ops.dtc_conv_dgrad(dyi, Wi, B, T, cin, d)
+    a16, _, _ = ops.dtc_conv_dgrad(dyi, Wi, B, T, cin, d, bf16=True)
+    assert torch.equal(a16, a32)

@@ -31,12 +31,13 @@ for li in range(6):
     sh = torch.randn(cin, device=dev) * 0.1
     W = torch.randn(cout, cin * 3, device=dev) * 0.05
     stats = torch.zeros(ops.NREP, 2, cout, dtype=torch.float64, device=dev)
-    t_full = timed(lambda: ops.dtc_conv_fwd(src, sc, sh, W, B, T, d, stats=stats, want_col=True))
-    t_nocol = timed(lambda: ops.dtc_conv_fwd(src, sc, sh, W, B, T, d, stats=stats, want_col=False))
-    t_bare = timed(lambda: ops.dtc_conv_fwd(src, sc, sh, W, B, T, d, stats=None, want_col=False))
-    t_noact = timed(lambda: ops.dtc_conv_fwd(src, None, None, W, B, T, d, stats=None, want_col=False))
-    dy = torch.randn(B * T, cout, device=dev)
-    t_dg = timed(lambda: ops.dtc_conv_dgrad(dy, W, B, T, cin, d))
-    fl = 2.0 * B * T * cin * 3 * cout
-    print(f"layer {li + 1} {cin:4d}->{cout:3d} d={d}: fwd {t_full:6.1f} us (no col {t_nocol:6.1f}, no col/stats {t_bare:6.1f}, "
-          f"no activation on load {t_noact:6.1f})  dgrad {t_dg:6.1f} us   {fl / 1e9:.2f} GFLOP")
+    for bf16 in (False, True):
+        t_full = timed(lambda: ops.dtc_conv_fwd(src, sc, sh, W, B, T, d, stats=stats, want_col=True, bf16=bf16))
+        t_nocol = timed(lambda: ops.dtc_conv_fwd(src, sc, sh, W, B, T, d, stats=stats, want_col=False, bf16=bf16))
+        t_bare = timed(lambda: ops.dtc_conv_fwd(src, sc, sh, W, B, T, d, stats=None, want_col=False, bf16=bf16))
+        t_noact = timed(lambda: ops.dtc_conv_fwd(src, None, None, W, B, T, d, stats=None, want_col=False, bf16=bf16))
+        dy = torch.randn(B * T, cout, device=dev)
+        t_dg = timed(lambda: ops.dtc_conv_dgrad(dy, W, B, T, cin, d, bf16=bf16))
+        fl = 2.0 * B * T * cin * 3 * cout
+        print(f"layer {li + 1} {cin:4d}->{cout:3d} d={d} {'bf16' if bf16 else 'fp32'}: fwd {t_full:6.1f} us (no col {t_nocol:6.1f}, no col/stats {t_bare:6.1f}, "
+              f"no activation on load {t_noact:6.1f})  dgrad {t_dg:6.1f} us   {fl / 1e9:.2f} GFLOP")
