@@ -15,6 +15,8 @@ LIB = os.path.join(PKG, "libpcaa_hip.so")
 STAMP = os.path.join(PKG, "csrc", ".build_stamp")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+# lab builds only (same-box A/B of a compile-time variant, e.g. PCAA_HIPCC_EXTRA=-DPCAA_V2_YRING=2); part of the digest
+FLAGS += os.environ.get("PCAA_HIPCC_EXTRA", "").split()
 
 
 def _hipcc():

@@ -27,6 +27,10 @@
 // registers are pending: every use sits behind an explicit s_waitcnt lgkmcnt(0) in this file.
 #pragma once
 
+#ifndef PCAA_V2_YRING
+#define PCAA_V2_YRING 2   // 16-row blocks of y kept in flight by the fused-dgrad epilogue.  4 measured the same in isolation and
+                          // +0.23 ms per STEP (the extra registers spill: 228 B of scratch per lane; docs/LAB_LOG.md section 9)
+#endif
 namespace v2 {
 
 constexpr int NT = 256;                       // threads: 4 waves
@@ -209,7 +213,10 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p, f32x4 (&a
   // the stored pre-activations of one 16-row block (4 rows per lane), requested one block ahead
   typedef typename std::conditional<kF32, f32x4, uint4>::type yraw_t;
   constexpr int YW = kF32 ? 2 : 1;                 // raw words of that type per row (8 columns)
-  yraw_t yv[2][4][YW];
+  // (round 4: with one 16-row block requested ahead the epilogue paid eight HBM round trips in sequence -- 7 us of a 35 us
+  // tile; now the whole tile's y is in flight at once (bf16: 32 x 16 B per lane; fp32: a ring of four blocks, three ahead))
+  constexpr int RING = PCAA_V2_YRING, AHEAD = RING - 1;
+  yraw_t yv[RING][4][YW];
   auto load_y = [&](int i, int b) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -222,18 +229,19 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p, f32x4 (&a
         yv[b][r][w] = *reinterpret_cast<const yraw_t*>(yp + (kF32 ? 4 * w : 0));
       }
   };
-  load_y(0, 0);
+#pragma unroll
+  for (int i = 0; i < AHEAD; ++i) load_y(i, i);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    if (i + 1 < 8) load_y(i + 1, (i + 1) & 1);
+    if (i + AHEAD < 8) load_y(i + AHEAD, (i + AHEAD) % RING);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       f32x2 y2[4];
       if constexpr (kF32) {
-        const f32x4 w0 = yv[i & 1][r][0], w1 = yv[i & 1][r][YW - 1];
+        const f32x4 w0 = yv[i % RING][r][0], w1 = yv[i % RING][r][YW - 1];
         y2[0] = f32x2{w0.x, w0.y}; y2[1] = f32x2{w0.z, w0.w}; y2[2] = f32x2{w1.x, w1.y}; y2[3] = f32x2{w1.z, w1.w};
       } else {
-        const uint4 w = yv[i & 1][r][0];
+        const uint4 w = yv[i % RING][r][0];
         y2[0] = f32x2{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u)};
         y2[1] = f32x2{__uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u)};
         y2[2] = f32x2{__uint_as_float(w.z << 16), __uint_as_float(w.z & 0xffff0000u)};

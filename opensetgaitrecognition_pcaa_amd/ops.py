@@ -183,7 +183,7 @@ class _KernelEvents:
 
 
 def _begin_timing(key):
-    return _KernelEvents() if key.startswith(("gemm_bf16_dma_kernel", "gemm_bf16_v2_kernel")) else _TorchEvents()
+    return _KernelEvents() if key.startswith(("gemm_bf16_dma_kernel", "gemm_bf16_v2_kernel", "gemm_bf16_v2rc_kernel")) else _TorchEvents()
 
 
 TIMER = None
@@ -340,6 +340,9 @@ def gemm_v2_enable(on=True):
     check(_lib.load().pcaa_gemm_v2_enable(int(bool(on))), "pcaa_gemm_v2_enable")
 
 
+_GEMM_V2_RC = os.environ.get("PCAA_GEMM_V2_RC", "1")[:1] != "0"     # read the same way by csrc/gemm_bf16.hip
+
+
 def _v2_takes(K, split_k=1, accumulate=False):
     """the dispatch rule of csrc/gemm_bf16.hip (launch_dma): the 4-wave loop takes a KC x KC launch without K splits whose
     contraction is at least five 64-deep steps long"""
@@ -353,6 +356,8 @@ def _dma_key(out_dtype, layout, v2=False):
     dt = 'bf16' if out_dtype == torch.bfloat16 else 'f32'
     if v2 and layout == KC:
         return f"gemm_bf16_v2_kernel<{dt},plain>"
+    if v2 and layout == RC and dt == 'f32' and _GEMM_V2["on"] and _GEMM_V2_RC:
+        return "gemm_bf16_v2rc_kernel<f32>"      # the weight gradients on the 4-wave loop (whole 256 x 256 tiles)
     lay = "KC" if layout == KC else "RC"
     return f"gemm_bf16_dma_kernel<{dt},{lay},{lay}>"
 
@@ -439,7 +444,7 @@ def gemm_slabs(A, a_layout, B, b_layout, M, N, K, split_k, out=None, accumulate=
     if timer is not None:
         dma = (math == PCAA_BF16 and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and a_layout == b_layout
                and M % 256 == 0 and N % 256 == 0 and K % 64 == 0)
-        key = _dma_key(torch.float32, a_layout) if dma else ("gemm_bf16_big_kernel" if math == PCAA_BF16 else "gemm_f32_kernel")
+        key = _dma_key(torch.float32, a_layout, M % 256 == 0 and N % 256 == 0 and (K // ns) % 64 == 0) if dma else ("gemm_bf16_big_kernel" if math == PCAA_BF16 else "gemm_f32_kernel")
         timer = timer if timer.wants(key) else None
     if timer is not None:
         ev = _begin_timing(key)
@@ -699,7 +704,8 @@ def gemm_slabs_split3(A, B, M, N, K, split_k, out=None):
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     timer = TIMER
-    key = "gemm_bf16_dma_kernel<f32,split3>"
+    key = ("gemm_bf16_v2rc_kernel<f32,split3>" if (_GEMM_V2["on"] and _GEMM_V2_RC and M % 256 == 0 and N % 256 == 0)
+           else "gemm_bf16_dma_kernel<f32,split3>")
     timer = timer if (timer is not None and timer.wants(key)) else None
     if timer is not None:
         ev = _begin_timing(key)

@@ -19,6 +19,8 @@ _V2_EPI = {"0": "plain", "1": "dgrad_bn", "3": "affine_elu", "4": "affine_elu", 
 
 
 def key_of(name):
+    if "gemm_bf16_v2rc_kernel" in name:     # the weight gradients on the 4-wave loop (SPLIT = false in the bf16 step)
+        return "gemm_bf16_v2rc_kernel<f32>" if ("Lb0E" in name or "<false>" in name) else "gemm_bf16_v2rc_kernel<f32,split3>"
     # round 4: the 4-wave tile loop, (anonymous namespace)::v2::gemm_bf16_v2_kernel<TC, EPI, SPLIT> -> ops.py's keys
     m = re.match(r"_ZN12_GLOBAL__N_12v219gemm_bf16_v2_kernelI(DF16b|f)Li(\d)ELb(\d)E", name)
     if m is None and "gemm_bf16_v2_kernel<bool _Accum, int, E, false, false>" in name:
