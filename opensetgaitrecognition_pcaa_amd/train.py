@@ -34,6 +34,11 @@ _ALIGN = 64  # floats; keeps every parameter view 256-B aligned inside the flat 
 _SIDE_STREAMS = {}
 
 
+# where the decoder's side-stream update is enqueued: "dec_bwd" (right after the decoder backward), "heads" (after the MLP
+# heads' backward launch), "pointnet" (before the PointNet backward); re-measured each time the kernels around it change
+_SIDE_ADAM_AT = os.environ.get("PCAA_SIDE_ADAM_AT", "dec_bwd")
+
+
 def _side_streams(device):
     """(adam, critic, wgrad) streams of ``device``, created on first use"""
     if device.type != "cuda":
@@ -833,7 +838,13 @@ class PCAATrainer:
 
             # right after the decoder backward, i.e. beside the heads' and the temporal block's backward (measured
             # against "after the heads' launch" 6.576 | 6.621 and "beside the PointNet backward GEMMs" 6.90 ms/step)
-            launch_side_adam()
+            at = _SIDE_ADAM_AT
+            if at == "pointnet":
+                hook = launch_side_adam
+            elif at == "heads":
+                hook_heads = launch_side_adam
+            else:
+                launch_side_adam()
         try:
             gv = self.flat_g.grad_views
             F_hip.encoder_backward(enc, st, dlogits if supervise else None, dsup, gout=self._enc_grads,
