@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--windows", type=int, default=5,
                     help="the timed region (exactly --steps steps between barrier + synchronize) is repeated this many "
                          "times; ms_per_step / value are the MEDIAN window, all windows are in config.windows_ms_per_step")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp16x3"])
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--points", type=int, default=128)
     ap.add_argument("--features", type=int, default=4)
@@ -352,7 +352,7 @@ def leg_infer(a, dev, steps, windows, with_cpu=False):
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    timer = ops.LaunchTimer(only_prefix="gemm_bf16_" if a.precision == "bf16" else "gemm_f32_kernel")
+    timer = ops.LaunchTimer(only_prefix="gemm_bf16_" if a.precision in ("bf16", "fp16x3") else "gemm_f32_kernel")
     ops.set_timer(timer)
     step()
     ops.set_timer(None)
@@ -522,7 +522,7 @@ def main():
         # HIP events on the kernel family the roofline reports: the start/stop events ride on the launch
         # itself (hipExtLaunchKernelGGL through pcaa_time_next_gemm), i.e. they are the kernel's own begin/end
         # timestamps -- the quantity rocprofv3's kernel trace reports -- on the stream it is launched on
-        timer = ops.LaunchTimer(only_prefix="gemm_bf16_" if a.precision == "bf16" else "gemm_f32_kernel")
+        timer = ops.LaunchTimer(only_prefix="gemm_bf16_" if a.precision in ("bf16", "fp16x3") else "gemm_f32_kernel")
     # the launches of the first `timed_steps` steps of the FIRST window carry the events
     # (graph mode: those steps run eagerly -- events cannot be read back from inside a replayed graph)
     timed_steps = min(a.steps, 2 if use_graph else 4) if timer is not None else 0

@@ -31,6 +31,29 @@ constexpr int LDS_BYTES = 2 * STAGE * 2;     // two stages: 128 KB
 #ifndef SCHED
 #define SCHED 1
 #endif
+#ifndef EXTRA
+#define EXTRA 0
+#endif
+#ifndef VARIANT
+#define VARIANT 0
+#endif
+// LAB knobs (timing only, results are garbage): drop one ingredient of the K loop to see what the step time is made of
+#ifndef NO_DMA
+#define NO_DMA 0
+#endif
+#ifndef NO_LDS
+#define NO_LDS 0
+#endif
+#ifndef NO_BAR
+#define NO_BAR 0
+#endif
+#if NO_BAR
+#define BAR_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define BAR_VM() asm volatile("s_waitcnt vmcnt(16)" ::: "memory")
+#else
+#define BAR_LGKM() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define BAR_VM() asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory")
+#endif
 #define SB() __builtin_amdgcn_sched_barrier(0)
 // The accumulators are pinned to the ACCUMULATOR register file ("a" constraint): left to the register allocator (the
 // builtin), a wave with 256 accumulator + 128 fragment registers got accumulators in both files, ~1 200
@@ -41,7 +64,11 @@ constexpr int LDS_BYTES = 2 * STAGE * 2;     // two stages: 128 KB
 // pending: every use is behind an explicit s_waitcnt lgkmcnt(0) placed in this file (before the two release barriers
 // and at the very end of the loop body -- ahead of any copy the back edge may need).
 __device__ __forceinline__ void lds_read(bf16x8& d, unsigned addr, int off) {
+#if NO_LDS
+  asm volatile("" : "+v"(d) : "v"(addr));
+#else
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(off));
+#endif
 }
 __device__ __forceinline__ void mfma(f32x4& c, const bf16x8& a, const bf16x8& b) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
@@ -123,8 +150,8 @@ __global__ __launch_bounds__(256) void gemm_v2(const bf16_t* __restrict__ A, con
       tile_coords(ntiles, nbn, lvb, ltm, ltn);
     }
   };
-  auto reqA = [&](bf16_t* st, int jj) { piece<false>(rA, K, ltm * BM, lkt * BK, st, wave * 8 + jj, voA); };
-  auto reqB = [&](bf16_t* st, int jj) { piece<true>(rB, K, ltn * BN, lkt * BK, st + OP_TILE, wave * 8 + jj, voB); };
+  auto reqA = [&](bf16_t* st, int jj) { if (!NO_DMA) piece<false>(rA, K, ltm * BM, lkt * BK, st, wave * 8 + jj, voA); };
+  auto reqB = [&](bf16_t* st, int jj) { if (!NO_DMA) piece<true>(rB, K, ltn * BN, lkt * BK, st + OP_TILE, wave * 8 + jj, voB); };
 
   f32x4 acc[8][8];
   bf16x8 af[2][8], bfr[2][8];
@@ -172,11 +199,20 @@ __global__ __launch_bounds__(256) void gemm_v2(const bf16_t* __restrict__ A, con
         const int i = m >> 3, j = m & 7;
         // second-half fragments of B, then of A, from the current stage
         if ((m & 1) == 1 && m < 16) lds_read(bfr[1][m >> 1], aB1, (m >> 1) * 2048);
-        if (m == 21) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // B image of this stage: dead
+#if VARIANT == 0
+        if (m == 21) BAR_LGKM();      // B image of this stage: dead
         if (m >= 24 && m < 40 && (m & 1) == 0) lds_read(af[1][(m - 24) >> 1], aA1, ((m - 24) >> 1) * 2048);
         if (m >= 23 && m < 39 && (m & 1) == 1) reqB(cur, (m - 23) >> 1);                  // 8 pieces of B(t + 2)
-        if (m == 46) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // A image: dead
+        if (m == 46) BAR_LGKM();      // A image: dead
         if (m >= 48 && (m & 3) == 0) reqA(cur, (m - 48) >> 2);                             // pieces 0..3 of A(t + 2)
+#elif VARIANT == 1
+        // B's requests one per FOUR MFMAs instead of every other one
+        if (m == 21) BAR_LGKM();
+        if (m >= 24 && m < 40 && (m & 1) == 0) lds_read(af[1][(m - 24) >> 1], aA1, ((m - 24) >> 1) * 2048);
+        if (m >= 23 && m < 55 && ((m - 23) & 3) == 0) reqB(cur, (m - 23) >> 2);
+        if (m == 46) BAR_LGKM();
+        if (m >= 49 && ((m - 49) & 3) == 0) reqA(cur, (m - 49) >> 2);
+#endif
         mfma(acc[i][j], af[0][i], bfr[0][j]);
 #if SCHED
         SB();
@@ -186,11 +222,15 @@ __global__ __launch_bounds__(256) void gemm_v2(const bf16_t* __restrict__ A, con
 #pragma unroll
       for (int m = 0; m < 64; ++m) {
         const int i = m >> 3, j = m & 7;
+#if VARIANT == 0
         if (m < 16 && (m & 3) == 0) reqA(cur, 4 + (m >> 2));                               // pieces 4..7 of A(t + 2)
+#elif VARIANT == 1
+        if (m < 16 && (m & 3) == 1) reqA(cur, 4 + (m >> 2));
+#endif
         // stage t + 1 has landed: everything but this step's own 16 requests (loads retire in order, so "at most 16
         // outstanding" means the older stage is complete whatever the previous tile's C stores -- which share the
         // counter -- are doing; they can only make the wait longer)
-        if (m == 20) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+        if (m == 20) BAR_VM();
         if (m >= 22 && m < 38 && (m & 1) == 0) lds_read(bfr[0][(m - 22) >> 1], aB0, ((m - 22) >> 1) * 2048);
         if (m >= 38 && m < 54 && (m & 1) == 0) lds_read(af[0][(m - 38) >> 1], aA0, ((m - 38) >> 1) * 2048);
         mfma(acc[i][j], af[1][i], bfr[1][j]);
@@ -198,6 +238,17 @@ __global__ __launch_bounds__(256) void gemm_v2(const bf16_t* __restrict__ A, con
         SB();
 #endif
       }
+#if EXTRA
+      // LAB: a third product per step on fragments already in registers (the split-fp16 mode's hi*lo term would be one):
+      // does the delivery-bound loop absorb 50 % more MFMAs?
+#pragma unroll
+      for (int m = 0; m < 64; ++m) {
+        mfma(acc[m >> 3][m & 7], af[1][m >> 3], bfr[1][m & 7]);
+#if SCHED
+        SB();
+#endif
+      }
+#endif
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next step's first-half fragments are in their registers
       advance();
       s ^= 1;
@@ -299,10 +350,14 @@ int main(int argc, char** argv) {
     printf("%s\n", hipGetErrorString(hipGetLastError()));
     return bad;
   }
+  const bool lab = NO_DMA || NO_LDS || NO_BAR;
+  if (VARIANT) printf("VARIANT=%d\n", VARIANT);
+  if (lab) printf("NO_DMA=%d NO_LDS=%d NO_BAR=%d EXTRA=%d\n", NO_DMA, NO_LDS, NO_BAR, EXTRA);
   for (int K : {512, 1024})
     for (int N : {512, 1024}) {
+      if (lab && !(K == 1024 && N == 1024)) continue;
       run<false>(A, B, C, sink, M, N, K);
-      run<true>(A, B, C, sink, M, N, K);
+      if (!lab) run<true>(A, B, C, sink, M, N, K);
     }
   (void)hipDeviceSynchronize();
   printf("%s\n", hipGetErrorString(hipGetLastError()));
