@@ -543,10 +543,21 @@ _FUSE_DTC = True
 _FUSE_DTC_BWD = True
 
 
-# PCAA_DTC_BF16=1 runs the temporal block's products on the bf16 MFMA pipe in the bf16 throughput mode.  Round 4 measured it
-# at the same time per layer and per step as the fp32-pipe kernels (the block is bound by its LDS image, not by MFMA rate:
-# docs/LAB_LOG.md section 9), so the default stays the exact fp32 products; the variant is kept, tested, behind this switch.
-_DTC_BF16 = os.environ.get("PCAA_DTC_BF16", "0") != "0"
+# The temporal block's products in the bf16 throughput mode (PCAA_DTC_BF16): "wide" (default) = the bf16 matrix pipe where
+# the two-sequence kernels take the layer (contraction over >= 128 channels, >= 64 output channels: layers 5 and 6 and
+# their adjoints -- csrc/dtc_fused.hip, dtc_pair_kernel), exact fp32 products elsewhere; "all" = the one-sequence bf16
+# variants as well (measured no faster than their fp32 forms: docs/LAB_LOG.md section 9); "0" = fp32 products everywhere.
+_DTC_BF16 = os.environ.get("PCAA_DTC_BF16", "wide")
+
+
+def _dtc_bf16(mode, kc, nc):
+    """kc: channels the product contracts over, nc: channels it produces (forward: cin, cout; adjoint: cout, cin) --
+    the same rule as pair_takes() in csrc/dtc_fused.hip"""
+    if mode != "bf16" or _DTC_BF16 == "0":
+        return False
+    if _DTC_BF16 in ("all", "1"):
+        return True
+    return kc >= 128 and kc % 32 == 0 and nc >= 64 and nc % 4 == 0 and os.environ.get("PCAA_DTC_PAIR", "1") != "0"
 
 
 def dtc_forward(a2d, B, T, layers, training, pool_time, mode="fp32"):
@@ -567,7 +578,7 @@ def dtc_forward(a2d, B, T, layers, training, pool_time, mode="fp32"):
             tail = ops.BnTailFwd(a.shape[0], conv.bias, bn, cout, sync=_sync_fn()) if training else None
             y, col = ops.dtc_conv_fwd(a, prev[0] if prev else None, prev[1] if prev else None, W2d, B, T,
                                       layer.dilation, stats=stats, want_col=training, tail=tail,
-                                      bf16=(mode == "bf16" and _DTC_BF16))
+                                      bf16=_dtc_bf16(mode, cin, cout))
             if training:
                 scale, shift, mean, rstd = tail.out
                 count = tail.count_out
@@ -631,7 +642,7 @@ def dtc_backward(saves, layers, B, T, d_last=None, dpool=None, need_dx=True, gou
                 out, stats, dy_used = ops.dtc_conv_dgrad(
                     dy, W2d, B, T, s.cin, s.dil, dz=dz, y=y, coef=coef, want_dy=dy is None,
                     below=(sb.y, sb.scale, sb.shift, sb.mean, sb.rstd) if sb else None, tail=btail,
-                    bf16=(mode == "bf16" and _DTC_BF16))
+                    bf16=_dtc_bf16(mode, s.cout, s.cin))
                 return (_FusedGrad(out, stats, fin=btail.out) if sb else out), dy_used
 
             dgrad_fn.forms_dy = s.cout <= 512

@@ -657,7 +657,11 @@ def test_heads_fwd_large_batch_and_unsupported_backward():
 # ---------------------------------------------------------------- fused temporal-block layer (dtc_fused.hip)
 @pytest.mark.parametrize("B,T,cin,cout,d,act", [(3, 30, 16, 32, 2, True), (2, 30, 1024, 16, 1, False),
                                                 (5, 30, 256, 512, 4, True), (4, 7, 64, 128, 1, True),
-                                                (64, 30, 32, 64, 4, True)])
+                                                (64, 30, 32, 64, 4, True),
+                                                # the two-sequence kernels (round 4): 64-column and 32-column workgroups,
+                                                # an odd batch, a short sequence, a ragged last chunk of columns
+                                                (64, 30, 256, 512, 4, True), (64, 30, 128, 256, 2, True),
+                                                (5, 17, 128, 80, 2, True), (7, 30, 160, 64, 1, False)])
 def test_dtc_conv_fwd_vs_fp64_conv1d(B, T, cin, cout, d, act):
     """Implicit-im2col causal dilated Conv1d (models.py:59-68, 75-76: padding 2d both sides, last 2d
     outputs dropped) with the previous layer's BatchNorm+ELU applied on load, against fp64 torch."""
@@ -737,7 +741,11 @@ def test_wgan_gp_dz_vs_autograd():
 
 
 @pytest.mark.parametrize("B,T,cin,cout,d", [(3, 30, 16, 32, 2), (2, 30, 1024, 16, 1), (5, 30, 256, 512, 4),
-                                            (4, 7, 64, 128, 1), (64, 30, 32, 64, 4), (2, 30, 20, 36, 2)])
+                                            (4, 7, 64, 128, 1), (64, 30, 32, 64, 4), (2, 30, 20, 36, 2),
+                                            # the two-sequence kernels: two staging passes (512 contraction channels),
+                                            # 64-column workgroups, an odd batch with a short sequence
+                                            (64, 30, 256, 512, 4), (64, 30, 384, 128, 1), (5, 17, 80, 160, 2),
+                                            (64, 30, 128, 256, 2)])
 def test_dtc_conv_dgrad_vs_fp64_autograd(B, T, cin, cout, d):
     """Adjoint of the causal dilated convolution w.r.t. its input (implicit col2im) against fp64 autograd of
     conv1d(padding=2d)[..., :-2d] (models.py:59-68, 75-76), and against the unfused dcol = dy.W + col2im."""
@@ -756,7 +764,8 @@ def test_dtc_conv_dgrad_vs_fp64_autograd(B, T, cin, cout, d):
     assert (da - two).abs().max().item() <= 1e-5 * scl
 
 
-@pytest.mark.parametrize("B,T,cin,cout,d", [(3, 30, 16, 32, 2), (5, 30, 256, 512, 4), (64, 30, 32, 64, 4)])
+@pytest.mark.parametrize("B,T,cin,cout,d", [(3, 30, 16, 32, 2), (5, 30, 256, 512, 4), (64, 30, 32, 64, 4),
+                                            (64, 30, 256, 512, 4), (64, 30, 384, 128, 1), (7, 19, 128, 256, 2)])
 def test_dtc_conv_dgrad_fused_bn_halves(B, T, cin, cout, d):
     """dy formed on load (dy = c0*dz + c1*y + c2) and the epilogue for the layer below (dz_below = da*ELU'(z),
     statistics {sum dz, sum dz*yhat}) against the separate passes."""
@@ -980,7 +989,8 @@ def test_gemm_split3_partial_row_tile():
 # temporal block on the bf16 MFMA pipe (round 4: the bf16 throughput mode's variants of the two kernels)
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,T,cin,cout,d,act", [(3, 30, 16, 32, 2, True), (2, 30, 1024, 16, 1, False), (5, 30, 256, 512, 4, True),
-                                                (64, 30, 128, 256, 2, True), (4, 30, 32, 64, 4, True), (2, 17, 64, 128, 1, True)])
+                                                (64, 30, 128, 256, 2, True), (4, 30, 32, 64, 4, True), (2, 17, 64, 128, 1, True),
+                                                (64, 30, 256, 512, 4, True), (5, 17, 128, 80, 2, True)])
 def test_dtc_conv_fwd_bf16_variant(B, T, cin, cout, d, act):
     """pcaa_dtc_conv_fwd_bf16 against fp64 conv1d of the bf16-ROUNDED operands (the kernel rounds the activated input
     and the weights as it builds the fragments; products exact, fp32 accumulate) and against the exact-fp32 kernel at
@@ -1010,7 +1020,7 @@ def test_dtc_conv_fwd_bf16_variant(B, T, cin, cout, d, act):
 
 
 @pytest.mark.parametrize("B,T,cin,cout,d", [(3, 30, 16, 32, 2), (2, 30, 1024, 16, 1), (5, 30, 256, 512, 4), (64, 30, 32, 64, 4),
-                                            (4, 30, 128, 256, 2)])
+                                            (4, 30, 128, 256, 2), (64, 30, 256, 512, 4), (64, 30, 384, 128, 1), (5, 17, 80, 160, 2)])
 def test_dtc_conv_dgrad_bf16_variant(B, T, cin, cout, d):
     """pcaa_dtc_conv_dgrad_bf16 with the fused BatchNorm halves (dy formed on load, ELU' + statistics of the layer below)
     against the exact-fp32 kernel: dy identical (formed in fp32 before the rounding), dz_below and the statistics at the
