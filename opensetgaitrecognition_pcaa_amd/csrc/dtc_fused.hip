@@ -973,9 +973,17 @@ static inline int pair_tile_floats(int kc) {
 }
 
 // the pair kernels take the wide layers: at least four chunks of contraction, whole chunks, at least 64 output channels
-static inline bool pair_takes(int kc, int nc, int ksplit) {
-  static const bool on = [] { const char* e = getenv("PCAA_DTC_PAIR"); return !(e != nullptr && e[0] == '0'); }();
-  return on && ksplit == 1 && kc >= 128 && kc % CC == 0 && nc >= 64 && nc % 4 == 0;
+static inline bool pair_takes(int kc, int nc, int ksplit, bool adj) {
+  // PCAA_DTC_PAIR: 0 = off, fwd / adj = that direction only (lab), anything else = both
+  static const int which = [] {
+    const char* e = getenv("PCAA_DTC_PAIR");
+    if (e == nullptr) return 3;
+    if (e[0] == '0') return 0;
+    if (e[0] == 'f') return 1;
+    if (e[0] == 'a') return 2;
+    return 3;
+  }();
+  return (which & (adj ? 2 : 1)) != 0 && ksplit == 1 && kc >= 128 && kc % CC == 0 && nc >= 64 && nc % 4 == 0;
 }
 
 template <bool ADJ, bool BF, int NT>
@@ -1034,7 +1042,7 @@ static int dtc_conv_fwd_impl(bool bf16, const float* src, const float* scale, co
                  "(pcaa_dtc_conv_ksplit)", MAX_CR);
   PCAA_CHECK_ARG(ksplit == 1 || (stats == nullptr && slab_stride >= (long)B * T * cout),
                  "pcaa_dtc_conv_fwd: ksplit > 1 writes slabs (no statistics): slab_stride >= B*T*cout");
-  if (pair_takes(cin, cout, ksplit)) {
+  if (pair_takes(cin, cout, ksplit, false)) {
     DtcPairParams pp{src, scale, shift, nullptr, nullptr, nullptr, nullptr, W, y, col, stats, nrep,
                      nullptr, nullptr, nullptr, nullptr, nullptr, B, T, cin, cout, dilation,
                      stats != nullptr ? pcaa_take_bn_tail(stats) : BnTail{}};
@@ -1091,7 +1099,7 @@ static int dtc_conv_dgrad_impl(bool bf16, const float* dy, const float* dz, cons
   const bool ep = ep_stats != nullptr;
   PCAA_CHECK_ARG(!ep || (ksplit == 1 && ep_y && ep_scale && ep_shift && ep_mean && ep_rstd && nrep >= 1),
                  "pcaa_dtc_conv_dgrad: the epilogue needs ksplit == 1 and ep_y, ep_scale, ep_shift, ep_mean, ep_rstd");
-  if (pair_takes(cout, cin, ksplit)) {
+  if (pair_takes(cout, cin, ksplit, true)) {
     DtcPairParams pp{dy, nullptr, nullptr, dz, y, coef, dy_out, W, out, nullptr, ep_stats, nrep,
                      ep_y, ep_scale, ep_shift, ep_mean, ep_rstd, B, T, cout, cin, dilation,
                      ep ? pcaa_take_bn_tail(ep_stats) : BnTail{}};

@@ -550,14 +550,16 @@ _FUSE_DTC_BWD = True
 _DTC_BF16 = os.environ.get("PCAA_DTC_BF16", "wide")
 
 
-def _dtc_bf16(mode, kc, nc):
+def _dtc_bf16(mode, kc, nc, adj=False):
     """kc: channels the product contracts over, nc: channels it produces (forward: cin, cout; adjoint: cout, cin) --
     the same rule as pair_takes() in csrc/dtc_fused.hip"""
     if mode != "bf16" or _DTC_BF16 == "0":
         return False
     if _DTC_BF16 in ("all", "1"):
         return True
-    return kc >= 128 and kc % 32 == 0 and nc >= 64 and nc % 4 == 0 and os.environ.get("PCAA_DTC_PAIR", "1") != "0"
+    which = os.environ.get("PCAA_DTC_PAIR", "1")[:1]
+    on = which not in ("0", "a" if not adj else "f")
+    return on and kc >= 128 and kc % 32 == 0 and nc >= 64 and nc % 4 == 0
 
 
 def dtc_forward(a2d, B, T, layers, training, pool_time, mode="fp32"):
@@ -642,7 +644,7 @@ def dtc_backward(saves, layers, B, T, d_last=None, dpool=None, need_dx=True, gou
                 out, stats, dy_used = ops.dtc_conv_dgrad(
                     dy, W2d, B, T, s.cin, s.dil, dz=dz, y=y, coef=coef, want_dy=dy is None,
                     below=(sb.y, sb.scale, sb.shift, sb.mean, sb.rstd) if sb else None, tail=btail,
-                    bf16=_dtc_bf16(mode, s.cout, s.cin))
+                    bf16=_dtc_bf16(mode, s.cout, s.cin, adj=True))
                 return (_FusedGrad(out, stats, fin=btail.out) if sb else out), dy_used
 
             dgrad_fn.forms_dy = s.cout <= 512
