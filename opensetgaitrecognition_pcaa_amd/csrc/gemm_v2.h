@@ -33,6 +33,24 @@
 #endif
 namespace v2 {
 
+// C stores with the non-temporal hint (PCAA_V2_NT_STORE=1, round 4 lab): alone the K = 512 layers gain 4-8 % (the result no
+// longer evicts the operands the K loop re-reads: 512 -> 1024 0.300 -> 0.282 ms) -- and the STEP loses 0.17 ms
+// (5.32 -> 5.49, same box): written the normal way, the tail of C is still in the L2 / the 256 MB memory-side cache when
+// the BatchNorm pass that follows reads it.  Off; profiles/r04_ab_nt_store.txt.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+#ifndef PCAA_V2_NT_STORE
+#define PCAA_V2_NT_STORE 0
+#endif
+__device__ __forceinline__ void store_nt(void* dst, const uint4& o) {
+  u32x4_t v = {o.x, o.y, o.z, o.w};
+  if (PCAA_V2_NT_STORE) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(dst));
+  else *reinterpret_cast<u32x4_t*>(dst) = v;
+}
+__device__ __forceinline__ void store_nt(float* dst, const f32x4& v) {
+  if (PCAA_V2_NT_STORE) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+  else *reinterpret_cast<f32x4*>(dst) = v;
+}
+
 constexpr int NT = 256;                       // threads: 4 waves
 constexpr int OP_TILE = 256 * 64;             // elements of one operand's stage image (32 KB)
 constexpr int STAGE = 2 * OP_TILE;            // A image, then B image (64 KB)
@@ -114,11 +132,11 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, f32x4 (&acc)
         o.y = pack2(out(acc[i][2][r], 2), out(acc[i][3][r], 3));
         o.z = pack2(out(acc[i][4][r], 4), out(acc[i][5][r], 5));
         o.w = pack2(out(acc[i][6][r], 6), out(acc[i][7][r], 7));
-        *reinterpret_cast<uint4*>(C + (long)(i * 16 + r) * p.ldc) = o;
+        store_nt(C + (long)(i * 16 + r) * p.ldc, o);
       } else {
         float* d = reinterpret_cast<float*>(C) + (long)(i * 16 + r) * p.ldc;
-        *reinterpret_cast<f32x4*>(d) = f32x4{out(acc[i][0][r], 0), out(acc[i][1][r], 1), out(acc[i][2][r], 2), out(acc[i][3][r], 3)};
-        *reinterpret_cast<f32x4*>(d + 4) = f32x4{out(acc[i][4][r], 4), out(acc[i][5][r], 5), out(acc[i][6][r], 6), out(acc[i][7][r], 7)};
+        store_nt(d, f32x4{out(acc[i][0][r], 0), out(acc[i][1][r], 1), out(acc[i][2][r], 2), out(acc[i][3][r], 3)});
+        store_nt(d + 4, f32x4{out(acc[i][4][r], 4), out(acc[i][5][r], 5), out(acc[i][6][r], 6), out(acc[i][7][r], 7)});
       }
     }
 }
@@ -269,15 +287,15 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p, f32x4 (&a
       if (RAG && i * 16 + r >= mrows) continue;
       if constexpr (kF32) {
         float* d = reinterpret_cast<float*>(C) + (long)(i * 16 + r) * p.ldc;
-        *reinterpret_cast<f32x4*>(d) = f32x4{dq[0].x, dq[0].y, dq[1].x, dq[1].y};
-        *reinterpret_cast<f32x4*>(d + 4) = f32x4{dq[2].x, dq[2].y, dq[3].x, dq[3].y};
+        store_nt(d, f32x4{dq[0].x, dq[0].y, dq[1].x, dq[1].y});
+        store_nt(d + 4, f32x4{dq[2].x, dq[2].y, dq[3].x, dq[3].y});
       } else {
         uint4 o;
         o.x = pack2(dq[0].x, dq[0].y);
         o.y = pack2(dq[1].x, dq[1].y);
         o.z = pack2(dq[2].x, dq[2].y);
         o.w = pack2(dq[3].x, dq[3].y);
-        *reinterpret_cast<uint4*>(C + (long)(i * 16 + r) * p.ldc) = o;
+        store_nt(C + (long)(i * 16 + r) * p.ldc, o);
       }
     }
   }

@@ -37,6 +37,9 @@ constexpr int LDS_BYTES = 2 * STAGE * 2;     // two stages: 128 KB
 #ifndef VARIANT
 #define VARIANT 0
 #endif
+#ifndef NT_STORE
+#define NT_STORE 0
+#endif
 // LAB knobs (timing only, results are garbage): drop one ingredient of the K loop to see what the step time is made of
 #ifndef NO_DMA
 #define NO_DMA 0
@@ -268,7 +271,13 @@ __global__ __launch_bounds__(256) void gemm_v2(const bf16_t* __restrict__ A, con
           o.y = pack2(acc[i][2][r], acc[i][3][r]);
           o.z = pack2(acc[i][4][r], acc[i][5][r]);
           o.w = pack2(acc[i][6][r], acc[i][7][r]);
+#if NT_STORE
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          u32x4 ov = {o.x, o.y, o.z, o.w};
+          __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(c0 + (long)(i * 16 + r) * N));
+#else
           *reinterpret_cast<uint4*>(c0 + (long)(i * 16 + r) * N) = o;      // 16 B per lane, 16 lanes = 256 contiguous bytes
+#endif
         }
     } else {
       float t = 0.f;
