@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PCAA_ABI_VERSION 13 /* pcaa_abi_version() of a library built from this header */
+#define PCAA_ABI_VERSION 14 /* pcaa_abi_version() of a library built from this header */
 
 #define PCAA_OK 0
 #define PCAA_ERR_INVALID_ARG 1
@@ -405,6 +405,17 @@ int pcaa_skinny_linear_wgrad_adam(const float* dz, long lddz, const float* x, lo
                                   float* exp_avg, float* exp_avg_sq, long ldw, int M, int N, int K,
                                   float beta1, float beta2, float eps, float grad_scale,
                                   const float* coef_dev, void* stream);
+/* ABI 14: the bf16 IMAGE of a decoder weight (W16 [N, ldw] bf16: every element = the weight rounded to nearest even, the
+ * conversion pcaa_skinny_linear_fwd / _dgrad apply in registers -- results are bit-identical).  _fwd_w16 / _dgrad_w16
+ * stream the image instead of the fp32 matrix: half the bytes of the two passes that sit on the step's critical path.
+ * The caller owns the image: train.PCAATrainer rebuilds it with pcaa_cast_bf16 behind each fused update (side stream) and
+ * whenever the weight's version counter moved.  (Writing the image from inside pcaa_skinny_linear_wgrad_adam was
+ * measured and dropped: 64-B partial lines from different CUs doubled that kernel's time.) */
+int pcaa_skinny_linear_fwd_w16(const float* x, long ldx, const void* W16, long ldw, const float* bias, int act,
+                               float* y, float* ws, long ws_floats, int M, int N, int K, int nsplit, void* stream);
+int pcaa_skinny_linear_dgrad_w16(const float* dz, long lddz, const void* W16, long ldw, float* dx,
+                                 const float* a_prev, int accumulate, float* ws, long ws_floats, int M, int N,
+                                 int K, int nsplit, void* stream);
 
 /* ------------------------------------------------------------------ temporal block, fused forward
  * One DilTempConv1d layer (models.py:37-79) in one launch: implicit im2col of the causal dilated

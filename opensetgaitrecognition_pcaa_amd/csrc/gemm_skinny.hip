@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "gemm_common.h"
 
@@ -168,9 +169,11 @@ __global__ __launch_bounds__(256) void skinny_dgrad_kernel(const float* __restri
 // a wave covers 64 columns with HALF the vector-memory instructions per byte.  The one-column kernel was bound
 // by those (7200 dword wave-loads per CU on the 7680x15360 layer: 3.2 TB/s against 4.5-5 of the other two).
 // grid (ceil(K/256), nsplit)
-template <bool F32 = false>
+// W16 (round 4): W is the bf16 image the fused update keeps beside the fp32 weights -- the same values the conversion
+// below produces (round to nearest even), half the bytes of the one stream this kernel is made of
+template <bool F32 = false, bool W16 = false>
 __global__ __launch_bounds__(256) void skinny_dgrad2_kernel(const float* __restrict__ dz, long lddz,
-                                                            const float* __restrict__ W, long ldw,
+                                                            const typename std::conditional<W16, bf16_t, float>::type* __restrict__ W, long ldw,
                                                             float* __restrict__ slabs, long slab_stride, int M,
                                                             int N, int K, int cps) {
   __shared__ __attribute__((aligned(16))) unsigned char sraw[2 * 64 * (F32 ? SPF * 4 : SP * 2)];
@@ -183,13 +186,14 @@ __global__ __launch_bounds__(256) void skinny_dgrad2_kernel(const float* __restr
   const int nch = min(cps, N / CH - c0);
   if (nch <= 0) return;
   const int lane_off = 8 * h * (int)ldw + min(col, K - 2);
-  const float* Wc = W + (long)c0 * CH * ldw;
+  const auto* Wc = W + (long)c0 * CH * ldw;
+  typedef typename std::conditional<W16, uint32_t, f32x2>::type wpair_t;      // this lane's two columns of one row
 
-  f32x2 wr[4][8];
+  wpair_t wr[4][8];
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) wr[s][e] = *reinterpret_cast<const f32x2*>(Wc + (long)(s * 16 + e) * ldw + lane_off);
+    for (int e = 0; e < 8; ++e) wr[s][e] = *reinterpret_cast<const wpair_t*>(Wc + (long)(s * 16 + e) * ldw + lane_off);
   SmallStage st;
   small_load(st, dz, lddz, M, c0 * CH, tid);
   if constexpr (F32) small_store_f32(st, sbuf32[0], tid); else small_store(st, sbuf[0], tid);
@@ -207,14 +211,29 @@ __global__ __launch_bounds__(256) void skinny_dgrad2_kernel(const float* __restr
     const bf16_t* cur = sbuf[c & 1];
     const float* cur32 = sbuf32[c & 1];
     if (more) small_load(st, dz, lddz, M, (c0 + c + 1) * CH, tid);
-    const float* Wn = Wc + (long)min(c + 1, nch - 1) * CH * ldw;     // last trip: harmless re-read
+    const auto* Wn = Wc + (long)min(c + 1, nch - 1) * CH * ldw;     // last trip: harmless re-read
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       float ev[8], od[8];
+      bf16x8 b0w, b1w;
+      if constexpr (W16) {
+        // even columns = low halves, odd columns = high halves of the eight dwords: two byte permutes per pair
+        uint4 lo, hi;
+        uint32_t* lp = reinterpret_cast<uint32_t*>(&lo);
+        uint32_t* hp = reinterpret_cast<uint32_t*>(&hi);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { ev[e] = wr[s][e].x; od[e] = wr[s][e].y; }
+        for (int e = 0; e < 4; ++e) {
+          lp[e] = __builtin_amdgcn_perm(wr[s][2 * e + 1], wr[s][2 * e], 0x05040100u);
+          hp[e] = __builtin_amdgcn_perm(wr[s][2 * e + 1], wr[s][2 * e], 0x07060302u);
+        }
+        b0w = __builtin_bit_cast(bf16x8, lo);
+        b1w = __builtin_bit_cast(bf16x8, hi);
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) wr[s][e] = *reinterpret_cast<const f32x2*>(Wn + (long)(s * 16 + e) * ldw + lane_off);
+        for (int e = 0; e < 8; ++e) { ev[e] = wr[s][e].x; od[e] = wr[s][e].y; }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wr[s][e] = *reinterpret_cast<const wpair_t*>(Wn + (long)(s * 16 + e) * ldw + lane_off);
       if constexpr (F32) {
         float a0[8], a1[8];
         frag_f32(cur32, l31, s, h, a0);
@@ -224,7 +243,8 @@ __global__ __launch_bounds__(256) void skinny_dgrad2_kernel(const float* __restr
         acc[1][0] = mfma8_f32(a1, ev, acc[1][0]);
         acc[1][1] = mfma8_f32(a1, od, acc[1][1]);
       } else {
-        const bf16x8 b0 = pack8(ev), b1 = pack8(od);
+        bf16x8 b0, b1;
+        if constexpr (W16) { b0 = b0w; b1 = b1w; } else { b0 = pack8(ev); b1 = pack8(od); }
         const bf16x8 a0 = small_frag(cur, 0, s, l31, h), a1 = small_frag(cur, 1, s, l31, h);
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
@@ -248,9 +268,9 @@ __global__ __launch_bounds__(256) void skinny_dgrad2_kernel(const float* __restr
 
 // ------------------------------------------------------------------ forward: y = x . W^T
 // grid (ceil(N/128), nsplit); wave w owns output columns (rows of W) [128 bx + 32 w, +32)
-template <bool F32 = false>
+template <bool F32 = false, bool W16 = false>
 __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, long ldx,
-                                                         const float* __restrict__ W, long ldw,
+                                                         const typename std::conditional<W16, bf16_t, float>::type* __restrict__ W, long ldw,
                                                          float* __restrict__ slabs, long slab_stride, int M,
                                                          int N, int K, int cps) {
   __shared__ __attribute__((aligned(16))) unsigned char sraw[2 * 64 * (F32 ? SPF * 4 : SP * 2)];
@@ -272,10 +292,11 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
   bf16_t* wl = wbuf[wave];
   float* wl32 = wbuf32[wave];
 
-  f32x4 wr[8];
-  const float* Wk = W + (long)c0 * CH;
+  typedef typename std::conditional<W16, uint2, f32x4>::type wquad_t;        // four consecutive k of one row
+  wquad_t wr[8];
+  const auto* Wk = W + (long)c0 * CH;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) wr[i] = load4(Wk + roff[i]);
+  for (int i = 0; i < 8; ++i) wr[i] = *reinterpret_cast<const wquad_t*>(Wk + roff[i]);
   SmallStage st;
   small_load(st, x, ldx, M, c0 * CH, tid);
   if constexpr (F32) small_store_f32(st, sbuf32[0], tid); else small_store(st, sbuf[0], tid);
@@ -292,7 +313,9 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
     const float* cur32 = sbuf32[c & 1];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      if constexpr (F32) {
+      if constexpr (W16) {
+        *reinterpret_cast<uint2*>(&wl[(4 * i + lr) * SP + kseg]) = wr[i];
+      } else if constexpr (F32) {
         *reinterpret_cast<f32x4*>(&wl32[(4 * i + lr) * SPF + kseg]) = wr[i];
       } else {
         uint2 u;
@@ -302,9 +325,9 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
       }
     }
     {
-      const float* Wn = Wk + (long)min(c + 1, nch - 1) * CH;      // last iteration: harmless re-read
+      const auto* Wn = Wk + (long)min(c + 1, nch - 1) * CH;      // last iteration: harmless re-read
 #pragma unroll
-      for (int i = 0; i < 8; ++i) wr[i] = load4(Wn + roff[i]);
+      for (int i = 0; i < 8; ++i) wr[i] = *reinterpret_cast<const wquad_t*>(Wn + roff[i]);
     }
     if (more) small_load(st, x, ldx, M, (c0 + c + 1) * CH, tid);
     // the wave reads back its own LDS image: LDS executes a wave's operations in order, the
@@ -644,9 +667,10 @@ extern "C" int pcaa_skinny_supported(int M, int N, int K) {
   return M >= 1 && M <= 64 && N >= 128 && K >= 64 && N % 64 == 0 && K % 64 == 0 && (long)N * K < (1L << 31) - (1L << 20);
 }
 
-static int skinny_fwd_impl(const float* x, long ldx, const float* W, long ldw, const float* bias, int act,
+static int skinny_fwd_impl(const float* x, long ldx, const void* Wv, int w16, long ldw, const float* bias, int act,
                            float* y, float* ws, long ws_floats, int M, int N, int K, int nsplit, int exact,
                            void* stream) {
+  const float* W = static_cast<const float*>(Wv);
   PCAA_CHECK_ARG(x && W && y && ws, "pcaa_skinny_linear_fwd: null pointer");
   PCAA_CHECK_ARG(pcaa_skinny_supported(M, N, K), "pcaa_skinny_linear_fwd: unsupported shape M=%d N=%d K=%d", M, N, K);
   PCAA_CHECK_ARG(ldx >= K && ldx % 4 == 0 && ldw >= K && ldw % 4 == 0 && ldw * (long)N < (1L << 31),
@@ -661,7 +685,10 @@ static int skinny_fwd_impl(const float* x, long ldx, const float* W, long ldw, c
   const long stride = (long)M * N;
   PCAA_CHECK_ARG(ws_floats >= stride * nsplit, "pcaa_skinny_linear_fwd: workspace too small");
   hipStream_t s = as_stream(stream);
-  if (exact)
+  if (w16)
+    hipLaunchKernelGGL((skinny_fwd_kernel<false, true>), dim3((unsigned)cdiv(N, 128), nsplit), dim3(256), 0, s, x, ldx,
+                       static_cast<const bf16_t*>(Wv), ldw, ws, stride, M, N, K, cps);
+  else if (exact)
     hipLaunchKernelGGL(skinny_fwd_kernel<true>, dim3((unsigned)cdiv(N, 128), nsplit), dim3(256), 0, s, x, ldx, W, ldw, ws,
                        stride, M, N, K, cps);
   else
@@ -674,17 +701,23 @@ static int skinny_fwd_impl(const float* x, long ldx, const float* W, long ldw, c
 extern "C" int pcaa_skinny_linear_fwd(const float* x, long ldx, const float* W, long ldw, const float* bias, int act,
                                       float* y, float* ws, long ws_floats, int M, int N, int K, int nsplit,
                                       void* stream) {
-  return skinny_fwd_impl(x, ldx, W, ldw, bias, act, y, ws, ws_floats, M, N, K, nsplit, 0, stream);
+  return skinny_fwd_impl(x, ldx, W, 0, ldw, bias, act, y, ws, ws_floats, M, N, K, nsplit, 0, stream);
+}
+extern "C" int pcaa_skinny_linear_fwd_w16(const float* x, long ldx, const void* W16, long ldw, const float* bias, int act,
+                                          float* y, float* ws, long ws_floats, int M, int N, int K, int nsplit,
+                                          void* stream) {
+  return skinny_fwd_impl(x, ldx, W16, 1, ldw, bias, act, y, ws, ws_floats, M, N, K, nsplit, 0, stream);
 }
 extern "C" int pcaa_skinny_linear_fwd_exact(const float* x, long ldx, const float* W, long ldw, const float* bias, int act,
                                             float* y, float* ws, long ws_floats, int M, int N, int K, int nsplit,
                                             void* stream) {
-  return skinny_fwd_impl(x, ldx, W, ldw, bias, act, y, ws, ws_floats, M, N, K, nsplit, 1, stream);
+  return skinny_fwd_impl(x, ldx, W, 0, ldw, bias, act, y, ws, ws_floats, M, N, K, nsplit, 1, stream);
 }
 
-static int skinny_dgrad_impl(const float* dz, long lddz, const float* W, long ldw, float* dx,
+static int skinny_dgrad_impl(const float* dz, long lddz, const void* Wv, int w16, long ldw, float* dx,
                              const float* a_prev, int accumulate, float* ws, long ws_floats, int M, int N,
                              int K, int nsplit, int exact, void* stream) {
+  const float* W = static_cast<const float*>(Wv);
   PCAA_CHECK_ARG(dz && W && dx && ws, "pcaa_skinny_linear_dgrad: null pointer");
   PCAA_CHECK_ARG(pcaa_skinny_supported(M, N, K), "pcaa_skinny_linear_dgrad: unsupported shape M=%d N=%d K=%d", M, N, K);
   PCAA_CHECK_ARG(lddz >= N && lddz % 4 == 0 && ldw >= K && ldw * (long)N < (1L << 31),
@@ -701,7 +734,12 @@ static int skinny_dgrad_impl(const float* dz, long lddz, const float* W, long ld
   // two columns per lane where the 8-B loads are aligned, else the one-column-per-lane kernel
   const bool pairs = (ldw % 2) == 0 && ((uintptr_t)W % 8) == 0;
   PCAA_CHECK_ARG(!exact || pairs, "pcaa_skinny_linear_dgrad_exact: W must be 8-B aligned with an even leading dimension");
-  if (exact)
+  PCAA_CHECK_ARG(!w16 || ((ldw % 2) == 0 && ((uintptr_t)Wv % 4) == 0 && K % 2 == 0),
+                 "pcaa_skinny_linear_dgrad_w16: the bf16 image must be 4-B aligned with an even leading dimension");
+  if (w16)
+    hipLaunchKernelGGL((skinny_dgrad2_kernel<false, true>), dim3((unsigned)cdiv(K, 256), nsplit), dim3(256), 0, s, dz, lddz,
+                       static_cast<const bf16_t*>(Wv), ldw, ws, stride, M, N, K, cps);
+  else if (exact)
     hipLaunchKernelGGL(skinny_dgrad2_kernel<true>, dim3((unsigned)cdiv(K, 256), nsplit), dim3(256), 0, s, dz, lddz, W, ldw,
                        ws, stride, M, N, K, cps);
   else if (pairs)
@@ -717,12 +755,17 @@ static int skinny_dgrad_impl(const float* dz, long lddz, const float* W, long ld
 extern "C" int pcaa_skinny_linear_dgrad(const float* dz, long lddz, const float* W, long ldw, float* dx,
                                         const float* a_prev, int accumulate, float* ws, long ws_floats, int M, int N,
                                         int K, int nsplit, void* stream) {
-  return skinny_dgrad_impl(dz, lddz, W, ldw, dx, a_prev, accumulate, ws, ws_floats, M, N, K, nsplit, 0, stream);
+  return skinny_dgrad_impl(dz, lddz, W, 0, ldw, dx, a_prev, accumulate, ws, ws_floats, M, N, K, nsplit, 0, stream);
+}
+extern "C" int pcaa_skinny_linear_dgrad_w16(const float* dz, long lddz, const void* W16, long ldw, float* dx,
+                                            const float* a_prev, int accumulate, float* ws, long ws_floats, int M, int N,
+                                            int K, int nsplit, void* stream) {
+  return skinny_dgrad_impl(dz, lddz, W16, 1, ldw, dx, a_prev, accumulate, ws, ws_floats, M, N, K, nsplit, 0, stream);
 }
 extern "C" int pcaa_skinny_linear_dgrad_exact(const float* dz, long lddz, const float* W, long ldw, float* dx,
                                               const float* a_prev, int accumulate, float* ws, long ws_floats, int M,
                                               int N, int K, int nsplit, void* stream) {
-  return skinny_dgrad_impl(dz, lddz, W, ldw, dx, a_prev, accumulate, ws, ws_floats, M, N, K, nsplit, 1, stream);
+  return skinny_dgrad_impl(dz, lddz, W, 0, ldw, dx, a_prev, accumulate, ws, ws_floats, M, N, K, nsplit, 1, stream);
 }
 
 static int skinny_wgrad_impl(const float* dz, long lddz, const float* x, long ldx, float* dW, long lddw,

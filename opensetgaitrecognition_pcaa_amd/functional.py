@@ -688,7 +688,7 @@ def _skinny_exact(mode, M, N, K):
     return mode in ("fp32", "fp16x3") and ops.skinny_supported(M, N, K)
 
 
-def linear_act_forward(x, lin, act, mode="fp32"):
+def linear_act_forward(x, lin, act, mode="fp32", W16=None):
     """act(x @ W^T + b); x [M,K] fp32 -> [M,N] fp32.  fp32 MFMA, or (bf16 mode,
     wide layers) bf16 MFMA with fp32 accumulation: the layer is bound by
     streaming W from HBM either way, the bf16 pipe just keeps the MFMA time out
@@ -696,7 +696,8 @@ def linear_act_forward(x, lin, act, mode="fp32"):
     M, K = x.shape
     N = lin.weight.shape[0]
     if _skinny(mode, M, N, K):
-        return ops.skinny_linear_fwd(x, lin.weight, lin.bias, act)
+        # W16: the weight's bf16 image, passed by a caller that vouches for it (PCAATrainer._refresh_w16): same result
+        return ops.skinny_linear_fwd(x, lin.weight, lin.bias, act, W16=W16)
     if _skinny_exact(mode, M, N, K):
         return ops.skinny_linear_fwd(x, lin.weight, lin.bias, act, exact=True)
     if _wide_bf16(mode, M, N, K):
@@ -714,7 +715,7 @@ def linear_act_forward(x, lin, act, mode="fp32"):
 
 
 def linear_act_backward(x, a_out, lin, act, d_out, need_dx=True, dW_out=None, db_out=None, dx_init=None,
-                        mode="fp32", d_is_pre=False, fuse_elu_in=False, update=None):
+                        mode="fp32", d_is_pre=False, fuse_elu_in=False, update=None, W16=None):
     """d_out is the gradient w.r.t. the layer output (d_is_pre: already w.r.t. its
     pre-activation).  Returns (dW, db, dx).  fuse_elu_in (skinny path only, x = ELU output of
     the layer below): dx is multiplied by ELU'(x), i.e. it is the gradient w.r.t. that layer's
@@ -734,7 +735,8 @@ def linear_act_backward(x, a_out, lin, act, d_out, need_dx=True, dW_out=None, db
         dx = None
         if need_dx:
             dx = ops.skinny_linear_dgrad(dz2, lin.weight, a_prev=x if fuse_elu_in else None, out=dx_init,
-                                         accumulate=dx_init is not None, exact=_skinny_exact(mode, M, N, K))
+                                         accumulate=dx_init is not None, exact=_skinny_exact(mode, M, N, K),
+                                         W16=W16)
         update(dz2, x)
         return None, db, dx
     exact = _skinny_exact(mode, M, N, K)
@@ -750,7 +752,7 @@ def linear_act_backward(x, a_out, lin, act, d_out, need_dx=True, dW_out=None, db
         dx = None
         if need_dx:
             dx = ops.skinny_linear_dgrad(dz2, lin.weight, a_prev=x if fuse_elu_in else None, out=dx_init,
-                                         accumulate=dx_init is not None, exact=exact)
+                                         accumulate=dx_init is not None, exact=exact, W16=W16)
         return dW, db, dx
     if fuse_elu_in:
         raise RuntimeError("linear_act_backward: fuse_elu_in is only served by the skinny path")
@@ -1156,7 +1158,9 @@ def dtc_stack(x, layers, training):
 # ======================================================================
 # CGDecoder (models.py:340-385)
 # ======================================================================
-def decoder_forward(dec, z, mode=None):
+def decoder_forward(dec, z, mode=None, images=None):
+    """``images`` {layer number: bf16 image of that layer's weight}: streamed instead of the fp32 matrix by the bf16
+    mode's weight-streaming kernels (same rounding, same result); only a caller that keeps them current passes them."""
     mode = get_precision() if mode is None else mode
     _require_gpu(z, "CGDecoder")
     if z.dim() != 2 or z.shape[1] != dec.dense1.weight.shape[1]:
@@ -1166,7 +1170,8 @@ def decoder_forward(dec, z, mode=None):
     # the chain then runs in the padded widths (padded activations are exactly 0) and the output is cut back
     layers = getattr(dec, "_pcaa_pad", None) or dec.dense_layers()
     for i, lin in enumerate(layers):
-        acts.append(linear_act_forward(acts[-1], lin, ACT_ELU if i < 4 else ACT_NONE, mode))
+        acts.append(linear_act_forward(acts[-1], lin, ACT_ELU if i < 4 else ACT_NONE, mode,
+                                       W16=(images or {}).get(i + 1)))
     out = acts[-1]
     S = dec.dense5.weight.shape[0]
     if out.shape[1] != S:
@@ -1175,7 +1180,7 @@ def decoder_forward(dec, z, mode=None):
 
 
 def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=None, mode=None, after_layer=None,
-                     updates=None):
+                     updates=None, images=None):
     """``grads_out`` {"denseI.weight"/"denseI.bias": destination}: for a padded decoder (see decoder_forward)
     these are the PADDED gradient tensors; without grads_out the returned gradients are cut to the parameter
     shapes.  ``updates`` {layer number: update(dz, x)}: those layers' weight gradients are formed and consumed by
@@ -1200,7 +1205,7 @@ def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=Non
         dW, db, d = linear_act_backward(acts[i], acts[i + 1], lin, ACT_ELU if i < 4 else ACT_NONE, d,
                                         need_dx=(i > 0 or need_dz), dW_out=dW_out, db_out=db_out,
                                         dx_init=dz_init if i == 0 else None, mode=mode, d_is_pre=pre,
-                                        fuse_elu_in=fuse, update=(updates or {}).get(i + 1))
+                                        fuse_elu_in=fuse, update=(updates or {}).get(i + 1), W16=(images or {}).get(i + 1))
         pre = fuse
         if after_layer is not None:
             after_layer(i + 1)       # trainer hook: layer i+1's weight / bias gradients are enqueued

@@ -781,11 +781,15 @@ def pick_split_k(M, N, K, target_blocks=1024, bk=32, tile=128):
     return max(1, min(s, K // (4 * bk) if K >= 4 * bk else 1))
 
 
-def cast_bf16(W2d, want_plain=True, want_transposed=True):
-    """bf16 shadows of an fp32 weight matrix [R,C]: (W16 [R,C], W16t [C,R])."""
+def cast_bf16(W2d, want_plain=True, want_transposed=True, out=None):
+    """bf16 shadows of an fp32 weight matrix [R,C]: (W16 [R,C], W16t [C,R]).  ``out``: the plain image's destination."""
     _chk(W2d, "cast_bf16.W", torch.float32, 2)
     R, C = W2d.shape
-    w = torch.empty((R, C), dtype=torch.bfloat16, device=W2d.device) if want_plain else None
+    if out is not None:
+        _chk(out, "cast_bf16.out", torch.bfloat16, 2)
+        if tuple(out.shape) != (R, C):
+            raise ValueError("cast_bf16: out shape")
+    w = out if out is not None else (torch.empty((R, C), dtype=torch.bfloat16, device=W2d.device) if want_plain else None)
     wt = torch.empty((C, R), dtype=torch.bfloat16, device=W2d.device) if want_transposed else None
     check(_lib.load().pcaa_cast_bf16(_p(W2d), _p(w), _p(wt), R, C, _s()), "pcaa_cast_bf16")
     return w, wt
@@ -1125,9 +1129,18 @@ def _skinny_timed(fn, flops, nbytes):
     timer.records.append(("gemm_skinny_kernel", flops, float(nbytes), ev))
 
 
-def skinny_linear_fwd(x, W, bias, act, exact=False):
+def _w16_image(W16, W, what):
+    """the bf16 image of weight W (pcaa_skinny_linear_*_w16): same shape, contiguous rows, bf16"""
+    _chk(W16, what, torch.bfloat16, 2)
+    if tuple(W16.shape) != tuple(W.shape) or W16.stride(1) != 1:
+        raise ValueError(f"{what}: the bf16 image must have the weight's shape {tuple(W.shape)}, got {tuple(W16.shape)}")
+    return W16
+
+
+def skinny_linear_fwd(x, W, bias, act, exact=False, W16=None):
     """act(x[M,K] @ W[N,K]^T + bias) with M <= 64: one streaming pass over W.  ``exact``: fp32 products on the fp32
-    matrix pipe (the parity modes) instead of bf16-rounded operands."""
+    matrix pipe (the parity modes) instead of bf16-rounded operands.  ``W16``: the bf16 image of W (every element the
+    weight rounded to nearest even -- what the kernel's own conversion produces): streamed instead of W, same result."""
     _chk(x, "skinny_fwd.x", torch.float32, 2)
     _chk(W, "skinny_fwd.W", torch.float32, 2)
     M, K = x.shape
@@ -1138,15 +1151,19 @@ def skinny_linear_fwd(x, W, bias, act, exact=False):
     ns = lib.pcaa_skinny_splits(0, M, N, K)
     ws = torch.empty(ns * M * N, dtype=torch.float32, device=x.device)
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    fn = lib.pcaa_skinny_linear_fwd_exact if exact else lib.pcaa_skinny_linear_fwd
-    _skinny_timed(lambda: check(fn(_p(x), x.stride(0), _p(W), W.stride(0), _p(bias), act,
+    if W16 is not None and not exact:
+        Wsrc, fn, wb = _w16_image(W16, W, "skinny_fwd.W16"), lib.pcaa_skinny_linear_fwd_w16, 2
+    else:
+        Wsrc, fn, wb = W, (lib.pcaa_skinny_linear_fwd_exact if exact else lib.pcaa_skinny_linear_fwd), 4
+    _skinny_timed(lambda: check(fn(_p(x), x.stride(0), _p(Wsrc), Wsrc.stride(0), _p(bias), act,
                                    _p(y), _p(ws), ws.numel(), M, N, K, ns, _s()),
-                                "pcaa_skinny_linear_fwd"), 2.0 * M * N * K, 4 * (N * K + M * K + M * N))
+                                "pcaa_skinny_linear_fwd"), 2.0 * M * N * K, wb * N * K + 4 * (M * K + M * N))
     return y
 
 
-def skinny_linear_dgrad(dz, W, a_prev=None, out=None, accumulate=False, exact=False):
-    """dx[M,K] (=|+=) (dz[M,N] @ W[N,K]) * ELU'(a_prev) (a_prev: ELU OUTPUT of the layer below or None)."""
+def skinny_linear_dgrad(dz, W, a_prev=None, out=None, accumulate=False, exact=False, W16=None):
+    """dx[M,K] (=|+=) (dz[M,N] @ W[N,K]) * ELU'(a_prev) (a_prev: ELU OUTPUT of the layer below or None).
+    ``W16``: the bf16 image of W, streamed instead of it (see skinny_linear_fwd)."""
     _chk(dz, "skinny_dgrad.dz", torch.float32, 2)
     _chk(W, "skinny_dgrad.W", torch.float32, 2)
     M, N = dz.shape
@@ -1168,11 +1185,14 @@ def skinny_linear_dgrad(dz, W, a_prev=None, out=None, accumulate=False, exact=Fa
     lib = _lib.load()
     ns = lib.pcaa_skinny_splits(1, M, N, K)
     ws = torch.empty(ns * M * K, dtype=torch.float32, device=dz.device)
-    fn = lib.pcaa_skinny_linear_dgrad_exact if exact else lib.pcaa_skinny_linear_dgrad
-    _skinny_timed(lambda: check(fn(_p(dz), dz.stride(0), _p(W), W.stride(0), _p(out),
+    if W16 is not None and not exact:
+        Wsrc, fn, wb = _w16_image(W16, W, "skinny_dgrad.W16"), lib.pcaa_skinny_linear_dgrad_w16, 2
+    else:
+        Wsrc, fn, wb = W, (lib.pcaa_skinny_linear_dgrad_exact if exact else lib.pcaa_skinny_linear_dgrad), 4
+    _skinny_timed(lambda: check(fn(_p(dz), dz.stride(0), _p(Wsrc), Wsrc.stride(0), _p(out),
                                    _p(a_prev), int(bool(accumulate)), _p(ws), ws.numel(),
                                    M, N, K, ns, _s()),
-                                "pcaa_skinny_linear_dgrad"), 2.0 * M * N * K, 4 * (N * K + M * K + M * N))
+                                "pcaa_skinny_linear_dgrad"), 2.0 * M * N * K, wb * N * K + 4 * (M * K + M * N))
     return out
 
 

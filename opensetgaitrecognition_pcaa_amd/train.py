@@ -406,6 +406,10 @@ class PCAATrainer:
                 shp = tuple(fg.padded[nm][0].shape) if nm in fg.padded else tuple(fg.params[k].shape)
                 self._dec_fused[i] = (o, (o + n + _ALIGN - 1) // _ALIGN * _ALIGN,      # up to the next parameter's offset
                                       fg.p[o:o + n].view(shp), fg.m[o:o + n].view(shp), fg.v[o:o + n].view(shp))
+        # layer -> [bf16 image of the weight, the version pair it stands for]: kept by the fused update, streamed by the
+        # decoder's forward / dgrad of single-process bf16 steps (_refresh_w16)
+        self._dec_w16 = {}
+        self.w16_casts = 0          # images (re)built by a cast pass: stays at one per layer unless the weights change outside
         self._side_adam_blocks = 256
         self._dp_chunks = 4
         # data-parallel bucketing: one all-reduce per decoder layer, issued as soon as that layer's gradient is
@@ -542,6 +546,47 @@ class PCAATrainer:
             fg.adam(lr, b1, b2, grad_scale=gs, lo=a, hi=b, advance=False, count=fg.sup_count)
         fg.adam(lr, b1, b2, grad_scale=gs, lo=b, hi=hi, advance=False, max_blocks=max_blocks)
 
+    def _w16_active(self, mode, B, collective):
+        """the layers whose weight a fused wgrad+Adam kernel will update in a step of this kind (the only updater that keeps
+        the bf16 image): layer -> (W, m, v) views"""
+        # PCAA_DEC_W16=1 turns the images on.  Off by default: measured (round 4, same box) the forward / dgrad kernels drop
+        # from 0.170 + 0.156 to 0.118 + 0.096 ms per step, but keeping the images current costs more than that -- written
+        # from inside the update kernel (64-B partial lines from different CUs) that kernel went 1.06 -> 2.1 ms, as a cast
+        # pass behind it the extra 0.9 GB of side-stream traffic: step 5.39-5.44 -> 5.48-5.53 ms, N=256 11.9-12.0 -> 12.3-12.6
+        # (profiles/r04_ab_dec_w16.txt).  The step is short of HBM bandwidth, not of decoder time.
+        if (self.decoder is None or not self.fused_decoder_update or collective or self._side is None or mode != "bf16"
+                or os.environ.get("PCAA_DEC_W16", "0") != "1"):
+            return {}
+        return {i: t for i, t in self._dec_fused.items() if F_hip._skinny(mode, B, t[2].shape[0], t[2].shape[1])}
+
+    def _refresh_w16(self, mode, B, collective):
+        """{layer: bf16 image of its weight} for a step of this kind (functional.decoder_forward / _backward stream the
+        images instead of the fp32 matrices: half the bytes, same rounding, same result).  An image stands for the
+        (flat-buffer, module-parameter) version pair it was built or last updated under: anything that writes the weights
+        through torch (load_state_dict, a broadcast, an all-gather) moves one of the two and the image is rebuilt here;
+        the flat Adam kernel, which writes through raw pointers, drops the image explicitly (else-branch below)."""
+        images = {}
+        if self.decoder is None:
+            return images
+        params = self.decoder.dense_layers()
+        active = self._w16_active(mode, B, collective)
+        for i, t in self._dec_fused.items():
+            if i not in active:
+                if i in self._dec_w16:
+                    self._dec_w16[i][1] = None          # this step's update will not keep it
+                continue
+            Wv = t[2]
+            ent = self._dec_w16.get(i)
+            if ent is None:
+                ent = self._dec_w16[i] = [torch.empty(Wv.shape, dtype=torch.bfloat16, device=Wv.device), None]
+            ver = (Wv._version, params[i - 1].weight._version)
+            if ent[1] != ver:
+                ops.cast_bf16(Wv, want_transposed=False, out=ent[0])
+                ent[1] = ver
+                self.w16_casts += 1
+            images[i] = ent[0]
+        return images
+
     def step(self, pcs, gt, z0, alphas, supervise=True):
         """One iteration of the reference's inner loop (PCAA_ablation.py:882-1021; variant 3: :514-655).
         pcs [B,C,T,N] fp32 (ideally a permuted view of point-major storage),
@@ -645,7 +690,8 @@ class PCAATrainer:
 
         # (4) G-step forward: decoder + Chamfer (+ fused gradient)
         hproj = st.hproj if self.decoder_projection_head is not None else sup_fv
-        rec, acts = F_hip.decoder_forward(dec, hproj, mode)
+        w16 = self._refresh_w16(mode, B, self.pg is not None and (self.world > 1 or self._force_collectives))
+        rec, acts = F_hip.decoder_forward(dec, hproj, mode, images=w16)
         F_hip.mark("dec_fwd")
         rec4 = rec.view(B, self.C, self.T, self.N)
         inv_bt = 1.0 / (B * self.T)
@@ -696,8 +742,11 @@ class PCAATrainer:
             for layer, (lo, hi, Wv, mv, vv) in self._dec_fused.items():
                 if F_hip._skinny(mode, B, Wv.shape[0], Wv.shape[1]) or F_hip._skinny_exact(mode, B, Wv.shape[0], Wv.shape[1]):
                     updates = updates or {}
-                    updates[layer] = lambda dz2, x, t=(Wv, mv, vv): deferred.append((dz2, x) + t)
+                    updates[layer] = lambda dz2, x, t=(Wv, mv, vv, w16.get(layer)): deferred.append((dz2, x) + t)
                     fused_ranges.append((lo, hi))
+        if not set(w16) <= set(updates or {}):
+            # an image is only current if THIS step's update of its weight rewrites it
+            raise RuntimeError("PCAATrainer: a bf16 weight image is in use for a layer whose update is not fused")
         dec_grads = self._dec_grads
         self._g16_direct = set()
         if collective and layer_hook is not None and self.grad_compress == "bf16" and mode == "bf16":
@@ -715,12 +764,12 @@ class PCAATrainer:
         if self.decoder_projection_head is not None:
             # the head's own backward (dh -> dsup, dW, db) runs inside the heads' backward launch below
             _, dh = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=dec_grads, mode=mode,
-                                           after_layer=layer_hook, updates=updates)
+                                           after_layer=layer_hook, updates=updates, images=w16)
             if joined is not None:
                 ops.current_stream().wait_event(joined)
         else:
             _, dsup = F_hip.decoder_backward(dec, acts, drec, need_dz=True, grads_out=dec_grads, dz_init=dsup,
-                                             mode=mode, after_layer=layer_hook, updates=updates)
+                                             mode=mode, after_layer=layer_hook, updates=updates, images=w16)
         # The decoder's gradients are final here (the projection head's follow with the encoder's: its backward
         # runs in the MLP heads' launch).  Data-parallel: their all-reduce goes out now, in a few chunks (the
         # collectives of one communicator run in order), so that the side-stream Adam of chunk i overlaps the
@@ -808,11 +857,15 @@ class PCAATrainer:
                     self._side.wait_event(ready)        # everything enqueued on the main stream so far
                     if self._wg is not None:
                         self._side.wait_stream(self._wg)   # ... and the decoder weight gradients on the wgrad stream
-                    for dz2, x, Wv, mv, vv in deferred:
+                    for dz2, x, Wv, mv, vv, w16 in deferred:
                         dz2.record_stream(self._side)
                         x.record_stream(self._side)
                         ops.skinny_linear_wgrad_adam_(dz2, x, Wv, mv, vv, *self.betas_g(), 1e-8, self.flat_g.coef_dev, gs,
                                                       exact=exact_dec)
+                        if w16 is not None:
+                            # the image follows its weight on this stream (a coalesced 6 B/param pass; written from inside
+                            # the update kernel -- 64-B partial lines from different CUs -- it doubled that kernel's time)
+                            ops.cast_bf16(Wv, want_transposed=False, out=w16)
                     for lo, hi, work in pending:
                         if hi <= self._dec_start:
                             continue                    # the projection-head slice is updated on the main stream
@@ -919,6 +972,7 @@ class PCAATrainer:
             for dst, src in zip(static, (pcs, gt, z0, alphas)):
                 dst.copy_(src)
             steps0 = (self.flat_g.step, self.flat_d.step)
+            self._refresh_w16(self.precision or F_hip.get_precision(), pcs.shape[0], False)      # not inside the capture
             graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize(self.device)
             # capture records the launches without running them: parameters, Adam state, BatchNorm
@@ -934,6 +988,9 @@ class PCAATrainer:
         for dst, src in zip(ent["static"], (pcs, gt, z0, alphas)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
+        # the replay streams the bf16 weight images the capture saw: rebuild them (eagerly, before the replay) if the
+        # weights were written from outside since
+        self._refresh_w16(self.precision or F_hip.get_precision(), pcs.shape[0], False)
         self.flat_g.step += 1
         self.flat_d.step += 1
         if supervise:

@@ -1050,3 +1050,23 @@ def test_dtc_conv_dgrad_bf16_variant(B, T, cin, cout, d):
     a32, _, _ = ops.dtc_conv_dgrad(dyi, Wi, B, T, cin, d)
     a16, _, _ = ops.dtc_conv_dgrad(dyi, Wi, B, T, cin, d, bf16=True)
     assert torch.equal(a16, a32)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# decoder weights as bf16 images (round 4, ABI 14): the weight-streaming kernels read half the bytes
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(64, 1920, 960), (64, 3840, 1920), (37, 256, 128), (64, 15360, 7680)])
+def test_skinny_w16_image_is_bitwise_the_fp32_stream(M, N, K):
+    """pcaa_skinny_linear_fwd_w16 / _dgrad_w16 on the bf16 image of W against the kernels that round W in registers: the
+    image holds exactly those roundings, so every output bit agrees."""
+    x, W, b = _rand((M, K), 201).to(DEV), _rand((N, K), 202, K ** -0.5).to(DEV), _rand((N,), 203, 0.1).to(DEV)
+    dz, a_prev = _rand((M, N), 204).to(DEV), _rand((M, K), 205).to(DEV)
+    W16 = W.bfloat16()
+    assert torch.equal(ops.cast_bf16(W, want_transposed=False)[0], W16)
+    y0 = ops.skinny_linear_fwd(x, W, b, ACT_ELU)
+    y1 = ops.skinny_linear_fwd(x, W, b, ACT_ELU, W16=W16)
+    assert torch.equal(y0, y1)
+    d0 = ops.skinny_linear_dgrad(dz, W, a_prev=a_prev)
+    d1 = ops.skinny_linear_dgrad(dz, W, a_prev=a_prev, W16=W16)
+    assert torch.equal(d0, d1)
