@@ -85,7 +85,7 @@ def test_steps_with_images_match_the_steps_without():
     assert l1[0] == l0[0], "the first step starts from identical state: identical kernels, identical result"
     _same_to_run_noise(l1, l0, w1, w0)
     _images_are_current(tr1)
-    n_img = len(tr1._w16_active("bf16", B, False))
+    n_img = len(tr1._dec_w16)
     assert n_img >= 3 and tr1.w16_casts == n_img, "one cast per layer, then the fused update keeps the image"
     assert tr0.w16_casts == 0 and not tr0._dec_w16
 
@@ -97,4 +97,4 @@ def test_a_weight_written_from_outside_is_noticed(graphed):
     tr0, l0, w0 = _run(steps, False, graphed=graphed, poke_at=poke)
     _same_to_run_noise(l1, l0, w1, w0)
     _images_are_current(tr1)
-    assert tr1.w16_casts == len(tr1._w16_active("bf16", B, False)) + 1, "exactly the poked layer was rebuilt"
+    assert tr1.w16_casts == len(tr1._dec_w16) + 1, "exactly the poked layer was rebuilt"
