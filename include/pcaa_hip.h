@@ -75,6 +75,12 @@ int pcaa_gemm(int math,
  * out (=|+=).  pcaa_gemm_num_splits tells how many splits pcaa_gemm / pcaa_gemm_slabs will
  * actually run for a requested split_k (K is cut into multiples of the kernel's K step). */
 int pcaa_gemm_num_splits(int math, int K, int split_k);
+/* ABI 14: n <= 8 small products C_i[M_i, N_i] += A_i^T . B_i in ONE launch (the temporal block's six weight gradients
+ * dW_l = dy_l^T . col_l, reference models.py:108-160 through autograd): A_i [K_i, M_i], B_i [K_i, N_i], C_i [M_i, N_i], all
+ * fp32 with contiguous rows, 16-B aligned, M_i and N_i multiples of 4; exact-fp32 MFMA; C_i is accumulated into (atomics
+ * over split_k[i] ranges of the contraction): the caller zeroes it. */
+int pcaa_gemm_group_rc_f32(int n, const void* const* A, const void* const* B, void* const* C, const int* M,
+                           const int* N, const int* K, const int* split_k, void* stream);
 /* Which tile loop serves the bf16 / split-fp16 KC x KC products without K splits (whole 256 x 256 tiles, contraction
  * >= 320 deep): 1 (default; environment PCAA_GEMM_V2=0 to start with 0) = the 4-wave loop of round 4 (csrc/gemm_v2.h:
  * 128 x 128 wave tiles, both operands requested two K steps ahead, the request stream continuous across tiles), 0 = the

@@ -157,19 +157,19 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[2][2
   }
 }
 
+// one 128 x 128 tile of one K range: ``bid`` = the tile's block number (XCD-aware map), ``split`` = the K range
 template <typename TA, typename TB, typename TC, int ALAY, int BLAY, bool VEC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+__device__ __forceinline__ void gemm_f32_body(const GemmParams& p, int bid, int split, float* smem) {
   constexpr int PA = FPitch<ALAY>::v, PB = FPitch<BLAY>::v;
-  __shared__ __attribute__((aligned(16))) float smem[F_BK * PA + F_BK * PB];
   float* sA = smem;
   float* sB = smem + F_BK * PA;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
   int tm, tn;
-  tile_coords(p.M, p.N, tm, tn);
+  xcd_tile_coords((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, bid, tm, tn);
 
-  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kbeg = split * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int nt = (kend - kbeg + F_BK - 1) / F_BK;
 
@@ -219,6 +219,35 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
   }
   epilogue<TC>(p, acc, smem, tm, tn, tid);
+}
+
+template <typename TA, typename TB, typename TC, int ALAY, int BLAY, bool VEC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[F_BK * FPitch<ALAY>::v + F_BK * FPitch<BLAY>::v];
+  gemm_f32_body<TA, TB, TC, ALAY, BLAY, VEC>(p, blockIdx.x, blockIdx.z, smem);
+}
+
+// Several small products in ONE launch (round 4: the temporal block's six weight gradients dW_l = dy_l^T . col_l were six
+// launches of 1-24 tiles x <= 15 K ranges each, 26-47 us apiece in a chain on the weight-gradient stream: 0.23 ms at
+// N = 32 and, sharing hardware queues with it, in the way of the dgrad chain -- without them the N = 32 step is 0.17 ms
+// shorter).  Block b of the launch belongs to product i with first[i] <= b < first[i + 1]; within it the tile number runs
+// fastest, then the K range.  fp32 RC x RC operands, fp32 result accumulated atomically (the caller zeroes it).
+constexpr int GROUP_MAX = 8;
+struct GemmGroup {
+  GemmParams p[GROUP_MAX];
+  int first[GROUP_MAX + 1];
+  int ntiles[GROUP_MAX];
+  int n;
+};
+__global__ __launch_bounds__(256) void gemm_f32_group_kernel(GemmGroup g) {
+  __shared__ __attribute__((aligned(16))) float smem[F_BK * FPitch<RC>::v + F_BK * FPitch<RC>::v];
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < GROUP_MAX; ++j)
+    if (j < g.n && (int)blockIdx.x >= g.first[j]) i = j;
+  const int local = (int)blockIdx.x - g.first[i];
+  const int split = local / g.ntiles[i], bid = local - split * g.ntiles[i];
+  gemm_f32_body<float, float, float, RC, RC, true>(g.p[i], bid, split, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -466,6 +495,42 @@ extern "C" int pcaa_gemm(int math,
                          int split_k, int accumulate, void* stream) {
   return gemm_impl(math, A, a_dtype, a_layout, lda, B, b_dtype, b_layout, ldb, C, c_dtype, ldc, M, N, K, bias,
                    colstats, nrep, split_k, accumulate, 0, stream);
+}
+
+/* n <= 8 products C_i[M_i, N_i] += A_i^T . B_i in one launch: A_i [K_i, M_i], B_i [K_i, N_i], C_i [M_i, N_i] fp32, contiguous
+ * rows (lda = M_i, ldb = N_i, ldc = N_i), 16-B aligned, M_i and N_i multiples of 4; C_i is ACCUMULATED into (atomics over
+ * the K ranges): the caller zeroes it.  split_k[i]: how many ranges product i's contraction is cut into. */
+extern "C" int pcaa_gemm_group_rc_f32(int n, const void* const* A, const void* const* B, void* const* C, const int* M,
+                                      const int* N, const int* K, const int* split_k, void* stream) {
+  PCAA_CHECK_ARG(n >= 1 && n <= GROUP_MAX && A && B && C && M && N && K && split_k, "pcaa_gemm_group_rc_f32: bad args (n <= %d)",
+                 GROUP_MAX);
+  GemmGroup g;
+  memset(&g, 0, sizeof(g));
+  g.n = n;
+  long total = 0;
+  for (int i = 0; i < n; ++i) {
+    PCAA_CHECK_ARG(A[i] && B[i] && C[i] && M[i] > 0 && N[i] > 0 && K[i] > 0 && split_k[i] >= 1,
+                   "pcaa_gemm_group_rc_f32: product %d: bad shape", i);
+    PCAA_CHECK_ARG((M[i] % 4) == 0 && (N[i] % 4) == 0 && ((uintptr_t)A[i] % 16) == 0 && ((uintptr_t)B[i] % 16) == 0 &&
+                   ((uintptr_t)C[i] % 16) == 0, "pcaa_gemm_group_rc_f32: product %d: M, N multiples of 4, 16-B aligned operands", i);
+    GemmParams& p = g.p[i];
+    p.A = A[i]; p.B = B[i]; p.C = C[i];
+    p.lda = M[i]; p.ldb = N[i]; p.ldc = N[i];
+    p.M = M[i]; p.N = N[i]; p.K = K[i];
+    p.nrep = 1;
+    p.atomic = 1;
+    p.nsplit = 1;
+    int kps = 0;
+    const int nsplit = gemm_num_splits(PCAA_F32, K[i], split_k[i], &kps);
+    p.k_per_split = kps;
+    g.ntiles[i] = (int)(cdiv(M[i], BM) * cdiv(N[i], BN));
+    g.first[i] = (int)total;
+    total += (long)g.ntiles[i] * nsplit;
+  }
+  for (int i = n; i <= GROUP_MAX; ++i) g.first[i] = (int)total;
+  PCAA_CHECK_ARG(total < (1L << 31), "pcaa_gemm_group_rc_f32: too many blocks");
+  hipLaunchKernelGGL(gemm_f32_group_kernel, dim3((unsigned)total), dim3(256), 0, as_stream(stream), g);
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_gemm_group_rc_f32");
 }
 
 // split-K without atomics: split s writes its partial product to slabs + s * slab_stride

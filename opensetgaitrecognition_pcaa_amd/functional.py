@@ -323,7 +323,7 @@ _MOMENT_STATS = os.environ.get("PCAA_MOMENT_STATS", "1") != "0"
 
 def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool_scale=1.0,
                        need_dinput=True, lhs=None, outs=None, below=None, below_W=None, dgrad_fn=None,
-                       below_bn=None, below_outs=None, wgrad_math=PCAA_F32):
+                       below_bn=None, below_outs=None, wgrad_math=PCAA_F32, defer_wgrad=None):
     """Backward of one (linear, BN, ELU) layer.  ``lhs`` is the GEMM's left
     operand ([rows, K]: the input activation or the im2col matrix).  ``outs`` =
     (dW, dgamma, dbeta) destination views (dW PRE-ZEROED: the trainer's flat
@@ -401,7 +401,11 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
         big = wgrad_math == PCAA_BF16 and cout >= 128 and K >= 128 and cout % 8 == 0
         sk = ops.pick_split_k(cout, K, rows_local, target_blocks=256, bk=64, tile=256) if big else ops.pick_split_k(cout, K, rows_local)
         wm = PCAA_BF16 if big else PCAA_F32
-        if dW_out is not None:
+        if defer_wgrad is not None and not big and dy.dtype == torch.float32 and lhs.dtype == torch.float32:
+            # the caller launches this product together with its siblings (dtc_backward: one grouped launch)
+            dW = dW_out if dW_out is not None else torch.zeros((cout, K), dtype=torch.float32, device=dy.device)
+            defer_wgrad.append((dy, lhs, dW, sk))
+        elif dW_out is not None:
             with _on_wgrad_stream(dy, lhs):
                 dW = ops.gemm(dy, RC, lhs, RC, cout, K, rows_local, out=dW_out, split_k=sk, accumulate=True, math=wm)
         else:
@@ -614,9 +618,15 @@ def dtc_forward(a2d, B, T, layers, training, pool_time, mode="fp32"):
 _DTC_WGRAD_BF16 = os.environ.get("PCAA_DTC_WGRAD_BF16", "0") != "0"
 
 
+# the temporal block's weight gradients: "wg" = one grouped launch on the weight-gradient stream, "main" = on the calling
+# stream, "0" = one launch per layer (rounds 1-3)
+_DTC_WGRAD_GROUP = os.environ.get("PCAA_DTC_WGRAD_GROUP", "wg")
+
+
 def dtc_backward(saves, layers, B, T, d_last=None, dpool=None, need_dx=True, gout=None, prefix="tc_block.dtc", mode="fp32"):
     grads = []
     wmath = PCAA_BF16 if (mode == "bf16" and _DTC_WGRAD_BF16) else PCAA_F32
+    defer = [] if _DTC_WGRAD_GROUP != "0" else None
     da = d_last
     for li in range(len(layers) - 1, -1, -1):
         layer, s = layers[li], saves[li]
@@ -651,10 +661,10 @@ def dtc_backward(saves, layers, B, T, d_last=None, dpool=None, need_dx=True, gou
         if li == len(layers) - 1 and dpool is not None:
             dW, dg, db, dcol = _bn_layer_backward(s, bn, W2d, "fp32", dpool=dpool, group_rows=T,
                                                   pool_scale=1.0 / T, need_dinput=need_in, lhs=s.col, outs=outs,
-                                                  dgrad_fn=dgrad_fn, wgrad_math=wmath)
+                                                  dgrad_fn=dgrad_fn, wgrad_math=wmath, defer_wgrad=defer)
         else:
             dW, dg, db, dcol = _bn_layer_backward(s, bn, W2d, "fp32", da=da, need_dinput=need_in, lhs=s.col,
-                                                  outs=outs, dgrad_fn=dgrad_fn, wgrad_math=wmath)
+                                                  outs=outs, dgrad_fn=dgrad_fn, wgrad_math=wmath, defer_wgrad=defer)
         zb = gout[f"{prefix}{li + 1}.conv1d.bias"] if gout is not None else torch.zeros_like(conv.bias)
         grads.append({"conv1d.weight": dW.view_as(conv.weight), "conv1d.bias": zb,
                       "batch_norm.weight": dg, "batch_norm.bias": db})
@@ -664,6 +674,16 @@ def dtc_backward(saves, layers, B, T, d_last=None, dpool=None, need_dx=True, gou
             da = dcol                       # already the gradient w.r.t. the layer's input
         else:
             da = ops.dtc_col2im(dcol, B, T, s.cin, s.dil)
+    if defer:
+        # the block's weight gradients dW_l = dy_l^T . col_l, all in one launch behind the dgrad chain (round 4: they were
+        # six launches of 26-47 us in a chain beside it; measured without them the N = 32 step was 0.17 ms shorter)
+        tensors = [t for d in defer for t in d[:3]]
+        for k in range(0, len(defer), 8):
+            if _DTC_WGRAD_GROUP == "main":
+                ops.gemm_group_rc_f32(defer[k:k + 8])
+            else:
+                with _on_wgrad_stream(*tensors):
+                    ops.gemm_group_rc_f32(defer[k:k + 8])
     grads.reverse()
     return grads, da
 

@@ -421,6 +421,26 @@ def gemm(A, a_layout, B, b_layout, M, N, K, *, lda=None, ldb=None, out=None, out
     return out
 
 
+def gemm_group_rc_f32(products):
+    """``products``: up to 8 tuples (A [K,M] fp32, B [K,N] fp32, C [M,N] fp32 -- accumulated into, the caller zeroes it --,
+    split_k): all of them C += A^T . B on the exact-fp32 matrix pipe in ONE launch (pcaa_gemm_group_rc_f32)."""
+    n = len(products)
+    if not 1 <= n <= 8:
+        raise ValueError("gemm_group_rc_f32: 1..8 products")
+    ptr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    ints = lambda vs: (ctypes.c_int * n)(*[int(v) for v in vs])
+    for A, B, C, sk in products:
+        _chk(A, "gemm_group.A", torch.float32, 2)
+        _chk(B, "gemm_group.B", torch.float32, 2)
+        _chk(C, "gemm_group.C", torch.float32)
+        if A.shape[0] != B.shape[0] or C.numel() != A.shape[1] * B.shape[1] or A.stride(0) != A.shape[1] or B.stride(0) != B.shape[1]:
+            raise ValueError("gemm_group_rc_f32: A [K,M], B [K,N] with contiguous rows, C [M,N]")
+    check(_lib.load().pcaa_gemm_group_rc_f32(
+        n, ptr([p[0] for p in products]), ptr([p[1] for p in products]), ptr([p[2] for p in products]),
+        ints([p[0].shape[1] for p in products]), ints([p[1].shape[1] for p in products]), ints([p[0].shape[0] for p in products]),
+        ints([p[3] for p in products]), _s()), "pcaa_gemm_group_rc_f32")
+
+
 def gemm_slabs(A, a_layout, B, b_layout, M, N, K, split_k, out=None, accumulate=False, math=PCAA_BF16,
                colstats=None, tail=None, reduce_ctx=None):
     """Split-K product without atomics: every split writes its partial [M,N] slab, a second

@@ -1070,3 +1070,23 @@ def test_skinny_w16_image_is_bitwise_the_fp32_stream(M, N, K):
     d0 = ops.skinny_linear_dgrad(dz, W, a_prev=a_prev)
     d1 = ops.skinny_linear_dgrad(dz, W, a_prev=a_prev, W16=W16)
     assert torch.equal(d0, d1)
+
+
+def test_gemm_group_rc_f32_vs_fp64():
+    """pcaa_gemm_group_rc_f32: six products of the temporal block's weight-gradient shapes (B*T = 1920 rows) in one launch,
+    accumulated into zeroed results, against fp64."""
+    R = 1920
+    shapes = [(16, 3072), (32, 48), (64, 96), (128, 192), (256, 384), (512, 768)]
+    prods, refs = [], []
+    for i, (m, n) in enumerate(shapes):
+        A, B = _rand((R, m), 300 + i), _rand((R, n), 320 + i)
+        C = torch.zeros((m, n), dtype=torch.float32, device=DEV)
+        prods.append((A.to(DEV), B.to(DEV), C, ops.pick_split_k(m, n, R)))
+        refs.append(A.double().t() @ B.double())
+    ops.gemm_group_rc_f32(prods)
+    for (A, B, C, sk), ref in zip(prods, refs):
+        assert (C.cpu().double() - ref).abs().max().item() <= 2e-6 * R ** 0.5 * ref.abs().max().item() + 1e-6
+    # a second launch accumulates
+    ops.gemm_group_rc_f32(prods[:2])
+    assert (prods[0][2].cpu().double() - 2 * refs[0]).abs().max().item() <= 4e-6 * R ** 0.5 * refs[0].abs().max().item() + 1e-6
+    assert (prods[2][2].cpu().double() - refs[2]).abs().max().item() <= 2e-6 * R ** 0.5 * refs[2].abs().max().item() + 1e-6
