@@ -1130,6 +1130,8 @@ bool launch_v2rc(const GemmParams& p, dim3 grid, hipStream_t s) {
 
 template <typename TC, int EPI, bool SPLIT>
 bool launch_v2_inst(const GemmParams& p, dim3 grid, hipStream_t s) {
+  // a partial last row tile stores (and, fused dgrad, reads y) through 32-bit buffer offsets over the whole matrix
+  if ((p.M % BM) != 0 && (long)p.M * p.ldc * (long)sizeof(TC) >= (1L << 32)) return false;
   return (p.M % BM) != 0 ? launch_v2_rag<TC, EPI, SPLIT, true>(p, grid, s) : launch_v2_rag<TC, EPI, SPLIT, false>(p, grid, s);
 }
 

@@ -121,12 +121,29 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, f32x4 (&acc)
   };
   static_assert(!(AFFINE && SC), "the eval epilogues take bf16 operands");
   TC* C = reinterpret_cast<TC*>(p.C) + row0 * p.ldc + c0;
+  // RAG: stores through a buffer resource that ends with row M - 1 (the hardware drops a store past it: no per-row
+  // predicates; see epilogue_dgrad_bn).  The range check covers the vector offset only: the row offset goes there.
+  buf_rsrc_t rC = make_rsrc(p.C, RAG ? (long)p.M * p.ldc * (long)sizeof(TC) : 0);
+  const unsigned voff0 = RAG ? (unsigned)((row0 * p.ldc + c0) * (long)sizeof(TC)) : 0u;
+  const unsigned rstep = RAG ? (unsigned)(p.ldc * (long)sizeof(TC)) : 0u;
+  (void)mrows;
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (RAG && i * 16 + r >= mrows) continue;
-      if constexpr (sizeof(TC) == 2) {
+      if constexpr (RAG) {
+        const unsigned vo = voff0 + (unsigned)(i * 16 + r) * rstep;
+        if constexpr (sizeof(TC) == 2) {
+          const u32x4_t o = {pack2(out(acc[i][0][r], 0), out(acc[i][1][r], 1)), pack2(out(acc[i][2][r], 2), out(acc[i][3][r], 3)),
+                             pack2(out(acc[i][4][r], 4), out(acc[i][5][r], 5)), pack2(out(acc[i][6][r], 6), out(acc[i][7][r], 7))};
+          __builtin_amdgcn_raw_buffer_store_b128(o, rC, vo, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4{out(acc[i][0][r], 0), out(acc[i][1][r], 1),
+                                                                                    out(acc[i][2][r], 2), out(acc[i][3][r], 3)}), rC, vo, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4{out(acc[i][4][r], 4), out(acc[i][5][r], 5),
+                                                                                    out(acc[i][6][r], 6), out(acc[i][7][r], 7)}), rC, vo + 16u, 0, 0);
+        }
+      } else if constexpr (sizeof(TC) == 2) {
         uint4 o;
         o.x = pack2(out(acc[i][0][r], 0), out(acc[i][1][r], 1));
         o.y = pack2(out(acc[i][2][r], 2), out(acc[i][3][r], 3));
@@ -176,23 +193,44 @@ __device__ __forceinline__ void epilogue_colstats(const GemmParams& p, f32x4 (&a
   // not zero-fill), so those rows of the A image hold whatever the stage held before, possibly NaN bit patterns
   const int mrows = (int)min((long)BM, (long)p.M - ((long)tm * BM + wm * 128 + 4 * (le >> 4)));
   float t1[8], t2[8];
+  if constexpr (RAG) {
+    // rows outermost: one validity test per row serves the lane's eight columns (columns outermost, the 32 row
+    // predicates stayed live across the whole loop nest: 360 B of scratch in the fp32-output instantiations)
+    f32x2 a1[8], a2[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    f32x2 a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+    for (int j = 0; j < 8; ++j) a1[j] = a2[j] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int r = 0; r < 4; r += 2) {
-        f32x2 v = {acc[i][j][r], acc[i][j][r + 1]};
-        if (RAG) {
-          if (i * 16 + r >= mrows) v.x = 0.f;
-          if (i * 16 + r + 1 >= mrows) v.y = 0.f;
+        const bool ok0 = i * 16 + r < mrows, ok1 = i * 16 + r + 1 < mrows;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const f32x2 v = {ok0 ? acc[i][j][r] : 0.f, ok1 ? acc[i][j][r + 1] : 0.f};
+          a1[j] += v;
+          a2[j] = __builtin_elementwise_fma(v, v, a2[j]);
         }
-        a1 += v;
-        a2 = __builtin_elementwise_fma(v, v, a2);
       }
-    t1[j] = (a1.x + a1.y) * os;                  // sums of (acc * os), (acc * os)^2: os is a power of two, exact
-    t2[j] = (a2.x + a2.y) * (os * os);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      t1[j] = (a1[j].x + a1[j].y) * os;
+      t2[j] = (a2[j].x + a2[j].y) * (os * os);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f32x2 a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 v = {acc[i][j][r], acc[i][j][r + 1]};
+          a1 += v;
+          a2 = __builtin_elementwise_fma(v, v, a2);
+        }
+      t1[j] = (a1.x + a1.y) * os;                  // sums of (acc * os), (acc * os)^2: os is a power of two, exact
+      t2[j] = (a2.x + a2.y) * (os * os);
+    }
   }
   colstats_finish(p, t1, t2, red, tm, tn, wm, wn, le, tid);
 }
@@ -235,16 +273,26 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p, f32x4 (&a
   // tile; now the whole tile's y is in flight at once (bf16: 32 x 16 B per lane; fp32: a ring of four blocks, three ahead))
   constexpr int RING = PCAA_V2_YRING, AHEAD = RING - 1;
   yraw_t yv[RING][4][YW];
+  // Partial last row tile (RAG): y is read and dz written through buffer resources that end with row M - 1 -- the
+  // hardware returns zeros for a row past M (finite: 0 * ELU'(NaN) would still be NaN in the column sums) and drops a
+  // store to one; no per-row pointer selects or store predicates (which, hoisted out of the unrolled loops, cost the
+  // bf16 instantiation 688 B of scratch per lane and 2.2x its time at the reference's default shape, 72 000 rows).
+  // The range check covers the VECTOR offset only, so the row offset goes there.
+  buf_rsrc_t rY = make_rsrc(p.ep_y, RAG ? (long)p.M * p.ldc * (long)sizeof(TE) : 0);
+  buf_rsrc_t rC = make_rsrc(p.C, RAG ? (long)p.M * p.ldc * (long)sizeof(TE) : 0);
+  const unsigned voff0 = RAG ? (unsigned)((row0 * p.ldc + c0) * (long)sizeof(TE)) : 0u;
+  const unsigned rstep = RAG ? (unsigned)(p.ldc * (long)sizeof(TE)) : 0u;
   auto load_y = [&](int i, int b) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int w = 0; w < YW; ++w) {
-        // (a row past M: its gradient is forced to zero below; its y is read from row 0 of the matrix -- any FINITE
-        // values: 0 * ELU'(NaN) would still be NaN in the column sums, and this lane's own first row may itself lie
-        // past M)
-        const TE* yp = (RAG && i * 16 + r >= mrows) ? reinterpret_cast<const TE*>(p.ep_y) + c0 : Y + (long)(i * 16 + r) * p.ldc;
-        yv[b][r][w] = *reinterpret_cast<const yraw_t*>(yp + (kF32 ? 4 * w : 0));
+        if constexpr (RAG) {
+          const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(rY, voff0 + (unsigned)(i * 16 + r) * rstep + 16u * w, 0, 0);
+          yv[b][r][w] = __builtin_bit_cast(yraw_t, raw);
+        } else {
+          yv[b][r][w] = *reinterpret_cast<const yraw_t*>(Y + (long)(i * 16 + r) * p.ldc + (kF32 ? 4 * w : 0));
+        }
       }
   };
 #pragma unroll
@@ -284,8 +332,16 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p, f32x4 (&a
         s2[h] = __builtin_elementwise_fma(d2, __builtin_elementwise_fma(y2[h], rs2[h], nm2[h]), s2[h]);
         dq[h] = d2;
       }
-      if (RAG && i * 16 + r >= mrows) continue;
-      if constexpr (kF32) {
+      if constexpr (RAG) {
+        const unsigned vo = voff0 + (unsigned)(i * 16 + r) * rstep;
+        if constexpr (kF32) {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4{dq[0].x, dq[0].y, dq[1].x, dq[1].y}), rC, vo, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4{dq[2].x, dq[2].y, dq[3].x, dq[3].y}), rC, vo + 16u, 0, 0);
+        } else {
+          const u32x4_t o = {pack2(dq[0].x, dq[0].y), pack2(dq[1].x, dq[1].y), pack2(dq[2].x, dq[2].y), pack2(dq[3].x, dq[3].y)};
+          __builtin_amdgcn_raw_buffer_store_b128(o, rC, vo, 0, 0);
+        }
+      } else if constexpr (kF32) {
         float* d = reinterpret_cast<float*>(C) + (long)(i * 16 + r) * p.ldc;
         store_nt(d, f32x4{dq[0].x, dq[0].y, dq[1].x, dq[1].y});
         store_nt(d + 4, f32x4{dq[2].x, dq[2].y, dq[3].x, dq[3].y});
