@@ -1,7 +1,7 @@
 // The KC x KC bf16 (and split-fp16) tile loop of round 4 -- included by gemm_bf16.hip inside its anonymous namespace.
 //
 // Restructured after hipBLASLt's hand-written gfx950 kernel (Custom_Cijk_Alik_Bljk_BBS_BH_..._MT256x256x64_MI16x16x1,
-// disassembled from torch's TensileLibrary_BB_BB_HA_Bias_SAV_UA_..._gfx950.co; DESIGN.md section 4 has the side-by-side):
+// disassembled from torch's TensileLibrary_BB_BB_HA_Bias_SAV_UA_..._gfx950.co; docs/LAB_LOG.md section 9 has the side-by-side):
 //   * FOUR waves (2 x 2), one per SIMD, 128 x 128 accumulators each (256 accumulator registers, pinned to the
 //     accumulator file): every fragment read from the LDS feeds 8 MFMAs -- 128 KB of fragment reads per K step
 //     instead of the 8-wave kernel's 192 KB;
