@@ -62,6 +62,15 @@ __device__ __forceinline__ void mfma(f32x4& c, const bf16x8& a, const bf16x8& b)
   if constexpr (F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
   else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
+// the first product of a tile: C = 0 as the inline constant instead of 256 v_accvgpr_write per wave and tile (PCAA_V2_ZERO_BY_MFMA)
+template <bool F16>
+__device__ __forceinline__ void mfma0(f32x4& c, const bf16x8& a, const bf16x8& b) {
+  if constexpr (F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+}
+#ifndef PCAA_V2_ZERO_BY_MFMA
+#define PCAA_V2_ZERO_BY_MFMA 1
+#endif
 __device__ __forceinline__ void lds_read(bf16x8& d, unsigned addr, int off) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(off));
 }
@@ -496,6 +505,56 @@ __global__ __launch_bounds__(NT) void gemm_bf16_v2_kernel(GemmParams p) {
     }                                                                                      \
   } while (0)
 
+  // One K step as a macro over the MFMA form of its first half (the tile's first step starts the accumulators from the
+  // constant 0: mfma0).  k-half 0: MFMAs on af[0] / bfr[0]; second-half fragments of B then A from the current stage;
+  // m = 21: B image of this stage dead (barrier); m = 22 of step 1: thread 0 draws this workgroup's NEXT tile (one tile
+  // ahead: the request cursor enters it three K steps before the MFMAs do) and hands it over through LDS -- request, wait
+  // and hand-off in ONE asm statement, so that the compiler never sees a register whose value is still on its way (a first
+  // version let the returned value "rest" in an asm output for two K steps: an instantiation that spilled that register
+  // right behind the asm handed out garbage tiles -- a memory access fault in the bf16 N = 32 step; a compiler-visible
+  // atomic instead dragged a spill slot and an s_waitcnt vmcnt(0) into the loop); the wait drains this wave's 16
+  // requests of the previous step, at least half a step old: ~0.5 us once per tile; m = 23..37: the 8 pieces of
+  // B(t + 2); m = 46: A image dead (barrier); m = 48..60: pieces 0..3 of A(t + 2).  k-half 1: MFMAs on af[1] / bfr[1];
+  // m = 0..12: pieces 4..7 of A(t + 2); m = 20: stage t + 1 has landed -- everything but this step's own 16 requests
+  // (loads retire in order, so "at most 16 outstanding" means the older stage is complete whatever the previous tile's
+  // stores, which share the counter, are doing) -- barrier; then the next step's first-half fragments of B and A.  At
+  // the end lgkmcnt(0): those fragments are in their registers; the ticket handed over in step 1 is read by every wave.
+#define V2_STEP(MFMA0_FN) \
+      bf16_t* cur = smem + s * STAGE; \
+      const unsigned cb = lds0 + (unsigned)s * (STAGE * 2), nb = lds0 + (unsigned)(s ^ 1) * (STAGE * 2); \
+      const unsigned aB1 = cb + (unsigned)(fB + kof1) * 2, aA1 = cb + (unsigned)(fA + kof1) * 2; \
+      const unsigned aB0 = nb + (unsigned)(fB + kof0) * 2, aA0 = nb + (unsigned)(fA + kof0) * 2; \
+_Pragma("unroll") \
+      for (int m = 0; m < 64; ++m) { \
+        const int i = m >> 3, j = m & 7; \
+        if ((m & 1) == 1 && m < 16) lds_read(bfr[1][m >> 1], aB1, (m >> 1) * 2048); \
+        if (m == 21) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        if (m == 22 && sched != nullptr && kt == 1 && tid == 0) { \
+          int tk; \
+          asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)\n\tds_write_b32 %3, %0\n\ts_waitcnt lgkmcnt(0)" \
+                       : "=&v"(tk) : "v"(sched + (vb & 7)), "v"(1), "v"(lds0 + SCRATCH_OFF + 4096) : "memory"); \
+        } \
+        if (m >= 24 && m < 40 && (m & 1) == 0) lds_read(af[1][(m - 24) >> 1], aA1, ((m - 24) >> 1) * 2048); \
+        if (m >= 23 && m < 39 && (m & 1) == 1) V2_REQ_B(cur, (m - 23) >> 1); \
+        if (m == 46) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        if (m >= 48 && (m & 3) == 0) V2_REQ_A(cur, (m - 48) >> 2); \
+        MFMA0_FN<SPLIT>(acc[i][j], af[0][i], bfr[0][j]); \
+        __builtin_amdgcn_sched_barrier(0); \
+      } \
+_Pragma("unroll") \
+      for (int m = 0; m < 64; ++m) { \
+        const int i = m >> 3, j = m & 7; \
+        if (m < 16 && (m & 3) == 0) V2_REQ_A(cur, 4 + (m >> 2)); \
+        if (m == 20) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory"); \
+        if (m >= 22 && m < 38 && (m & 1) == 0) lds_read(bfr[0][(m - 22) >> 1], aB0, ((m - 22) >> 1) * 2048); \
+        if (m >= 38 && m < 54 && (m & 1) == 0) lds_read(af[0][(m - 38) >> 1], aA0, ((m - 38) >> 1) * 2048); \
+        mfma<SPLIT>(acc[i][j], af[1][i], bfr[1][j]); \
+        __builtin_amdgcn_sched_barrier(0); \
+      } \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+      if (sched != nullptr && kt == 1) nvb = (vb & 7) + 8 * ((gstride >> 3) + __builtin_amdgcn_readfirstlane(words[0])); \
+      V2_ADVANCE(); \
+      s ^= 1;
   f32x4 acc[8][8];
   bf16x8 af[2][8], bfr[2][8];
   // prologue: stages 0 and 1 of the first tile
@@ -522,61 +581,18 @@ __global__ __launch_bounds__(NT) void gemm_bf16_v2_kernel(GemmParams p) {
     xcd_tile_coords(nbm, nbn, vb, tm, tn);
     asm volatile("" : "+v"(ln));
     lane_consts(ln);
+    if (!PCAA_V2_ZERO_BY_MFMA) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_nop 4" ::: "memory");
-    for (int kt = 0; kt < nt; ++kt) {
-      bf16_t* cur = smem + s * STAGE;              // this step's stage = destination of the requests for step t + 2
-      // LDS byte addresses of the fragment reads: second half of this stage, first half of the next
-      const unsigned cb = lds0 + (unsigned)s * (STAGE * 2), nb = lds0 + (unsigned)(s ^ 1) * (STAGE * 2);
-      const unsigned aB1 = cb + (unsigned)(fB + kof1) * 2, aA1 = cb + (unsigned)(fA + kof1) * 2;
-      const unsigned aB0 = nb + (unsigned)(fB + kof0) * 2, aA0 = nb + (unsigned)(fA + kof0) * 2;
-      // ---------------- k-half 0: MFMAs on af[0] / bfr[0]
-#pragma unroll
-      for (int m = 0; m < 64; ++m) {
-        const int i = m >> 3, j = m & 7;
-        if ((m & 1) == 1 && m < 16) lds_read(bfr[1][m >> 1], aB1, (m >> 1) * 2048);
-        if (m == 21) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // B image of this stage: dead
-        if (m == 22 && sched != nullptr && kt == 1 && tid == 0) {
-          // tickets: thread 0 draws this workgroup's NEXT tile (one tile ahead: the request cursor enters it three K
-          // steps before the MFMAs do) and hands it over through LDS -- request, wait and hand-off in ONE asm statement,
-          // so that the compiler never sees a register whose value is still on its way (a first version let the
-          // returned value "rest" in an asm output for two K steps: an instantiation that spilled that register right
-          // behind the asm handed out garbage tiles -- a memory access fault in the bf16 N = 32 step; a compiler-visible
-          // atomic instead dragged a spill slot and an s_waitcnt vmcnt(0) into the loop).  The wait drains this wave's
-          // 16 requests of the previous step, which are at least half a step old here: ~0.5 us once per tile.
-          int tk;
-          asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)\n\tds_write_b32 %3, %0\n\ts_waitcnt lgkmcnt(0)"
-                       : "=&v"(tk) : "v"(sched + (vb & 7)), "v"(1), "v"(lds0 + SCRATCH_OFF + 4096) : "memory");
-        }
-        if (m >= 24 && m < 40 && (m & 1) == 0) lds_read(af[1][(m - 24) >> 1], aA1, ((m - 24) >> 1) * 2048);
-        if (m >= 23 && m < 39 && (m & 1) == 1) V2_REQ_B(cur, (m - 23) >> 1);                  // 8 pieces of B(t + 2)
-        if (m == 46) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // A image: dead
-        if (m >= 48 && (m & 3) == 0) V2_REQ_A(cur, (m - 48) >> 2);                             // pieces 0..3 of A(t + 2)
-        mfma<SPLIT>(acc[i][j], af[0][i], bfr[0][j]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // ---------------- k-half 1: MFMAs on af[1] / bfr[1]
-#pragma unroll
-      for (int m = 0; m < 64; ++m) {
-        const int i = m >> 3, j = m & 7;
-        if (m < 16 && (m & 3) == 0) V2_REQ_A(cur, 4 + (m >> 2));                               // pieces 4..7 of A(t + 2)
-        // stage t + 1 has landed: everything but this step's own 16 requests (loads retire in order, so "at most 16
-        // outstanding" means the older stage is complete whatever the previous tile's stores -- which share the counter
-        // -- are doing: they can only make the wait longer)
-        if (m == 20) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-        if (m >= 22 && m < 38 && (m & 1) == 0) lds_read(bfr[0][(m - 22) >> 1], aB0, ((m - 22) >> 1) * 2048);
-        if (m >= 38 && m < 54 && (m & 1) == 0) lds_read(af[0][(m - 38) >> 1], aA0, ((m - 38) >> 1) * 2048);
-        mfma<SPLIT>(acc[i][j], af[1][i], bfr[1][j]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next step's first-half fragments are in their registers
-      // the ticket was handed over in the first half of step 1 (two barriers ago): every wave reads it
-      if (sched != nullptr && kt == 1) nvb = (vb & 7) + 8 * ((gstride >> 3) + __builtin_amdgcn_readfirstlane(words[0]));
-      V2_ADVANCE();
-      s ^= 1;
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      asm volatile("s_nop 4" ::: "memory");
+    }
+    if (PCAA_V2_ZERO_BY_MFMA) {
+      { const int kt = 0; V2_STEP(mfma0) }
+      for (int kt = 1; kt < nt; ++kt) { V2_STEP(mfma) }
+    } else {
+      for (int kt = 0; kt < nt; ++kt) { V2_STEP(mfma) }
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results (the asm hides the hazard from the compiler)
     // (split operands: the images hold value * 2^k; the epilogues multiply by p.out_scale -- an exact power of two -- as
@@ -613,6 +629,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_v2_kernel(GemmParams p) {
   }
 }
 
+#undef V2_STEP
 #undef V2_REQ_A
 #undef V2_REQ_B
 #undef V2_ADVANCE
