@@ -68,6 +68,9 @@ __device__ __forceinline__ void mfma0(f32x4& c, const bf16x8& a, const bf16x8& b
   if constexpr (F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
   else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
 }
+#ifndef PCAA_V2_BIAS_BRANCH
+#define PCAA_V2_BIAS_BRANCH 1      // lab builds: 0 = the bias add folded into the one store expression (rounds 1-4a)
+#endif
 #ifndef PCAA_V2_ZERO_BY_MFMA
 #define PCAA_V2_ZERO_BY_MFMA 1
 #endif
@@ -106,7 +109,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // RAG (every epilogue): the tile hangs over the last row of a matrix whose row count is not a multiple of 256 -- the
 // rows past M were requested out of the operand's buffer range (they read as zeros, so their accumulators and their
 // share of the column statistics are zero) and are neither loaded from y nor stored.
-template <typename TC, bool AFFINE, bool SC, bool RAG>
+// HASB: a bias is added (no BatchNorm layer of the train step has one -- BatchNorm cancels it -- and with the add folded
+// into the one store expression every launch paid 256 v_add_f32 of 0.0 per wave and tile: the caller branches once)
+template <typename TC, bool AFFINE, bool SC, bool RAG, bool HASB = true>
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, f32x4 (&acc)[8][8], int tm, int tn, int wm, int wn, int le) {
   const float os = SC ? p.out_scale : 1.f;
   const int l15 = le & 15, q = le >> 4;
@@ -116,7 +121,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, f32x4 (&acc)
   float bv[8], esc[8], esh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    bv[j] = p.bias != nullptr ? p.bias[c0 + j] : 0.f;
+    bv[j] = (HASB && p.bias != nullptr) ? p.bias[c0 + j] : 0.f;
     esc[j] = AFFINE ? p.ep_scale[c0 + j] : 1.f;
     esh[j] = AFFINE ? p.ep_shift[c0 + j] : 0.f;
   }
@@ -125,7 +130,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, f32x4 (&acc)
       v = fmaf(v + bv[j], esc[j], esh[j]);
       return v > 0.f ? v : __expf(v) - 1.f;
     } else {
-      return (SC ? v * os : v) + bv[j];
+      return HASB ? (SC ? v * os : v) + bv[j] : (SC ? v * os : v);
     }
   };
   static_assert(!(AFFINE && SC), "the eval epilogues take bf16 operands");
@@ -607,7 +612,13 @@ _Pragma("unroll") \
     } else if constexpr (EPI == EPI_POOL1 || EPI == EPI_POOL2 || EPI == EPI_POOL4) {
       epilogue_affine_meanpool<EPI == EPI_POOL1 ? 1 : (EPI == EPI_POOL2 ? 2 : 4), RAG>(p, acc, tm, tn, wm, wn, le);
     } else {
-      epilogue_store<TC, false, SPLIT, RAG>(p, acc, tm, tn, wm, wn, le);
+      if constexpr (PCAA_V2_BIAS_BRANCH && (sizeof(TC) == 2 || SPLIT)) {
+        if (p.bias != nullptr) epilogue_store<TC, false, SPLIT, RAG, true>(p, acc, tm, tn, wm, wn, le);
+        else epilogue_store<TC, false, SPLIT, RAG, false>(p, acc, tm, tn, wm, wn, le);
+      } else {
+        // (fp32 results of bf16 operands: two copies of this epilogue cost the instantiation 500-700 B of scratch)
+        epilogue_store<TC, false, SPLIT, RAG, true>(p, acc, tm, tn, wm, wn, le);
+      }
       if (p.colstats != nullptr) epilogue_colstats<SPLIT, RAG>(p, acc, red, tm, tn, wm, wn, le, te);
     }
     if (nvb >= ntiles) break;
