@@ -337,9 +337,11 @@ __device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p, f32x4 (&a
         if constexpr (kF32) {
           g = f32x2{elu_grad_from_pre(y2[h].x * sc2[h].x + sh2[h].x), elu_grad_from_pre(y2[h].y * sc2[h].y + sh2[h].y)};
         } else {
-          f32x2 z2 = __builtin_elementwise_fma(y2[h], sc2[h], sh2[h]);
-          z2 = __builtin_elementwise_min(z2, f32x2{0.f, 0.f});
-          g = f32x2{__builtin_amdgcn_exp2f(z2.x), __builtin_amdgcn_exp2f(z2.y)};
+          // ELU'(z) = min(exp2(z log2e), 1): the [0, 1] clamp is the exp instruction's own output modifier (was: a v_min
+          // of z against 0 in front of every exp -- 256 per wave and tile)
+          const f32x2 z2 = __builtin_elementwise_fma(y2[h], sc2[h], sh2[h]);
+          g = f32x2{__builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_exp2f(z2.x), 0.f), 1.f),
+                    __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_exp2f(z2.y), 0.f), 1.f)};
         }
         const f32x2 d2 = dav * g;
         s1[h] += d2;
