@@ -127,7 +127,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, f32x4 (&acc)
   }
   auto out = [&](float v, int j) __attribute__((always_inline)) {
     if constexpr (AFFINE) {
-      v = fmaf(v + bv[j], esc[j], esh[j]);
+      v = fmaf(HASB ? v + bv[j] : v, esc[j], esh[j]);
       return v > 0.f ? v : __expf(v) - 1.f;
     } else {
       return HASB ? (SC ? v * os : v) + bv[j] : (SC ? v * os : v);
@@ -610,7 +610,7 @@ _Pragma("unroll") \
     if constexpr (EPI == EPI_DGRAD_BN) {
       epilogue_dgrad_bn<TC, SPLIT, RAG>(p, acc, red, tm, tn, wm, wn, le, te);
     } else if constexpr (EPI == EPI_AFFINE) {
-      epilogue_store<TC, true, false, RAG>(p, acc, tm, tn, wm, wn, le);
+      epilogue_store<TC, true, false, RAG, false>(p, acc, tm, tn, wm, wn, le);      // (pcaa_gemm_affine_elu takes no bias: the caller folds it into the shift)
     } else if constexpr (EPI == EPI_POOL1 || EPI == EPI_POOL2 || EPI == EPI_POOL4) {
       epilogue_affine_meanpool<EPI == EPI_POOL1 ? 1 : (EPI == EPI_POOL2 ? 2 : 4), RAG>(p, acc, tm, tn, wm, wn, le);
     } else {
