@@ -101,6 +101,15 @@ __device__ __forceinline__ void piece(buf_rsrc_t r, long ld, int row0, int koff,
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// ELU of z given z2 = z * log2(e) (the caller folds log2e into the affine): max(z2, 0) * ln2 + (clamp(exp2(z2)) - 1) --
+// the [0, 1] clamp is the exp instruction's own output modifier, so exp2 of a positive z2 contributes 1 - 1 = 0 and of a
+// negative one exp(z) - 1; no compare / select pair and no separate multiply by log2e per element (the eval epilogues
+// spent ~1 000 of their 1 800 vector instructions per wave and tile on those)
+__device__ __forceinline__ float elu_from_z2(float z2) {
+  const float e = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_exp2f(z2), 0.f), 1.f);
+  return fmaf(__builtin_fmaxf(z2, 0.f), 0.6931471805599453f, e - 1.f);
+}
+
 // ---------------------------------------------------------------------------------------------------- epilogues
 // accumulator geometry: wave (wm, wn) owns rows wm * 128 .. + 127, columns wn * 128 .. + 127 of the tile; block (i, j),
 // register r of lane (c = lane & 15, q = lane >> 4) is row 16 i + 4 q + r, column 8 c + j.
@@ -122,13 +131,12 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, f32x4 (&acc)
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     bv[j] = (HASB && p.bias != nullptr) ? p.bias[c0 + j] : 0.f;
-    esc[j] = AFFINE ? p.ep_scale[c0 + j] : 1.f;
-    esh[j] = AFFINE ? p.ep_shift[c0 + j] : 0.f;
+    esc[j] = AFFINE ? p.ep_scale[c0 + j] * 1.4426950408889634f : 1.f;      // (AFFINE: times log2e, see elu_from_z2)
+    esh[j] = AFFINE ? p.ep_shift[c0 + j] * 1.4426950408889634f : 0.f;
   }
   auto out = [&](float v, int j) __attribute__((always_inline)) {
     if constexpr (AFFINE) {
-      v = fmaf(HASB ? v + bv[j] : v, esc[j], esh[j]);
-      return v > 0.f ? v : __expf(v) - 1.f;
+      return elu_from_z2(fmaf(HASB ? v + bv[j] : v, esc[j], esh[j]));
     } else {
       return HASB ? (SC ? v * os : v) + bv[j] : (SC ? v * os : v);
     }
@@ -395,15 +403,12 @@ __device__ __forceinline__ void epilogue_affine_meanpool(const GemmParams& p, f3
     float sum[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float esc = p.ep_scale[c0 + j], esh = p.ep_shift[c0 + j];
+      const float esc = p.ep_scale[c0 + j] * 1.4426950408889634f, esh = p.ep_shift[c0 + j] * 1.4426950408889634f;
       float s = 0.f;
 #pragma unroll
       for (int i = g0; i < g0 + BPG; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float z = fmaf(acc[i][j][r], esc, esh);
-          s += z > 0.f ? z : __expf(z) - 1.f;
-        }
+        for (int r = 0; r < 4; ++r) s += elu_from_z2(fmaf(acc[i][j][r], esc, esh));
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
       sum[j] = s * inv_n;
