@@ -6,6 +6,11 @@ WGAN-GP D-step, Chamfer, both Adams -- on synthetic mmGait10-shaped batches).
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        # outside a torchrun environment: starts that same command as a child
+                                        # (before any GPU call), forwards rank 0's line, exits with its status
+
+``--gpus`` is binding: under a launcher WORLD_SIZE must equal it (anything else exits non-zero with the command to
+run), so a line's ``n_gpus`` is always the N that was asked for.
 
 Workload at every N: BASELINE config[1], B=64 sequences per GPU, T=30, N=128
 points, C=4 features, K=8 classes, inputs resident in HBM before the timed
@@ -186,10 +191,9 @@ def cpu_baseline(B, N, C, K, T, budget_s=150.0):
             "seconds_per_step": times, "median_s": med,
             "phases_s": pmed,
             "phases_frac": {k: v / sum(pmed.values()) for k, v in pmed.items()},
-            "sample": f"oracle (plain PyTorch fp32: einsum / matmul contractions, measured on par with ATen's conv2d on "
-                      f"this torch) at B={sample_b} of the workload's {B}, N={N}, C={C}; {threads} threads (best of "
-                      f"{cands} on a warm B={cal_b} calibration step: "
-                      f"{ {t: round(v, 2) for t, v in trials.items()} } s) on a {ncpu}-CPU host, torch {torch.__version__}"}
+            "sample": f"oracle (plain PyTorch fp32) at B={sample_b} of the workload's {B}, N={N}, C={C}; {threads} threads "
+                      f"(best of {cands} on a B={cal_b} calibration step) of a {ncpu}-CPU host; 1 warm-up + 3 timed steps",
+            "thread_calibration_s": {str(t): round(v, 2) for t, v in trials.items()}}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -462,8 +466,69 @@ def workload_infer(a, dev):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# --gpus N is honoured: either this process IS one of N ranks (torchrun environment, WORLD_SIZE == N), or it becomes
+# the launcher of N ranks.  Decided before anything touches the GPU; the launcher never does.
+# ---------------------------------------------------------------------------------------------------------------
+def torchrun_command(gpus, argv, port=None):
+    """The command the contract launches for N > 1 (and the one this file starts as a CHILD when asked for N > 1
+    outside a torchrun environment)."""
+    if port is None:
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def resolve_world(a, argv, environ=None):
+    """-> ("rank", world) when this process runs the bench itself, ("launch", cmd) when it must start ``--gpus`` ranks
+    as child processes.  ``--gpus`` != WORLD_SIZE is always an error (SystemExit, non-zero): a line whose n_gpus is not
+    the N that was asked for is worse than no line."""
+    environ = os.environ if environ is None else environ
+    ws = environ.get("WORLD_SIZE")
+    if a.gpus < 1:
+        raise SystemExit(f"bench.py: --gpus {a.gpus}: need at least one GPU")
+    if ws is not None:
+        if int(ws) != a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={ws}: launch exactly one rank per GPU, e.g.\n  "
+                             + " ".join(torchrun_command(a.gpus, argv, port=29500)))
+        return "rank", int(ws)
+    if a.gpus == 1:
+        return "rank", 1
+    if a.workload != "train":
+        raise SystemExit("bench.py: --workload sweep / infer are single-GPU workloads")
+    return "launch", torchrun_command(a.gpus, argv)
+
+
+def launch_ranks(a, cmd):
+    """Parent of an N > 1 run started as plain ``python bench.py --gpus N``: N children through torch.distributed.run
+    (one per GPU, RCCL unless --backend gloo), their output forwarded as it comes (rank 0 prints the JSON line), exit
+    status = theirs.  No HIP call is made in this process: device_count() does not initialise the GPU on this image,
+    and nothing is exec'ed -- the children are ordinary subprocesses."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if a.backend == "nccl" and "PCAA_BENCH_DEVICE" not in os.environ and have < a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but this node shows {have} GPU(s)")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    print("bench.py: starting %d ranks: %s" % (a.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT)
+    try:
+        rc = proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        rc = proc.wait()
+    raise SystemExit(rc)
+
+
 def main():
     a = parse()
+    mode, what = resolve_world(a, sys.argv[1:])
+    if mode == "launch":
+        return launch_ranks(a, what)
     if a.workload != "train":
         if int(os.environ.get("WORLD_SIZE", "1")) > 1:
             raise SystemExit("bench.py: --workload sweep / infer are single-GPU workloads")
@@ -637,7 +702,8 @@ def main():
                 trl.step(pcs, gt, z0, al)
             barrier()
             d = max_over_ranks(time.perf_counter() - t_0)
-            exposed = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in trl.comm_events)
+            torch.cuda.synchronize()
+            exposed = sorted(trl.exposed_comm_us())
             exp_us = max_over_ranks(statistics.median(exposed)) if exposed else None
             dp_legs.append({"dp_mode": mode_, "grad_buckets": "bf16" if comp == "bf16" else "fp32", "sync_bn": sbn,
                             "ms_per_step": d / lsteps * 1e3, "value": world * B * lsteps / d, "steps": lsteps,
@@ -698,12 +764,12 @@ def main():
         if dp_legs is not None:
             line["dp_legs"] = {"note": "every exchange scheme of the data-parallel step, timed in this run (3 warm-up + "
                                        "`steps` steps, barrier + synchronize on both sides, max over ranks); exposed_comm_us = "
-                                       "median over the steps (max over ranks) of the main stream's time between the point "
-                                       "where it needs the encoder gradients reduced and the point where every decoder "
-                                       "bucket is back (HIP events, train.PCAATrainer.time_comm); the line's `value` is the "
+                                       "median over the steps (max over ranks) of the time the main stream spends waiting for "
+                                       "exchanges: from the point where it needs the encoder gradients reduced to the point "
+                                       "where every decoder bucket is back, + (ZeRO) the waits for the all-gathers of the "
+                                       "updated decoder shards, + (SyncBN) every synchronous statistics all-reduce (HIP "
+                                       "events, train.PCAATrainer.time_comm / exposed_comm_us); the line's `value` is the "
                                        "leg marked is_default", "legs": dp_legs}
-        if parity_leg is not None:
-            line["parity_mode"] = parity_leg
         if batcher_leg is not None:
             line["with_batcher"] = batcher_leg
         if sweep is not None:
@@ -755,6 +821,12 @@ def main():
                 cb = line["cpu_baseline"]
                 cb["phases_vs_gpu"] = {k: {"cpu_s": cb["phases_s"].get(k), "gpu_us": sections["phases_us"].get(k)}
                                        for k in cb["phases_s"]}
+        # order of the line's tail (a log reader that keeps only the last few KB of stdout must still see them): the CPU
+        # baseline, then the dominant kernel's roofline, then the parity-grade legs -- the long legs come before
+        if "roofline" in line:
+            line["roofline"] = line.pop("roofline")
+        if parity_leg is not None:
+            line["parity_mode"] = parity_leg
         print(json.dumps(line), flush=True)
     if pg is not None:
         dist.destroy_process_group()

@@ -506,7 +506,7 @@ int pcaa_gemm_slabs_split3(const void* A, const void* B, int layout, long lda, l
 int pcaa_split_f16(const float* src, void* dst_img, long rows, int ch, int transpose, float img_scale, void* stream);
 /* Range guard of the images (round 4): fp16 holds |x| <= 65504 while the fp32 tensors of the reference have no limit.
  * Every image producer saturates a scaled value that leaves that range (finite hi, lo = 0) and sets *dev_flag
- * (device int32, registered per calling thread; NULL = no flag) to 1; NaN inputs set it too.  The caller reads the
+ * (device int32, registered per calling thread; NULL = no flag) to 1; NaN inputs set it too and stay NaN in the image.  The caller reads the
  * flag when it next synchronises (PCAATrainer.check()) and must not trust that step's products. */
 int pcaa_set_range_flag(int* dev_flag);
 int pcaa_bn_act_fwd_split(const float* y, void* a_img, const float* scale, const float* shift, long rows,

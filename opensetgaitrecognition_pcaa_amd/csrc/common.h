@@ -89,7 +89,9 @@ int* pcaa_range_flag_ptr();      // host: the registered device flag of the call
 __device__ __forceinline__ float split_guard(float v, int* oflow) {
   if (!(fabsf(v) <= SPLIT_MAX)) {
     if (oflow) *oflow = 1;
-    v = fminf(fmaxf(v, -SPLIT_MAX), SPLIT_MAX);      // (fminf / fmaxf drop a NaN operand: a NaN saturates too, flagged)
+    // a NaN stays NaN (fminf / fmaxf drop a NaN operand and would have turned it into -65504 -- a
+    // diverged step must keep showing NaN losses, not finite ones); +-inf and finite outliers saturate
+    if (v == v) v = fminf(fmaxf(v, -SPLIT_MAX), SPLIT_MAX);
   }
   return v;
 }

@@ -554,9 +554,20 @@ extern "C" int pcaa_gemm_slabs(int math,
 bool pcaa_gemm_v2_is_enabled();      // gemm_bf16.hip
 // M need not be a multiple of 256 where the 4-wave tile loop serves the launch (round 4: it reads the rows past M as
 // zeros and skips them on the way out): contraction >= 320 deep, KC operands
-static bool ragged_m_ok(int K) { return pcaa_gemm_v2_is_enabled() && K >= 320; }
+//  the predicates and the entry points' argument checks together state everything launch_dma asks of a
+// ragged launch, so that a shape reported as supported cannot end in PCAA_ERR_LAUNCH: the result (and the fused dgrad's
+// y) is addressed through 32-bit buffer offsets over ceil(M / 256) * 256 rows (the rows past M wrap otherwise), its
+// leading dimension is a multiple of 8 elements and 16-B aligned, and the first-layer recompute variant
+// (pcaa_gemm_dgrad_bn with x) has no ragged instantiation.
+static bool ragged_m_ok(int M, int N, int K) {
+  // N columns of at most 4 bytes: the predicate's bound; the entry points re-check with the real ld and element size
+  return pcaa_gemm_v2_is_enabled() && K >= 320 && (long)cdiv(M, 256) * 256 * N * 4 < (1L << 32);
+}
+static bool ragged_out_ok(int M, const void* C, long ldc, int elem) {
+  return (M % 256) == 0 || ((ldc % 8) == 0 && ((uintptr_t)C % 16) == 0 && (long)cdiv(M, 256) * 256 * ldc * elem < (1L << 32));
+}
 extern "C" int pcaa_gemm_split3_supported(int M, int N, int K) {
-  return M > 0 && N > 0 && K > 0 && ((M % 256) == 0 || ragged_m_ok(K)) && (N % 256) == 0 && (K % 64) == 0;
+  return M > 0 && N > 0 && K > 0 && ((M % 256) == 0 || ragged_m_ok(M, N, K)) && (N % 256) == 0 && (K % 64) == 0;
 }
 
 static int gemm_split3_impl(const void* A, const void* B, int layout, long lda, long ldb, void* C, long ldc, int M, int N,
@@ -569,6 +580,8 @@ static int gemm_split3_impl(const void* A, const void* B, int layout, long lda, 
                  "launch (KC operands, K >= 320, no K split) (M=%d N=%d K=%d)", M, N, K);
   PCAA_CHECK_ARG((M % 256) == 0 || (split_k <= 1 && c_split_stride == 0), "pcaa_gemm_split3: a partial last row tile needs a "
                  "single K pass");
+  PCAA_CHECK_ARG(ragged_out_ok(M, C, ldc, 4), "pcaa_gemm_split3: a partial last row tile needs ldc %% 8 == 0, a 16-B aligned "
+                 "C and ceil(M / 256) * 256 * ldc * 4 < 4 GiB (M=%d ldc=%ld)", M, ldc);
   PCAA_CHECK_ARG((long)K * 3 < (1L << 31), "pcaa_gemm_split3: K too large");
   const long a_cols = layout == KC ? 2L * K : 2L * M, b_cols = layout == KC ? 2L * K : 2L * N;
   PCAA_CHECK_ARG(lda >= a_cols && ldb >= b_cols && ldc >= N && (lda % 8) == 0 && (ldb % 8) == 0,
@@ -616,7 +629,7 @@ extern "C" int pcaa_gemm_slabs_split3(const void* A, const void* B, int layout, 
 }
 
 extern "C" int pcaa_gemm_dgrad_bn_supported(int M, int N, int K) {
-  return M > 0 && N > 0 && K > 0 && ((M % 256) == 0 || ragged_m_ok(K)) && (N % 256) == 0 && (K % 64) == 0;
+  return M > 0 && N > 0 && K > 0 && ((M % 256) == 0 || ragged_m_ok(M, N, K)) && (N % 256) == 0 && (K % 64) == 0;
 }
 
 extern "C" int pcaa_gemm_dgrad_bn(const void* dy, long lddy, const void* Wt, long ldw, const void* y, void* dz,
@@ -631,6 +644,8 @@ extern "C" int pcaa_gemm_dgrad_bn(const void* dy, long lddy, const void* Wt, lon
                  "(M=%d N=%d K=%d)", M, N, K);
   PCAA_CHECK_ARG(lddy >= K && ldw >= K && ld >= N && (lddy % 8) == 0 && (ldw % 8) == 0 && (ld % 8) == 0 && nrep >= 1,
                  "pcaa_gemm_dgrad_bn: bad leading dimension / nrep");
+  PCAA_CHECK_ARG((M % 256) == 0 || (x == nullptr && ragged_out_ok(M, dz, ld, 2)), "pcaa_gemm_dgrad_bn: a partial last row tile "
+                 "needs the y variant and ceil(M / 256) * 256 * ld * 2 < 4 GiB (M=%d ld=%ld)", M, ld);
   PCAA_CHECK_ARG(((uintptr_t)dy % 16) == 0 && ((uintptr_t)Wt % 16) == 0 && (!y || ((uintptr_t)y % 16) == 0) &&
                  ((uintptr_t)dz % 16) == 0 && ((uintptr_t)scale % 16) == 0 && ((uintptr_t)shift % 16) == 0 &&
                  ((uintptr_t)mean % 16) == 0 && ((uintptr_t)rstd % 16) == 0, "pcaa_gemm_dgrad_bn: 16-B alignment");
@@ -661,6 +676,8 @@ extern "C" int pcaa_gemm_dgrad_bn_split3(const void* dy_img, long lddy, const vo
                  "of 64 (M=%d N=%d K=%d)", M, N, K);
   PCAA_CHECK_ARG((long)K * 3 < (1L << 31) && lddy >= 2L * K && ldw >= 2L * K && ld >= N && (lddy % 8) == 0 &&
                  (ldw % 8) == 0 && (ld % 4) == 0 && nrep >= 1, "pcaa_gemm_dgrad_bn_split3: bad leading dimension / nrep");
+  PCAA_CHECK_ARG(ragged_out_ok(M, dz, ld, 4), "pcaa_gemm_dgrad_bn_split3: a partial last row tile needs ld %% 8 == 0 and "
+                 "ceil(M / 256) * 256 * ld * 4 < 4 GiB (M=%d ld=%ld)", M, ld);
   PCAA_CHECK_ARG(((uintptr_t)dy_img % 16) == 0 && ((uintptr_t)Wt_img % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
                  ((uintptr_t)dz % 16) == 0 && ((uintptr_t)scale % 16) == 0 && ((uintptr_t)shift % 16) == 0 &&
                  ((uintptr_t)mean % 16) == 0 && ((uintptr_t)rstd % 16) == 0, "pcaa_gemm_dgrad_bn_split3: 16-B alignment");
@@ -694,6 +711,8 @@ extern "C" int pcaa_gemm_affine_elu(const void* A, long lda, const void* W, long
                  "pcaa_gemm_affine_elu: bad leading dimension");
   PCAA_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0,
                  "pcaa_gemm_affine_elu: 16-B alignment");
+  PCAA_CHECK_ARG(ragged_out_ok(M, out, ldo, pool_rows ? 4 : 2), "pcaa_gemm_affine_elu: a partial last row tile needs ldo %% 8 "
+                 "== 0 and ceil(M / 256) * 256 * ldo * size < 4 GiB (M=%d ldo=%ld)", M, ldo);
   GemmParams p;
   memset(&p, 0, sizeof(p));
   p.A = A; p.B = W; p.C = out;

@@ -1130,8 +1130,10 @@ bool launch_v2rc(const GemmParams& p, dim3 grid, hipStream_t s) {
 
 template <typename TC, int EPI, bool SPLIT>
 bool launch_v2_inst(const GemmParams& p, dim3 grid, hipStream_t s) {
-  // a partial last row tile stores (and, fused dgrad, reads y) through 32-bit buffer offsets over the whole matrix
-  if ((p.M % BM) != 0 && (long)p.M * p.ldc * (long)sizeof(TC) >= (1L << 32)) return false;
+  // a partial last row tile stores (and, fused dgrad, reads y) through 32-bit buffer offsets over the whole matrix; the
+  // epilogues form offsets for every row of the last tile, also those past M, which the buffer's range check only
+  // drops as long as they do not wrap: the bound is on the PADDED row count
+  if ((p.M % BM) != 0 && (long)cdiv(p.M, BM) * BM * p.ldc * (long)sizeof(TC) >= (1L << 32)) return false;
   return (p.M % BM) != 0 ? launch_v2_rag<TC, EPI, SPLIT, true>(p, grid, s) : launch_v2_rag<TC, EPI, SPLIT, false>(p, grid, s);
 }
 
@@ -1353,9 +1355,13 @@ bool pcaa_launch_gemm_bf16_big(const GemmParams& p_in, int a_dtype, int a_layout
                                         p.c_split_stride == 0);
   if (!af && !bf && m_ok && (p.N % BN) == 0 && (p.K % BK) == 0 && (p.k_per_split % BK) == 0 &&
       a_layout == b_layout) {
-    if (a_layout == KC)
-      return cf ? launch_dma<float, KC, KC, EPI_PLAIN>(p, grid, stream) : launch_dma<bf16_t, KC, KC, EPI_PLAIN>(p, grid, stream);
-    if (cf) return launch_dma<float, RC, RC, EPI_PLAIN>(p, grid, stream);
+    if (a_layout == KC) {
+      const bool ok = cf ? launch_dma<float, KC, KC, EPI_PLAIN>(p, grid, stream) : launch_dma<bf16_t, KC, KC, EPI_PLAIN>(p, grid, stream);
+      // a partial last row tile the 4-wave loop declined (ldc, alignment, size): the register-staged kernel below
+      if (ok || (p.M % BM) == 0) return ok;
+    } else if (cf) {
+      return launch_dma<float, RC, RC, EPI_PLAIN>(p, grid, stream);
+    }
   }
   if (p.seg_len > 0) return false;       // split-fp16 operands are served by the LDS-DMA kernel only
   if (a_layout == KC && b_layout == KC) {

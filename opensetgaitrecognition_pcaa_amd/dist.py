@@ -37,3 +37,23 @@ def allreduce_sum_(t, group):
     if group is not None and dist.get_world_size(group) > 1:
         dist.all_reduce(t, group=group)
     return t
+
+
+def zero_tail_multiple(world, chunks, align):
+    """The sharded decoder optimizer (ZeRO-1, train.PCAATrainer dp_zero) cuts the decoder region of the flat buffer into
+    ``chunks`` pieces, each reduce-scattered into ``world`` slices of whole ``align``-float (256-B) lines: the region is
+    zero-padded to a multiple of this many floats."""
+    return world * chunks * align
+
+
+def zero_slices(dec_start, total, world, chunks, rank):
+    """[(chunk_lo, chunk_hi, mine_lo, mine_hi)] in flat-buffer element coordinates: chunk c of the decoder region
+    [dec_start, total) and rank ``rank``'s slice of it (what reduce_scatter_tensor leaves on this rank, what its Adam
+    updates, what all_gather_into_tensor puts back).  The region's length must be a multiple of world * chunks."""
+    n_all = total - dec_start
+    if n_all % (world * chunks):
+        raise ValueError(f"decoder region of {n_all} floats does not split into {chunks} chunks x {world} ranks")
+    n = n_all // chunks
+    per = n // world
+    return [(dec_start + c * n, dec_start + (c + 1) * n, dec_start + c * n + rank * per, dec_start + c * n + (rank + 1) * per)
+            for c in range(chunks)]

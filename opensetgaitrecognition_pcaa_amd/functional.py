@@ -87,7 +87,16 @@ def _sync_stats(stats, count):
     if g is None:
         return count
     import torch.distributed as dist
-    dist.all_reduce(stats, group=g)
+    ev = _SYNC_BN.get("events")
+    if ev is not None:
+        # PCAATrainer.time_comm: these all-reduces are synchronous on the main stream -- all of their time is exposed
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dist.all_reduce(stats, group=g)
+        e1.record()
+        ev.append((e0, e1))
+    else:
+        dist.all_reduce(stats, group=g)
     _SYNC_BN["collectives"] = _SYNC_BN.get("collectives", 0) + 1          # PCAATrainer folds these into its comm record
     _SYNC_BN["payload_bytes"] = _SYNC_BN.get("payload_bytes", 0) + stats.numel() * stats.element_size()
     return count * dist.get_world_size(g)
@@ -401,7 +410,12 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
         big = wgrad_math == PCAA_BF16 and cout >= 128 and K >= 128 and cout % 8 == 0
         sk = ops.pick_split_k(cout, K, rows_local, target_blocks=256, bk=64, tile=256) if big else ops.pick_split_k(cout, K, rows_local)
         wm = PCAA_BF16 if big else PCAA_F32
-        if defer_wgrad is not None and not big and dy.dtype == torch.float32 and lhs.dtype == torch.float32:
+        # the grouped launch stages 16-B quads of both operands: cout % 4, K % 4 and 16-B aligned bases (ADVICE round 4:
+        # channel counts outside the product's own, e.g. DilTempConv1d(6, 10), keep the per-layer product below)
+        groupable = (cout % 4 == 0 and K % 4 == 0 and dy.data_ptr() % 16 == 0 and lhs.data_ptr() % 16 == 0
+                     and (dW_out is None or dW_out.data_ptr() % 16 == 0))
+        if (defer_wgrad is not None and not big and groupable and dy.dtype == torch.float32
+                and lhs.dtype == torch.float32):
             # the caller launches this product together with its siblings (dtc_backward: one grouped launch)
             dW = dW_out if dW_out is not None else torch.zeros((cout, K), dtype=torch.float32, device=dy.device)
             defer_wgrad.append((dy, lhs, dW, sk))
@@ -453,7 +467,8 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
                                                       below.rstd, tail=btail), fin=btail.out if btail else None)
             elif (_FUSE_DGRAD_BN and below is not None and below.y is None and below_W is not None
                   and below.mean is not None and below.a_in.dtype == torch.float32
-                  and below.a_in.shape[0] == rows_local and ops.gemm_dgrad_bn_supported(rows_local, K, cout)):
+                  and below.a_in.shape[0] == rows_local and rows_local % 256 == 0      # (no ragged recompute variant)
+                  and ops.gemm_dgrad_bn_supported(rows_local, K, cout)):
                 # the layer below is the first PointNet layer on its recompute path: y is rebuilt in the epilogue
                 d_lhs = _FusedGrad(*ops.gemm_dgrad_bn(dy, Wt, None, below.scale, below.shift, below.mean, below.rstd,
                                                       points=below.a_in, W1=below_W))

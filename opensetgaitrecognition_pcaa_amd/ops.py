@@ -656,7 +656,11 @@ def _range_flag(device):
 def range_check(device=None, reset=True):
     """Raise FloatingPointError if an fp16x3-mode operand image saturated on ``device`` since the last check (one
     host sync).  The products of such a step are wrong; rerun it with precision "fp32"."""
-    idxs = list(_RANGE_FLAGS) if device is None else [torch.device(device).index or 0]
+    if device is None:
+        idxs = list(_RANGE_FLAGS)
+    else:
+        dev = torch.device(device)       # an index-less "cuda" is the CURRENT device, as in _range_flag
+        idxs = [dev.index if dev.index is not None else torch.cuda.current_device()]
     for idx in idxs:
         t = _RANGE_FLAGS.get(idx)
         if t is not None and int(t.item()):

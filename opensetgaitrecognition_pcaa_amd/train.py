@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import constants
+from . import dist as pdist
 from . import functional as F_hip
 from . import ops
 from ._lib import ACT_ELU
@@ -243,12 +244,16 @@ class PCAATrainer:
             raise ValueError("grad_compress must be None or 'bf16'")
         self.grad_compress = grad_compress
         self.comm = {"collectives": 0, "payload_bytes": 0}     # of the LAST step (gradient / parameter exchanges)
-        # bench.py's data-parallel legs: with ``time_comm`` set, every step appends a pair of timing events on the main
-        # stream around the place where it must have the gradients back -- from just before the (synchronous) all-reduce
-        # of the encoder + head gradients to just after the waits for the decoder buckets: what the step pays for
-        # communication it could not hide ("exposed"), measured where it is paid
+        # bench.py's data-parallel legs: with ``time_comm`` set, every step appends ONE LIST of timing-event pairs on the
+        # main stream, one pair around every place where that stream waits for an exchange: (1) from just before the
+        # (synchronous) all-reduce of the encoder + head gradients to just after the waits for the decoder buckets;
+        # (2) ZeRO: the waits for the all-gathers of the updated decoder shards (they come after the encoder's Adam);
+        # (3) SyncBN: each synchronous statistics all-reduce (functional._sync_stats).  The sum over a step's pairs is
+        # what the step pays for communication it could not hide ("exposed"), measured where it is paid.
+        # exposed_comm_us() turns the record into microseconds per step.
         self.time_comm = False
         self.comm_events = []
+        self._step_events = None
         if variant not in ("v4", "base", "v1", "v3"):
             raise ValueError(f"PCAATrainer: unknown variant {variant!r}")
         head = variant in ("v4", "v1")
@@ -348,7 +353,7 @@ class PCAATrainer:
             self._zero = False
         if self._zero:
             first_dec = next(n for n, _ in g_named if n.startswith("G."))
-            tail = (first_dec, self.world * self._zero_chunks * _ALIGN)
+            tail = (first_dec, pdist.zero_tail_multiple(self.world, self._zero_chunks, _ALIGN))
         self.flat_g = FlatBuffer(g_named, self.device, padded_shapes=pads, tail_multiple=tail)
         if pads:
             from types import SimpleNamespace
@@ -427,6 +432,9 @@ class PCAATrainer:
         if self._zero:
             n = (self.flat_g.total - self._dec_start) // self._zero_chunks
             self._zero_len = n                                            # floats per chunk (divisible by world * 64)
+            import torch.distributed as dist
+            self._zero_slices = pdist.zero_slices(self._dec_start, self.flat_g.total, self.world, self._zero_chunks,
+                                                  dist.get_rank(self.pg))
             self._zero_g = [torch.empty(n // self.world, dtype=torch.float32, device=self.device)
                             for _ in range(self._zero_chunks)]            # this rank's reduced gradient slice
             self._zero_p = [torch.empty(n // self.world, dtype=torch.float32, device=self.device)
@@ -594,7 +602,13 @@ class PCAATrainer:
         ``supervise=False`` (``i % SUPERVISION_FREQUENCY != 0``): no cross-entropy term, and the parameters only it
         reaches are left alone by Adam, as in the reference.  Returns a dict of DEVICE tensors (no host sync)."""
         with self._sync_bn():
-            return self._step(pcs, gt, z0, alphas, supervise)
+            try:
+                return self._step(pcs, gt, z0, alphas, supervise)
+            finally:
+                F_hip._SYNC_BN["events"] = None
+                if self._step_events:
+                    self.comm_events.append(self._step_events)
+                self._step_events = None
 
     def _step(self, pcs, gt, z0, alphas, supervise):
         if not self._flat_ready:
@@ -611,6 +625,8 @@ class PCAATrainer:
         self._enc_region.zero_()
         self.comm = {"collectives": 0, "payload_bytes": 0}
         F_hip._SYNC_BN["collectives"] = F_hip._SYNC_BN["payload_bytes"] = 0
+        step_events = self._step_events = [] if self.time_comm else None
+        F_hip._SYNC_BN["events"] = step_events if self._sync_bn_group is not None else None
 
         # (1) encoder forward (train-mode BatchNorm)
         # (the decoder projection head rides in the launch of the MLP heads)
@@ -779,8 +795,7 @@ class PCAATrainer:
         zero_gather = []
         if zero:
             import torch.distributed as dist
-            fg, n, w = self.flat_g, self._zero_len, self.world
-            rank = dist.get_rank(self.pg)
+            fg, n = self.flat_g, self._zero_len
             if self._wg is not None:
                 ops.current_stream().wait_stream(self._wg)   # the decoder's dW/db were written on that stream
             scatter = []
@@ -806,8 +821,7 @@ class PCAATrainer:
                 with ops.on_stream(self._side):
                     self._side.wait_event(ready)
                     for c in range(self._zero_chunks):
-                        lo = self._dec_start + c * n + rank * (n // w)      # this rank's slice of chunk c
-                        hi = lo + n // w
+                        lo, hi = self._zero_slices[c][2:]                   # this rank's slice of chunk c
                         scatter[c].wait()
                         if z16:
                             ops.adam_step_dev_g16_(fg.p[lo:hi], self._zero_g16[c], fg.m[lo:hi], fg.v[lo:hi], cfg["B1"],
@@ -919,11 +933,18 @@ class PCAATrainer:
         if ev_c0 is not None:
             ev_c1 = torch.cuda.Event(enable_timing=True)
             ev_c1.record()
-            self.comm_events.append((ev_c0, ev_c1))
+            step_events.append((ev_c0, ev_c1))
         if zero:
             self._adam_g(0, self._dec_start, supervise, gs)
+            if ev_c0 is not None:
+                ev_g0 = torch.cuda.Event(enable_timing=True)
+                ev_g0.record()
             for work in zero_gather:
                 work.wait()                                      # next forward reads the gathered decoder
+            if ev_c0 is not None:
+                ev_g1 = torch.cuda.Event(enable_timing=True)
+                ev_g1.record()
+                step_events.append((ev_g0, ev_g1))
         elif early:
             self._adam_g(0, self._dec_start, supervise, gs)
             ops.current_stream().wait_event(done[0])      # next forward reads the updated decoder
@@ -938,6 +959,11 @@ class PCAATrainer:
         tot = rec_loss + loss_g + (sup_loss if supervise else 0.0)
         return {"d_loss": d_losses[0], "gp": d_losses[1], "rec_loss": rec_loss, "loss_g": loss_g,
                 "sup_loss": sup_loss, "tot_loss": tot, "preds": preds, "out_labels": logits, "sup_fvs": sup_fv}
+
+    def exposed_comm_us(self):
+        """Microseconds per recorded step (``time_comm``) the main stream spent waiting for exchanges: the sum over the
+        step's event pairs (gradient all-reduce window, ZeRO all-gather waits, SyncBN statistics).  Synchronise first."""
+        return [sum(e0.elapsed_time(e1) for e0, e1 in pairs) * 1e3 for pairs in self.comm_events]
 
     # ------------------------------------------------------------------ hipGraph replay of the step
     def prefers_graph(self, B, N):

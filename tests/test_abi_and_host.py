@@ -88,3 +88,21 @@ def test_deterministic_fill_is_reproducible():
     syn.deterministic_fill_(b, 5)
     for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
         assert torch.equal(va, vb), k
+
+
+def test_ragged_row_tile_predicates_bound_the_padded_size():
+    """a partial last row tile is served through 32-bit buffer offsets formed for every row of the
+    PADDED tile; the *_supported predicates must refuse a result whose padded size reaches 4 GiB (rows past M would
+    wrap into the first rows) instead of reporting it supported and failing -- or corrupting -- at launch."""
+    lib = _lib.load()
+    for fn in (lib.pcaa_gemm_split3_supported, lib.pcaa_gemm_dgrad_bn_supported):
+        assert fn(72000, 512, 512) == 1                    # the reference's default shape: B=16, N=150 (ragged, small)
+        assert fn(72000, 512, 256) == 0                    # contraction too short for the 4-wave loop's hand-off
+        assert fn(4194304, 256, 512) == 1                  # whole tiles: no bound
+        assert fn(4194304 - 1, 256, 512) == 0              # ragged, padded rows x 256 columns x 4 B = 4 GiB
+        assert fn(4194304 - 257, 256, 512) == 1
+    # a ragged launch with the first-layer recompute variant / an unaligned result is an argument error, not a launch error
+    one = ctypes.c_void_p(16)
+    rc = lib.pcaa_gemm_dgrad_bn(one, 512, one, 512, None, one, 512, one, one, one, one, one, 1, 1000, 512, 512,
+                                one, 4, one, None)
+    assert rc == 1 and b"partial last row tile" in lib.pcaa_last_error()

@@ -1,0 +1,280 @@
+"""Rehearsal of the multi-GPU run's world-size-dependent code at the largest world this one-GPU box admits
+(VERDICT round 4, item 1b).  BASELINE config[2] is 8 ranks; a GPU box lets at most 6 processes of one user hold the card
+at once and the test runner itself is one of them, so the GPU part runs WORLD = 4 ranks (gloo transport, every rank on
+cuda:0, B = 2 sequences per rank, N = 32) -- the fallback the verdict names -- and the world-8 arithmetic that needs no
+GPU (ZeRO-1 partition of the real decoder region, row sharding, the torchrun command) runs at world 8 on the CPU.
+
+Every exchange scheme of ``bench.py``'s ``dp_legs`` is stepped twice from the same state:
+
+* (all-reduce | ZeRO-1) x (fp32 | bf16 buckets) with SyncBN: the data-parallel step then IS the reference's
+  single-process step on the global batch -> compared with the oracle's ``v4_train_step`` on all 8 sequences
+  (fp32 buckets: 1e-4 on losses / embeddings, labels bit-exact; bf16 buckets: step 0 identical -- losses precede the
+  exchange -- step 1 within the bf16 gate);
+* bench.py's default (all-reduce, bf16 buckets, per-rank BatchNorm), in fp32 and in the bf16 throughput mode: each
+  rank's step-0 losses against the oracle's step on that rank's shard alone;
+* always: replicas bit-identical after the steps, collectives counted, ZeRO's gathered decoder = all-reduce's.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORLD = int(os.environ.get("PCAA_REHEARSAL_WORLD", "4"))
+SHAPE = dict(Bper=2, N=32, C=4, K=4, seeds=[10, 11, 12, 13, 14], steps=2)
+KEYS = ("d_loss", "gp", "rec_loss", "loss_g", "sup_loss", "tot_loss")
+# (dp_mode, grad_compress, sync_bn, precision)
+SCHEMES = [("allreduce", None, True, "fp32"), ("allreduce", "bf16", True, "fp32"), ("zero", None, True, "fp32"),
+           ("zero", "bf16", True, "fp32"), ("allreduce", "bf16", False, "fp32"), ("allreduce", "bf16", False, "bf16")]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _cfg(B):
+    from opensetgaitrecognition_pcaa_amd import constants
+    cfg = dict(constants.CONFIG)
+    cfg.update(NMAX=SHAPE["N"], TRAIN_CLASSES=list(range(SHAPE["K"])), BATCH_SIZE=B, LR=1e-4, B1=0.9, B2=0.99,
+               GP_WEIGHT=15, ADV_WEIGHT=1, SUP_LATENT_DIM=32)
+    return cfg
+
+
+def _inputs(world, step):
+    from opensetgaitrecognition_pcaa_amd import constants, synthetic as syn
+    Bg, N, C, K = SHAPE["Bper"] * world, SHAPE["N"], SHAPE["C"], SHAPE["K"]
+    return (syn.synthetic_pcs(Bg, constants.NSTEPS, N, C, seed=500 + step), syn.synthetic_labels(Bg, K, seed=600 + step),
+            syn.synthetic_z0(Bg, 32, seed=700 + step), syn.synthetic_alphas(Bg, seed=800 + step))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# CPU: what depends on the world size and needs no GPU, at world 8
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_zero_partition_of_the_real_decoder_region_at_every_world_size(world):
+    """FlatBuffer's tail padding + dist.zero_slices at the decoder of BASELINE config[1] (N=128: 156.8 M parameters;
+    shapes only -- meta tensors): chunks tile the region, every rank's slices are disjoint, equal, 256-B aligned."""
+    from opensetgaitrecognition_pcaa_amd import dist as pdist
+    from opensetgaitrecognition_pcaa_amd.train import _ALIGN
+    S = 30 * 4 * 128
+    widths = [64, S // 16, S // 8, S // 4, S // 2, S]
+    sizes = [256] + [o * i for i, o in zip(widths[:-1], widths[1:])] + widths[1:]      # an encoder stand-in, W's, biases
+    chunks = 4
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + _ALIGN - 1) // _ALIGN * _ALIGN
+    dec_start = offs[1]
+    mult = pdist.zero_tail_multiple(world, chunks, _ALIGN)
+    total = dec_start + (total - dec_start + mult - 1) // mult * mult
+    seen = np.zeros((total - dec_start) // _ALIGN, dtype=np.int32)           # one counter per 256-B line
+    for rank in range(world):
+        sl = pdist.zero_slices(dec_start, total, world, chunks, rank)
+        assert len(sl) == chunks
+        for c, (clo, chi, lo, hi) in enumerate(sl):
+            assert clo == dec_start + c * (total - dec_start) // chunks and chi - clo == (total - dec_start) // chunks
+            assert clo <= lo < hi <= chi and (hi - lo) * world == chi - clo
+            assert lo % _ALIGN == 0 and hi % _ALIGN == 0, "slices start on 256-byte lines"
+            seen[(lo - dec_start) // _ALIGN:(hi - dec_start) // _ALIGN] += 1
+    assert (seen == 1).all(), "every line of the decoder region belongs to exactly one (rank, chunk)"
+    with pytest.raises(ValueError):
+        pdist.zero_slices(dec_start, total + 1, max(world, 2), chunks, 0)
+
+
+def test_row_sharding_at_world_eight_reassembles_the_global_batch():
+    from opensetgaitrecognition_pcaa_amd import dist as pdist, synthetic as syn
+    z0 = syn.synthetic_z0(512, 32, seed=3)                  # config[2]: global batch 512 = 8 x 64
+    parts = [pdist.shard_rows(z0, r, 8) for r in range(8)]
+    assert all(p.shape[0] == 64 for p in parts) and torch.equal(torch.cat(parts), z0)
+    with pytest.raises(ValueError):
+        pdist.shard_rows(z0[:510], 0, 8)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# GPU: WORLD ranks on the one card
+# ------------------------------------------------------------------------------------------------------------
+def _worker(rank, world, port, q, means_np):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        sys.path.insert(0, ROOT)
+        import torch.distributed as dist
+        from opensetgaitrecognition_pcaa_amd import constants, dist as pdist, synthetic as syn
+        from opensetgaitrecognition_pcaa_amd.train import PCAATrainer
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        constants.NFEATURES = SHAPE["C"]
+        recs = []
+        for mode, compress, sbn, precision in SCHEMES:
+            tr = PCAATrainer(_cfg(SHAPE["Bper"]), device="cuda:0", precision=precision, process_group=dist.group.WORLD,
+                             sync_bn=sbn, dp_zero=(mode == "zero"), grad_compress=compress)
+            for mod, seed in zip((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head,
+                                  tr.discriminator_projection_head), SHAPE["seeds"]):
+                syn.deterministic_fill_(mod, seed)
+            tr.set_prior_means(torch.from_numpy(means_np))
+            tr.finalize()
+            tr.train()
+            tr.time_comm = True
+            rec = {"scheme": (mode, compress, sbn, precision), "local": [], "global": [], "preds": [], "fvs": []}
+            for s in range(SHAPE["steps"]):
+                pcs, gt, z0, al = (pdist.shard_rows(t, rank, world).contiguous() for t in _inputs(world, s))
+                out = tr.step(pcs.cuda().permute(0, 3, 1, 2), gt.cuda(), z0.cuda(), al.cuda())
+                lv = torch.stack([out[k].detach().double().reshape(()) for k in KEYS]).cpu()
+                rec["local"].append(lv.numpy().copy())
+                dist.all_reduce(lv)
+                rec["global"].append((lv / world).numpy())
+                rec["preds"].append(out["preds"].cpu().numpy())
+                rec["fvs"].append(out["sup_fvs"].cpu().numpy())
+            torch.cuda.synchronize()
+            tr.check()
+            for fb, nm in ((tr.flat_g, "g"), (tr.flat_d, "d")):
+                flat = fb.p.detach().cpu()
+                ref = flat.clone()
+                dist.broadcast(ref, src=0)
+                rec[f"replicas_equal_{nm}"] = bool(torch.equal(flat, ref))
+            rec["comm"] = dict(tr.comm)
+            rec["exposed_us"] = tr.exposed_comm_us()
+            rec["pairs_per_step"] = [len(p) for p in tr.comm_events]
+            rec["zero"] = bool(tr._zero)
+            if rank == 0:
+                fg = tr.flat_g
+                rec["params"] = {n: fg.params[fg.names.index(n)].detach().cpu().numpy()
+                                 for n in ("E.MLP_sup1.0.weight", "E.pc_block.pointnet2.module.0.weight", "GPH.0.weight",
+                                           "G.dense1.weight", "G.dense3.bias")}
+                w5 = tr.decoder.dense5.weight.detach()
+                rec["dense5_rows"] = w5[:: w5.shape[0] // 16][:16].cpu().numpy()
+                rec["dec_l2"] = float(fg.p[tr._dec_start:].double().norm())
+            recs.append(rec)
+            del tr
+            torch.cuda.empty_cache()
+        q.put((rank, recs, None))
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, None, traceback.format_exc() + repr(e)))
+
+
+def _oracle_state():
+    from opensetgaitrecognition_pcaa_amd import constants, models, synthetic as syn
+    from oracle import pcaa_oracle as O
+    saved = constants.NFEATURES
+    constants.NFEATURES = SHAPE["C"]
+    K, N, C = SHAPE["K"], SHAPE["N"], SHAPE["C"]
+    mods = (models.CGEncoder(K, nmax_points=N, use_projection_head=True).float(),
+            models.CGDecoder(input_dim=64, nmax_points=N).float(), models.CGDiscriminator(K).float(),
+            torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.ELU()).float(),
+            torch.nn.Sequential(torch.nn.Linear(64, 32), torch.nn.ELU()).float())
+    constants.NFEATURES = saved
+    for m, s in zip(mods, SHAPE["seeds"]):
+        syn.deterministic_fill_(m, s)
+    means = O.sample_distant_points(32, K, 10, 10).float()
+    return O.V4State(*({k: v.detach().clone() for k, v in m.state_dict().items()} for m in mods), means, C,
+                     constants.NSTEPS, N, K), means
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_every_dp_scheme_at_the_largest_world_this_box_admits_vs_oracle():
+    sys.path.insert(0, ROOT)
+    from oracle import pcaa_oracle as O
+    world = WORLD
+    assert 2 <= world <= 5, "a GPU box admits 6 processes on the card, this runner included"
+    # ---- oracle: the global-batch trajectory (SyncBN schemes) and every shard's first step (per-rank BatchNorm)
+    st, means = _oracle_state()
+    ref_steps = []
+    for s in range(SHAPE["steps"]):
+        pcs, gt, z0, al = _inputs(world, s)
+        r = O.v4_train_step(st, pcs.permute(0, 3, 1, 2), gt, z0, al, _cfg(SHAPE["Bper"] * world))
+        ref_steps.append({"losses": np.array([r[k].item() for k in KEYS]), "preds": r["preds"].numpy(),
+                          "fvs": r["sup_fvs"].numpy(), "logits": r["out_labels"].numpy()})
+    ref_params = {"E.MLP_sup1.0.weight": st.enc["MLP_sup1.0.weight"].numpy().copy(),
+                  "E.pc_block.pointnet2.module.0.weight": st.enc["pc_block.pointnet2.module.0.weight"].numpy().copy(),
+                  "GPH.0.weight": st.gph["0.weight"].numpy().copy(), "G.dense1.weight": st.dec["dense1.weight"].numpy().copy(),
+                  "G.dense3.bias": st.dec["dense3.bias"].numpy().copy()}
+    w5 = st.dec["dense5.weight"]
+    ref_rows = w5[:: w5.shape[0] // 16][:16].numpy().copy()
+    shard_losses = []
+    pcs, gt, z0, al = _inputs(world, 0)
+    per = SHAPE["Bper"]
+    for r in range(world):
+        st_r, _ = _oracle_state()
+        sl = slice(r * per, (r + 1) * per)
+        o = O.v4_train_step(st_r, pcs[sl].permute(0, 3, 1, 2), gt[sl], z0[sl], al[sl], _cfg(per))
+        shard_losses.append(np.array([o[k].item() for k in KEYS]))
+        del st_r
+
+    # ---- the ranks
+    ctx = mp.get_context("spawn")
+    port, q = _free_port(), ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, means.numpy())) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, recs, err = q.get(timeout=800)
+        assert err is None, f"rank {rank}: {err}"
+        res[rank] = recs
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+
+    dec_l2 = {}
+    for i, scheme in enumerate(SCHEMES):
+        mode, compress, sbn, precision = scheme
+        R = [res[r][i] for r in range(world)]
+        assert all(tuple(x["scheme"]) == scheme for x in R)
+        assert all(x["replicas_equal_g"] and x["replicas_equal_d"] for x in R), f"{scheme}: replicas diverged"
+        assert all(x["zero"] == (mode == "zero") for x in R)
+        comm = R[0]["comm"]
+        assert comm["collectives"] >= 7 and comm["payload_bytes"] > 0, scheme
+        # the exposed-communication record: one list of event pairs per step; ZeRO adds the wait for
+        # its all-gathers, SyncBN one pair per statistics all-reduce
+        assert len(R[0]["exposed_us"]) == SHAPE["steps"] and all(u >= 0 for u in R[0]["exposed_us"])
+        want_pairs = 1 + (1 if mode == "zero" else 0)
+        if sbn:
+            assert all(n > want_pairs for n in R[0]["pairs_per_step"]), scheme
+        else:
+            assert all(n == want_pairs for n in R[0]["pairs_per_step"]), scheme
+        dec_l2[scheme] = R[0]["dec_l2"]
+        if not sbn:
+            tol = 1e-4 if precision == "fp32" else 2e-2
+            for r in range(world):
+                assert np.allclose(R[r]["local"][0], shard_losses[r], rtol=tol, atol=1e-5 if precision == "fp32" else 2e-2), \
+                    (scheme, r, R[r]["local"][0], shard_losses[r])
+            continue
+        exact = compress is None
+        for s in range(SHAPE["steps"]):
+            ref = ref_steps[s]
+            tol = 1e-4 if (s == 0 or exact) else 2e-2
+            tol = tol if s == 0 else max(tol, 5e-4)
+            for r in range(world):
+                assert np.allclose(R[r]["global"][s], ref["losses"], rtol=tol, atol=1e-5 if tol <= 5e-4 else 2e-2), \
+                    (scheme, s, r, R[r]["global"][s], ref["losses"])
+            preds = np.concatenate([R[r]["preds"][s] for r in range(world)])
+            fvs = np.concatenate([R[r]["fvs"][s] for r in range(world)])
+            scale = np.abs(ref["fvs"]).max()
+            if s == 0 or exact:
+                top2 = np.sort(ref["logits"], axis=1)[:, -2:]
+                tied = (top2[:, 1] - top2[:, 0]) <= 1e-4 * np.abs(ref["logits"]).max()
+                assert np.array_equal(preds[~tied], ref["preds"][~tied]), (scheme, s, "argmax labels must be bit-exact")
+                assert np.abs(fvs - ref["fvs"]).max() <= (1e-4 if s == 0 else 5e-4) * scale, (scheme, s)
+            else:
+                assert np.abs(fvs - ref["fvs"]).max() <= 5e-2 * scale, (scheme, s)
+        # parameters after the two Adam steps (+-lr per element and step; sign flips of rounding-noise gradients rare)
+        steps = SHAPE["steps"]
+        for n, b in list(ref_params.items()) + [("dense5_rows", ref_rows)]:
+            a = R[0]["dense5_rows"] if n == "dense5_rows" else R[0]["params"][n]
+            err = np.abs(a.astype(np.float64) - b.astype(np.float64))
+            assert err.max() <= 5e-5 * np.abs(b).max() + 2.0e-4 * steps * 1.001, (scheme, n, err.max())
+            assert err.mean() <= (4e-6 if exact else 4e-5), (scheme, n, err.mean())
+    # ZeRO's gathered decoder against the all-reduce's, same buckets: the same reduced gradients met the same Adam
+    for comp in (None, "bf16"):
+        a, z = dec_l2[("allreduce", comp, True, "fp32")], dec_l2[("zero", comp, True, "fp32")]
+        assert abs(a - z) <= 1e-6 * a, (comp, a, z)

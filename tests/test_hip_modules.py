@@ -521,3 +521,34 @@ def test_empty_and_single_inputs():
     ref = O.cg_encoder_forward(xpm.permute(0, 3, 1, 2), sd, True, True)
     _close(logits, ref[0], what="B=1 logits")
     _close(fv, ref[1], what="B=1 sup_fv")
+
+
+@pytest.mark.parametrize("cin,cout,d", [(6, 10, 2), (5, 7, 1), (12, 10, 4)])
+def test_dil_temp_conv1d_odd_channel_counts_forward_backward_vs_oracle(cin, cout, d):
+    """the temporal block's weight gradients are deferred into one grouped launch that stages 16-byte
+    quads (cout % 4, 3 cin % 4).  A DilTempConv1d whose channel counts are not multiples of four -- outside the
+    product's own widths, inside the drop-in module's contract (models.py:46-55 takes any in_chs / out_chs) -- must keep
+    the per-layer product: forward, input gradient and all four parameter gradients against the oracle under autograd."""
+    F_hip.set_precision("fp32")
+    B = 3
+    layer = models.DilTempConv1d(cin, cout, d).float()
+    syn.deterministic_fill_(layer, 7)
+    sd = {k: v.detach().clone().double() for k, v in layer.state_dict().items()}
+    layer = layer.to(DEV).train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, cin, T, generator=g)
+    r = torch.randn(B, cout, T, generator=g)
+    xg = x.to(DEV).requires_grad_(True)
+    out = layer(xg)
+    (out * r.to(DEV)).sum().backward()
+    names = ("conv1d.weight", "batch_norm.weight", "batch_norm.bias")
+    xr = x.double().requires_grad_(True)
+    for k in names:
+        sd[k].requires_grad_(True)
+    ref = O.dil_temp_conv1d(xr, sd, "", d, training=True, update_stats=False)
+    grads = torch.autograd.grad((ref * r.double()).sum(), [xr] + [sd[k] for k in names])
+    _close(out, ref, what="forward")
+    _close(xg.grad, grads[0], 5e-4, what="dx")
+    got = dict(layer.named_parameters())
+    for k, gr in zip(names, grads[1:]):
+        _close(got[k].grad, gr, 5e-4, what=k)

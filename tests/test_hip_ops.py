@@ -925,9 +925,19 @@ def test_split_image_range_guard_saturates_and_flags():
     with pytest.raises(FloatingPointError):
         ops.range_check()
     y2 = y.clone(); y2[0, 0] = float("nan")
-    ops.bn_act_fwd_split(y2, scale, shift)
+    a2 = ops.bn_act_fwd_split(y2, scale, shift)
+    # a NaN raises the flag AND stays NaN (it used to come out as -65504, so a diverged step showed
+    # finite losses until the once-per-epoch check); its neighbours are untouched
+    assert torch.isnan(a2.float()[0, 0]) and torch.isfinite(a2.float()[0, 1:]).all() and torch.isfinite(a2.float()[1:]).all()
     with pytest.raises(FloatingPointError):
         ops.range_check()
+    # the device argument resolves like the flag's own key: an index-less "cuda" is the current device
+    ops.bn_act_fwd_split(big, scale, shift)
+    with pytest.raises(FloatingPointError):
+        ops.range_check("cuda")
+    ops.bn_act_fwd_split(big, scale, shift)
+    with pytest.raises(FloatingPointError):
+        ops.range_check(torch.device("cuda", torch.cuda.current_device()))
     # the first layer's producer
     x = torch.randn(512, 4, device=DEV) * 1e3
     Wp = torch.randn(512, 4, device=DEV) * 100.0
