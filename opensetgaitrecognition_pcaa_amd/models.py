@@ -57,6 +57,11 @@ class DilTempConv1d(torch.nn.Module):
         _check_elu(activation)
         if kernel_size != 3 or stride != 1:
             raise NotImplementedError("HIP path: kernel_size=3, stride=1 (the only use in the reference)")
+        if out_chs % 4 != 0 or 256 % (out_chs // 4) != 0:
+            # the BatchNorm / ELU passes move 16-byte quads of channels, a power-of-two number of them per 256-thread
+            # workgroup (every width of the reference -- 16 ... 512, constants.py:37 -- qualifies)
+            raise NotImplementedError("HIP path: DilTempConv1d out_chs must be a multiple of 4 and a power of two times 4 up "
+                                      f"to 1024 (got {out_chs})")
         self.dilation = int(dilation)
         self.padding = int(np.floor((kernel_size - 1) * dilation))
         # bias=True regardless of use_bias, as in the reference (models.py:67)

@@ -11,6 +11,11 @@ import numpy as np
 import torch
 
 
+_BIG_FILLS = {}                      # (shape, seed, index) -> array, insertion-ordered: oldest evicted first
+_BIG_FILL_MIN = 1 << 22              # floats
+_BIG_FILL_BUDGET = 1 << 30           # floats kept in total (4 GB)
+
+
 def fill_tensor_like(name: str, shape, seed: int, index: int) -> np.ndarray:
     """Documented fill formula.  ``index`` is the position in state_dict order.
 
@@ -34,8 +39,19 @@ def fill_tensor_like(name: str, shape, seed: int, index: int) -> np.ndarray:
             return (1.0 + 0.1 * rng.standard_normal(shape)).astype(np.float32)
         return (0.05 * rng.standard_normal(shape)).astype(np.float32)
     fan_in = int(np.prod(shape[1:]))
+    key = (shape, int(seed), int(index))
+    hit = _BIG_FILLS.get(key)
+    if hit is not None:
+        return hit
     out = rng.standard_normal(shape, dtype=np.float32)
     out *= np.float32(1.0 / math.sqrt(fan_in))
+    n = out.size
+    if n >= _BIG_FILL_MIN:
+        # the wide decoder matrices (up to 470 M floats, seconds of draws each) are asked for again and again by tests and
+        # bench legs that build the same architecture from the same seeds: keep the most recent ones (read-only)
+        _BIG_FILLS[key] = out
+        while sum(v.size for v in _BIG_FILLS.values()) > _BIG_FILL_BUDGET and len(_BIG_FILLS) > 1:
+            _BIG_FILLS.pop(next(iter(_BIG_FILLS)))
     return out
 
 

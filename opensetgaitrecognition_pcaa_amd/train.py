@@ -205,11 +205,13 @@ class PCAATrainer:
     def __init__(self, config, n_classes=None, device="cuda", variant="v4", precision=None,
                  process_group=None, sync_bn=False, learn_centroids=False, dp_zero=False, grad_compress=None,
                  force_collectives=False, fused_decoder_update=True):
-        """``fused_decoder_update`` (single process, bf16 mode): the decoder's wide weight gradients are formed and
-        consumed by one kernel per layer that applies Adam in place (pcaa_skinny_linear_wgrad_adam) -- those
+        """``fused_decoder_update`` (single process, every precision mode since round 5; "all" is the older spelling of
+        True): the decoder's wide weight gradients are formed and consumed by one kernel per layer that applies Adam in
+        place (pcaa_skinny_linear_wgrad_adam; the parity modes "fp32" / "fp16x3" use its fp32-product form) -- those
         gradients never exist in ``flat_g.g`` (``self.gradless_ranges`` lists the [lo, hi) element ranges the last step
-        left without one); pass False to keep them (gradient inspection, parity tests: the resulting parameters are
-        bit-identical either way); "all" extends it to the parity modes (fp32-product kernels; the bench's parity legs).
+        left without one); pass False to keep them (gradient inspection, clipping, the parity tests that read them: the
+        resulting parameters are bit-identical either way at the op level, and the trainer-level bridge holds the fused
+        run to the gate two unfused runs meet, tests/test_round2_parity.py).
         Data-parallel options (``process_group`` given): ``dp_zero`` True = sharded decoder optimizer
         (reduce-scatter, Adam on 1/world of the decoder, all-gather; default off); ``grad_compress="bf16"`` = the decoder's gradient buckets cross the wire as bf16 (half the
         bytes; fp32 master gradients, moments and weights; each bucket is rounded once before the sum and the sum
@@ -237,9 +239,8 @@ class PCAATrainer:
         self._dp_zero_arg = bool(dp_zero)
         self._force_collectives = bool(force_collectives)
         self.fused_decoder_update = bool(fused_decoder_update)
-        # "all": the parity modes too (fp32-product kernels) -- not the default there: their tests read the decoder's weight
-        # gradients, which a fused update never writes (gradless_ranges)
-        self.fused_exact = fused_decoder_update == "all"
+        # the parity modes too (fp32-product kernels); tests that read the decoder's weight gradients pass False
+        self.fused_exact = bool(fused_decoder_update)
         if grad_compress not in (None, "bf16"):
             raise ValueError("grad_compress must be None or 'bf16'")
         self.grad_compress = grad_compress

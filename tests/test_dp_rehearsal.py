@@ -245,9 +245,14 @@ def test_every_dp_scheme_at_the_largest_world_this_box_admits_vs_oracle():
         dec_l2[scheme] = R[0]["dec_l2"]
         if not sbn:
             tol = 1e-4 if precision == "fp32" else 2e-2
+            # d_loss, gp, rec_loss, sup_loss: functions of the rank's own forward.  loss_g (and tot_loss) are taken with
+            # the critic AFTER its update, which under data parallelism used the gradients of ALL ranks -- the oracle's
+            # shard-alone step updates it from one shard: compared at the size of one Adam step of the critic instead
+            own = [0, 1, 2, 4]
             for r in range(world):
-                assert np.allclose(R[r]["local"][0], shard_losses[r], rtol=tol, atol=1e-5 if precision == "fp32" else 2e-2), \
-                    (scheme, r, R[r]["local"][0], shard_losses[r])
+                assert np.allclose(R[r]["local"][0][own], shard_losses[r][own], rtol=tol,
+                                   atol=1e-5 if precision == "fp32" else 2e-2), (scheme, r, R[r]["local"][0], shard_losses[r])
+                assert abs(R[r]["local"][0][3] - shard_losses[r][3]) <= 2e-2, (scheme, r, R[r]["local"][0], shard_losses[r])
             continue
         exact = compress is None
         for s in range(SHAPE["steps"]):

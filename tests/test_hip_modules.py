@@ -156,13 +156,13 @@ def test_discriminator_and_wgan_gp_vs_golden(tag):
         _close(p.grad, sd[name].grad, 2e-4, floor=1e-2, what=name)   # sum(w) = 0: db3 is ~0 here
 
 
-def _trainer_from_golden(m, precision="fp32"):
+def _trainer_from_golden(m, precision="fp32", fused=True):
     B, N, C, K = m["B"], m["N"], m["C"], m["K"]
     constants.NFEATURES = C
     cfg = dict(constants.CONFIG)
     cfg.update(NMAX=N, TRAIN_CLASSES=list(range(K)), BATCH_SIZE=B, LR=1e-4, B1=0.9, B2=0.99,
                GP_WEIGHT=15, ADV_WEIGHT=1, SUP_LATENT_DIM=32)
-    tr = PCAATrainer(cfg, precision=precision)
+    tr = PCAATrainer(cfg, precision=precision, fused_decoder_update=fused)
     s = m["fill_seeds"]
     for mod, seed in zip((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head,
                           tr.discriminator_projection_head), s):
@@ -172,10 +172,14 @@ def _trainer_from_golden(m, precision="fp32"):
     return tr
 
 
-def test_v4_train_steps_vs_golden():
+@pytest.mark.parametrize("fused", [False, True])
+def test_v4_train_steps_vs_golden(fused):
+    """``fused=True``: the trainer's default since round 5 -- the decoder's wide layers take their Adam update inside the
+    fp32-product weight-gradient kernel, so their gradients never exist (``gradless_ranges``); the trajectory and the
+    parameters after every step are held to the same gates against the reference's golden as the unfused run."""
     g, m = load_golden("v4_B6_N32_C4_K4")
     B, N, C, K, steps = m["B"], m["N"], m["C"], m["K"], m["steps"]
-    tr = _trainer_from_golden(m)
+    tr = _trainer_from_golden(m, fused=fused)
     tr.set_prior_means(torch.from_numpy(g["means"]))
     for s in range(steps):
         pcs = syn.synthetic_pcs(B, T, N, C, seed=m["pcs_seed0"] + s).to(DEV).permute(0, 3, 1, 2)
@@ -201,11 +205,19 @@ def test_v4_train_steps_vs_golden():
                 check_against_record(g, "s0.dgrad.", name, tr.flat_d.grad_views["D." + name], 2e-4, scale_floor=1e-3)
             wscale = max(float(np.abs(g[k]).max()) for k in g.files
                          if k.startswith("s0.ggrad.E.") and k.endswith("weight::full"))
+            gradless = 0
             for name, gv in tr.flat_g.grad_views.items():
                 if is_pre_bn_bias(name):
                     assert float(gv.abs().max()) <= 1e-4 * wscale + 1e-4
                     continue
+                off = tr.flat_g.offsets[tr.flat_g.names.index(name)]
+                if any(lo <= off < hi for lo, hi in tr.gradless_ranges):
+                    assert float(gv.abs().max()) == 0.0, "a fused layer must not write a weight gradient"
+                    gradless += 1
+                    continue
                 check_against_record(g, "s0.ggrad.", name, gv, 5e-4)
+            # the wide layers (stored zero-padded to multiples of 64 at this N) take the fused update, none with fused=False
+            assert gradless == len(tr.gradless_ranges) and (gradless >= 2) == fused, (gradless, tr.gradless_ranges)
         if s in (0, steps - 1):
             for nm, mod in tr.modules().items():
                 for name, v in mod.state_dict().items():
@@ -523,12 +535,20 @@ def test_empty_and_single_inputs():
     _close(fv, ref[1], what="B=1 sup_fv")
 
 
-@pytest.mark.parametrize("cin,cout,d", [(6, 10, 2), (5, 7, 1), (12, 10, 4)])
+def test_dil_temp_conv1d_refuses_output_widths_the_elementwise_kernels_cannot_take():
+    """The HIP path's BatchNorm / ELU passes move 16-byte quads of channels: an output width that is not a multiple of
+    four (never used by the reference: DTC_FILTERS, constants.py:37) is refused at construction, not deep inside forward."""
+    for bad in (10, 12, 2048):
+        with pytest.raises(NotImplementedError, match="multiple of 4"):
+            models.DilTempConv1d(6, bad, 2)
+
+
+@pytest.mark.parametrize("cin,cout,d", [(6, 32, 2), (5, 8, 1), (10, 16, 4)])
 def test_dil_temp_conv1d_odd_channel_counts_forward_backward_vs_oracle(cin, cout, d):
     """the temporal block's weight gradients are deferred into one grouped launch that stages 16-byte
-    quads (cout % 4, 3 cin % 4).  A DilTempConv1d whose channel counts are not multiples of four -- outside the
-    product's own widths, inside the drop-in module's contract (models.py:46-55 takes any in_chs / out_chs) -- must keep
-    the per-layer product: forward, input gradient and all four parameter gradients against the oracle under autograd."""
+    quads (cout % 4, 3 cin % 4).  A DilTempConv1d whose INPUT width is not a multiple of four -- outside the product's own
+    widths, inside the drop-in module's contract (models.py:46-55) -- must keep the per-layer product: forward, input
+    gradient and the parameter gradients against the oracle under autograd."""
     F_hip.set_precision("fp32")
     B = 3
     layer = models.DilTempConv1d(cin, cout, d).float()

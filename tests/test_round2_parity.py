@@ -388,8 +388,12 @@ def test_fused_decoder_update_performs_the_unfused_step(B, N, precision):
     means = O.sample_distant_points(32, K, 10, 10).float()
     states = []
     try:
-        # (the parity modes take the fused update only on request: fused_decoder_update="all", fp32-product kernels)
-        for fused, graphed in ((False, False), ("all", False)) + ((("all", True),) if N == 32 else ()):
+        # parity modes (fp32-product kernels, the trainer's default since round 5): a SECOND unfused run measures what
+        # two runs of the same step differ by (order of the fp64 statistics atomics -> rounding noise -> Adam's sign-like
+        # first steps), and the fused run must stay within that
+        exact = precision != "bf16"
+        for fused, graphed in ((False, False),) + (((False, False),) if exact else ()) + ((True, False),) + \
+                ((("all", True),) if N == 32 else ()):
             tr, _ = _v4_trainer(B, N, C, K, [0, 1, 2, 3, 4], precision, fused=fused)
             tr.set_prior_means(means)
             tr.finalize()
@@ -412,11 +416,28 @@ def test_fused_decoder_update_performs_the_unfused_step(B, N, precision):
     finally:
         constants.NFEATURES = saved
     base = states[0]
-    for other in states[1:]:
+
+    def diff(other):
         dp = (base[0] - other[0]).abs()
-        assert float(dp.max()) <= 2 * lr * steps + 1e-7, float(dp.max())
-        assert float(dp.mean()) <= 0.1 * lr * steps, float(dp.mean())     # a missing / doubled update: ~lr per step
-        for k in (1, 2):
-            rel = float((base[k] - other[k]).norm() / base[k].norm())
-            assert rel <= 5e-2, (k, rel)      # the moments carry the bf16-mode gradient noise of three steps (~2e-2)
-        assert abs(base[3] - other[3]) <= 2e-2 * abs(base[3])
+        return (float(dp.max()), float(dp.mean()), float((base[1] - other[1]).norm() / base[1].norm()),
+                float((base[2] - other[2]).norm() / base[2].norm()), abs(base[3] - other[3]) / abs(base[3]))
+
+    noise = None
+    if exact:
+        noise = diff(states[1])                     # unfused against unfused: the run-to-run gate
+        states = [states[0]] + states[2:]
+        print(f"{precision} B={B} N={N}: unfused run-to-run (max dp, mean dp, rel m, rel v, rel rec_loss) = {noise}")
+    for other in states[1:]:
+        d = diff(other)
+        print(f"{precision} B={B} N={N}: fused against unfused = {d}")
+        assert d[0] <= 2 * lr * steps + 1e-7, d
+        assert d[1] <= 0.1 * lr * steps, d          # a missing / doubled update: ~lr per step
+        if exact:
+            # held to what two unfused runs differ by (x3: one sample of a noise level), with floors at the level of one
+            # flipped rounding-noise sign per 10^4 elements / fp32 summation order
+            assert d[1] <= 3 * noise[1] + 1e-4 * lr * steps, (d, noise)
+            assert d[2] <= 3 * noise[2] + 2e-5 and d[3] <= 3 * noise[3] + 2e-5, (d, noise)
+            assert d[4] <= 3 * noise[4] + 1e-5, (d, noise)
+        else:
+            assert d[2] <= 5e-2 and d[3] <= 5e-2, d      # the moments carry the bf16-mode gradient noise of three steps (~2e-2)
+            assert d[4] <= 2e-2, d

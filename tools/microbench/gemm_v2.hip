@@ -77,6 +77,11 @@ __device__ __forceinline__ void mfma(f32x4& c, const bf16x8& a, const bf16x8& b)
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
+// the first product of a tile: C = 0 as the inline constant (the product kernel's mfma0)
+__device__ __forceinline__ void mfma0(f32x4& c, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+}
+
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   bf16x2 b;
@@ -293,6 +298,239 @@ __global__ __launch_bounds__(256) void gemm_v2(const bf16_t* __restrict__ A, con
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the surplus stages must have landed before the LDS is released
 }
 
+
+// =====================================================================================================================
+// ROUND 5 LAB: the tile epilogue UNDER the next tile's first K step.
+// One wave per SIMD and all 256 accumulator registers in use: there is no second accumulator set, and a second workgroup
+// per CU would need 256 x 128 tiles (1.5x the operand requests per MFMA, the very ingredient that bounds the loop).  But a
+// tile's FIRST K step starts every accumulator from the MFMA's zero constant (mfma0), in row-block order: right before the
+// eight mfma0 of row block i overwrite acc[i][0..7], those 32 registers still hold the PREVIOUS tile's results.  So the
+// previous tile's epilogue is cut into eight slices, one per row block: read the 32 accumulators (v_accvgpr_read), issue
+// the eight mfma0, and convert + store the 4 rows x 8 columns between them -- the stores' issue, their latency and (with
+// STATS) the column statistics run in the shadow of MFMAs instead of in front of them.  The first-half loop of that step
+// becomes VALU-bound (~48-80 vector instructions per eight MFMAs), ~+0.5 ... 1.1 us per tile against the ~3.8 us the
+// stores cost behind the loop.
+// Stores share vmcnt with the LDS-DMA requests, and the loop's "stage t + 1 has landed" test is a COUNTED wait
+// (vmcnt(16): only this step's own requests may be outstanding): 32 stores issued in between would have to complete
+// first.  The step that carries an epilogue therefore waits for stage t + 1 with vmcnt(0) BEFORE its first store (the
+// requests are a whole step old by then) and only needs the barrier at the usual place; by the counted wait of the
+// step after it the stores are more than a step old.
+// C is addressed through a buffer resource re-based per tile: row offsets live in the scalar offset, no vector address
+// arithmetic per store.
+template <bool STATS>
+__global__ __launch_bounds__(256) void gemm_v2o(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                bf16_t* __restrict__ C, int M, int N, int K, float* colsum) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = N / BN, ntiles = (M / BM) * nbn, nt = K / BK;
+  rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)(unsigned)((long)M * K * 2), 0x00020000);
+  rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, (int)(unsigned)((long)N * K * 2), 0x00020000);
+  unsigned voA[2], voB[2];
+  int l15, q, kof0, kof1, fA, fB;
+  auto lane_consts = [&](int ln) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int g = (ln & 7) ^ ((4 * e + (ln >> 4)) & 7);
+      voA[e] = (unsigned)((ln >> 3) * (long)K * 2 + 16 * g);
+      voB[e] = (unsigned)(8 * (ln >> 3) * (long)K * 2 + 16 * g);
+    }
+    l15 = ln & 15;
+    q = ln >> 4;
+    kof0 = ((q) ^ (l15 >> 1)) * 8;
+    kof1 = ((4 + q) ^ (l15 >> 1)) * 8;
+    fA = (wm * 128 + l15) * 64;
+    fB = OP_TILE + (wn * 128 + l15) * 64;
+  };
+  int ln = lane;
+  lane_consts(ln);
+  const int gstride_l = gridDim.x;
+  int lvb = blockIdx.x, lkt = 0;
+  int ltm, ltn;
+  tile_coords(ntiles, nbn, lvb, ltm, ltn);
+#define O_ADVANCE()                                   \
+  do {                                                \
+    if (++lkt == nt) {                                \
+      lkt = 0;                                        \
+      lvb += gstride_l;                               \
+      if (lvb >= ntiles) lvb = blockIdx.x;            \
+      tile_coords(ntiles, nbn, lvb, ltm, ltn);        \
+    }                                                 \
+  } while (0)
+#define O_REQ_A(st, jj) piece<false>(rA, K, ltm * BM, lkt * BK, (st), wave * 8 + (jj), voA)
+#define O_REQ_B(st, jj) piece<true>(rB, K, ltn * BN, lkt * BK, (st) + OP_TILE, wave * 8 + (jj), voB)
+
+  f32x4 acc[8][8];
+  bf16x8 af[2][8], bfr[2][8];
+  int vb = blockIdx.x;
+  if (vb >= ntiles) return;
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) O_REQ_B(smem, jj);
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) O_REQ_A(smem, jj);
+  O_ADVANCE();
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) O_REQ_B(smem + STAGE, jj);
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) O_REQ_A(smem + STAGE, jj);
+  O_ADVANCE();
+  asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(smem + fB + j * 1024 + kof0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(smem + fA + i * 1024 + kof0);
+
+  int s = 0;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+  const int gstride = gridDim.x;
+  // the finished tile whose results are still in the accumulators: its C window as a buffer resource + this lane's offset
+  rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(C, 0, 0, 0x00020000);
+  unsigned voC = 0;
+  const unsigned rowb = (unsigned)N * 2u;
+  float cs[8], cs2[8];                                // STATS: this lane's running column sums / sums of squares of the tile being stored
+  // E: 0 = first tile of the workgroup (nothing to store), 1 = the previous tile's results leave under this step
+#define O_STEP(MF0, E)                                                                                                  \
+  {                                                                                                                     \
+    bf16_t* cur = smem + s * STAGE;                                                                                     \
+    const unsigned cb = lds0 + (unsigned)s * (STAGE * 2), nb = lds0 + (unsigned)(s ^ 1) * (STAGE * 2);                  \
+    const unsigned aB1 = cb + (unsigned)(fB + kof1) * 2, aA1 = cb + (unsigned)(fA + kof1) * 2;                          \
+    const unsigned aB0 = nb + (unsigned)(fB + kof0) * 2, aA0 = nb + (unsigned)(fA + kof0) * 2;                          \
+    f32x4 old[8];                                                                                                       \
+    _Pragma("unroll") for (int m = 0; m < 64; ++m) {                                                                    \
+      const int i = m >> 3, j = m & 7;                                                                                  \
+      if ((m & 1) == 1 && m < 16) lds_read(bfr[1][m >> 1], aB1, (m >> 1) * 2048);                                       \
+      if (m == 21) BAR_LGKM();                                                                                          \
+      if (m >= 24 && m < 40 && (m & 1) == 0) lds_read(af[1][(m - 24) >> 1], aA1, ((m - 24) >> 1) * 2048);               \
+      if (m >= 23 && m < 39 && (m & 1) == 1) O_REQ_B(cur, (m - 23) >> 1);                                               \
+      if (m == 46) BAR_LGKM();                                                                                          \
+      if (m >= 48 && (m & 3) == 0) O_REQ_A(cur, (m - 48) >> 2);                                                         \
+      if (E) {                                                                                                          \
+        if (j == 0) {                                                                                                   \
+          /* explicit reads: an SSA alias would keep the old accumulator value alive BESIDE the one mfma0 defines */    \
+          _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) {                                                            \
+            _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                                          \
+              float t_;                                                                                                 \
+              asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t_) : "a"(acc[i][jj][rr]));                               \
+              old[jj][rr] = t_;                                                                                         \
+            }                                                                                                           \
+          }                                                                                                             \
+        }                                                                                                               \
+        if (m == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* stage t + 1 landed, before the first store */ \
+        if (j >= 4) {                                                                                                   \
+          const int r = j - 4;                                                                                          \
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));                                                   \
+          const u32x4 o = {pack2(old[0][r], old[1][r]), pack2(old[2][r], old[3][r]), pack2(old[4][r], old[5][r]),        \
+                           pack2(old[6][r], old[7][r])};                                                                \
+          __builtin_amdgcn_raw_buffer_store_b128(o, rC, voC, (i * 16 + r) * rowb, 0);                                   \
+          if (STATS) {                                                                                                  \
+            /* the empty asm pins each add to its slot: left alone, the adds are SUNK to their only use behind the    \
+               step, and the 256 old values they need stay live until then (126 spilled registers) */                  \
+            _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) {                                                          \
+              cs[jj] += old[jj][r];                                                                                     \
+              cs2[jj] = fmaf(old[jj][r], old[jj][r], cs2[jj]);                                                          \
+              asm volatile("" : "+v"(cs[jj]), "+v"(cs2[jj]));                                                           \
+            }                                                                                                           \
+          }                                                                                                             \
+        }                                                                                                               \
+      }                                                                                                                 \
+      MF0(acc[i][j], af[0][i], bfr[0][j]);                                                                              \
+      SB();                                                                                                             \
+    }                                                                                                                   \
+    _Pragma("unroll") for (int m = 0; m < 64; ++m) {                                                                    \
+      const int i = m >> 3, j = m & 7;                                                                                  \
+      if (m < 16 && (m & 3) == 0) O_REQ_A(cur, 4 + (m >> 2));                                                           \
+      if (m == 20) {                                                                                                    \
+        if (E) asm volatile("s_barrier" ::: "memory");                                                                  \
+        else BAR_VM();                                                                                                  \
+      }                                                                                                                 \
+      if (m >= 22 && m < 38 && (m & 1) == 0) lds_read(bfr[0][(m - 22) >> 1], aB0, ((m - 22) >> 1) * 2048);              \
+      if (m >= 38 && m < 54 && (m & 1) == 0) lds_read(af[0][(m - 38) >> 1], aA0, ((m - 38) >> 1) * 2048);               \
+      mfma(acc[i][j], af[1][i], bfr[1][j]);                                                                             \
+      SB();                                                                                                             \
+    }                                                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                  \
+    O_ADVANCE();                                                                                                        \
+    s ^= 1;                                                                                                             \
+  }
+
+  // The workgroup's FIRST tile is peeled out of the tile loop: one body whose first step sometimes carries an epilogue
+  // and sometimes not defines every accumulator in two branches, and the merge cost 750-1200 B of scratch (the round-4
+  // finding about `if (kt == 0)` inside the K loop, again)
+#define O_TILE_DONE()                                                                                                   \
+  {                                                                                                                     \
+    int le = lane;                                                                                                      \
+    asm volatile("" : "+v"(le));                                                                                        \
+    rC = __builtin_amdgcn_make_buffer_rsrc(C + (long)(tm * BM + wm * 128) * N + tn * BN + wn * 128, 0,                  \
+                                           (int)(128u * rowb), 0x00020000);                                             \
+    voC = (unsigned)(4 * (le >> 4)) * rowb + 16u * (unsigned)(le & 15);                                                 \
+  }
+  int tm, tn;
+  tile_coords(ntiles, nbn, vb, tm, tn);
+  O_STEP(mfma0, 0)
+  for (int kt = 1; kt < nt; ++kt) O_STEP(mfma, 0)
+  O_TILE_DONE()
+  vb += gstride;
+  while (vb < ntiles) {
+    tile_coords(ntiles, nbn, vb, tm, tn);
+    asm volatile("" : "+v"(ln));
+    lane_consts(ln);
+    if (STATS) {
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) cs[jj] = cs2[jj] = 0.f;
+    }
+    O_STEP(mfma0, 1)
+    if (STATS) {
+      float t = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) t += cs[jj] + cs2[jj];
+      if (t == 12345.f) colsum[tid] = t;               // (lab: the sums are formed, their hand-off is not timed here)
+    }
+    for (int kt = 1; kt < nt; ++kt) O_STEP(mfma, 0)
+    O_TILE_DONE()
+    vb += gstride;
+  }
+  // the last tile of this workgroup: the stand-alone epilogue
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 o = {pack2(acc[i][0][r], acc[i][1][r]), pack2(acc[i][2][r], acc[i][3][r]), pack2(acc[i][4][r], acc[i][5][r]),
+                       pack2(acc[i][6][r], acc[i][7][r])};
+      __builtin_amdgcn_raw_buffer_store_b128(o, rC, voC, (i * 16 + r) * rowb, 0);
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef O_STEP
+#undef O_TILE_DONE
+#undef O_ADVANCE
+#undef O_REQ_A
+#undef O_REQ_B
+}
+
+template <bool STATS>
+static float run_o(const bf16_t* A, const bf16_t* B, bf16_t* C, float* sink, int M, int N, int K, int reps = 8) {
+  auto kern = gemm_v2o<STATS>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  float best = 1e9f;
+  for (int rep = 0; rep < reps; ++rep) {
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(256), dim3(256), LDS_BYTES, 0, A, B, C, M, N, K, sink);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  const double fl = 2.0 * M * N * K, tiles = (double)(M / 256) * (N / 256) / 256;
+  printf("gemm_v2o %s [%d,%d]x[%d,%d]^T  %.3f ms  %.0f TF  %.1f us per tile\n",
+         STATS ? "stores under step 0 + sums" : "stores under step 0       ", M, K, N, K, best, fl / best / 1e9, best * 1e3 / tiles);
+  return best;
+}
+
 template <bool STORE>
 static float run(const bf16_t* A, const bf16_t* B, bf16_t* C, float* sink, int M, int N, int K, int reps = 8) {
   auto kern = gemm_v2<STORE>;
@@ -338,9 +576,14 @@ int main(int argc, char** argv) {
     int bad = 0;
     for (int K : {128, 512, 1024})
       for (int N : {256, 512}) {
+      for (int variant = 0; variant < 3; ++variant) {
         (void)hipMemset(C, 0, (size_t)M * NMAX * 2);
         (void)hipFuncSetAttribute((const void*)gemm_v2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        hipLaunchKernelGGL(gemm_v2<true>, dim3(3), dim3(256), LDS_BYTES, 0, A, B, C, M, N, K, sink);
+        (void)hipFuncSetAttribute((const void*)gemm_v2o<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_v2o<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (variant == 0) hipLaunchKernelGGL(gemm_v2<true>, dim3(3), dim3(256), LDS_BYTES, 0, A, B, C, M, N, K, sink);
+        if (variant == 1) hipLaunchKernelGGL(gemm_v2o<false>, dim3(3), dim3(256), LDS_BYTES, 0, A, B, C, M, N, K, sink);
+        if (variant == 2) hipLaunchKernelGGL(gemm_v2o<true>, dim3(1), dim3(256), LDS_BYTES, 0, A, B, C, M, N, K, sink);
         (void)hipDeviceSynchronize();
         unsigned short* hc = (unsigned short*)malloc((size_t)M * N * 2);
         (void)hipMemcpy(hc, C, (size_t)M * N * 2, hipMemcpyDeviceToHost);
@@ -352,9 +595,10 @@ int main(int argc, char** argv) {
           const double err = fabs(ref - (double)bf2f(hc[(size_t)r * N + c])) / (fabs(ref) + 1.0);
           if (err > worst) worst = err;
         }
-        printf("check K=%d N=%d: worst relative error of 4000 samples %.3e %s\n", K, N, worst, worst < 1e-2 ? "ok" : "BAD");
+        printf("check variant %d K=%d N=%d: worst relative error of 4000 samples %.3e %s\n", variant, K, N, worst, worst < 1e-2 ? "ok" : "BAD");
         if (!(worst < 1e-2)) bad = 1;
         free(hc);
+      }
       }
     printf("%s\n", hipGetErrorString(hipGetLastError()));
     return bad;
@@ -367,6 +611,8 @@ int main(int argc, char** argv) {
       if (lab && !(K == 1024 && N == 1024)) continue;
       run<false>(A, B, C, sink, M, N, K);
       if (!lab) run<true>(A, B, C, sink, M, N, K);
+      if (!lab) run_o<false>(A, B, C, sink, M, N, K);
+      if (!lab) run_o<true>(A, B, C, sink, M, N, K);
     }
   (void)hipDeviceSynchronize();
   printf("%s\n", hipGetErrorString(hipGetLastError()));
