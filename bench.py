@@ -63,9 +63,12 @@ def parse():
     ap.add_argument("--workload", default="train", choices=["train", "sweep", "infer"],
                     help="train: BASELINE config[1] (default, the driver's line, with the other configs as extra keys); "
                          "sweep / infer: config[3] / config[4] as a line of their own")
-    ap.add_argument("--dp-mode", default="allreduce", choices=["allreduce", "zero"],
-                    help="data-parallel exchange of the decoder gradients: per-layer all-reduce buckets (default) or "
-                         "reduce-scatter + sharded Adam + all-gather (ZeRO-1)")
+    ap.add_argument("--dp-mode", default="auto", choices=["auto", "allreduce", "zero", "gather"],
+                    help="data-parallel exchange of the decoder gradients: per-layer all-reduce buckets, reduce-scatter + "
+                         "sharded Adam + all-gather (ZeRO-1), or gather: the wide layers all-gather their two small "
+                         "weight-gradient operands and every rank forms the global gradient inside the fused "
+                         "weight-gradient + Adam kernel (round 5; bf16 mode, world x batch <= 512).  auto = gather in the bf16 "
+                         "throughput mode (a tenth of the bytes, no separate Adam pass), all-reduce in the parity modes")
     ap.add_argument("--dp-force", action="store_true",
                     help="N=1 only: create a 1-rank RCCL group and issue the step's collectives on it (exercises the RCCL "
                          "calls and measures their fixed cost on one GPU)")
@@ -90,6 +93,8 @@ def parse():
     a = ap.parse_args()
     if a.grad_compress == "auto":
         a.grad_compress = "bf16" if a.precision == "bf16" else "none"
+    if a.dp_mode == "auto":
+        a.dp_mode = "gather" if a.precision == "bf16" else "allreduce"
     a.windows = max(1, a.windows)
     return a
 
@@ -255,6 +260,7 @@ def build_trainer(a, N, dev, pg, precision, fill="deterministic"):
     cfg.update(NMAX=N, TRAIN_CLASSES=list(range(a.classes)), BATCH_SIZE=a.batch)
     tr = PCAATrainer(cfg, device=dev, precision=precision, process_group=pg, sync_bn=a.sync_bn,
                      dp_zero=(a.dp_mode == "zero") and pg is not None,
+                     dp_gather=(a.dp_mode == "gather") and pg is not None,
                      grad_compress=None if a.grad_compress == "none" else a.grad_compress,
                      force_collectives=a.dp_force,
                      fused_decoder_update=("all" if a.decoder_update == "fused" else False))
@@ -558,8 +564,8 @@ def main():
     constants.NFEATURES = C
     F_hip.set_precision(a.precision)
     tr, cfg = build_trainer(a, N, dev, pg, a.precision)
-    decoder_update = "fused wgrad+adam" if (tr.fused_decoder_update and world == 1 and a.precision == "bf16"
-                                            and not a.dp_force) else "wgrad, adam"
+    decoder_update = "fused wgrad+adam" if (tr.fused_decoder_update and a.precision == "bf16" and
+                                            ((world == 1 and not a.dp_force) or a.dp_mode == "gather")) else "wgrad, adam"
     pcs, gt, z0, al = make_inputs(B, T, N, C, K, dev, rank)
 
     def barrier():
@@ -678,13 +684,13 @@ def main():
     # Data-parallel legs (round 4): the driver runs `bench.py --gpus N` ONCE per N, so that one
     # invocation also times every exchange scheme the trainer has -- (all-reduce | ZeRO-1 reduce-scatter + sharded Adam +
     # all-gather) x (fp32 | bf16 gradient buckets), and SyncBN -- each with the communication time the step could not
-    # hide.  ``value`` stays the documented default (all-reduce, bf16 buckets in the bf16 mode, per-rank BatchNorm).
+    # hide.  ``value`` is the documented default (bf16 mode: gathered operands; parity modes: all-reduce; per-rank BatchNorm).
     dp_legs = None
     if (world > 1 or a.dp_force) and not a.no_extra_legs:
         import copy
         dp_legs = []
         combos = [("allreduce", "bf16", False), ("allreduce", "none", False), ("zero", "bf16", False),
-                  ("zero", "none", False), ("allreduce", "bf16", True)]
+                  ("zero", "none", False), ("allreduce", "bf16", True), ("gather", "bf16", False)]
         if a.precision != "bf16":
             combos = [("allreduce", "none", False), ("zero", "none", False), ("allreduce", "none", True)]
         lsteps = max(1, min(a.steps, 10))
@@ -755,6 +761,7 @@ def main():
                        "dp": {"mode": a.dp_mode if world > 1 else "none",
                               "grad_compress": a.grad_compress if (world > 1 or a.dp_force) else "none",
                               "collectives_per_step": comm["collectives"], "payload_bytes_per_step": comm["payload_bytes"],
+                              # (gather: its payload is almost all all-gathered operands -- (w-1)/w of it per rank)
                               "ring_wire_bytes_per_rank": (2.0 * (world - 1) / world * comm["payload_bytes"]
                                                            if a.dp_mode == "allreduce" else
                                                            1.0 * (world - 1) / world * comm["payload_bytes"])},

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PCAA_ABI_VERSION 14 /* pcaa_abi_version() of a library built from this header */
+#define PCAA_ABI_VERSION 15 /* pcaa_abi_version() of a library built from this header */
 
 #define PCAA_OK 0
 #define PCAA_ERR_INVALID_ARG 1
@@ -411,6 +411,18 @@ int pcaa_skinny_linear_wgrad_adam(const float* dz, long lddz, const float* x, lo
                                   float* exp_avg, float* exp_avg_sq, long ldw, int M, int N, int K,
                                   float beta1, float beta2, float eps, float grad_scale,
                                   const float* coef_dev, void* stream);
+/* ABI 15 (round 5): the same fused update from GATHERED rows -- the data-parallel step's exchange for the batch-skinny
+ * decoder layers.  dz [M, lddz], x [M, ldx] hold the rows of ALL ranks stacked (M = world * B <= 512, all-gathered: 4 M
+ * (N + K) bytes instead of the gradient's 4 N K); every rank forms the global gradient dz^T x in registers and applies
+ * the identical Adam update (grad_scale = 1 / world: the reference's mean over the global batch, PCAA_ablation.py:1008-
+ * 1021 at BATCH_SIZE = world * B).  bf16 products, fp32 accumulation over the rows in ascending order; M <= 64 gives the
+ * bits of pcaa_skinny_linear_wgrad_adam. */
+int pcaa_skinny_linear_wgrad_adam_rows(const float* dz, long lddz, const float* x, long ldx, float* W,
+                                       float* exp_avg, float* exp_avg_sq, long ldw, int M, int N, int K,
+                                       float beta1, float beta2, float eps, float grad_scale,
+                                       const float* coef_dev, int rows_alloc, void* stream);
+/* (x is read in whole 64-row chunks: rows_alloc = the rows x is allocated for, >= the next of 64 / 128 / 256 / 512 above
+ * M; the rows past M must hold finite values -- they meet zeros) */
 /* ABI 14: the bf16 IMAGE of a decoder weight (W16 [N, ldw] bf16: every element = the weight rounded to nearest even, the
  * conversion pcaa_skinny_linear_fwd / _dgrad apply in registers -- results are bit-identical).  _fwd_w16 / _dgrad_w16
  * stream the image instead of the fp32 matrix: half the bytes of the two passes that sit on the step's critical path.

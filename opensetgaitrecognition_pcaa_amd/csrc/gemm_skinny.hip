@@ -616,6 +616,127 @@ __global__ __launch_bounds__(256) void skinny_wgrad_adam_kernel(const float* __r
   }
 }
 
+// ------------------------------------------------------------------ round 5: the same update from GATHERED rows
+// Data parallel, the weight gradient of a batch-skinny layer is dW = sum over ranks of dz_r^T . x_r = DZ^T . X with the
+// ranks' rows stacked: DZ [world * B, N], X [world * B, K].  The gradient is 4 N K bytes per rank on the wire (2 N K as
+// bf16); DZ and X together are 4 world B (N + K) -- for the decoder's 7680 -> 15360 layer at 8 x 64 rows 47 MB against
+// 472 MB.  So the data-parallel step all-gathers the layer's two small operands instead of all-reducing its gradient,
+// and every rank forms the GLOBAL gradient itself, in registers, inside this fused update: the exchange shrinks ~10x, the
+// gradient still never reaches HBM, and the separate Adam pass over the decoder (28 B per parameter) that an all-reduce
+// forces does not exist.  (The reference has no multi-GPU path; single process this is pcaa_skinny_linear_wgrad_adam.)
+// MC chunks of 64 rows (M <= 64 MC): the dz fragments of ALL chunks stay in the LDS (16 KB per chunk), the contraction
+// of a 128 x 32 fragment set runs over them with x requested one chunk ahead; everything else -- fragment ring, Adam
+// arithmetic, store pattern -- is the single-process kernel's.  bf16 products (the throughput mode).
+template <int JL, bool FULLN, int NB, int MC>
+__global__ __launch_bounds__(256) void skinny_wgrad_adam_rows_kernel(const float* __restrict__ dz, long lddz,
+                                                                     const float* __restrict__ x, long ldx,
+                                                                     float* __restrict__ W, float* __restrict__ mo,
+                                                                     float* __restrict__ vo, long ldw, int M, int N, int K,
+                                                                     float b1, float b2, float eps, float grad_scale,
+                                                                     const float* __restrict__ coef) {
+  static_assert(NB == 2 || NB == 4, "fragment buffers: a ring of 2 or 4");
+  extern __shared__ __attribute__((aligned(16))) bf16x8 apan_rows[];           // [MC][row fragment i][k-step s][lane]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  const float step_size = coef[0], inv_bc2_sqrt = coef[1];
+  const int n0 = blockIdx.y * 128;
+  const int kb = (blockIdx.x * 4 + wave) * (32 * JL);
+  const int jn = kb < K ? min(JL, (K - kb) / 32) : 0;
+  {
+    const int s = wave;
+#pragma unroll
+    for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned ncol = (unsigned)min(n0 + 32 * i + l31, N - 1);
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int m = 64 * mc + 16 * s + 8 * h + e;
+          const float v = dz[(unsigned)min(m, M - 1) * (unsigned)lddz + ncol];
+          t[e] = m < M ? v : 0.f;                          // rows past M contribute nothing, whatever x holds there
+        }
+        apan_rows[((mc * 4 + i) * 4 + s) * 64 + lane] = pack8(t);
+      }
+  }
+  // x[row][col]: row = 64 mc + 16 s + 8 h + e, col = kb + 32 j + l31 -- one vector offset per lane, everything else in
+  // the (uniform) scalar offset of a buffer load.  The scalar offset is outside the buffer's range check: the caller
+  // allocates x for 64 MC rows (the rows past M hold finite values -- zeros -- and meet zero dz fragments)
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)(unsigned)(64L * MC * ldx * 4), 0x00020000);
+  const unsigned xv = (unsigned)(8 * h) * (unsigned)ldx * 4u + (unsigned)(min(kb, K - 32) + l31) * 4u;
+  auto load_x = [&](float (&br)[4][8], int mc, int j) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned so = (unsigned)(64 * mc + 16 * s + e) * (unsigned)ldx * 4u + 128u * (unsigned)j;
+        br[s][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, xv, so, 0));
+      }
+  };
+  float br[4][8];
+  load_x(br, 0, 0);
+
+  const unsigned row0 = (unsigned)(n0 + 4 * h);
+  unsigned o0 = row0 * (unsigned)ldw + (unsigned)kb + l31;
+  float pw[NB][16], pm[NB][16], pv[NB][16];
+  const int nfrag = 4 * jn;
+  auto fetch = [&](int f, int b) {
+    if (f >= nfrag) return;
+    const unsigned base = o0 + 32u * (unsigned)(f >> 2);
+    const int i = f & 3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned rr = 32 * i + (r & 3) + 8 * (r >> 2);
+      if (FULLN || row0 + rr < (unsigned)N) {
+        const unsigned o = base + rr * (unsigned)ldw;
+        pw[b][r] = W[o]; pm[b][r] = mo[o]; pv[b][r] = vo[o];
+      }
+    }
+  };
+#pragma unroll
+  for (int f = 0; f < NB - 1; ++f) fetch(f, f);
+  __syncthreads();
+
+  for (int j = 0; j < jn; ++j) {
+    asm volatile("" : "+v"(o0) : : "memory");
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int mc = 0; mc < MC; ++mc) {
+      bf16x8 bf[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bf[s] = pack8(br[s]);
+      // the next chunk's x (behind the last chunk: the first chunk of the next column step; last step: a harmless re-read)
+      if (mc + 1 < MC) load_x(br, mc + 1, j);
+      else load_x(br, 0, min(j + 1, jn - 1));
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apan_rows[((mc * 4 + i) * 4 + s) * 64 + lane], bf[s], acc[i], 0, 0, 0);
+    }
+    const unsigned base = o0 + 32u * (unsigned)j;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = i % NB;
+      fetch(4 * j + i + NB - 1, (i + NB - 1) % NB);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned rr = 32 * i + (r & 3) + 8 * (r >> 2);
+        if (FULLN || row0 + rr < (unsigned)N) {
+          const unsigned o = base + rr * (unsigned)ldw;
+          adam_update(pw[b][r], pm[b][r], pv[b][r], acc[i][r] * grad_scale, b1, b2, eps, step_size, inv_bc2_sqrt);
+          W[o] = pw[b][r];
+          mo[o] = pm[b][r];
+          vo[o] = pv[b][r];
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ slab reduction (+ bias/ELU, or * ELU'(a_prev))
 __global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* __restrict__ slabs, int ns, long stride,
                                                             float* __restrict__ out, const float* __restrict__ bias,
@@ -859,6 +980,62 @@ static int skinny_wgrad_adam_impl(const float* dz, long lddz, const float* x, lo
 #undef WA_PICK
 #undef WA_LAUNCH
   PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_wgrad_adam");
+}
+
+// gathered rows (data parallel): M = world * B <= 512 rows in chunks of 64
+template <int MC>
+static int launch_wgrad_adam_rows(const float* dz, long lddz, const float* x, long ldx, float* W, float* exp_avg,
+                                  float* exp_avg_sq, long ldw, int M, int N, int K, float beta1, float beta2, float eps,
+                                  float grad_scale, const float* coef_dev, hipStream_t st) {
+  constexpr int NB = 2;
+  constexpr size_t lds = (size_t)MC * 4 * 4 * 64 * sizeof(bf16x8);
+  auto ntile = [&](int jl) { return cdiv(K, 4 * 32 * jl) * cdiv(N, 128); };
+  const int jl = ntile(4) >= 1024 ? 4 : (ntile(2) >= 1024 ? 2 : 1);
+  const bool full = N % 128 == 0;
+#define WR_LAUNCH(JL, FULL)                                                                                            \
+  do {                                                                                                                 \
+    auto kern = skinny_wgrad_adam_rows_kernel<JL, FULL, NB, MC>;                                                       \
+    static bool configured = false;                                                                                    \
+    if (!configured) {                                                                                                 \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        return 1;                                                                                                      \
+      configured = true;                                                                                               \
+    }                                                                                                                  \
+    hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(K, 4 * 32 * JL), (unsigned)cdiv(N, 128)), dim3(256), lds, st, dz, lddz, x, \
+                       ldx, W, exp_avg, exp_avg_sq, ldw, M, N, K, beta1, beta2, eps, grad_scale, coef_dev);            \
+  } while (0)
+  if (full) { if (jl == 4) WR_LAUNCH(4, true); else if (jl == 2) WR_LAUNCH(2, true); else WR_LAUNCH(1, true); }
+  else { if (jl == 4) WR_LAUNCH(4, false); else if (jl == 2) WR_LAUNCH(2, false); else WR_LAUNCH(1, false); }
+#undef WR_LAUNCH
+  return 0;
+}
+
+extern "C" int pcaa_skinny_linear_wgrad_adam_rows(const float* dz, long lddz, const float* x, long ldx, float* W,
+                                                  float* exp_avg, float* exp_avg_sq, long ldw, int M, int N, int K,
+                                                  float beta1, float beta2, float eps, float grad_scale,
+                                                  const float* coef_dev, int rows_alloc, void* stream) {
+  PCAA_CHECK_ARG(dz && x && W && exp_avg && exp_avg_sq && coef_dev, "pcaa_skinny_linear_wgrad_adam_rows: null pointer");
+  PCAA_CHECK_ARG(M >= 1 && M <= 512 && N >= 1 && K >= 32 && K % 32 == 0,
+                 "pcaa_skinny_linear_wgrad_adam_rows: unsupported shape M=%d N=%d K=%d (M <= 512, K %% 32 == 0)", M, N, K);
+  {
+    const int mc = M <= 64 ? 1 : (M <= 128 ? 2 : (M <= 256 ? 4 : 8));
+    PCAA_CHECK_ARG(rows_alloc >= 64 * mc, "pcaa_skinny_linear_wgrad_adam_rows: x must be allocated (and finite) for %d rows, "
+                   "got %d", 64 * mc, rows_alloc);
+  }
+  PCAA_CHECK_ARG(lddz >= N && ldx >= K && ldw >= K, "pcaa_skinny_linear_wgrad_adam_rows: bad leading dimensions");
+  PCAA_CHECK_ARG((long)M * lddz < (1L << 31) && 512L * ldx < (1L << 30) && (long)N * ldw < (1L << 30) &&
+                 ((uintptr_t)x % 4) == 0, "pcaa_skinny_linear_wgrad_adam_rows: operands beyond 32-bit offsets");
+  hipStream_t st = as_stream(stream);
+  int rc;
+  if (M <= 64) rc = launch_wgrad_adam_rows<1>(dz, lddz, x, ldx, W, exp_avg, exp_avg_sq, ldw, M, N, K, beta1, beta2, eps, grad_scale, coef_dev, st);
+  else if (M <= 128) rc = launch_wgrad_adam_rows<2>(dz, lddz, x, ldx, W, exp_avg, exp_avg_sq, ldw, M, N, K, beta1, beta2, eps, grad_scale, coef_dev, st);
+  else if (M <= 256) rc = launch_wgrad_adam_rows<4>(dz, lddz, x, ldx, W, exp_avg, exp_avg_sq, ldw, M, N, K, beta1, beta2, eps, grad_scale, coef_dev, st);
+  else rc = launch_wgrad_adam_rows<8>(dz, lddz, x, ldx, W, exp_avg, exp_avg_sq, ldw, M, N, K, beta1, beta2, eps, grad_scale, coef_dev, st);
+  if (rc != 0) {
+    pcaa_set_error("pcaa_skinny_linear_wgrad_adam_rows: cannot raise the dynamic LDS limit");
+    return PCAA_ERR_LAUNCH;
+  }
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_wgrad_adam_rows");
 }
 
 extern "C" int pcaa_skinny_linear_wgrad_adam(const float* dz, long lddz, const float* x, long ldx, float* W,

@@ -1271,6 +1271,39 @@ def skinny_linear_wgrad_adam_(dz, x, W, exp_avg, exp_avg_sq, beta1, beta2, eps, 
     return W
 
 
+def gathered_rows_alloc(m):
+    """rows a gathered operand of ``m`` valid rows must be allocated for (skinny_linear_wgrad_adam_rows_ reads whole
+    64-row chunks: 64, 128, 256 or 512); None if m is beyond the kernel's 512"""
+    for r in (64, 128, 256, 512):
+        if m <= r:
+            return r
+    return None
+
+
+def skinny_linear_wgrad_adam_rows_(dz_all, x_all, m, W, exp_avg, exp_avg_sq, beta1, beta2, eps, coef_dev, grad_scale=1.0):
+    """The fused weight-gradient + Adam update from GATHERED rows (data parallel; pcaa_skinny_linear_wgrad_adam_rows):
+    ``dz_all`` [R, N], ``x_all`` [R, K] hold the rows of all ranks stacked in their first ``m`` rows (R =
+    gathered_rows_alloc(m); the rows behind m must be finite -- the buffers are zero-initialised once).
+    W[N,K] <- Adam(W, grad_scale * dz_all[:m]^T @ x_all[:m]) in place, bf16 products."""
+    _chk(dz_all, "skinny_wgrad_adam_rows.dz", torch.float32, 2)
+    _chk(x_all, "skinny_wgrad_adam_rows.x", torch.float32, 2)
+    R, N = dz_all.shape
+    K = x_all.shape[1]
+    need = gathered_rows_alloc(int(m))
+    if need is None or x_all.shape[0] != R or R < need:
+        raise ValueError(f"skinny_linear_wgrad_adam_rows_: {m} valid rows need buffers of {need} rows, got {R} / {x_all.shape[0]}")
+    for t, nm in ((W, "W"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, "skinny_wgrad_adam_rows." + nm, torch.float32)
+        if tuple(t.shape) != (N, K):
+            raise ValueError(f"skinny_linear_wgrad_adam_rows_: {nm} must be [{N},{K}], got {tuple(t.shape)}")
+    _chk(coef_dev, "skinny_wgrad_adam_rows.coef", torch.float32)
+    _skinny_timed(lambda: check(_lib.load().pcaa_skinny_linear_wgrad_adam_rows(
+        _p(dz_all), dz_all.stride(0), _p(x_all), x_all.stride(0), _p(W), _p(exp_avg), _p(exp_avg_sq), K, int(m), N, K,
+        float(beta1), float(beta2), float(eps), float(grad_scale), _p(coef_dev), R, _s()),
+        "pcaa_skinny_linear_wgrad_adam_rows"), 2.0 * m * N * K, 4 * (6 * N * K + m * K + m * N))
+    return W
+
+
 def total(x, scale=1.0):
     _chk(x, "sum.x", torch.float32)
     out = torch.empty((), dtype=torch.float32, device=x.device)

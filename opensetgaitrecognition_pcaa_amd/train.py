@@ -204,7 +204,7 @@ class PCAATrainer:
 
     def __init__(self, config, n_classes=None, device="cuda", variant="v4", precision=None,
                  process_group=None, sync_bn=False, learn_centroids=False, dp_zero=False, grad_compress=None,
-                 force_collectives=False, fused_decoder_update=True):
+                 force_collectives=False, fused_decoder_update=True, dp_gather=False):
         """``fused_decoder_update`` (single process, every precision mode since round 5; "all" is the older spelling of
         True): the decoder's wide weight gradients are formed and consumed by one kernel per layer that applies Adam in
         place (pcaa_skinny_linear_wgrad_adam; the parity modes "fp32" / "fp16x3" use its fp32-product form) -- those
@@ -216,7 +216,13 @@ class PCAATrainer:
         (reduce-scatter, Adam on 1/world of the decoder, all-gather; default off); ``grad_compress="bf16"`` = the decoder's gradient buckets cross the wire as bf16 (half the
         bytes; fp32 master gradients, moments and weights; each bucket is rounded once before the sum and the sum
         is accumulated in bf16 by the collective: relative error of a reduced element ~2^-8).
-        ``force_collectives`` issues the collectives on a 1-rank group too (exercises the RCCL calls on one GPU)."""
+        ``force_collectives`` issues the collectives on a 1-rank group too (exercises the RCCL calls on one GPU).
+        ``dp_gather`` (round 5; bf16 mode with the fused update): the wide decoder layers exchange their two small
+        weight-gradient operands -- dz [B, out] and x [B, in], all-gathered over the ranks -- instead of the gradient
+        (4 world B (in + out) bytes against 4 in out: ~10x less on the wire), and every rank forms the GLOBAL gradient
+        inside the fused weight-gradient + Adam kernel (pcaa_skinny_linear_wgrad_adam_rows): the update stays 24 B per
+        parameter and no Adam pass over the decoder follows the exchange.  Applies while world * B <= 512; mathematically
+        the all-reduce scheme's step (sum over ranks of dz_r^T x_r = stacked-rows product)."""
         self.cfg = dict(config)
         self.K = n_classes if n_classes is not None else len(config["TRAIN_CLASSES"])
         self.N = config["NMAX"]
@@ -237,6 +243,10 @@ class PCAATrainer:
             if sync_bn:
                 self._sync_bn_group = process_group
         self._dp_zero_arg = bool(dp_zero)
+        self._dp_gather = bool(dp_gather)
+        if self._dp_gather and self._dp_zero_arg:
+            raise ValueError("PCAATrainer: dp_gather and dp_zero are alternatives")
+        self._gather_bufs = {}          # (layer, rows_alloc) -> (dz_all, x_all): zero-initialised once, reused every step
         self._force_collectives = bool(force_collectives)
         self.fused_decoder_update = bool(fused_decoder_update)
         # the parity modes too (fp32-product kernels); tests that read the decoder's weight gradients pass False
@@ -759,8 +769,46 @@ class PCAATrainer:
             for layer, (lo, hi, Wv, mv, vv) in self._dec_fused.items():
                 if F_hip._skinny(mode, B, Wv.shape[0], Wv.shape[1]) or F_hip._skinny_exact(mode, B, Wv.shape[0], Wv.shape[1]):
                     updates = updates or {}
-                    updates[layer] = lambda dz2, x, t=(Wv, mv, vv, w16.get(layer)): deferred.append((dz2, x) + t)
+                    updates[layer] = lambda dz2, x, t=(Wv, mv, vv, w16.get(layer)): deferred.append((dz2, x) + t + (None,))
                     fused_ranges.append((lo, hi))
+        # Data parallel, dp_gather: the same fused update from the ranks' stacked rows.  A layer's callback runs where the
+        # backward has just formed dz2: the two all-gathers go out from there (the collective's own stream picks up behind
+        # what is enqueued here; this stream does not wait) and the update kernel follows on the Adam side stream once both
+        # are back -- no gradient bucket, no all-reduce, no separate Adam pass for these layers.
+        rows_all = self.world * B
+        gather = (collective and self._dp_gather and not zero and mode == "bf16" and self.fused_decoder_update
+                  and self._side is not None and ops.gathered_rows_alloc(rows_all) is not None)
+        if gather:
+            import torch.distributed as dist
+            R = ops.gathered_rows_alloc(rows_all)
+
+            def gather_update(layer, Wv, mv, vv):
+                def cb(dz2, x):
+                    key = (layer, R)
+                    if key not in self._gather_bufs:
+                        self._gather_bufs[key] = (torch.zeros((R, dz2.shape[1]), dtype=torch.float32, device=self.device),
+                                                  torch.zeros((R, x.shape[1]), dtype=torch.float32, device=self.device))
+                    dz_all, x_all = self._gather_bufs[key]
+                    works = []
+                    for dst, src in ((dz_all, dz2), (x_all, x)):
+                        src = src.contiguous()
+                        self._count(4 * rows_all * src.shape[1])
+                        works.append(dist.all_gather_into_tensor(dst[:rows_all], src, group=self.pg, async_op=True))
+                    deferred.append((dz_all, x_all, Wv, mv, vv, None, works))
+                return cb
+
+            for layer, (lo, hi, Wv, mv, vv) in self._dec_fused.items():
+                if F_hip._skinny(mode, B, Wv.shape[0], Wv.shape[1]):
+                    updates = updates or {}
+                    updates[layer] = gather_update(layer, Wv, mv, vv)
+                    fused_ranges.append((lo, hi))
+            if layer_hook is not None:
+                # the per-layer gradient buckets only for what the gathered update does not take
+                plain_hook, taken = layer_hook, set(updates or {})
+
+                def layer_hook(layer):
+                    if layer not in taken:
+                        plain_hook(layer)
         if not set(w16) <= set(updates or {}):
             # an image is only current if THIS step's update of its weight rewrites it
             raise RuntimeError("PCAATrainer: a bf16 weight image is in use for a layer whose update is not fused")
@@ -769,6 +817,8 @@ class PCAATrainer:
         if collective and layer_hook is not None and self.grad_compress == "bf16" and mode == "bf16":
             dec_grads = dict(dec_grads)
             for layer, (lo, view16) in self._dec_grads16.items():
+                if updates and layer in updates:
+                    continue                     # (dp_gather: no gradient of this layer exists in any form)
                 # same size rule as _allreduce's compressed path: one predicate decides both
                 if F_hip._skinny(mode, B, view16.shape[0], view16.shape[1]) and view16.numel() >= self._COMPRESS_MIN:
                     dec_grads[f"dense{layer}.weight"] = view16
@@ -835,6 +885,19 @@ class PCAATrainer:
                         zero_gather.append(dist.all_gather_into_tensor(
                             fg.p[self._dec_start + c * n:self._dec_start + (c + 1) * n], self._zero_p[c],
                             group=self.pg, async_op=True))
+        elif gather and not early_buckets:
+            # every wide layer went out as gathered operands: what is left of the decoder region is its first layer and
+            # the biases -- one contiguous range in front of the wide weights (finalize), one small all-reduce
+            rest_hi = min(lo for lo, _ in fused_ranges) if fused_ranges else self.flat_g.total
+            if self._wg is not None:
+                ops.current_stream().wait_stream(self._wg)
+            if rest_hi > self._dec_start:
+                pending.append((self._dec_start, rest_hi,
+                                self._allreduce(self.flat_g.g[self._dec_start:rest_hi], async_op=True)))
+            tail_lo = max(hi for _, hi in fused_ranges) if fused_ranges else self.flat_g.total
+            if tail_lo < self.flat_g.total:
+                pending.append((tail_lo, self.flat_g.total,
+                                self._allreduce(self.flat_g.g[tail_lo:self.flat_g.total], async_op=True)))
         elif early_buckets:
             # per-layer buckets are on the wire already; what is left of the decoder region is its head
             # (first layer): its weight gradient was written on the wgrad stream, its bias gradient on this one
@@ -872,9 +935,15 @@ class PCAATrainer:
                     self._side.wait_event(ready)        # everything enqueued on the main stream so far
                     if self._wg is not None:
                         self._side.wait_stream(self._wg)   # ... and the decoder weight gradients on the wgrad stream
-                    for dz2, x, Wv, mv, vv, w16 in deferred:
+                    for dz2, x, Wv, mv, vv, w16, works in deferred:
                         dz2.record_stream(self._side)
                         x.record_stream(self._side)
+                        if works is not None:
+                            for wk in works:
+                                wk.wait()               # this stream waits for the two all-gathers of THIS layer only
+                            ops.skinny_linear_wgrad_adam_rows_(dz2, x, rows_all, Wv, mv, vv, *self.betas_g(), 1e-8,
+                                                               self.flat_g.coef_dev, gs)
+                            continue
                         ops.skinny_linear_wgrad_adam_(dz2, x, Wv, mv, vv, *self.betas_g(), 1e-8, self.flat_g.coef_dev, gs,
                                                       exact=exact_dec)
                         if w16 is not None:

@@ -12,6 +12,9 @@ Every exchange scheme of ``bench.py``'s ``dp_legs`` is stepped twice from the sa
   exchange -- step 1 within the bf16 gate);
 * bench.py's default (all-reduce, bf16 buckets, per-rank BatchNorm), in fp32 and in the bf16 throughput mode: each
   rank's step-0 losses against the oracle's step on that rank's shard alone;
+* round 5's gathered-operands scheme (``dp_gather``: the wide decoder layers all-gather dz and x, every rank forms the
+  global gradient inside the fused update kernel) in the bf16 mode: per-rank step-0 losses against the shard oracle, and
+  the decoder after two steps against the all-reduce scheme's of the same mode;
 * always: replicas bit-identical after the steps, collectives counted, ZeRO's gathered decoder = all-reduce's.
 """
 import os
@@ -29,7 +32,8 @@ SHAPE = dict(Bper=2, N=32, C=4, K=4, seeds=[10, 11, 12, 13, 14], steps=2)
 KEYS = ("d_loss", "gp", "rec_loss", "loss_g", "sup_loss", "tot_loss")
 # (dp_mode, grad_compress, sync_bn, precision)
 SCHEMES = [("allreduce", None, True, "fp32"), ("allreduce", "bf16", True, "fp32"), ("zero", None, True, "fp32"),
-           ("zero", "bf16", True, "fp32"), ("allreduce", "bf16", False, "fp32"), ("allreduce", "bf16", False, "bf16")]
+           ("zero", "bf16", True, "fp32"), ("allreduce", "bf16", False, "fp32"), ("allreduce", "bf16", False, "bf16"),
+           ("gather", None, False, "bf16")]
 
 
 def _free_port():
@@ -114,7 +118,7 @@ def _worker(rank, world, port, q, means_np):
         recs = []
         for mode, compress, sbn, precision in SCHEMES:
             tr = PCAATrainer(_cfg(SHAPE["Bper"]), device="cuda:0", precision=precision, process_group=dist.group.WORLD,
-                             sync_bn=sbn, dp_zero=(mode == "zero"), grad_compress=compress)
+                             sync_bn=sbn, dp_zero=(mode == "zero"), grad_compress=compress, dp_gather=(mode == "gather"))
             for mod, seed in zip((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head,
                                   tr.discriminator_projection_head), SHAPE["seeds"]):
                 syn.deterministic_fill_(mod, seed)
@@ -143,6 +147,7 @@ def _worker(rank, world, port, q, means_np):
             rec["exposed_us"] = tr.exposed_comm_us()
             rec["pairs_per_step"] = [len(p) for p in tr.comm_events]
             rec["zero"] = bool(tr._zero)
+            rec["gathered_layers"] = sorted(k[0] for k in tr._gather_bufs)
             if rank == 0:
                 fg = tr.flat_g
                 rec["params"] = {n: fg.params[fg.names.index(n)].detach().cpu().numpy()
@@ -234,6 +239,7 @@ def test_every_dp_scheme_at_the_largest_world_this_box_admits_vs_oracle():
         assert all(x["zero"] == (mode == "zero") for x in R)
         comm = R[0]["comm"]
         assert comm["collectives"] >= 7 and comm["payload_bytes"] > 0, scheme
+        assert R[0]["gathered_layers"] == ([2, 3, 4, 5] if mode == "gather" else []), scheme
         # the exposed-communication record: one list of event pairs per step; ZeRO adds the wait for
         # its all-gathers, SyncBN one pair per statistics all-reduce
         assert len(R[0]["exposed_us"]) == SHAPE["steps"] and all(u >= 0 for u in R[0]["exposed_us"])
@@ -279,6 +285,15 @@ def test_every_dp_scheme_at_the_largest_world_this_box_admits_vs_oracle():
             err = np.abs(a.astype(np.float64) - b.astype(np.float64))
             assert err.max() <= 5e-5 * np.abs(b).max() + 2.0e-4 * steps * 1.001, (scheme, n, err.max())
             assert err.mean() <= (4e-6 if exact else 4e-5), (scheme, n, err.mean())
+    # the gathered-operands scheme against the gradient all-reduce of the same mode: the same step (bf16 buckets round the
+    # reduced gradient once more; Adam's +-lr noise gate), at a fraction of the bytes
+    ga = next(res[0][i] for i, sc in enumerate(SCHEMES) if sc == ("gather", None, False, "bf16"))
+    ar = next(res[0][i] for i, sc in enumerate(SCHEMES) if sc == ("allreduce", "bf16", False, "bf16"))
+    d5 = np.abs(ga["dense5_rows"] - ar["dense5_rows"])
+    assert d5.mean() <= 3e-5 and d5.max() <= 4.5e-4, (d5.mean(), d5.max())
+    for n in ga["params"]:
+        assert np.abs(ga["params"][n] - ar["params"][n]).mean() <= 5e-5, n
+    assert ga["comm"]["payload_bytes"] < 0.5 * ar["comm"]["payload_bytes"]
     # ZeRO's gathered decoder against the all-reduce's, same buckets: the same reduced gradients met the same Adam
     for comp in (None, "bf16"):
         a, z = dec_l2[("allreduce", comp, True, "fp32")], dec_l2[("zero", comp, True, "fp32")]

@@ -490,6 +490,53 @@ def test_skinny_wgrad_adam_equals_wgrad_then_adam_bitwise(M, N, K):
         assert torch.equal(Wa, Wb) and torch.equal(ma, mb) and torch.equal(va, vb), ("exact", s)
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 256, 128), (37, 192, 160), (5, 128, 1024), (128, 256, 128), (6, 512, 256), (192, 960, 1920),
+                                   (256, 192, 160), (300, 128, 96), (512, 384, 512), (512, 1920, 960)])
+def test_skinny_wgrad_adam_rows_gathered_update(M, N, K):
+    """Round 5 (dp_gather): the fused weight-gradient + Adam update from the ranks' stacked rows, M = world * B up to
+    512.  M <= 64: the bits of the single-process kernel.  Beyond: the gradient it forms is the bf16-operand product with
+    fp32 accumulation over ALL rows -- checked through the Adam state it leaves: exp_avg = (1 - beta1) * grad after one step
+    from zero moments, against an fp64 product of the rounded operands (1e-5 of the largest entry); the buffers' rows
+    behind M (zeros, as the trainer allocates them) and a NaN-free W outside [N, K] are left alone."""
+    from opensetgaitrecognition_pcaa_amd.train import StepCount
+    R = ops.gathered_rows_alloc(M)
+    W0 = _rand((N, K), 400, 0.05).to(DEV)
+    dzb = torch.zeros((R, N), device=DEV)
+    xb = torch.zeros((R, K), device=DEV)
+    dzb[:M] = _rand((M, N), 401, 0.3).to(DEV)
+    xb[:M] = _rand((M, K), 402, 1.0).to(DEV)
+    if M < R:
+        xb[M:] = 7.0                      # finite garbage behind the valid rows: must meet zero dz fragments
+        dzb[M:] = 3.0                     # ... and dz rows behind M are masked by the kernel itself
+    W, m, v = W0.clone(), torch.zeros_like(W0), torch.zeros_like(W0)
+    c = StepCount(DEV)
+    c.advance(1e-3, 0.9, 0.99)
+    ops.skinny_linear_wgrad_adam_rows_(dzb, xb, M, W, m, v, 0.9, 0.99, 1e-8, c.coef_dev, grad_scale=0.5)
+    torch.cuda.synchronize()
+    g64 = 0.5 * (dzb[:M].bfloat16().double().t() @ xb[:M].bfloat16().double())
+    got = m.double() / 0.1                # exp_avg after the first step = (1 - beta1) * grad
+    assert (got - g64).abs().max().item() <= 1e-5 * g64.abs().max().item() + 1e-7
+    assert torch.isfinite(W).all() and not torch.equal(W, W0)
+    if M <= 64:
+        Wb, mb, vb = W0.clone(), torch.zeros_like(W0), torch.zeros_like(W0)
+        cb = StepCount(DEV)
+        cb.advance(1e-3, 0.9, 0.99)
+        ops.skinny_linear_wgrad_adam_(dzb[:M], xb[:M], Wb, mb, vb, 0.9, 0.99, 1e-8, cb.coef_dev, grad_scale=0.5)
+        assert torch.equal(W, Wb) and torch.equal(m, mb) and torch.equal(v, vb), "M <= 64: the single-process kernel's bits"
+    else:
+        # the rows in 64-row chunks through the two-kernel path, summed: the same gradient up to fp32 summation order
+        dW = sum(ops.skinny_linear_wgrad(dzb[r:min(r + 64, M)], xb[r:min(r + 64, M)]) for r in range(0, M, 64))
+        Wc, mc, vc = W0.clone(), torch.zeros_like(W0), torch.zeros_like(W0)
+        cc = StepCount(DEV)
+        cc.advance(1e-3, 0.9, 0.99)
+        ops.adam_step_dev_(Wc, dW, mc, vc, 0.9, 0.99, 1e-8, cc.coef_dev, 0.5)
+        assert (m - mc).abs().max().item() <= 2e-6 * mc.abs().max().item()
+        assert (W - Wc).abs().max().item() <= 2.1e-3          # one Adam step of lr 1e-3: sign flips where the gradient is rounding noise
+        assert (W - Wc).abs().mean().item() <= 1e-6
+    with pytest.raises(ValueError):
+        ops.skinny_linear_wgrad_adam_rows_(dzb[:8], xb[:8], 600, W, m, v, 0.9, 0.99, 1e-8, c.coef_dev)
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 256, 128), (37, 192, 160), (64, 960, 1920), (16, 4544, 2304)])
 def test_skinny_wgrad_bf16_output_is_the_rounded_fp32_gradient(M, N, K):
     """pcaa_skinny_linear_wgrad_bf16 (the data-parallel step's bf16 gradient buckets are produced directly): the same

@@ -16,7 +16,7 @@ ap.add_argument("--points", type=int, default=128)
 ap.add_argument("--fused", default="on", choices=["on", "off"], help="decoder weight-gradient + Adam fusion")
 ap.add_argument("--dp-force", action="store_true", help="1-rank RCCL group: the data-parallel step's collectives and hand-offs")
 ap.add_argument("--grad-compress", default="bf16", choices=["none", "bf16"])
-ap.add_argument("--dp-mode", default="allreduce", choices=["allreduce", "zero"])
+ap.add_argument("--dp-mode", default="allreduce", choices=["allreduce", "zero", "gather"])
 a = ap.parse_args()
 pg = None
 if a.dp_force:
@@ -31,7 +31,7 @@ cfg = dict(constants.CONFIG); cfg.update(NMAX=N, TRAIN_CLASSES=list(range(K)), B
 F_hip.set_precision(a.precision)
 tr = PCAATrainer(cfg, device="cuda", precision=a.precision, fused_decoder_update=("all" if a.fused != "off" else False), process_group=pg,
                  force_collectives=a.dp_force, grad_compress=None if a.grad_compress == "none" else a.grad_compress,
-                 dp_zero=a.dp_mode == "zero" and pg is not None)
+                 dp_zero=a.dp_mode == "zero" and pg is not None, dp_gather=a.dp_mode == "gather" and pg is not None)
 for i, m in enumerate((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head, tr.discriminator_projection_head)):
     syn.deterministic_fill_(m, i)
 tr.set_prior_means(sample_distant_points(32, K, 10, 10)); tr.finalize(); tr.train()
