@@ -96,8 +96,9 @@ int pcaa_gemm_slabs(int math,
  * layer's stored pre-activation y[M,N] and writes  dz = da * ELU'(y*scale+shift)  (bf16, same ld as y)
  * while adding {sum dz, sum dz*(y-mean)*rstd} per column into stats (as pcaa_bn_act_bwd_dz does in a
  * separate pass).  All operands bf16, M and N multiples of 256, K of 64.
- * y == NULL: the layer below is the first PointNet layer on its recompute path; its pre-activation is
- * rebuilt as x[M,xc] . W1[N,xc]^T (fp32, xc <= 8) and dz feeds pcaa_pointnet_in_bwd_wgrad(dz_is_pre). */
+ * x, xc, W1: must be NULL / 0 / NULL -- the variant of rounds 1-4 that rebuilt y of the first PointNet layer from the
+ * points in the epilogue (never faster than the separate statistics pass) left with the 8-wave kernel in round 5; y is
+ * required. */
 /* Eval-mode PointNet layer in one launch (models.py:6-34 with BatchNorm2d in eval mode: a per-channel affine map
  * known before the product): out[M,N] bf16 = ELU(scale[n] * (A[M,K] . W[N,K]^T) + shift[n]), A and W bf16,
  * contraction contiguous; same shape rule as pcaa_gemm_dgrad_bn_supported.  pool_rows in {32, 64, 128}: the

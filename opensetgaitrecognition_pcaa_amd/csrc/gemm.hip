@@ -566,8 +566,11 @@ static bool ragged_m_ok(int M, int N, int K) {
 static bool ragged_out_ok(int M, const void* C, long ldc, int elem) {
   return (M % 256) == 0 || ((ldc % 8) == 0 && ((uintptr_t)C % 16) == 0 && (long)cdiv(M, 256) * 256 * ldc * elem < (1L << 32));
 }
+// (round 5: the 4-wave loops are the only LDS-DMA kernels left -- a contraction of at least five 64-deep steps, three
+// K-long passes for the split operands)
 extern "C" int pcaa_gemm_split3_supported(int M, int N, int K) {
-  return M > 0 && N > 0 && K > 0 && ((M % 256) == 0 || ragged_m_ok(M, N, K)) && (N % 256) == 0 && (K % 64) == 0;
+  return M > 0 && N > 0 && K > 0 && pcaa_gemm_v2_is_enabled() && 3L * K >= 320 &&
+         ((M % 256) == 0 || ragged_m_ok(M, N, K)) && (N % 256) == 0 && (K % 64) == 0;
 }
 
 static int gemm_split3_impl(const void* A, const void* B, int layout, long lda, long ldb, void* C, long ldc, int M, int N,
@@ -629,7 +632,8 @@ extern "C" int pcaa_gemm_slabs_split3(const void* A, const void* B, int layout, 
 }
 
 extern "C" int pcaa_gemm_dgrad_bn_supported(int M, int N, int K) {
-  return M > 0 && N > 0 && K > 0 && ((M % 256) == 0 || ragged_m_ok(M, N, K)) && (N % 256) == 0 && (K % 64) == 0;
+  return M > 0 && N > 0 && K >= 320 && pcaa_gemm_v2_is_enabled() && ((M % 256) == 0 || ragged_m_ok(M, N, K)) &&
+         (N % 256) == 0 && (K % 64) == 0;
 }
 
 extern "C" int pcaa_gemm_dgrad_bn(const void* dy, long lddy, const void* Wt, long ldw, const void* y, void* dz,
@@ -637,15 +641,18 @@ extern "C" int pcaa_gemm_dgrad_bn(const void* dy, long lddy, const void* Wt, lon
                                   const float* rstd, double* stats, int nrep, int M, int N, int K,
                                   const float* x, int xc, const float* W1, void* stream) {
   PCAA_CHECK_ARG(dy && Wt && dz && scale && shift && mean && rstd && stats, "pcaa_gemm_dgrad_bn: null pointer");
-  PCAA_CHECK_ARG((y != nullptr) != (x != nullptr), "pcaa_gemm_dgrad_bn: exactly one of y / x");
-  PCAA_CHECK_ARG(!x || (W1 && xc >= 1 && xc <= 8 && ((uintptr_t)x % 16) == 0),
-                 "pcaa_gemm_dgrad_bn: recompute needs W1, 1 <= xc <= 8 and a 16-B aligned x");
+  // (x / xc / W1: the first-layer recompute variant of rounds 1-4 -- y rebuilt from the points in the epilogue; it lived in
+  // the 8-wave kernel, was never faster than the separate statistics pass and left with that kernel in round 5.  The
+  // arguments stay in the signature; passing them is an argument error.)
+  (void)xc; (void)W1;
+  PCAA_CHECK_ARG(y != nullptr && x == nullptr, "pcaa_gemm_dgrad_bn: y is required (the recompute variant -- x, xc, W1 -- was "
+                 "removed in round 5)");
   PCAA_CHECK_ARG(pcaa_gemm_dgrad_bn_supported(M, N, K), "pcaa_gemm_dgrad_bn: M, N must be multiples of 256 and K of 64 "
                  "(M=%d N=%d K=%d)", M, N, K);
   PCAA_CHECK_ARG(lddy >= K && ldw >= K && ld >= N && (lddy % 8) == 0 && (ldw % 8) == 0 && (ld % 8) == 0 && nrep >= 1,
                  "pcaa_gemm_dgrad_bn: bad leading dimension / nrep");
-  PCAA_CHECK_ARG((M % 256) == 0 || (x == nullptr && ragged_out_ok(M, dz, ld, 2)), "pcaa_gemm_dgrad_bn: a partial last row tile "
-                 "needs the y variant and ceil(M / 256) * 256 * ld * 2 < 4 GiB (M=%d ld=%ld)", M, ld);
+  PCAA_CHECK_ARG(ragged_out_ok(M, dz, ld, 2), "pcaa_gemm_dgrad_bn: a partial last row tile needs ceil(M / 256) * 256 * ld * 2 "
+                 "< 4 GiB (M=%d ld=%ld)", M, ld);
   PCAA_CHECK_ARG(((uintptr_t)dy % 16) == 0 && ((uintptr_t)Wt % 16) == 0 && (!y || ((uintptr_t)y % 16) == 0) &&
                  ((uintptr_t)dz % 16) == 0 && ((uintptr_t)scale % 16) == 0 && ((uintptr_t)shift % 16) == 0 &&
                  ((uintptr_t)mean % 16) == 0 && ((uintptr_t)rstd % 16) == 0, "pcaa_gemm_dgrad_bn: 16-B alignment");
@@ -656,7 +663,6 @@ extern "C" int pcaa_gemm_dgrad_bn(const void* dy, long lddy, const void* Wt, lon
   p.M = M; p.N = N; p.K = K;
   p.colstats = stats; p.nrep = nrep;
   p.ep_y = y; p.ep_scale = scale; p.ep_shift = shift; p.ep_mean = mean; p.ep_rstd = rstd;
-  p.ep_x = x; p.ep_w1 = W1; p.ep_xc = xc;
   if (!pcaa_launch_gemm_dgrad_bn(p, as_stream(stream))) {
     pcaa_set_error("pcaa_gemm_dgrad_bn: launch configuration failed");
     return PCAA_ERR_LAUNCH;
@@ -672,8 +678,9 @@ extern "C" int pcaa_gemm_dgrad_bn_split3(const void* dy_img, long lddy, const vo
                                          float out_scale, void* stream) {
   PCAA_CHECK_ARG(dy_img && Wt_img && y && dz && scale && shift && mean && rstd && stats,
                  "pcaa_gemm_dgrad_bn_split3: null pointer");
-  PCAA_CHECK_ARG(pcaa_gemm_dgrad_bn_supported(M, N, K), "pcaa_gemm_dgrad_bn_split3: M, N must be multiples of 256 and K "
-                 "of 64 (M=%d N=%d K=%d)", M, N, K);
+  // (the split operands walk three K-long passes: the same shape rule as pcaa_gemm_split3)
+  PCAA_CHECK_ARG(pcaa_gemm_split3_supported(M, N, K), "pcaa_gemm_dgrad_bn_split3: M, N must be multiples of 256 and K "
+                 "of 64, 3 K >= 320 (M=%d N=%d K=%d)", M, N, K);
   PCAA_CHECK_ARG((long)K * 3 < (1L << 31) && lddy >= 2L * K && ldw >= 2L * K && ld >= N && (lddy % 8) == 0 &&
                  (ldw % 8) == 0 && (ld % 4) == 0 && nrep >= 1, "pcaa_gemm_dgrad_bn_split3: bad leading dimension / nrep");
   PCAA_CHECK_ARG(ragged_out_ok(M, dz, ld, 4), "pcaa_gemm_dgrad_bn_split3: a partial last row tile needs ld %% 8 == 0 and "

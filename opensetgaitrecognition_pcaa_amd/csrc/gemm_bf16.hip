@@ -280,75 +280,24 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_big_kernel(GemmParams p) {
 }
 
 // ===========================================================================
-// LDS-DMA kernel: both operands already bf16 in HBM, shapes whole tiles
-// (M % 256 == N % 256 == 0, K-range % 64 == 0).  Tiles go HBM -> LDS with
-// global_load_lds_dwordx4 (no VGPR staging, no ds_write pass); the LDS images are
-// unpadded, so the bank-conflict fix is an XOR swizzle applied to the per-lane
-// SOURCE address (the DMA writes LDS linearly: base + lane*16) and again on the
-// fragment reads:
-//   KC image [256 rows][64 k] (128-B rows): 16-B granule g of row r holds global k-granule
-//     g ^ ((r>>1)&7)  -> ds_read_b128 of 16 consecutive rows hits 16 distinct 16-B slots
-//     (for the 32x32x16 fragment: 32 rows x one granule pair; for the 16x16x32 fragment:
-//     16 rows x 4 granules -- both conflict-free with this swizzle).
-//   RC image [64 k][256 rows] (512-B rows): 16-B granule c of k-row k holds global row-granule
-//     c ^ 4*(k&3)     -> the 4 k-rows of a transpose read land on disjoint bank quarters.
-// One barrier per 64-deep step.  Ring: THREE stages of the A operand, two of B (5 x 32 KB = all 160 KB of the LDS):
-// between the MFMAs of step t a wave issues its pieces of B(t+1) and then of A(t+2) (one 1-KB piece in front of every
-// 8th of the step's MFMAs); at the barrier it waits with a counted vmcnt(4) -- everything but its four youngest
-// pieces, A(t+2).  See the kernel for why the depth goes to A, and tools/microbench/cu_load_bw.hip for the
-// bytes-in-flight curve of a CU that motivates it.
-//
-// Measured and rejected (tools/gemm_lab.py history, docs/LAB_LOG.md section 4): touching the streamed operand's lines in L2
-// a few K steps ahead with one plain global_load_dword per lane and step (a software L2 prefetch behind a counted
-// vmcnt(1)) made every shape 3-10 % SLOWER (those loads queue in front of the pieces); round 1's five-slot ring gave
-// the third stage to B -- the L2-resident weights -- and measured nothing.
+// The LDS-DMA tile loops (csrc/gemm_v2.h, namespace v2): both operands already bf16 (or [hi | lo] fp16 images) in HBM;
+// tiles go HBM -> LDS with buffer_load_dwordx4 ... lds (no VGPR staging, no ds_write pass); the LDS images are unpadded,
+// so the bank-conflict fix is an XOR swizzle applied to the per-lane SOURCE address (the DMA writes LDS linearly: base +
+// lane * 16) and again on the fragment reads:
+//   KC image [256 rows][64 k] (128-B rows): 16-B granule g of row r holds global k-granule g ^ ((r >> 1) & 7);
+//   RC image [64 k][256 rows] (512-B rows): 16-B granule c of k-row k holds global row-granule c ^ 4 (k & 3) -- the 4
+//     k-rows of a transpose read land on disjoint bank quarters.
+// Rounds 1-3 ran an 8-wave kernel here (A in a ring of three stages, B of two, 128 x 64 wave tiles); round 4's 4-wave
+// loops replaced it on every shape the product launches and round 5 removed it (profiles/r05_bench_kernel_names.txt,
+// r05_tests_kernel_names.txt: no BASELINE config reached it; the few test shapes that did -- K < 320, K-split atomics --
+// take the register-staged kernel above).  docs/LAB_LOG.md sections 4, 7, 9 keep its history.
 // ===========================================================================
-constexpr int D_TILE = 256 * 64;                       // elements per operand per stage (32 KB)
-constexpr int D_LDS_BYTES = 5 * D_TILE * 2;            // 163840: A in a ring of three stages, B of two -- all of the LDS
-
-// one of the 4 pieces a wave moves per tile
-// PERM (KC, the B operand of the 16x16x32 kernels): LDS row l = 16 j + c of every 64-row group holds operand row
-// 4 c + j of that group.  The fragment reads do not change (lane c of column block j still reads LDS row 16 j + c,
-// conflict-free as before), but the accumulator a lane holds in block j is now output column 4 c + j: the four
-// blocks of a lane are four ADJACENT columns of one row, and the epilogue stores them straight from registers
-// (8 B per lane, 16 lanes = one 128-B line per row) -- no LDS transpose, no lane exchange (see epilogue_full_tile).
-__device__ __forceinline__ int perm_row(int l) { return (l & ~63) + 4 * (l & 15) + ((l >> 4) & 3); }
-
-template <int LAY, bool PERM = false>
-__device__ __forceinline__ void dma_piece(const bf16_t* __restrict__ base, long ld, int row0, int R, int k0,
-                                          bf16_t* s_tile, int wave, int lane, int j) {
-  const int p = wave * 4 + j;       // 1-KB piece index, 32 per tile
-  const bf16_t* src;
-  if (LAY == KC) {
-    const int r = 8 * p + (lane >> 3);
-    const int g = (lane & 7) ^ ((r >> 1) & 7);
-    src = base + (long)min(row0 + (PERM ? perm_row(r) : r), R - 1) * ld + k0 + 8 * g;
-  } else {
-    const int k = 2 * p + (lane >> 5);
-    const int c = (lane & 31) ^ (4 * (k & 3));
-    src = base + (long)(k0 + k) * ld + row0 + 8 * c;
-  }
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)(s_tile + p * 512), 16, 0, 0);
-}
-
-template <int LAY>
-__device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ base, long ld, int row0, int R, int k0,
-                                         bf16_t* s_tile, int wave, int lane) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) dma_piece<LAY>(base, ld, row0, R, k0, s_tile, wave, lane, j);
-}
-
-// The same piece through a buffer resource (buffer_load_dwordx4 ... offen lds): the per-lane part of the source address
-// is a 32-bit offset that never changes (row-in-piece, swizzled granule; it depends on the piece only through its
-// parity), everything else -- tile origin, piece, K step -- is wave-uniform and rides in the scalar offset.  A piece
-// then costs the vector ALU nothing (the flat form spent ~7 VALU instructions per piece on 64-bit address arithmetic,
-// on the issue port the MFMAs share).  Whole-tile shapes only: no row clamp; operands below 4 GiB.
 typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
 __device__ __forceinline__ buf_rsrc_t make_rsrc(const void* base, long bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(unsigned)bytes, 0x00020000);
 }
-// per-lane byte offsets for pieces of even / odd index
+// per-lane byte offsets for pieces of even / odd index (a piece = 1 KB of a stage image; the per-lane part of its source
+// address never changes, everything else -- tile origin, piece, K step -- is wave-uniform and rides in the scalar offset)
 template <int LAY, bool PERM = false>
 __device__ __forceinline__ void piece_lane_offsets(long ld, int lane, unsigned (&voff)[2]) {
 #pragma unroll
@@ -362,352 +311,11 @@ __device__ __forceinline__ void piece_lane_offsets(long ld, int lane, unsigned (
     }
   }
 }
-// wave (scalar) and j select the piece p = 4 wave + j; row0 / k0 as in dma_piece
-template <int LAY, bool PERM = false>
-__device__ __forceinline__ void dma_piece_buf(buf_rsrc_t rsrc, long ld, int row0, int k0, bf16_t* s_tile, int wave,
-                                              const unsigned (&voff)[2], int j, long extra = 0) {
-  const int p = wave * 4 + j;
-  // PERM: piece p = LDS rows 8p .. 8p+7 = lanes c = 8 (p & 1) + 0..7 of column block (p >> 1) & 3 of group p >> 3
-  const int prow = PERM ? 64 * (p >> 3) + 32 * (p & 1) + ((p >> 1) & 3) : 8 * p;
-  const unsigned soff = LAY == KC ? (unsigned)(((long)(row0 + prow) * ld + k0 + extra) * 2)
-                                  : (unsigned)(((long)(k0 + 2 * p) * ld + row0 + extra) * 2);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(s_tile + p * 512), 16,
-                                           voff[j & 1], soff, 0, 0);
-}
-
-// Accumulator layouts of the two bf16 MFMA shapes (a wave owns 128 rows x 64 columns of the tile):
-//   MF = 32: v_mfma_f32_32x32x16_bf16, 4 x 2 blocks of f32x16; MF = 16: v_mfma_f32_16x16x32_bf16, 8 x 4 blocks of f32x4.
-// In both, registers r (even) and r+1 of a block are two consecutive rows of one column, neighbouring lanes
-// hold neighbouring columns, and the lanes that share a column differ in the high lane bits only.
-template <int MF> struct AccLayout;
-template <> struct AccLayout<32> {
-  typedef f32x16 vec;
-  static constexpr int MB = 4, NB = 2, NR = 16;
-  [[maybe_unused]] static constexpr int BR = 32;
-  static __device__ __forceinline__ int row(int i, int r, int lane) { return i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
-  static __device__ __forceinline__ int col(int j, int lane) { return j * 32 + (lane & 31); }
-  static __device__ __forceinline__ float colreduce(float v) { return v + __shfl_xor(v, 32, 64); }
-  static __device__ __forceinline__ bool col_leader(int lane) { return lane < 32; }
-};
-template <> struct AccLayout<16> {
-  typedef f32x4 vec;
-  static constexpr int MB = 8, NB = 4, NR = 4, BR = 16;
-  static __device__ __forceinline__ int row(int i, int r, int lane) { return i * 16 + 4 * (lane >> 4) + r; }
-  // (the B operand's rows are permuted on their way into the LDS, dma_piece<KC, PERM>: block j of lane c is column 4 c + j)
-  static __device__ __forceinline__ int col(int j, int lane) { return 4 * (lane & 15) + j; }
-  static __device__ __forceinline__ float colreduce(float v) {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
-  }
-  static __device__ __forceinline__ bool col_leader(int lane) { return lane < 16; }
-};
-
-
-// LDS scratch of the epilogues: the column statistics' [2 stats][2 wm][256 cols] floats, in the ring's last two slots (the
-// ones the NEXT tile's first stages do not use, see the kernel).  (Rounds 1-2 also kept eight 4.5-KB wave images here:
-// the accumulators went through the LDS to become row-contiguous 16-B stores.  With the B operand's rows permuted on
-// their way in -- dma_piece<KC, PERM> -- a lane's four column blocks ARE four adjacent columns, and the tile leaves
-// straight from the registers.)
-constexpr int EP_RED_OFFSET = 0;
 // workgroup barrier that leaves vector-memory operations (the next tile's LDS-DMA pieces, this tile's C stores) alone
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Full-tile epilogue (M, N multiples of 256: no bounds checks).
-//   bf16 out : park_bf16, then 16-B-per-lane row-contiguous stores (8 lanes = one whole 128-B line per row).
-//   fp32 out : plain stores (slab split-K: C is offset by split * c_split_stride) or atomics.
-// AFFINE (bf16 out, eval-mode BatchNorm): the stored value is ELU(scale[col]*acc + shift[col]) -- with running
-// statistics the BatchNorm is a per-channel affine map known BEFORE the product, so the activation leaves the
-// GEMM directly and the separate BN+ELU pass over [P, ch] (read + write) of the train-mode path is gone.
-template <typename TC, int MF, bool AFFINE>
-__device__ __forceinline__ void epilogue_full_tile(const GemmParams& p,
-                                                   typename AccLayout<MF>::vec (&acc)[AccLayout<MF>::MB][AccLayout<MF>::NB],
-                                                   bf16_t* smem, int tm, int tn, int tid, int split) {
-  typedef AccLayout<MF> L;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const bool add_bias = p.bias != nullptr && (!p.atomic || split == 0);
-  if constexpr (sizeof(TC) == 2) {
-    // 16x16x32 layout: lane (c = lane & 15, q = lane >> 4) holds rows 16 i + 4 q + r of columns 4 c .. 4 c + 3 (one per
-    // column block j): two v_cvt_pk_bf16_f32 and one 8-B store per row; the 16 lanes of a q are one 128-B line
-    static_assert(MF == 16, "bf16 output leaves the 16x16x32 kernels only");
-    const int l15 = lane & 15, q = lane >> 4;
-    float bv[4], esc[4], esh[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int gc = tn * BN + wn * 64 + 4 * l15 + j;
-      bv[j] = add_bias ? p.bias[gc] : 0.f;
-      esc[j] = AFFINE ? p.ep_scale[gc] : 1.f;
-      esh[j] = AFFINE ? p.ep_shift[gc] : 0.f;
-    }
-    bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + (long)(tm * BM + wm * 128 + 4 * q) * p.ldc + tn * BN + wn * 64 + 4 * l15;
-    auto out = [&](float v, int j) {
-      if constexpr (AFFINE) {
-        v = fmaf(v + bv[j], esc[j], esh[j]);
-        return v > 0.f ? v : __expf(v) - 1.f;
-      } else {
-        return add_bias ? v + bv[j] : v;       // (uniform) the BatchNorm layers pass no bias
-      }
-    };
-#pragma unroll
-    for (int i = 0; i < L::MB; ++i)
-#pragma unroll
-      for (int r = 0; r < L::NR; ++r) {
-        uint2 o;
-        o.x = pack2(out(acc[i][0][r], 0), out(acc[i][1][r], 1));
-        o.y = pack2(out(acc[i][2][r], 2), out(acc[i][3][r], 3));
-        *reinterpret_cast<uint2*>(C + (long)(i * 16 + r) * p.ldc) = o;
-      }
-  } else {
-    float* C = reinterpret_cast<float*>(p.C) + (long)split * p.c_split_stride +
-               (long)(tm * BM + wm * 128) * p.ldc + tn * BN + wn * 64;
-    if constexpr (MF == 16) {
-      // the lane's four column blocks are four adjacent floats of a row: one 16-B store (16 lanes = 256 B of the row)
-      if (!p.atomic && (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0 && (p.c_split_stride & 3) == 0) {
-        const int l15 = lane & 15, q = lane >> 4;
-        const f32x4 bv = add_bias ? load4(p.bias + tn * BN + wn * 64 + 4 * l15) : f32x4{0.f, 0.f, 0.f, 0.f};
-        float* Cl = C + (long)(4 * q) * p.ldc + 4 * l15;
-#pragma unroll
-        for (int i = 0; i < L::MB; ++i)
-#pragma unroll
-          for (int r = 0; r < L::NR; ++r)
-            *reinterpret_cast<f32x4*>(Cl + (long)(i * 16 + r) * p.ldc) =
-                f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]} + bv;
-        return;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < L::NB; ++j) {
-      const int cl = L::col(j, lane);
-      const float bv = add_bias ? p.bias[tn * BN + wn * 64 + cl] : 0.f;
-#pragma unroll
-      for (int i = 0; i < L::MB; ++i)
-#pragma unroll
-        for (int r = 0; r < L::NR; ++r) {
-          float* dst = C + (long)L::row(i, r, lane) * p.ldc + cl;
-          const float v = acc[i][j][r] + bv;
-          if (p.atomic) atomicAdd(dst, v);
-          else *dst = v;
-        }
-    }
-  }
-}
-
-// BatchNorm column statistics (sum, sum of squares) of the bias-free accumulator; the caller's LDS is free
-// (the epilogue above ended on a barrier).  fp64 atomics into replica tm % nrep.
-template <int MF>
-__device__ __forceinline__ void epilogue_colstats(const GemmParams& p,
-                                                  typename AccLayout<MF>::vec (&acc)[AccLayout<MF>::MB][AccLayout<MF>::NB],
-                                                  unsigned char* smem_raw, int tm, int tn, int tid) {
-  typedef AccLayout<MF> L;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  float* red = reinterpret_cast<float*>(smem_raw) + EP_RED_OFFSET / 2;   // [2 stats][2 wm][256 cols], behind the images
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-  for (int j = 0; j < L::NB; ++j) {
-    f32x2 a1 = {0.f, 0.f}, a2 = {0.f, 0.f};      // two partial sums each: v_pk_add_f32 / v_pk_fma_f32
-#pragma unroll
-    for (int i = 0; i < L::MB; ++i)
-#pragma unroll
-      for (int r = 0; r < L::NR; r += 2) {
-        const f32x2 v = {acc[i][j][r], acc[i][j][r + 1]};
-        a1 += v;
-        a2 = __builtin_elementwise_fma(v, v, a2);
-      }
-    float s1 = L::colreduce(a1.x + a1.y);
-    float s2 = L::colreduce(a2.x + a2.y);
-    if (L::col_leader(lane)) {
-      const int col = wn * 64 + L::col(j, lane);
-      red[(0 * 2 + wm) * 256 + col] = s1;
-      red[(1 * 2 + wm) * 256 + col] = s2;
-    }
-  }
-  lds_barrier();
-  const int stat = tid >> 8, col = tid & 255;
-  const double v = (double)red[(stat * 2 + 0) * 256 + col] + (double)red[(stat * 2 + 1) * 256 + col];
-  unsafeAtomicAdd(&p.colstats[((long)(tm % p.nrep) * 2 + stat) * p.N + tn * BN + col], v);
-}
-
-// Eval-mode LAST PointNet layer: BatchNorm (affine) + ELU + the mean over the N points of a frame
-// (AvgPool2d((1,N)), models.py:242-243, :282) straight from the accumulators: a wave holds 128 rows x 64
-// columns of the tile = groups of 32*IPG consecutive rows (IPG = N/32 in {1,2,4}), so a group's column mean is
-// a sum over the lane's registers plus the cross-lane fold of the lanes that share the column; the [P, ch]
-// activation is never written or re-read (2 x 8 GB per 1024 sequences at N=128).  out fp32 [P/N, ch].
-template <int MF, int IPG>
-__device__ __forceinline__ void epilogue_affine_meanpool(const GemmParams& p,
-                                                         typename AccLayout<MF>::vec (&acc)[AccLayout<MF>::MB][AccLayout<MF>::NB],
-                                                         int tm, int tn, int tid) {
-  typedef AccLayout<MF> L;
-  constexpr int BPG = 32 * IPG / L::BR;          // accumulator row-blocks per group
-  static_assert(L::MB % BPG == 0, "groups must not straddle waves");
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  float* out = reinterpret_cast<float*>(p.C);
-  const float inv_n = 1.f / (32 * IPG);
-#pragma unroll
-  for (int j = 0; j < L::NB; ++j) {
-    const int col = tn * BN + wn * 64 + L::col(j, lane);
-    const float esc = p.ep_scale[col], esh = p.ep_shift[col];
-#pragma unroll
-    for (int g0 = 0; g0 < L::MB; g0 += BPG) {
-      float sum = 0.f;
-#pragma unroll
-      for (int i = g0; i < g0 + BPG; ++i)
-#pragma unroll
-        for (int r = 0; r < L::NR; ++r) {
-          const float z = fmaf(acc[i][j][r], esc, esh);
-          sum += z > 0.f ? z : __expf(z) - 1.f;
-        }
-      sum = L::colreduce(sum);
-      const long grp = ((long)tm * BM + wm * 128 + g0 * L::BR) / (32 * IPG);
-      if (L::col_leader(lane)) out[grp * p.ldc + col] = sum * inv_n;
-    }
-  }
-}
-
-// dgrad epilogue fused with the BatchNorm+ELU backward of the layer BELOW (pcaa_gemm_dgrad_bn):
-// the tile of da = dy.Wt never reaches HBM as such -- on its way out each lane loads the 8 B of that layer's stored
-// pre-activation y that belong to its four adjacent columns of a row and writes
-//   dz = da * ELU'(y*scale + shift)
-// while accumulating the column sums {dz, dz * (y-mean)*rstd} the BatchNorm backward needs.  That
-// replaces a separate pass that re-read da and y (0.31 ms per step for PointNet layers 2-3).
-// POINTS: the layer below is the first PointNet layer on its recompute path -- its pre-activation was
-// never stored, y[row][col] = sum_c x[row][c] * W1[col][c] (C <= 8 point features) is rebuilt here.
-// TE = float (the split-fp16 parity mode, round 3): y and dz are fp32 (16 B per lane and row) and ELU' is the exact
-// expression of the separate pass (bn_act_bwd_dz_kernel<float>), not the exp2 form of the bf16 mode.
-template <int MF, bool POINTS, typename TE = bf16_t>
-__device__ __forceinline__ void epilogue_dgrad_bn(const GemmParams& p,
-                                                  typename AccLayout<MF>::vec (&acc)[AccLayout<MF>::MB][AccLayout<MF>::NB],
-                                                  bf16_t* smem, int tm, int tn, int tid) {
-  static_assert(MF == 16, "built for the 16x16x32 accumulator layout (a lane = 4 adjacent columns)");
-  constexpr bool kF32 = sizeof(TE) == 4;
-  static_assert(!(kF32 && POINTS), "the recompute form exists for the bf16 mode only");
-  typedef AccLayout<MF> L;
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int l15 = lane & 15, q = lane >> 4;
-  const int c0 = tn * BN + wn * 64 + 4 * l15;                  // the lane's first column
-  const long row0 = (long)tm * BM + wm * 128 + 4 * q;          // its first row (rows 16 i + r further on)
-  TE* C = reinterpret_cast<TE*>(p.C) + row0 * p.ldc + c0;
-  const TE* Y = reinterpret_cast<const TE*>(p.ep_y) + row0 * p.ldc + c0;               // same shape and ld as C
-  // The element-wise part runs on column PAIRS with packed fp32 instructions: ELU'(z) = exp(min(z, 0)) =
-  // exp2(min(z log2e, 0)) with log2e folded into the affine coefficients (no compare / select), yhat = y rstd - mean rstd
-  // as one fused multiply-add.
-  f32x2 sc2[2], sh2[2], rs2[2], nm2[2], s1[2], s2[2];
-  {
-    constexpr float kLog2e = kF32 ? 1.f : 1.4426950408889634f;
-    const f32x4 a = load4(p.ep_scale + c0), b = load4(p.ep_shift + c0), c = load4(p.ep_mean + c0), d = load4(p.ep_rstd + c0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      sc2[h] = f32x2{a[2 * h] * kLog2e, a[2 * h + 1] * kLog2e};
-      sh2[h] = f32x2{b[2 * h] * kLog2e, b[2 * h + 1] * kLog2e};
-      rs2[h] = f32x2{d[2 * h], d[2 * h + 1]};
-      nm2[h] = f32x2{-c[2 * h] * d[2 * h], -c[2 * h + 1] * d[2 * h + 1]};
-      s1[h] = f32x2{0.f, 0.f};
-      s2[h] = f32x2{0.f, 0.f};
-    }
-  }
-  const int xc = p.ep_xc;
-  float w1[4][8];
-  const float* X = nullptr;
-  if (POINTS) {
-    X = p.ep_x + row0 * xc;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) w1[j][c] = c < xc ? p.ep_w1[(long)(c0 + j) * xc + c] : 0.f;
-  }
-  typedef typename std::conditional<kF32, f32x4, uint2>::type yraw_t;
-  yraw_t yv[2][4];                       // the stored pre-activations of one 16-row block, requested one block ahead
-  auto load_y = [&](int i, int b) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) yv[b][r] = *reinterpret_cast<const yraw_t*>(Y + (long)(i * 16 + r) * p.ldc);
-  };
-  if (!POINTS) load_y(0, 0);
-#pragma unroll
-  for (int i = 0; i < L::MB; ++i) {
-    if (!POINTS && i + 1 < L::MB) load_y(i + 1, (i + 1) & 1);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      f32x2 y2[2];
-      if (POINTS) {
-        const float* xr = X + (long)(i * 16 + r) * xc;
-        float xv[8];
-        if (xc == 4) {
-          const f32x4 t = load4(xr);
-          xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w; xv[4] = xv[5] = xv[6] = xv[7] = 0.f;
-        } else {
-#pragma unroll
-          for (int c = 0; c < 8; ++c) xv[c] = c < xc ? xr[c] : 0.f;
-        }
-        float yy[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float a = 0.f;
-#pragma unroll
-          for (int c = 0; c < 8; ++c) a = fmaf(w1[j][c], xv[c], a);             // same order as pointnet_in.hip
-          yy[j] = a;
-        }
-        y2[0] = f32x2{yy[0], yy[1]};
-        y2[1] = f32x2{yy[2], yy[3]};
-      } else if constexpr (kF32) {
-        const f32x4 w = yv[i & 1][r];
-        y2[0] = f32x2{w.x, w.y};
-        y2[1] = f32x2{w.z, w.w};
-      } else {
-        const uint2 w = yv[i & 1][r];
-        y2[0] = f32x2{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u)};
-        y2[1] = f32x2{__uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u)};
-      }
-      f32x2 dq[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const f32x2 dav = {acc[i][2 * h][r], acc[i][2 * h + 1][r]};
-        f32x2 g;
-        if constexpr (kF32) {
-          // the separate pass's arithmetic (elementwise.hip, bn_act_bwd_dz_kernel<float>): z = y*scale + shift, yhat = (y - mean)*rstd
-          g = f32x2{elu_grad_from_pre(y2[h].x * sc2[h].x + sh2[h].x), elu_grad_from_pre(y2[h].y * sc2[h].y + sh2[h].y)};
-        } else {
-          f32x2 z2 = __builtin_elementwise_fma(y2[h], sc2[h], sh2[h]);
-          z2 = __builtin_elementwise_min(z2, f32x2{0.f, 0.f});
-          g = f32x2{__builtin_amdgcn_exp2f(z2.x), __builtin_amdgcn_exp2f(z2.y)};
-        }
-        const f32x2 d2 = dav * g;
-        s1[h] += d2;
-        s2[h] = __builtin_elementwise_fma(d2, __builtin_elementwise_fma(y2[h], rs2[h], nm2[h]), s2[h]);
-        dq[h] = d2;
-      }
-      if constexpr (kF32) {
-        *reinterpret_cast<f32x4*>(C + (long)(i * 16 + r) * p.ldc) = f32x4{dq[0].x, dq[0].y, dq[1].x, dq[1].y};
-      } else {
-        uint2 o;
-        o.x = pack2(dq[0].x, dq[0].y);
-        o.y = pack2(dq[1].x, dq[1].y);
-        *reinterpret_cast<uint2*>(C + (long)(i * 16 + r) * p.ldc) = o;
-      }
-    }
-  }
-  // the four lanes q = 0..3 of a column quad hold partial sums over different rows: fold them (2 steps)
-  float t1[4], t2[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    t1[c] = L::colreduce(s1[c >> 1][c & 1]);
-    t2[c] = L::colreduce(s2[c >> 1][c & 1]);
-  }
-  float* red = reinterpret_cast<float*>(smem) + EP_RED_OFFSET / 2;      // [2 stats][2 wm][256 cols]
-  if (L::col_leader(lane)) {
-    *reinterpret_cast<f32x4*>(&red[(0 * 2 + wm) * 256 + wn * 64 + 4 * l15]) = f32x4{t1[0], t1[1], t1[2], t1[3]};
-    *reinterpret_cast<f32x4*>(&red[(1 * 2 + wm) * 256 + wn * 64 + 4 * l15]) = f32x4{t2[0], t2[1], t2[2], t2[3]};
-  }
-  lds_barrier();
-  const int stat = tid >> 8, col = tid & 255;
-  const double v = (double)red[(stat * 2 + 0) * 256 + col] + (double)red[(stat * 2 + 1) * 256 + col];
-  unsafeAtomicAdd(&p.colstats[((long)(tm % p.nrep) * 2 + stat) * p.N + tn * BN + col], v);
-}
-
 // what leaves the kernel
-enum { EPI_PLAIN = 0, EPI_DGRAD_BN = 1, EPI_DGRAD_BN_POINTS = 2, EPI_AFFINE = 3, EPI_POOL1 = 4, EPI_POOL2 = 5, EPI_POOL4 = 6 };
+enum { EPI_PLAIN = 0, EPI_DGRAD_BN = 1, EPI_AFFINE = 3, EPI_POOL1 = 4, EPI_POOL2 = 5, EPI_POOL4 = 6 };
 
 // per-lane element offset of fragment rows [row_base, row_base+32) at k-step 0 (row_base % 32 == 0), 32x32x16 shape
 template <int LAY>
@@ -718,371 +326,12 @@ __device__ __forceinline__ int dma_frag_offset(int row_base, int lane) {
   return (8 * h + q) * 256 + ((((ch >> 3) ^ (4 * q)) << 3) | (ch & 7));
 }
 
-template <int LAY>
-__device__ __forceinline__ bf16x8 dma_load_frag(const bf16_t* s, int off, int kstep, const int (&kofs)[4]) {
-  if (LAY == KC) return *reinterpret_cast<const bf16x8*>(s + off + kofs[kstep]);
-  const bf16_t* p = s + off + kstep * 16 * 256;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * 256));
-  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-  u.s.a = lo;
-  u.s.b = hi;
-  return u.v;
-}
+#include "gemm_v2.h"      // the 4-wave tile loops (namespace v2)
 
-// the two MFMA shapes on bf16 operands, or (F16: the split-operand instantiations) on fp16 operands -- same operand
-// bytes, same lane maps, same rate; only the element format differs
-template <bool F16>
-__device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
-  if constexpr (F16) {
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
-  } else {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-}
-template <bool F16>
-__device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
-  if constexpr (F16) {
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
-  } else {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  }
-}
-
-// end of a K step: the next stage's DMA pieces have landed (every wave waits for its own, then the barrier)
-// every wave waits for its own pieces of the stage the next step reads, then the barrier; keep_far: the wave's four
-// youngest pieces (the A stage two steps ahead) stay in flight
-__device__ __forceinline__ void step_barrier(bool keep_far) {
-  if (keep_far) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-#include "gemm_v2.h"      // round 4: the 4-wave KC x KC tile loop (namespace v2)
-
-template <typename TC, int ALAY, int BLAY, int EPI, int MF, bool BUF, bool SPLIT = false>
-__global__ __launch_bounds__(NTHREADS) void gemm_bf16_dma_kernel(GemmParams p) {
-  typedef AccLayout<MF> L;
-  static_assert(MF == 32 || (ALAY == KC && BLAY == KC), "the 16x16x32 fragments are built for KC operands");
-  constexpr bool PERMB = MF == 16;     // B's rows permuted into the LDS: a lane's four column blocks are adjacent columns
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: piece indices and LDS bases are SGPR math
-  const int wm = wave >> 2, wn = wave & 3;
-  // Tiles: a launch without K splits may start fewer workgroups than tiles (one per CU); workgroup b then walks the
-  // tiles b, b + gridDim.x, ... of the XCD-aware order (gridDim.x is a multiple of 8: all of them on b's XCD, and
-  // the workgroups of an XCD are on neighbouring tiles at any time, as with one workgroup per tile).
-  constexpr bool PERSIST = ALAY == KC;             // the wgrad (RC x RC) launches split K: one tile per workgroup
-  const int nbm = p.M / BM, nbn = p.N / BN;
-  int vb = blockIdx.x;
-  int tm, tn;
-  const int split = block_coords(p, nbm, nbn, tm, tn);
-
-  const int kbeg = split * p.k_per_split;
-  const int kend = min(p.K, kbeg + p.k_per_split);
-  const int nt = (kend - kbeg) / BK;
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
-  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
-  // buffer resources over the whole operands (A: M x lda or K x lda elements, B likewise)
-  buf_rsrc_t rA = make_rsrc(A, 0), rB = make_rsrc(B, 0);
-  unsigned voA[2] = {0, 0}, voB[2] = {0, 0};
-  if (BUF) {
-    const int krows = SPLIT ? p.seg_len : p.K;           // rows of a row-contracted operand as it lies in memory
-    rA = make_rsrc(A, (long)(ALAY == KC ? p.M : krows) * p.lda * 2);
-    rB = make_rsrc(B, (long)(BLAY == KC ? p.N : krows) * p.ldb * 2);
-    piece_lane_offsets<ALAY>(p.lda, lane, voA);
-    piece_lane_offsets<BLAY, PERMB>(p.ldb, lane, voB);
-  }
-  // per-lane constants of the K loop are rebuilt at the top of every tile from an opaque copy of the lane id, so that
-  // they do not stay in registers across the epilogue (which needs them all: accumulators + 64 of operands)
-  int ln = lane;
-  // one 1-KB piece of the A (which = 0) or B (1) tile of the K step starting at k0 into stage image s_tile
-  auto piece_of = [&](int tmx, int tnx, int which, int k0, bf16_t* s_tile, int j) {
-    long extra = 0;
-    if constexpr (SPLIT) {
-      // split-fp16 operands: K step k0 of the 3 * seg_len long contraction lies in segment seg (scalar arithmetic:
-      // k0 is wave-uniform); that segment's hi / lo half of the operand starts `extra` elements further on
-      const int seg = (k0 >= p.seg_len ? 1 : 0) + (k0 >= 2 * p.seg_len ? 1 : 0);
-      k0 -= seg * p.seg_len;
-      const long* so = which == 0 ? p.seg_off_a : p.seg_off_b;
-      extra = seg == 0 ? so[0] : (seg == 1 ? so[1] : so[2]);
-    }
-    if (BUF) {
-      if (which == 0) dma_piece_buf<ALAY>(rA, p.lda, tmx * BM, k0, s_tile, wave, voA, j, extra);
-      else dma_piece_buf<BLAY, PERMB>(rB, p.ldb, tnx * BN, k0, s_tile, wave, voB, j, extra);
-    } else {
-      if (which == 0) dma_piece<ALAY>(A + extra, p.lda, tmx * BM, p.M, k0, s_tile, wave, lane, j);
-      else dma_piece<BLAY, PERMB>(B + extra, p.ldb, tnx * BN, p.N, k0, s_tile, wave, lane, j);
-    }
-  };
-  auto piece = [&](int which, int k0, bf16_t* s_tile, int j) { piece_of(tm, tn, which, k0, s_tile, j); };
-  // LDS images of the operands' stages: slots A0 A1 A2 B0 B1 (5 x 32 KB = all of the LDS).  A -- the operand
-  // streamed from HBM in the forward / dgrad products: a quarter of its lines miss the L2 and take ~2 us -- has THREE
-  // stages and is requested TWO K steps ahead; B (there: the L2-resident weights) keeps two.  A stage lands as a
-  // whole only when its slowest piece has: with one step of distance the step waited for that HBM round trip
-  // (2 750 cycles for a stage against 2 048 of MFMA, round 1's stamps); same-box A/B of the two rings on the three
-  // PointNet shapes: forward +9..12 %, fused dgrad +8..12 %, wgrad (both operands streamed) +3..4 %.
-  // Order in memory: A0 A1 B0 | A2 B1.  A tile's FIRST stages -- A(0), B(0), A(1) -- go to the first three slots;
-  // the epilogue works in the last two (64 KB: eight 4.5-KB wave images + the statistics scratch), so a workgroup
-  // that has another tile to do requests that tile's first stages BEFORE its epilogue and they land beside it.
-  auto slotA = [&](int i) { return smem + (i < 2 ? i : 3) * D_TILE; };
-  auto slotB = [&](int i) { return smem + (i == 0 ? 2 : 4) * D_TILE; };
-  bf16_t* epi = smem + 3 * D_TILE;
-  // first stages of tile (tmx, tnx): the order the first barrier's counted wait relies on
-  auto first_stages = [&](int tmx, int tnx) {
-    if (nt > 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) piece_of(tmx, tnx, 0, kbeg, slotA(0), j);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) piece_of(tmx, tnx, 1, kbeg, slotB(0), j);
-      if (nt > 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) piece_of(tmx, tnx, 0, kbeg + BK, slotA(1), j);
-      }
-    }
-  };
-  typename L::vec acc[L::MB][L::NB];
-  first_stages(tm, tn);
-  bool primed = false;             // this tile's first stages were requested during the previous tile's epilogue
-  // Which tile next?  With p.sched the workgroups of an XCD draw tickets from that XCD's counter (positions
-  // gridDim.x / 8, ... of its range: the first gridDim.x / 8 are the workgroups' own first tiles), so a workgroup
-  // that got its CU late -- the chip shared with another stream's kernels or a collective -- simply does fewer
-  // tiles.  Thread 0 draws the ticket at the top of a tile (the round trip hides under the K loop) and hands it
-  // to the other waves through LDS when the loop is over.  Every workgroup ends on a ticket beyond the range; the
-  // last one to finish resets the counters for the next launch.  No waiting on other workgroups anywhere.
-  int* const sched = PERSIST && !p.split_fast && (int)gridDim.x < nbm * nbn ? p.sched : nullptr;
-  int* const ticket_lds = reinterpret_cast<int*>(epi + EP_RED_OFFSET) + 2 * 2 * 256;      // behind the statistics scratch
-  for (;;) {
-  int ticket = 0;
-  if (sched != nullptr && tid == 0) ticket = atomicAdd(&sched[vb & 7], 1);
-#pragma unroll
-  for (int i = 0; i < L::MB; ++i)
-#pragma unroll
-    for (int j = 0; j < L::NB; ++j)
-#pragma unroll
-      for (int r = 0; r < L::NR; ++r) acc[i][j][r] = 0.f;
-  // first tile: A(1) -- the four youngest pieces -- may stay in flight; later tiles: the stages have had the whole
-  // epilogue to land, and the epilogue's C stores share the counter: everything
-  step_barrier(!primed && nt > 1);
-  if (PERSIST) {
-    asm volatile("" : "+v"(ln));
-    if (BUF) {
-      piece_lane_offsets<ALAY>(p.lda, ln, voA);
-      piece_lane_offsets<BLAY, PERMB>(p.ldb, ln, voB);
-    }
-  }
-  int ia = 0;                                   // A slot of the current step (t mod 3)
-
-  if constexpr (MF == 32) {
-    const int l31 = ln & 31, half = ln >> 5;
-    int offA[4], offB[2], kofs[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) offA[i] = dma_frag_offset<ALAY>(wm * 128 + i * 32, ln);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) offB[j] = dma_frag_offset<BLAY>(wn * 64 + j * 32, ln);
-    {
-      const int swz = (l31 >> 1) & 7;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) kofs[s] = ((2 * s + half) ^ swz) * 8;
-    }
-    // the fine interleave (one DMA piece in front of every 4 MFMAs) is the order of the KC x KC instantiations;
-    // the RC x RC (wgrad) instantiation measured 0-8 % slower with it (transpose reads: two ds_read_b64_tr_b16
-    // per fragment) and issues the whole next stage at the top of the step
-    constexpr bool kFine = ALAY == KC;
-    for (int t = 0; t < nt; ++t) {
-      const bf16_t* sA = slotA(ia);
-      const bf16_t* sB = slotB(t & 1);
-      bf16_t* nA = slotA(ia == 0 ? 2 : ia - 1);            // stage t + 2
-      bf16_t* nB = slotB((t + 1) & 1);                     // stage t + 1
-      const int k0 = kbeg + (t + 1) * BK, k0A = k0 + BK;
-      const bool more = t + 1 < nt, moreA = t + 2 < nt;
-      if (!kFine && more) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) piece(1, k0, nB, j);
-      }
-      // software-pipelined fragment reads: the 6 ds_reads of k-step ks+1 are issued before the 8
-      // MFMAs of k-step ks, so only the first read group of a stage exposes LDS latency
-      bf16x8 af[2][4], bfr[2][2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[0][i] = dma_load_frag<ALAY>(sA, offA[i], 0, kofs);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) bfr[0][j] = dma_load_frag<BLAY>(sB, offB[j], 0, kofs);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int cur = ks & 1, nxt = cur ^ 1;
-        if (ks < 3) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) af[nxt][i] = dma_load_frag<ALAY>(sA, offA[i], ks + 1, kofs);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) bfr[nxt][j] = dma_load_frag<BLAY>(sB, offB[j], ks + 1, kofs);
-        }
-        // pin: next step's reads stay ABOVE this step's MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          if (kFine) {
-            const int pc = 2 * ks + g;                     // B first: the four youngest pieces are A's
-            if (pc < 4) { if (more) piece(1, k0, nB, pc); }
-            else if (moreA) piece(0, k0A, nA, pc - 4);
-          } else if (moreA && ks >= 2) {
-            piece(0, k0A, nA, 2 * (ks - 2) + g);           // the far stage: requested in the second half of the step
-          }
-#pragma unroll
-          for (int i = 2 * g; i < 2 * g + 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[i][j] = mfma_32x32x16<SPLIT>(af[cur][i], bfr[cur][j], acc[i][j]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      step_barrier(moreA);
-      ia = ia == 2 ? 0 : ia + 1;
-    }
-  } else {
-    // ---- 16x16x32 fragments: lane holds 8 consecutive k of row (lane & 15); k-granule 4*s2 + (lane >> 4)
-    const int l15 = ln & 15, q = ln >> 4;
-    int offA[8], offB[4], kofs[2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) offA[i] = (wm * 128 + i * 16 + l15) * 64;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) offB[j] = (wn * 64 + j * 16 + l15) * 64;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) kofs[s2] = ((4 * s2 + q) ^ (l15 >> 1)) * 8;
-    for (int t = 0; t < nt; ++t) {
-      const bf16_t* sA = slotA(ia);
-      const bf16_t* sB = slotB(t & 1);
-      bf16_t* nA = slotA(ia == 0 ? 2 : ia - 1);            // stage t + 2
-      bf16_t* nB = slotB((t + 1) & 1);                     // stage t + 1
-      const int k0 = kbeg + (t + 1) * BK, k0A = k0 + BK;
-      const bool more = t + 1 < nt, moreA = t + 2 < nt;
-      // a step = 2 k-halves (32 deep) x 2 row-halves (64 rows): 4 blocks of 16 MFMAs; fragment reads of the next
-      // block are issued before the MFMAs of the current one; two DMA pieces per block, one per 8 MFMAs
-      bf16x8 af[2][4], bfr[2][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(sB + offB[j] + kofs[0]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(sA + offA[i] + kofs[0]);
-#pragma unroll
-      for (int blk = 0; blk < 4; ++blk) {
-        const int s2 = blk >> 1, h = blk & 1, cur = blk & 1, nxt = cur ^ 1;
-        if (blk < 3) {
-          const int ns2 = (blk + 1) >> 1, nh = (blk + 1) & 1;
-          if (nh == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[ns2 & 1][j] = *reinterpret_cast<const bf16x8*>(sB + offB[j] + kofs[ns2]);
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) af[nxt][i] = *reinterpret_cast<const bf16x8*>(sA + offA[4 * nh + i] + kofs[ns2]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          {
-            const int pc = 2 * blk + g;                    // B first: the four youngest pieces are A's
-            if (pc < 4) { if (more) piece(1, k0, nB, pc); }
-            else if (moreA) piece(0, k0A, nA, pc - 4);
-          }
-#pragma unroll
-          for (int i = 2 * g; i < 2 * g + 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[4 * h + i][j] = mfma_16x16x32<SPLIT>(af[cur][i], bfr[s2 & 1][j], acc[4 * h + i][j]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      step_barrier(moreA);
-      ia = ia == 2 ? 0 : ia + 1;
-    }
-  }
-  // the next tile of this workgroup: its first stages go out now and land beside the epilogue
-  int vb2 = vb + (int)gridDim.x;
-  if (sched != nullptr) {
-    if (tid == 0) *ticket_lds = ticket;
-    lds_barrier();
-    vb2 = (vb & 7) + 8 * ((int)(gridDim.x >> 3) + __builtin_amdgcn_readfirstlane(*ticket_lds));
-  }
-  const bool has_next = PERSIST && !p.split_fast && vb2 < nbm * nbn;
-  int tm2 = 0, tn2 = 0;
-  if (has_next) {
-    xcd_tile_coords(nbm, nbn, vb2, tm2, tn2);
-    first_stages(tm2, tn2);
-  }
-  if constexpr (SPLIT) {
-    // the operand images hold value * 2^k: back to the value's scale (exact power of two)
-    const float os = p.out_scale;
-#pragma unroll
-    for (int i = 0; i < L::MB; ++i)
-#pragma unroll
-      for (int j = 0; j < L::NB; ++j)
-#pragma unroll
-        for (int r = 0; r < L::NR; ++r) acc[i][j][r] *= os;
-  }
-  // the epilogue's per-lane address arithmetic must not be hoisted out of the tile loop (it would sit in ~40
-  // registers through the K loop): it is derived from an opaque copy of the thread id
-  int te = tid;
-  if (PERSIST) asm volatile("" : "+v"(te));
-  if constexpr (EPI == EPI_DGRAD_BN || EPI == EPI_DGRAD_BN_POINTS) {
-    epilogue_dgrad_bn<MF, EPI == EPI_DGRAD_BN_POINTS, TC>(p, acc, epi, tm, tn, te);
-  } else if constexpr (EPI == EPI_AFFINE) {
-    epilogue_full_tile<TC, MF, true>(p, acc, epi, tm, tn, te, split);
-  } else if constexpr (EPI == EPI_POOL1 || EPI == EPI_POOL2 || EPI == EPI_POOL4) {
-    epilogue_affine_meanpool<MF, EPI == EPI_POOL1 ? 1 : (EPI == EPI_POOL2 ? 2 : 4)>(p, acc, tm, tn, te);
-  } else {
-    epilogue_full_tile<TC, MF, false>(p, acc, epi, tm, tn, te, split);
-    if (p.colstats != nullptr) epilogue_colstats<MF>(p, acc, reinterpret_cast<unsigned char*>(epi), tm, tn, te);
-  }
-  if (!has_next) {
-    if (sched != nullptr && tid == 0 && atomicAdd(&sched[8], 1) == (int)gridDim.x - 1) {
-#pragma unroll
-      for (int i = 0; i < 9; ++i) atomicExch(&sched[i], 0);
-    }
-    break;
-  }
-  vb = vb2;
-  tm = tm2;
-  tn = tn2;
-  primed = true;
-  }
-  // this workgroup's tiles are done: if the launch carries the BatchNorm finalize of its statistics, the last
-  // workgroup to get here runs it (bn_tail.h)
-  if constexpr (PERSIST && (EPI == EPI_PLAIN || EPI == EPI_DGRAD_BN || EPI == EPI_DGRAD_BN_POINTS)) {
-    // read from the kernel-argument segment HERE, through a pointer the compiler cannot see through: referenced as
-    // p.tail its 20 fields are fetched at kernel entry and sit in (spilled) SGPRs through the whole tile loop
-    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ka));
-    const BnTail tail = *reinterpret_cast<const BnTail*>(ka + offsetof(GemmParams, tail));
-    bn_tail_run(tail, tid, NTHREADS, gridDim.x, ticket_lds + 1);
-  }
-}
-
-// MFMA shape per instantiation.  KC x KC (forward / dgrad): v_mfma_f32_16x16x32_bf16 -- same cycles per FLOP as
-// 32x32x16, but the chip holds a higher clock on it (MI355X_MICROARCH.md, DVFS item 7); same-box A/B on the three
-// PointNet shapes (median of 5 interleaved rounds): forward +9.2 / -0.7 / +2.6 %, fused dgrad +4.4 / +4.0 / +1.9 %.
-// RC x RC (wgrad) keeps 32x32x16: its fragments come from ds_read_b64_tr_b16 pairs laid out for that shape.
-template <typename TC, int ALAY, int BLAY, int EPI, bool BUF, bool SPLIT = false>
-bool launch_dma_inst(const GemmParams& p, dim3 grid, hipStream_t s) {
-  constexpr int MF = ALAY == KC ? 16 : 32;
-  static bool configured = false;
-  auto kern = gemm_bf16_dma_kernel<TC, ALAY, BLAY, EPI, MF, BUF, SPLIT>;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            D_LDS_BYTES) != hipSuccess)
-      return false;
-    configured = true;
-  }
-  const PcaaLaunchEvents ev = pcaa_take_launch_events();
-  if (ev.start != nullptr)
-    hipExtLaunchKernelGGL(kern, grid, dim3(NTHREADS), D_LDS_BYTES, s, ev.start, ev.stop, 0, p);
-  else
-    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), D_LDS_BYTES, s, p);
-  return true;
-}
 
 // The 4-wave tile loop (gemm_v2.h) serves every KC x KC launch without K splits whose contraction is at least five
-// 64-deep steps long (its ticket hand-off needs four of them); pcaa_gemm_v2_enable(0) routes them back to the 8-wave loop (A/B).
+// 64-deep steps long (its ticket hand-off needs four of them); pcaa_gemm_v2_enable(0) declines them all (lab A/B against
+// the register-staged kernel; the fused entry points then report their shapes unsupported).
 static int g_v2_enabled = -1;
 bool pcaa_gemm_v2_is_enabled();
 static bool v2_enabled() {
@@ -1202,7 +451,7 @@ bool launch_dma(const GemmParams& p_in, dim3 grid_in, hipStream_t s) {
     if (g < grid.x) p.sched = sched_slot(s);
     grid.x = g;
     // every workgroup of such a launch owns at least one tile and adds to colstats: the launch can carry the finalize
-    if ((EPI == EPI_PLAIN || EPI == EPI_DGRAD_BN || EPI == EPI_DGRAD_BN_POINTS) && p.colstats != nullptr && grid.y == 1)
+    if ((EPI == EPI_PLAIN || EPI == EPI_DGRAD_BN) && p.colstats != nullptr && grid.y == 1)
       p.tail = pcaa_take_bn_tail(p.colstats);
   }
   // buffer addressing needs each operand below 4 GiB (32-bit offsets); the flat form serves anything larger.  Same-box
@@ -1214,7 +463,7 @@ bool launch_dma(const GemmParams& p_in, dim3 grid_in, hipStream_t s) {
   // (advisor, round 3) every path that does not launch hands the tail back: resolve() then runs the stand-alone finalize
   bool ok = false;
   bool decided = false;
-  if constexpr (ALAY == KC && BLAY == KC && EPI != EPI_DGRAD_BN_POINTS) {
+  if constexpr (ALAY == KC && BLAY == KC) {
     // PCAA_GEMM_TICKETS=0: fixed tile shares in the 4-wave loop (A/B of the ticket draw's once-per-tile drain)
     static const bool tickets = [] { const char* e = getenv("PCAA_GEMM_TICKETS"); return !(e != nullptr && e[0] == '0'); }();
     if (!tickets) p.sched = nullptr;
@@ -1246,24 +495,9 @@ bool launch_dma(const GemmParams& p_in, dim3 grid_in, hipStream_t s) {
       decided = true;
     }
   }
-  if (!decided && (p.M % BM) != 0) decided = true;      // a partial last row tile: the 4-wave loop only (ok stays false)
-  if (!decided) {
-  if constexpr ((EPI == EPI_PLAIN || (EPI == EPI_DGRAD_BN && ALAY == KC)) && sizeof(TC) == 4) {
-    // split-fp16 operands (pcaa_gemm_split3, pcaa_gemm_dgrad_bn_split3): fp32 result only
-    if (p.seg_len > 0) {
-      ok = buf ? launch_dma_inst<TC, ALAY, BLAY, EPI, true, true>(p, grid, s)
-               : launch_dma_inst<TC, ALAY, BLAY, EPI, false, true>(p, grid, s);
-      decided = true;
-    } else if (EPI == EPI_DGRAD_BN) {
-      decided = true;                                // fp32 dz exists for the split operands only
-    }
-  }
-  if (!decided) {
-    if (p.seg_len > 0) ok = false;
-    else ok = buf ? launch_dma_inst<TC, ALAY, BLAY, EPI, true>(p, grid, s)
-                  : launch_dma_inst<TC, ALAY, BLAY, EPI, false>(p, grid, s);
-  }
-  }
+  // (anything else -- a contraction shorter than five steps, K splits with atomics, a partial tile the loop cannot take --
+  // is declined: the caller falls back to the register-staged kernel, the fused entry points report the shape unsupported)
+  (void)decided;
   if (!ok) pcaa_rearm_bn_tail(p.tail);
   return ok;
 }
@@ -1301,7 +535,7 @@ bool pcaa_launch_gemm_dgrad_bn(const GemmParams& p_in, hipStream_t stream) {
     p.k_per_split = p.K;
     return launch_dma<float, KC, KC, EPI_DGRAD_BN>(p, dim3((unsigned)ntiles, 1, 1), stream);
   }
-  if (p.ep_y == nullptr) return launch_dma<bf16_t, KC, KC, EPI_DGRAD_BN_POINTS>(p, dim3((unsigned)ntiles, 1, 1), stream);
+  if (p.ep_y == nullptr) return false;
   return launch_dma<bf16_t, KC, KC, EPI_DGRAD_BN>(p, dim3((unsigned)ntiles, 1, 1), stream);
 }
 
@@ -1356,11 +590,13 @@ bool pcaa_launch_gemm_bf16_big(const GemmParams& p_in, int a_dtype, int a_layout
   if (!af && !bf && m_ok && (p.N % BN) == 0 && (p.K % BK) == 0 && (p.k_per_split % BK) == 0 &&
       a_layout == b_layout) {
     if (a_layout == KC) {
-      const bool ok = cf ? launch_dma<float, KC, KC, EPI_PLAIN>(p, grid, stream) : launch_dma<bf16_t, KC, KC, EPI_PLAIN>(p, grid, stream);
-      // a partial last row tile the 4-wave loop declined (ldc, alignment, size): the register-staged kernel below
-      if (ok || (p.M % BM) == 0) return ok;
+      // (declined -- a contraction shorter than five steps, K splits, a partial last row tile it cannot address: the
+      // register-staged kernel below)
+      if (cf ? launch_dma<float, KC, KC, EPI_PLAIN>(p, grid, stream) : launch_dma<bf16_t, KC, KC, EPI_PLAIN>(p, grid, stream))
+        return true;
     } else if (cf) {
-      return launch_dma<float, RC, RC, EPI_PLAIN>(p, grid, stream);
+      // (declined -- atomics, a partial tile, an operand beyond 4 GiB: the register-staged kernel below)
+      if (launch_dma<float, RC, RC, EPI_PLAIN>(p, grid, stream)) return true;
     }
   }
   if (p.seg_len > 0) return false;       // split-fp16 operands are served by the LDS-DMA kernel only

@@ -18,7 +18,7 @@ struct GemmParams {
   long c_split_stride;   // slab split-K: split s stores its partial tile at C + s * c_split_stride (no atomics)
   // dgrad fused with the BatchNorm+ELU backward of the layer below (pcaa_gemm_dgrad_bn)
   const void* ep_y; const float* ep_scale; const float* ep_shift; const float* ep_mean; const float* ep_rstd;
-  const float* ep_x; const float* ep_w1; int ep_xc;   // ep_y == NULL: y = x[M,xc] . W1[N,xc]^T is recomputed
+  int ep_xc;   // pcaa_gemm_affine_elu: rows per mean-pool group (0: the activation itself leaves)
   // LDS-DMA kernel, one workgroup per CU: 9 zero-initialised ints (8 per-XCD tile tickets + a count of finished
   // workgroups, reset by the last one); NULL: every workgroup walks a fixed share of the tiles
   int* sched;

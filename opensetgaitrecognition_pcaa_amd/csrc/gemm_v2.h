@@ -101,6 +101,21 @@ __device__ __forceinline__ void piece(buf_rsrc_t r, long ld, int row0, int koff,
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// the lane id, re-read from the hardware where it is needed (volatile: not hoisted).  Round 5: the tile loop keeps all 256
+// vector registers busy, so a lane id kept live across it -- for the per-tile lane constants, the epilogues, the
+// "thread 0" tests -- was spilled at kernel entry and reloaded from scratch once per tile (8-28 B of scratch in every
+// instantiation); two mbcnt instead.
+// value of lane (le ^ mask): __shfl_xor derives its index from the compiler's own lane id, which is loop-invariant, kept
+// live across the tile loop and spilled there; here the index comes from the caller's freshly read lane id
+__device__ __forceinline__ float xor_lane(float v, int le, int mask) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((le ^ mask) << 2, __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ int lane_id_now() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 // ELU of z given z2 = z * log2(e) (the caller folds log2e into the affine): max(z2, 0) * ln2 + (clamp(exp2(z2)) - 1) --
 // the [0, 1] clamp is the exp instruction's own output modifier, so exp2 of a positive z2 contributes 1 - 1 = 0 and of a
 // negative one exp(z) - 1; no compare / select pair and no separate multiply by log2e per element (the eval epilogues
@@ -186,10 +201,10 @@ __device__ __forceinline__ void colstats_finish(const GemmParams& p, float (&t1)
                                                 int wm, int wn, int le, int tid) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    t1[j] += __shfl_xor(t1[j], 16, 64);
-    t1[j] += __shfl_xor(t1[j], 32, 64);
-    t2[j] += __shfl_xor(t2[j], 16, 64);
-    t2[j] += __shfl_xor(t2[j], 32, 64);
+    t1[j] += xor_lane(t1[j], le, 16);
+    t1[j] += xor_lane(t1[j], le, 32);
+    t2[j] += xor_lane(t2[j], le, 16);
+    t2[j] += xor_lane(t2[j], le, 32);
   }
   if (le < 16) {
     float* d1 = &red[(0 * 2 + wm) * 256 + wn * 128 + 8 * le];
@@ -236,7 +251,7 @@ __device__ __forceinline__ void epilogue_colstats(const GemmParams& p, f32x4 (&a
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       t1[j] = (a1[j].x + a1[j].y) * os;
-      t2[j] = (a2[j].x + a2[j].y) * (os * os);
+      t2[j] = ((a2[j].x + a2[j].y) * os) * os;      // (two scalar-operand multiplies: the splat of os^2 was hoisted out of the tile loop and spilled)
     }
   } else {
 #pragma unroll
@@ -251,7 +266,7 @@ __device__ __forceinline__ void epilogue_colstats(const GemmParams& p, f32x4 (&a
           a2 = __builtin_elementwise_fma(v, v, a2);
         }
       t1[j] = (a1.x + a1.y) * os;                  // sums of (acc * os), (acc * os)^2: os is a power of two, exact
-      t2[j] = (a2.x + a2.y) * (os * os);
+      t2[j] = ((a2.x + a2.y) * os) * os;
     }
   }
   colstats_finish(p, t1, t2, red, tm, tn, wm, wn, le, tid);
@@ -409,8 +424,8 @@ __device__ __forceinline__ void epilogue_affine_meanpool(const GemmParams& p, f3
       for (int i = g0; i < g0 + BPG; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s += elu_from_z2(fmaf(acc[i][j][r], esc, esh));
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
+      s += xor_lane(s, le, 16);
+      s += xor_lane(s, le, 32);
       sum[j] = s * inv_n;
     }
     const long grp = ((long)tm * BM + wm * 128 + g0 * 16) / (32 * IPG);
@@ -438,8 +453,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_v2_kernel(GemmParams p) {
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
   float* red = reinterpret_cast<float*>(smem_raw + SCRATCH_OFF);            // [2 stats][2 wm][256 cols]
   int* words = reinterpret_cast<int*>(smem_raw + SCRATCH_OFF + 4096);      // [0]: next-tile hand-off, [1]: finalize flag
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN, ntiles = nbm * nbn;      // (the last row tile may be partial)
   const int seg_steps = (SPLIT ? p.seg_len : p.K) / BK;                  // K steps per segment
@@ -467,8 +481,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_v2_kernel(GemmParams p) {
     fA = (wm * 128 + l15) * 64;                                          // + 1024 i per row block
     fB = OP_TILE + (wn * 128 + l15) * 64;                                // + 1024 j
   };
-  int ln = lane;
-  lane_consts(ln);
+  lane_consts(lane_id_now());
 
   // request cursor: (tile, segment, k within the segment); two K steps ahead of the MFMAs, across tile boundaries.
   // The buffer resources are re-based on the cursor's tile rows, so any operand size is addressable.
@@ -541,7 +554,7 @@ _Pragma("unroll") \
         const int i = m >> 3, j = m & 7; \
         if ((m & 1) == 1 && m < 16) lds_read(bfr[1][m >> 1], aB1, (m >> 1) * 2048); \
         if (m == 21) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
-        if (m == 22 && sched != nullptr && kt == 1 && tid == 0) { \
+        if (m == 22 && sched != nullptr && kt == 1 && wave == 0 && lane_id_now() == 0) { \
           int tk; \
           asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)\n\tds_write_b32 %3, %0\n\ts_waitcnt lgkmcnt(0)" \
                        : "=&v"(tk) : "v"(sched + (vb & 7)), "v"(1), "v"(lds0 + SCRATCH_OFF + 4096) : "memory"); \
@@ -591,8 +604,7 @@ _Pragma("unroll") \
   for (;;) {
     int tm, tn;
     xcd_tile_coords(nbm, nbn, vb, tm, tn);
-    asm volatile("" : "+v"(ln));
-    lane_consts(ln);
+    lane_consts(lane_id_now());
     if (!PCAA_V2_ZERO_BY_MFMA) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
@@ -609,9 +621,7 @@ _Pragma("unroll") \
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results (the asm hides the hazard from the compiler)
     // (split operands: the images hold value * 2^k; the epilogues multiply by p.out_scale -- an exact power of two -- as
     // they read the accumulators: rescaling them in place would move all 256 through the vector registers and back)
-    int le = lane, te = tid;
-    asm volatile("" : "+v"(le));
-    asm volatile("" : "+v"(te));
+    const int le = lane_id_now(), te = le + 64 * wave;
     if constexpr (EPI == EPI_DGRAD_BN) {
       epilogue_dgrad_bn<TC, SPLIT, RAG>(p, acc, red, tm, tn, wm, wn, le, te);
     } else if constexpr (EPI == EPI_AFFINE) {
@@ -633,6 +643,7 @@ _Pragma("unroll") \
     nvb = vb + gstride;                  // (tickets: replaced at kt == 2 of the tile that starts now)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the surplus stages have landed before the LDS is released
+  const int tid = lane_id_now() + 64 * wave;
   if (sched != nullptr && tid == 0 && atomicAdd(&sched[8], 1) == gstride - 1) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) atomicExch(&sched[i], 0);

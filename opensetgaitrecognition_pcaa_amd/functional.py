@@ -320,10 +320,9 @@ _BIG_WGRAD_ASIDE = False
 # ... but the split-K slab reductions that follow them (12 us each, three per step, needed only by Adam) do leave it
 _REDUCE_ASIDE = os.environ.get("PCAA_REDUCE_ASIDE", "1") != "0"
 _FUSE_DGRAD_BN = True
-# the same fusion into the dgrad above the FIRST layer (y rebuilt from the points in the epilogue; the kernel and
-# ops.gemm_dgrad_bn(points=...) exist and are tested) measured slower: the layer-2 dgrad went 0.195 -> 0.361 ms
-# (64 FMAs + 192 live registers per lane in the epilogue) to save a 0.10 ms statistics pass -> off.
-_FUSE_DGRAD_POINTS = False
+# (the same fusion into the dgrad above the FIRST layer -- y rebuilt from the points in the epilogue -- measured slower in
+# round 1: the layer-2 dgrad went 0.195 -> 0.361 ms to save a 0.10 ms statistics pass; it lived in the 8-wave kernel only
+# and was removed with it in round 5)
 # first PointNet layer, bf16 mode: one pass over the incoming gradient instead of two (ops.pointnet_in_bwd_onepass)
 _ONEPASS_IN_BWD = os.environ.get("PCAA_ONEPASS_IN_BWD", "1") != "0"
 # first PointNet layer, forward: BatchNorm statistics from the points' second moments instead of a pass over [P, cout]
@@ -465,13 +464,6 @@ def _bn_layer_backward(s, bn, W2d, mode, da=None, dpool=None, group_rows=0, pool
                                           dbeta=below_outs[2] if below_outs else None, sync=_sync_fn())
                 d_lhs = _FusedGrad(*ops.gemm_dgrad_bn(dy, Wt, below.y, below.scale, below.shift, below.mean,
                                                       below.rstd, tail=btail), fin=btail.out if btail else None)
-            elif (_FUSE_DGRAD_BN and below is not None and below.y is None and below_W is not None
-                  and below.mean is not None and below.a_in.dtype == torch.float32
-                  and below.a_in.shape[0] == rows_local and rows_local % 256 == 0      # (no ragged recompute variant)
-                  and ops.gemm_dgrad_bn_supported(rows_local, K, cout)):
-                # the layer below is the first PointNet layer on its recompute path: y is rebuilt in the epilogue
-                d_lhs = _FusedGrad(*ops.gemm_dgrad_bn(dy, Wt, None, below.scale, below.shift, below.mean, below.rstd,
-                                                      points=below.a_in, W1=below_W))
             else:
                 d_lhs = ops.gemm(dy, KC, Wt, KC, rows_local, K, cout, out_dtype=torch.bfloat16, math=PCAA_BF16)
         else:
@@ -501,11 +493,7 @@ def pointnet_backward(saves, layers, mode, d_last=None, dpool=None, pool_rows=0,
         # the layer below: its BatchNorm and gradient destinations, for the finalize the fused dgrad can carry
         below_bn = layers[li - 1].module[1] if li > 0 else None
         below_outs = _layer_outs(gout, f"{prefix}{li}.", "module.0.weight", "module.1.weight", "module.1.bias") if li > 0 else None
-        # weight of the layer below when that layer is a recompute layer whose backward will not need dx
         below_W = None
-        if _FUSE_DGRAD_POINTS and li == 1 and saves[0].y is None and not need_dx:
-            c0 = layers[0].module[0]
-            below_W = c0.weight.view(saves[0].cout, saves[0].cin)
         if s.y is None and da is not None and not need_in:
             # recompute path of the first layer: two passes over da (one, when the dgrad above already applied
             # ELU' and reduced the statistics), nothing else is read or written

@@ -183,7 +183,7 @@ class _KernelEvents:
 
 
 def _begin_timing(key):
-    return _KernelEvents() if key.startswith(("gemm_bf16_dma_kernel", "gemm_bf16_v2_kernel", "gemm_bf16_v2rc_kernel")) else _TorchEvents()
+    return _KernelEvents() if key.startswith(("gemm_bf16_v2_kernel", "gemm_bf16_v2rc_kernel")) else _TorchEvents()
 
 
 TIMER = None
@@ -334,8 +334,9 @@ _GEMM_V2 = {"on": os.environ.get("PCAA_GEMM_V2", "1") != "0"}
 
 
 def gemm_v2_enable(on=True):
-    """Route the KC x KC bf16 / split-fp16 products without K splits through the 4-wave tile loop (csrc/gemm_v2.h;
-    default) or the 8-wave loop of rounds 1-3 (A/B, fallback): pcaa_gemm_v2_enable."""
+    """Lab switch (pcaa_gemm_v2_enable): with ``on=False`` the 4-wave tile loops (csrc/gemm_v2.h) decline every launch --
+    plain products then take the register-staged 256 x 256 kernel, the fused entry points report their shapes unsupported.
+    (Rounds 1-4 routed to the 8-wave loop here; round 5 removed it.)"""
     _GEMM_V2["on"] = bool(on)
     check(_lib.load().pcaa_gemm_v2_enable(int(bool(on))), "pcaa_gemm_v2_enable")
 
@@ -351,15 +352,15 @@ def _v2_takes(K, split_k=1, accumulate=False):
 
 def _dma_key(out_dtype, layout, v2=False):
     """LaunchTimer / PMC key of one LDS-DMA GEMM instantiation (rocprofv3 lists them as separate kernels): the 4-wave
-    loop's v2::gemm_bf16_v2_kernel<__bf16, 0, false> = PointNet forward / plain dgrad, the 8-wave
-    gemm_bf16_dma_kernel<float, 1, 1, 0> = wgrad."""
+    loops' v2::gemm_bf16_v2_kernel<__bf16, 0, false> = PointNet forward / plain dgrad, v2::gemm_bf16_v2rc_kernel = the
+    weight gradients; anything they decline runs on the register-staged gemm_bf16_big_kernel (timed with stream events)."""
     dt = 'bf16' if out_dtype == torch.bfloat16 else 'f32'
     if v2 and layout == KC:
         return f"gemm_bf16_v2_kernel<{dt},plain>"
     if v2 and layout == RC and dt == 'f32' and _GEMM_V2["on"] and _GEMM_V2_RC:
         return "gemm_bf16_v2rc_kernel<f32>"      # the weight gradients on the 4-wave loop (whole 256 x 256 tiles)
     lay = "KC" if layout == KC else "RC"
-    return f"gemm_bf16_dma_kernel<{dt},{lay},{lay}>"
+    return f"gemm_bf16_big_kernel<{dt},{lay},{lay}>"
 
 
 def gemm(A, a_layout, B, b_layout, M, N, K, *, lda=None, ldb=None, out=None, out_dtype=torch.float32,
@@ -545,7 +546,7 @@ def gemm_affine_elu(a, W16, scale, shift, pool_rows=0):
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     timer = TIMER
     # eval-mode epilogues (BatchNorm affine + ELU [+ mean-pool])
-    key = "gemm_bf16_v2_kernel<bf16,affine_elu>" if _v2_takes(K) else "gemm_bf16_dma_kernel<bf16,KC,KC,affine_elu>"
+    key = "gemm_bf16_v2_kernel<bf16,affine_elu>"
     timer = timer if (timer is not None and timer.wants(key)) else None
     if timer is not None:
         ev = _begin_timing(key)
@@ -562,34 +563,23 @@ def gemm_dgrad_bn_supported(M, N, K):
     return bool(_lib.load().pcaa_gemm_dgrad_bn_supported(int(M), int(N), int(K)))
 
 
-def gemm_dgrad_bn(dy, Wt, y, scale, shift, mean, rstd, points=None, W1=None, tail=None):
+def gemm_dgrad_bn(dy, Wt, y, scale, shift, mean, rstd, tail=None):
     """dz[M,N] = (dy[M,K] @ Wt[N,K]^T) * ELU'(y*scale+shift) plus the BatchNorm-backward statistics of
     the layer that owns y -- the dgrad of the layer above fused with the first half of this layer's
-    backward.  Returns (dz bf16, stats)."""
+    backward.  Returns (dz bf16, stats).  (The variant that rebuilt y of the FIRST PointNet layer from the points in the
+    epilogue -- measured slower than the separate statistics pass in round 1, never on -- left with the 8-wave kernel.)"""
     _chk(dy, "gemm_dgrad_bn.dy", torch.bfloat16, 2)
     _chk(Wt, "gemm_dgrad_bn.Wt", torch.bfloat16, 2)
+    _chk(y, "gemm_dgrad_bn.y", torch.bfloat16, 2)
     M, K = dy.shape
     N = Wt.shape[0]
-    if Wt.shape[1] != K:
+    if Wt.shape[1] != K or tuple(y.shape) != (M, N):
         raise ValueError("gemm_dgrad_bn: shape mismatch")
-    xc = 0
-    if y is None:
-        # layer below = first PointNet layer on its recompute path: y = points . W1^T is rebuilt in the epilogue
-        _chk(points, "gemm_dgrad_bn.points", torch.float32, 2)
-        _chk(W1, "gemm_dgrad_bn.W1", torch.float32, 2)
-        xc = points.shape[1]
-        if points.shape[0] != M or tuple(W1.shape) != (N, xc) or not 1 <= xc <= 8:
-            raise ValueError("gemm_dgrad_bn: points / W1 shape mismatch")
-        dz = torch.empty((M, N), dtype=torch.bfloat16, device=dy.device)
-    else:
-        _chk(y, "gemm_dgrad_bn.y", torch.bfloat16, 2)
-        if tuple(y.shape) != (M, N):
-            raise ValueError("gemm_dgrad_bn: shape mismatch")
-        dz = torch.empty_like(y)
+    dz = torch.empty_like(y)
     stats = new_stats(N, dy.device)
     timer = TIMER
     # its own instantiation (epilogue carries ELU' + statistics)
-    key = "gemm_bf16_v2_kernel<bf16,dgrad_bn>" if (_v2_takes(K) and points is None) else "gemm_bf16_dma_kernel<bf16,KC,KC,dgrad_bn>"
+    key = "gemm_bf16_v2_kernel<bf16,dgrad_bn>"
     timer = timer if (timer is not None and timer.wants(key)) else None
     if timer is not None:
         ev = _begin_timing(key)
@@ -597,7 +587,7 @@ def gemm_dgrad_bn(dy, Wt, y, scale, shift, mean, rstd, points=None, W1=None, tai
         tail.arm(stats)
     check(_lib.load().pcaa_gemm_dgrad_bn(_p(dy), dy.stride(0), _p(Wt), Wt.stride(0), _p(y), _p(dz), dz.stride(0),
                                          _p(scale), _p(shift), _p(mean), _p(rstd), _p(stats), NREP, M, N, K,
-                                         _p(points) if y is None else None, xc, _p(W1) if y is None else None, _s()),
+                                         None, 0, None, _s()),
           "pcaa_gemm_dgrad_bn")
     if timer is not None:
         ev.end()
@@ -701,7 +691,7 @@ def gemm_split3(A, B, layout, M, N, K, colstats=None, tail=None, out=None):
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     timer = TIMER
-    key = "gemm_bf16_v2_kernel<f32,split3>" if (layout == KC and _v2_takes(3 * K)) else "gemm_bf16_dma_kernel<f32,split3>"
+    key = "gemm_bf16_v2_kernel<f32,split3>" if layout == KC else "gemm_bf16_v2rc_kernel<f32,split3>"
     timer = timer if (timer is not None and timer.wants(key)) else None
     if timer is not None:
         ev = _begin_timing(key)
@@ -728,8 +718,7 @@ def gemm_slabs_split3(A, B, M, N, K, split_k, out=None):
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     timer = TIMER
-    key = ("gemm_bf16_v2rc_kernel<f32,split3>" if (_GEMM_V2["on"] and _GEMM_V2_RC and M % 256 == 0 and N % 256 == 0)
-           else "gemm_bf16_dma_kernel<f32,split3>")
+    key = "gemm_bf16_v2rc_kernel<f32,split3>"
     timer = timer if (timer is not None and timer.wants(key)) else None
     if timer is not None:
         ev = _begin_timing(key)
@@ -774,7 +763,7 @@ def bn_bwd_dy_split(dz, y, coef):
 
 
 def gemm_dgrad_bn_split3_supported(M, N, K):
-    return bool(_lib.load().pcaa_gemm_dgrad_bn_supported(M, N, K))
+    return bool(_lib.load().pcaa_gemm_split3_supported(int(M), int(N), int(K)))
 
 
 def gemm_dgrad_bn_split3(dy, wt, y, scale, shift, mean, rstd, tail=None):

@@ -101,8 +101,8 @@ def test_ragged_row_tile_predicates_bound_the_padded_size():
         assert fn(4194304, 256, 512) == 1                  # whole tiles: no bound
         assert fn(4194304 - 1, 256, 512) == 0              # ragged, padded rows x 256 columns x 4 B = 4 GiB
         assert fn(4194304 - 257, 256, 512) == 1
-    # a ragged launch with the first-layer recompute variant / an unaligned result is an argument error, not a launch error
+    # the first-layer recompute variant left with the 8-wave kernel: passing x is an argument error, not a launch error
     one = ctypes.c_void_p(16)
     rc = lib.pcaa_gemm_dgrad_bn(one, 512, one, 512, None, one, 512, one, one, one, one, one, 1, 1000, 512, 512,
                                 one, 4, one, None)
-    assert rc == 1 and b"partial last row tile" in lib.pcaa_last_error()
+    assert rc == 1 and b"recompute variant" in lib.pcaa_last_error()

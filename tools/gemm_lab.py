@@ -23,8 +23,9 @@ from opensetgaitrecognition_pcaa_amd._lib import KC, PCAA_BF16, RC  # noqa: E402
 
 
 def lab_set(v, *_):
-    """variant 0 = the shipped default (round 4: the 4-wave tile loop, csrc/gemm_v2.h); variant 1 = the 8-wave loop of
-    rounds 1-3 (pcaa_gemm_v2_enable(0)): `--variants 0:0,1:0` A/Bs them in interleaved rounds of one process"""
+    """variant 0 = the shipped default (the 4-wave tile loops, csrc/gemm_v2.h); variant 1 = pcaa_gemm_v2_enable(0): the
+    loops decline every launch (round 5 removed the 8-wave loop this used to route to: plain products then run on the
+    register-staged kernel, the fused roles are unsupported and skipped)"""
     _lib.load().pcaa_gemm_v2_enable(0 if int(v) == 1 else 1)
 
 
