@@ -758,7 +758,7 @@ def main():
                        # gradient / parameter exchanges of one step: number of collectives, payload bytes, and what a
                        # ring moves per rank and direction for them (2 (w-1)/w x payload for an all-reduce; the
                        # reduce-scatter + all-gather pair of --dp-mode zero moves the same)
-                       "dp": {"mode": a.dp_mode if world > 1 else "none",
+                       "dp": {"mode": a.dp_mode if (world > 1 or a.dp_force) else "none",
                               "grad_compress": a.grad_compress if (world > 1 or a.dp_force) else "none",
                               "collectives_per_step": comm["collectives"], "payload_bytes_per_step": comm["payload_bytes"],
                               # (gather: its payload is almost all all-gathered operands -- (w-1)/w of it per rank)
