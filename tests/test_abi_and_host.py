@@ -106,3 +106,33 @@ def test_ragged_row_tile_predicates_bound_the_padded_size():
     rc = lib.pcaa_gemm_dgrad_bn(one, 512, one, 512, None, one, 512, one, one, one, one, one, 1, 1000, 512, 512,
                                 one, 4, one, None)
     assert rc == 1 and b"recompute variant" in lib.pcaa_last_error()
+
+
+def test_steady_kernel_stats_keeps_only_the_timed_steps(tmp_path):
+    """tools/steady_kernel_stats.py (round 5, evidence hygiene): a rocprofv3 kernel trace of bench.py holds warm-up steps
+    whose launches rocprofv3's own --stats summary averages in; the reduction keeps the last ``--steps`` steps (a step =
+    the launches between two cross_entropy_kernel launches) so that its AverageNs is what roofline.achieved is built from."""
+    import csv
+    import subprocess
+    import sys
+    d = tmp_path / "prof" / "runc"
+    d.mkdir(parents=True)
+    rows, t = [], 0
+    for step in range(7):                                   # 2 warm-up + 5 timed
+        dur = 900_000 if step < 2 else 250_000              # warm-up GEMMs are slower (first touch)
+        for name, ns in (("gemm_bf16_v2_kernel<bf16>", dur), ("bn_act_fwd_kernel", 100_000), ("gemm_bf16_v2_kernel<bf16>", dur),
+                         ("cross_entropy_kernel(float const*)", 7_000), ("adam_kernel", 50_000)):
+            rows.append({"Kernel_Name": name, "Start_Timestamp": t, "End_Timestamp": t + ns})
+            t += ns + 1000
+    with open(d / "1_kernel_trace.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0]))
+        w.writeheader()
+        w.writerows(rows)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "steady_kernel_stats.py"), str(tmp_path / "prof"),
+                          "--steps", "5", "--flop-per-launch", "257.7e9"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    out = {r["Name"]: r for r in csv.DictReader(res.stdout.splitlines())}
+    g = out["gemm_bf16_v2_kernel<bf16>"]
+    assert int(g["Calls"]) == 10 and float(g["AverageNs"]) == 250000.0, "warm-up launches must not be averaged in"
+    assert "1030.8 TFLOP/s" in res.stderr and "0.412" in res.stderr

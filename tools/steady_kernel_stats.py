@@ -5,7 +5,9 @@ rocprofv3's own ``*_kernel_stats.csv`` averages the warm-up launches with the ti
 bench line's 0.401 on the same trace).  This reads the ``*_kernel_trace.csv`` of the same run, keeps only the LAST
 ``--steps`` train steps (a step = everything between two ``cross_entropy_kernel`` launches, which run exactly once per
 step) and writes the summary in rocprofv3's stats layout, so that the dominant kernel's AverageNs here is the figure
-``roofline.achieved`` is computed from.
+``roofline.achieved`` is computed from.  (The window is rotated by the part of a step that precedes its cross-entropy
+launch: it holds the encoder forward of every timed step and the remainder of the step BEFORE each -- the last warm-up
+step's backward stands in for the last timed step's; with >= 2 warm-up steps both are steady state.)
 
     python tools/steady_kernel_stats.py <rocprofv3 output dir> --steps 5 [--flop-per-launch 257.7e9] > profiles/rNN_steady_kernel_stats.csv
 """
