@@ -86,6 +86,24 @@ def _full_step(precision, means, fused=False):
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_config1_full_size_step_vs_reference_golden(precision):
+    """Round 5: the parity-grade modes at BASELINE config[1] against ONE iteration of the REFERENCE's own loop body at
+    that shape (tests/golden/full_B64_N128.npz, make_golden_fullsize.py) -- no oracle in between: losses / embeddings /
+    logits 1e-4, argmax labels bit-exact, every recorded gradient 5e-4 (large tensors: l2 and 1 024 strided samples)."""
+    from helpers import check_step_against_full_golden, full_golden
+    g, m = full_golden(FULL["B"], FULL["N"])
+    assert m["fill_seeds"] == FULL["seeds"]
+    tr, out = _full_step(precision, torch.from_numpy(g["means"]))
+    n = check_step_against_full_golden(
+        g, [out[k].item() for k in LOSS_KEYS], out["preds"], out["sup_fvs"], out["out_labels"],
+        {name: gv.detach().cpu() for name, gv in tr.flat_g.grad_views.items()},
+        {name[2:]: gv.detach().cpu() for name, gv in tr.flat_d.grad_views.items() if name.startswith("D.")},
+        what=f"config[1] {precision} vs the reference")
+    assert n >= 40
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
 def test_config1_full_size_fp32_step_vs_oracle(full_size_oracle, precision):
     """The parity-grade modes at the benchmarked size: the launch paths only this size takes (XCD-pinned split-K of the
     PointNet weight gradients over K = 245 760 rows, 16 statistics replicas, the skinny decoder kernels at M = 64).
