@@ -5,7 +5,9 @@ bench.py's deterministic fills (seeds 0..4) and input seeds (1234..1237):
 
 * ``full_B64_N128.npz``   -- BASELINE config[1] (what bench.py's ``value`` times);
 * ``full_B128_N128.npz``  -- the 2-rank data-parallel step's global batch (2 x 64 sequences, SyncBN);
-* ``full_B64_N256.npz``   -- the sweep's largest point (627 M-parameter decoder).
+* ``full_B64_N256.npz``, ``full_B64_N64.npz``, ``full_B64_N32.npz`` -- the point-subsampling sweep (config[3]; N=256: the
+  627 M-parameter decoder; N=32: the shape timed through hipGraph replay);
+* ``full_B16_N150.npz``   -- the reference's own operating point (constants.py:29,55; decoder widths 1125 ... 18000).
 
 Rounds 2-4 pinned these shapes through the CPU oracle only (itself pinned by the small goldens); the oracle step took
 50-60 s of host time per shape inside the GPU suite.  These files pin them by the reference directly, and
@@ -15,7 +17,7 @@ Weights never travel: the files hold losses, labels, logits, embeddings, and per
 tensor up to 65 536 elements, else (sum, l2, 1 024 strided samples); post-step parameters the same way for the tensors the
 tests look at.  ~0.6 MB per shape.
 
-    python tests/golden/make_golden_fullsize.py            # ~3 min, ~40 GB of host memory at the largest shape
+    python tests/golden/make_golden_fullsize.py [BxN ...]  # ~3 min for all six, ~40 GB of host memory at the largest shape
 """
 import itertools
 import json
@@ -130,7 +132,8 @@ def case(B, N):
 
 def main():
     torch.manual_seed(0)
-    for B, N in ((64, 128), (128, 128), (64, 256)):
+    only = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]          # e.g. 64x32 16x150; default: all
+    for B, N in only or ((64, 128), (128, 128), (64, 256), (64, 64), (64, 32), (16, 150)):
         rec = case(B, N)
         path = os.path.join(HERE, f"full_B{B}_N{N}.npz")
         np.savez_compressed(path, **rec)
@@ -139,8 +142,8 @@ def main():
     with open(prov) as f:
         p = json.load(f)
     p.setdefault("scripts", {})["make_golden_fullsize.py"] = (
-        "full_B64_N128.npz, full_B128_N128.npz, full_B64_N256.npz: one train_variant4 iteration of the REFERENCE at the "
-        "benchmarked shapes (bench.py's fills and input seeds)")
+        "full_B{64,128}_N128.npz, full_B64_N{256,64,32}.npz, full_B16_N150.npz: one train_variant4 iteration of the "
+        "REFERENCE at the benchmarked shapes (bench.py's fills and input seeds)")
     with open(prov, "w") as f:
         json.dump(p, f, indent=1)
 

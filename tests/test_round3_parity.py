@@ -1,4 +1,7 @@
-"""Round-3 parity evidence (GPU): the CPU oracle at EVERY shape bench.py times.
+"""Round-3 parity evidence (GPU): a reference for EVERY shape bench.py times.  Since round 5 the train-step references
+come from goldens generated from the REFERENCE ITSELF at these shapes (tests/golden/full_B*_N*.npz,
+make_golden_fullsize.py: one train_variant4 iteration with bench.py's fills and seeds) -- `_oracle_step` serves a shape
+from its golden when one exists and from the CPU oracle otherwise; the eval-mode encoder tests use the oracle.
 
 * BASELINE config[3] (point-subsampling sweep) at the benchmarked batch: one V4 train step at B=64 for N=64 and
   N=256 -- the launch paths only these shapes take (split-K choices, 16 statistics replicas, the skinny decoder
