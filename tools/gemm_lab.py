@@ -81,13 +81,16 @@ def main():
             ops.gemm(x, KC, W16, KC, P, cout, cin, colstats=stats, out=y, out_dtype=torch.bfloat16, math=PCAA_BF16)
             return stats
 
+        def fwd_plain():
+            return ops.gemm(x, KC, W16, KC, P, cout, cin, out=y, out_dtype=torch.bfloat16, math=PCAA_BF16)
+
         def dgrad_bn():
             return ops.gemm_dgrad_bn(dy, Wt16, ybelow, scale, shift, mean, rstd)
 
         def wgrad():
             return ops.gemm_slabs(dy, RC, x, RC, cout, cin, P, sk, out=dW, math=PCAA_BF16)
 
-        cases = {"fwd+stats": fwd, "dgrad_bn": dgrad_bn, "wgrad": wgrad}
+        cases = {"fwd+stats": fwd, "fwd": fwd_plain, "dgrad_bn": dgrad_bn, "wgrad": wgrad}
         times = {(c, v): [] for c in cases for v in variants}
         for v in variants:                          # correctness first
             lab_set(*v)

@@ -77,6 +77,18 @@ __device__ __forceinline__ void mfma(f32x4& c, const bf16x8& a, const bf16x8& b)
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
+// LAB (round 5, MFMA32=1, TIMING ONLY -- the products are garbage): the same K loop issuing HALF as many MFMAs of twice the
+// length (v_mfma_f32_32x32x16_bf16: 32 cycles of matrix pipe per 4-cycle issue instead of 16).  Question: is the 20-35 % that
+// the 16 requests per wave and step cost issue time that a longer MFMA would cover (one wave per SIMD: while a request sits
+// at the head of the wave's instruction stream nothing else issues, and a 16-cycle MFMA drains before the next one starts)?
+#ifndef MFMA32
+#define MFMA32 0
+#endif
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void mfma32(f32x16& c, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
 // the first product of a tile: C = 0 as the inline constant (the product kernel's mfma0)
 __device__ __forceinline__ void mfma0(f32x4& c, const bf16x8& a, const bf16x8& b) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
@@ -162,6 +174,9 @@ __global__ __launch_bounds__(256) void gemm_v2(const bf16_t* __restrict__ A, con
   auto reqB = [&](bf16_t* st, int jj) { if (!NO_DMA) piece<true>(rB, K, ltn * BN, lkt * BK, st + OP_TILE, wave * 8 + jj, voB); };
 
   f32x4 acc[8][8];
+#if MFMA32
+  f32x16 acc32[4][4];
+#endif
   bf16x8 af[2][8], bfr[2][8];
 
   int vb = blockIdx.x;
@@ -195,6 +210,14 @@ __global__ __launch_bounds__(256) void gemm_v2(const bf16_t* __restrict__ A, con
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if MFMA32
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+#endif
     for (int kt = 0; kt < nt; ++kt) {
       bf16_t* cur = smem + s * STAGE;              // stage of this step (and destination of the requests for step t + 2)
       // LDS byte addresses of the fragment reads: second half of this stage, first half of the next
@@ -221,7 +244,12 @@ __global__ __launch_bounds__(256) void gemm_v2(const bf16_t* __restrict__ A, con
         if (m == 46) BAR_LGKM();
         if (m >= 49 && ((m - 49) & 3) == 0) reqA(cur, (m - 49) >> 2);
 #endif
+#if MFMA32
+        (void)i; (void)j;
+        if (m & 1) mfma32(acc32[m >> 4][(m >> 2) & 3], af[0][2 * (m >> 4) + ((m >> 1) & 1)], bfr[0][2 * ((m >> 2) & 3) + ((m >> 1) & 1)]);
+#else
         mfma(acc[i][j], af[0][i], bfr[0][j]);
+#endif
 #if SCHED
         SB();
 #endif
@@ -241,7 +269,12 @@ __global__ __launch_bounds__(256) void gemm_v2(const bf16_t* __restrict__ A, con
         if (m == 20) BAR_VM();
         if (m >= 22 && m < 38 && (m & 1) == 0) lds_read(bfr[0][(m - 22) >> 1], aB0, ((m - 22) >> 1) * 2048);
         if (m >= 38 && m < 54 && (m & 1) == 0) lds_read(af[0][(m - 38) >> 1], aA0, ((m - 38) >> 1) * 2048);
+#if MFMA32
+        (void)i; (void)j;
+        if (m & 1) mfma32(acc32[m >> 4][(m >> 2) & 3], af[1][2 * (m >> 4) + ((m >> 1) & 1)], bfr[1][2 * ((m >> 2) & 3) + ((m >> 1) & 1)]);
+#else
         mfma(acc[i][j], af[1][i], bfr[1][j]);
+#endif
 #if SCHED
         SB();
 #endif
@@ -290,6 +323,14 @@ __global__ __launch_bounds__(256) void gemm_v2(const bf16_t* __restrict__ A, con
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) t += acc[i][j].x + acc[i][j].y + acc[i][j].z + acc[i][j].w;
+#if MFMA32
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) t += acc32[i][j][e];
+#endif
       if (t == 12345.f) sink[tid] = t;
     }
     vb += gstride;
@@ -603,12 +644,13 @@ int main(int argc, char** argv) {
     printf("%s\n", hipGetErrorString(hipGetLastError()));
     return bad;
   }
-  const bool lab = NO_DMA || NO_LDS || NO_BAR;
+  const bool lab = NO_DMA || NO_LDS || NO_BAR || MFMA32;
+  if (MFMA32) printf("MFMA32=1 (timing only)\n");
   if (VARIANT) printf("VARIANT=%d\n", VARIANT);
   if (lab) printf("NO_DMA=%d NO_LDS=%d NO_BAR=%d EXTRA=%d\n", NO_DMA, NO_LDS, NO_BAR, EXTRA);
   for (int K : {512, 1024})
     for (int N : {512, 1024}) {
-      if (lab && !(K == 1024 && N == 1024)) continue;
+      if (lab && !MFMA32 && !(K == 1024 && N == 1024)) continue;
       run<false>(A, B, C, sink, M, N, K);
       if (!lab) run<true>(A, B, C, sink, M, N, K);
       if (!lab) run_o<false>(A, B, C, sink, M, N, K);
