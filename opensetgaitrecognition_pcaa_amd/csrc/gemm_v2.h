@@ -74,6 +74,9 @@ __device__ __forceinline__ void mfma0(f32x4& c, const bf16x8& a, const bf16x8& b
 #ifndef PCAA_V2_ZERO_BY_MFMA
 #define PCAA_V2_ZERO_BY_MFMA 1
 #endif
+#ifndef PCAA_V2_FUSED_STATS
+#define PCAA_V2_FUSED_STATS 1      // lab builds: 0 = C stores, then the column statistics in a second walk (rounds 4-5a)
+#endif
 __device__ __forceinline__ void lds_read(bf16x8& d, unsigned addr, int off) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(off));
 }
@@ -219,6 +222,58 @@ __device__ __forceinline__ void colstats_finish(const GemmParams& p, float (&t1)
   unsafeAtomicAdd(&p.colstats[base], (double)red[(0 * 2 + 0) * 256 + tid] + (double)red[(0 * 2 + 1) * 256 + tid]);
   unsafeAtomicAdd(&p.colstats[base + p.N], (double)red[(1 * 2 + 0) * 256 + tid] + (double)red[(1 * 2 + 1) * 256 + tid]);
   lds_barrier();      // the scratch is free again (the next tile's epilogue, or the finalize's flag word)
+}
+
+// Whole tiles, no bias (every BatchNorm'd product of the train step): C = acc AND the column statistics in ONE walk over
+// the accumulators -- rows r, r + 1 of a row block together: the pair feeds the packed statistics (v_pk_add / v_pk_fma on
+// the register pair) and two stores.  Separately (epilogue_store, then epilogue_colstats) every accumulator crosses from
+// the accumulator file to the vector registers twice: 512 v_accvgpr_read per wave and tile instead of 256.
+template <typename TC, bool SC>
+__device__ __forceinline__ void epilogue_store_colstats(const GemmParams& p, f32x4 (&acc)[8][8], float* red, int tm, int tn, int wm,
+                                                        int wn, int le, int tid) {
+  const float os = SC ? p.out_scale : 1.f;
+  const int l15 = le & 15, q = le >> 4;
+  TC* C = reinterpret_cast<TC*>(p.C) + ((long)tm * BM + wm * 128 + 4 * q) * p.ldc + tn * BN + wn * 128 + 8 * l15;
+  f32x2 a1[8], a2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a1[j] = a2[j] = f32x2{0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+      f32x2 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[j] = f32x2{acc[i][j][r], acc[i][j][r + 1]};
+        a1[j] += v[j];
+        a2[j] = __builtin_elementwise_fma(v[j], v[j], a2[j]);
+        if constexpr (SC) v[j] *= f32x2{os, os};
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        TC* d = C + (long)(i * 16 + r + e) * p.ldc;
+        if constexpr (sizeof(TC) == 2) {
+          uint4 o;
+          o.x = pack2(v[0][e], v[1][e]);
+          o.y = pack2(v[2][e], v[3][e]);
+          o.z = pack2(v[4][e], v[5][e]);
+          o.w = pack2(v[6][e], v[7][e]);
+          store_nt(d, o);
+        } else {
+          float* df = reinterpret_cast<float*>(d);
+          store_nt(df, f32x4{v[0][e], v[1][e], v[2][e], v[3][e]});
+          store_nt(df + 4, f32x4{v[4][e], v[5][e], v[6][e], v[7][e]});
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);      // (one row pair at a time: hoisted accumulator reads of later pairs spilled the next tile's fragments)
+    }
+  float t1[8], t2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    t1[j] = (a1[j].x + a1[j].y) * os;
+    t2[j] = ((a2[j].x + a2[j].y) * os) * os;
+  }
+  colstats_finish(p, t1, t2, red, tm, tn, wm, wn, le, tid);
 }
 
 // BatchNorm column statistics (sum, sum of squares) of the bias-free accumulator
@@ -629,6 +684,15 @@ _Pragma("unroll") \
     } else if constexpr (EPI == EPI_POOL1 || EPI == EPI_POOL2 || EPI == EPI_POOL4) {
       epilogue_affine_meanpool<EPI == EPI_POOL1 ? 1 : (EPI == EPI_POOL2 ? 2 : 4), RAG>(p, acc, tm, tn, wm, wn, le);
     } else {
+      if constexpr (PCAA_V2_FUSED_STATS && !RAG && sizeof(TC) == 2 && !SPLIT) {
+        if (p.bias == nullptr && p.colstats != nullptr) {
+          epilogue_store_colstats<TC, SPLIT>(p, acc, red, tm, tn, wm, wn, le, te);
+          if (nvb >= ntiles) break;
+          vb = nvb;
+          nvb = vb + gstride;
+          continue;
+        }
+      }
       if constexpr (PCAA_V2_BIAS_BRANCH && (sizeof(TC) == 2 || SPLIT)) {
         if (p.bias != nullptr) epilogue_store<TC, false, SPLIT, RAG, true>(p, acc, tm, tn, wm, wn, le);
         else epilogue_store<TC, false, SPLIT, RAG, false>(p, acc, tm, tn, wm, wn, le);
