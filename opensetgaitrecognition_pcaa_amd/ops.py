@@ -930,7 +930,14 @@ def pointnet_in_bwd_onepass(da, x2d, W2d, scale, shift, mean, rstd, tail, mom=No
         pivot_mom = mom.clone()
         pivot_count = tail.sync(pivot_mom, P)
     stats = new_stats(cout, da.device)
-    G = torch.zeros((NREP, cout, C), dtype=torch.float32, device=da.device)     # replica b % NREP of workgroup b
+    # replica b % NREP of workgroup b; zeroed with the step's statistics (StatsPool.begin: one fill per step) -- a fill of
+    # its own sat on the critical path between the last product of the backward and this launch
+    nG = NREP * cout * C
+    raw = STATS_POOL.take_raw((nG + 1) // 2) if (STATS_POOL is not None and STATS_POOL.buf.device == da.device) else None
+    if raw is None:
+        G = torch.zeros((NREP, cout, C), dtype=torch.float32, device=da.device)
+    else:
+        G = raw.view(torch.float32)[:nG].view(NREP, cout, C)
     tail.arm(stats)
     check(lib.pcaa_pointnet_in_bwd_onepass(_p(da), _dt(da), _p(x2d), C, _p(W2d), _p(scale), _p(shift), _p(mean), _p(rstd),
                                            _p(stats), NREP, _p(G), P, cout, _p(pivot_mom), 1.0 / pivot_count, _s()),
