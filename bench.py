@@ -72,6 +72,12 @@ def parse():
     ap.add_argument("--dp-force", action="store_true",
                     help="N=1 only: create a 1-rank RCCL group and issue the step's collectives on it (exercises the RCCL "
                          "calls and measures their fixed cost on one GPU)")
+    ap.add_argument("--dp-emulate", type=int, default=0, metavar="W",
+                    help="N=1 only: time ONE RANK'S PROGRAM of a W-rank data-parallel job on this GPU (PCAATrainer "
+                         "emulate_world: gradient scale 1/W, 64 W stacked rows in the gathered decoder update, every collective "
+                         "replaced by a device operation of the same bytes).  The line says `emulated`; n_gpus stays 1 and value "
+                         "is this one rank's sequences/s.  Without the flag the default line carries the same measurement for "
+                         "W in (2, 4, 8) under `dp_emulated`, with a `scale_projection` from stated xGMI figures")
     ap.add_argument("--grad-compress", default="auto", choices=["auto", "none", "bf16"],
                     help="decoder gradient buckets cross the wire as bf16 (fp32 master gradients, moments and weights); auto "
                          "= bf16 in the bf16 throughput mode, none in the fp32 parity mode (docs/LAB_LOG.md section 6)")
@@ -252,7 +258,7 @@ def device_fill_(module, seed):
             t.copy_(torch.randn(t.shape, generator=g, device=t.device) / fan_in ** 0.5)
 
 
-def build_trainer(a, N, dev, pg, precision, fill="deterministic"):
+def build_trainer(a, N, dev, pg, precision, fill="deterministic", emulate_world=0):
     from opensetgaitrecognition_pcaa_amd import constants, synthetic as syn
     from opensetgaitrecognition_pcaa_amd.train import PCAATrainer
     from opensetgaitrecognition_pcaa_amd.utils import sample_distant_points
@@ -260,9 +266,9 @@ def build_trainer(a, N, dev, pg, precision, fill="deterministic"):
     cfg.update(NMAX=N, TRAIN_CLASSES=list(range(a.classes)), BATCH_SIZE=a.batch)
     tr = PCAATrainer(cfg, device=dev, precision=precision, process_group=pg, sync_bn=a.sync_bn,
                      dp_zero=(a.dp_mode == "zero") and pg is not None,
-                     dp_gather=(a.dp_mode == "gather") and pg is not None,
+                     dp_gather=(a.dp_mode == "gather") and (pg is not None or bool(emulate_world)),
                      grad_compress=None if a.grad_compress == "none" else a.grad_compress,
-                     force_collectives=a.dp_force,
+                     force_collectives=a.dp_force, emulate_world=emulate_world,
                      fused_decoder_update=("all" if a.decoder_update == "fused" else False))
     for i, m in enumerate((tr.encoder, tr.decoder, tr.discriminator, tr.decoder_projection_head,
                            tr.discriminator_projection_head)):
@@ -430,6 +436,74 @@ def leg_sections(tr, inputs, steps=10):
             "note": "median over %d steps of event intervals on the main stream; D-step: critic stream, hidden" % steps}
 
 
+XGMI_LINKS, XGMI_LINK_GBS = 7, 153.0      # per GPU: 7 point-to-point links x ~153 GB/s (MI355X_MICROARCH.md)
+
+
+def leg_dp_emulated(a, dev, N, worlds=(2, 4, 8), steps=10, warmup=3):
+    """One rank's program of a W-rank job on this one GPU (PCAATrainer emulate_world / dist.EmulatedExchange), for each W
+    and each decoder exchange scheme, beside the single-process step built and timed the same way; and what those numbers
+    say about W real GPUs under STATED assumptions (`scale_projection`).  Nothing here is a multi-GPU measurement."""
+    import copy
+    from opensetgaitrecognition_pcaa_amd import constants
+    B, C, K, T = a.batch, a.features, a.classes, constants.NSTEPS
+    inputs = make_inputs(B, T, N, C, K, dev)
+
+    def run(world, mode):
+        aa = copy.copy(a)
+        aa.dp_mode, aa.dp_force, aa.sync_bn = mode, False, False
+        aa.grad_compress = "bf16" if a.precision == "bf16" else "none"
+        tr, _ = build_trainer(aa, N, dev, None, a.precision, fill="device", emulate_world=world)
+        for _ in range(warmup):
+            tr.step(*inputs)
+        ms_list, out = time_single_gpu(lambda: tr.step(*inputs), steps, 3)
+        ent = {"world": world, "dp_mode": tr.dp_scheme, "ms_per_step": statistics.median(ms_list), "windows_ms_per_step": ms_list,
+               "steps": steps, "finite_loss": bool(torch.isfinite(out["tot_loss"]).item()),
+               "collectives_per_step": tr.comm["collectives"], "payload_bytes_per_step": tr.comm["payload_bytes"],
+               "gather_payload_bytes": tr.comm.get("gather_bytes", 0), "allreduce_payload_bytes": tr.comm.get("allreduce_bytes", 0)}
+        del tr
+        torch.cuda.empty_cache()
+        return ent
+
+    base = run(0, "allreduce")
+    legs = []
+    default_mode = "gather" if a.precision == "bf16" else "allreduce"
+    for w in worlds:
+        for mode in ((default_mode, "allreduce") if default_mode != "allreduce" else ("allreduce",)):
+            if mode == "allreduce" and w != max(worlds):
+                continue                       # the all-reduce rank program does not depend on W: timed once, at the largest
+            ent = run(w, mode)
+            # bytes this rank puts on / takes off the wire per step: an all-gather delivers the other ranks' (w-1)/w of its
+            # payload, a ring all-reduce moves 2 (w-1)/w of its payload per rank and direction
+            wire = (w - 1) / w * ent["gather_payload_bytes"] + 2.0 * (w - 1) / w * ent["allreduce_payload_bytes"]
+            agg_ms = wire / (XGMI_LINKS * XGMI_LINK_GBS * 1e9) * 1e3
+            link_ms = wire / (XGMI_LINK_GBS * 1e9) * 1e3
+            ent["vs_single_process_step"] = ent["ms_per_step"] / base["ms_per_step"]
+            ent["scale_projection"] = {
+                "wire_bytes_per_rank": wire,
+                "wire_ms_all_links": agg_ms, "wire_ms_one_link": link_ms,
+                # weak scaling: W ranks each finish 64 sequences per step
+                "projected_ms_per_step": ent["ms_per_step"] + agg_ms,
+                "projected_value": w * B / (ent["ms_per_step"] + agg_ms) * 1e3,
+                "projected_speedup_vs_1gpu": w * base["ms_per_step"] / (ent["ms_per_step"] + agg_ms),
+                "pessimistic_one_link_exposed": {"projected_ms_per_step": ent["ms_per_step"] + link_ms,
+                                                 "projected_speedup_vs_1gpu": w * base["ms_per_step"] / (ent["ms_per_step"] + link_ms)}}
+            legs.append(ent)
+    return {"label": "EMULATED on one GPU -- not a multi-GPU measurement",
+            "what": "one rank's program of a W-rank weak-scaling job (B=%d per rank, N=%d): gradient scale 1/W, the fused decoder "
+                    "update from 64 W stacked rows (pcaa_skinny_linear_wgrad_adam_rows), every collective replaced by a device "
+                    "operation of the same bytes on its own stream (all-reduce: in-place scale, all-gather: own rows + W-1 staged "
+                    "copies); 3 warm-up + `steps` steps x 3 windows, median" % (B, N),
+            "single_process_step": base, "legs": legs,
+            "assumptions": ["scale_projection adds the rank's wire bytes over %d xGMI links x %.0f GB/s (all links busy, a direct "
+                            "all-gather on the fully connected node) with NO overlap credited although the gathers are waited for "
+                            "on the side stream only; `pessimistic_one_link_exposed` prices the same bytes over ONE link (a ring), "
+                            "still fully exposed" % (XGMI_LINKS, XGMI_LINK_GBS),
+                            "no latency term (4-10 collectives per step at ~20-40 us each would add 0.1-0.4 ms if none overlapped), "
+                            "no rank skew, per-rank BatchNorm (no SyncBN exchange)",
+                            "the emulated collectives occupy one HIP stream like RCCL's, but run as copy / scale kernels on the CUs "
+                            "rather than as RCCL's kernels: CU contention of the real collectives is approximated, not reproduced"]}
+
+
 def workload_sweep(a, dev):
     """BASELINE config[3] as a line of its own: the train step at N in {32,64,128,256}, B=64, one GPU."""
     from opensetgaitrecognition_pcaa_amd import constants, functional as F_hip
@@ -547,6 +621,10 @@ def main():
     import torch.distributed as dist
     from opensetgaitrecognition_pcaa_amd import constants, functional as F_hip, ops
 
+    if a.dp_emulate and (world > 1 or a.dp_force):
+        raise SystemExit("bench.py: --dp-emulate W times one rank's program on ONE GPU: use it with --gpus 1 and without --dp-force")
+    if a.dp_emulate and a.dp_mode == "zero":
+        raise SystemExit("bench.py: --dp-emulate covers --dp-mode gather / allreduce")
     dev_index = int(os.environ.get("PCAA_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -563,9 +641,7 @@ def main():
     B, N, C, K, T = a.batch, a.points, a.features, a.classes, constants.NSTEPS
     constants.NFEATURES = C
     F_hip.set_precision(a.precision)
-    tr, cfg = build_trainer(a, N, dev, pg, a.precision)
-    decoder_update = "fused wgrad+adam" if (tr.fused_decoder_update and a.precision == "bf16" and
-                                            ((world == 1 and not a.dp_force) or a.dp_mode == "gather")) else "wgrad, adam"
+    tr, cfg = build_trainer(a, N, dev, pg, a.precision, emulate_world=a.dp_emulate)
     pcs, gt, z0, al = make_inputs(B, T, N, C, K, dev, rank)
 
     def barrier():
@@ -615,7 +691,15 @@ def main():
     dt = statistics.median(windows_s)
     loss_ok = bool(torch.isfinite(out["tot_loss"]).item())
     comm = dict(tr.comm)
-    single = world == 1 and not a.dp_force
+    single = world == 1 and not a.dp_force and not a.dp_emulate
+    # what the timed steps DID with the decoder's gradients (the trainer falls back from the gathered-operand scheme to
+    # all-reduce buckets when world x batch > 512 rows or without its side stream: the line reports the scheme that ran)
+    dp_scheme = tr.dp_scheme
+    decoder_update = "fused wgrad+adam" if (tr.fused_decoder_update and dp_scheme in ("none", "gather")
+                                            and tr._side is not None) else "wgrad, adam"
+    if a.dp_mode == "gather" and dp_scheme not in ("gather", "none") and "--dp-mode" in sys.argv:
+        raise SystemExit(f"bench.py: --dp-mode gather was asked for but the step ran the {dp_scheme!r} scheme "
+                         f"(gathered operands need world x batch <= 512 rows, bf16 mode and the fused update)")
 
     def timed_leg(trainer, batches, steps, warmup):
         """warmup untimed + steps timed trainer steps; ``batches`` yields (pcs, gt).  Same bracket as the main
@@ -635,7 +719,7 @@ def main():
         sections = leg_sections(tr, (pcs, gt, z0, al))
 
     batcher_leg = None
-    if not a.no_batcher_leg and not use_graph and world == 1:
+    if not a.no_batcher_leg and not use_graph and single:
         # datasets.py batch collation inside the timed loop: a packed point-major store of `pool` synthetic crops
         # resident in HBM, every step's batch gathered from it in the DataLoader's shuffled order
         # (DeviceBatcher = pcaa_gather_rows), then the same train step
@@ -661,7 +745,7 @@ def main():
     torch.cuda.empty_cache()
 
     parity_leg = None
-    if a.precision == "bf16" and not a.no_parity_mode and not use_graph and world == 1:
+    if a.precision == "bf16" and not a.no_parity_mode and not use_graph and single:
         # the SAME workload in the two parity-grade modes -- the modes the 1e-4 / bit-exact label tests run in
         # (tests/test_round2_parity.py::test_config1_full_size_fp32_step_vs_oracle, both parametrisations):
         # "fp16x3": fp32 storage, PointNet products as three bf16 MFMA passes over [hi | lo] operand images;
@@ -711,7 +795,7 @@ def main():
             torch.cuda.synchronize()
             exposed = sorted(trl.exposed_comm_us())
             exp_us = max_over_ranks(statistics.median(exposed)) if exposed else None
-            dp_legs.append({"dp_mode": mode_, "grad_buckets": "bf16" if comp == "bf16" else "fp32", "sync_bn": sbn,
+            dp_legs.append({"dp_mode": mode_, "dp_scheme_ran": trl.dp_scheme, "grad_buckets": "bf16" if comp == "bf16" else "fp32", "sync_bn": sbn,
                             "ms_per_step": d / lsteps * 1e3, "value": world * B * lsteps / d, "steps": lsteps,
                             "exposed_comm_us": exp_us,
                             "collectives_per_step": trl.comm["collectives"],
@@ -720,9 +804,12 @@ def main():
             del trl
             torch.cuda.empty_cache()
 
-    sweep = infer = c5 = ref_default = None
+    sweep = infer = c5 = ref_default = dp_emulated = None
     if single and not a.no_extra_legs and a.precision == "bf16":
         esteps = max(1, min(a.steps, 10))
+        # BASELINE config[2] (8 x MI355X, global B=512) has never had a node to run on: one rank's program of a world of
+        # 2 / 4 / 8 on this GPU, and the projection that follows from it under stated link figures
+        dp_emulated = leg_dp_emulated(a, dev, N, steps=esteps)
         # BASELINE config[3]: the point-subsampling sweep (train_pointsubsampling.py:19-71), 10 steps x 3 windows each
         sweep = [leg_train_shape(a, dev, n, C, esteps, 3) for n in (32, 64, 128, 256)]
         # BASELINE config[4]: open-set inference at B=1024 (inference_PCAA.py:382-469)
@@ -739,13 +826,29 @@ def main():
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = world * B * a.steps / dt
+        dp_on = world > 1 or a.dp_force or bool(a.dp_emulate)
+        workload = (f"PCAA V4 train step (enc+dec+disc fwd/bwd, WGAN-GP, Chamfer, 2x Adam), "
+                    f"B={B}/GPU T={T} N={N} C={C} K={K}, BASELINE config[1]")
+        if dp_on:
+            # what `value` timed under data parallelism, in the workload string itself
+            scheme_words = {"gather": "dp_gather: the wide decoder layers all-gather their weight-gradient operands and every rank "
+                                      "forms the global gradient inside the fused wgrad+Adam kernel; encoder / head / critic "
+                                      "gradients all-reduced",
+                            "allreduce": "all-reduce of every gradient (per-layer decoder buckets, "
+                                         + ("bf16" if a.grad_compress == "bf16" else "fp32") + " on the wire)",
+                            "zero": "ZeRO-1: decoder gradients reduce-scattered, sharded Adam, parameters all-gathered; the rest all-reduced",
+                            "none": "no exchange"}[dp_scheme]
+            workload += f"; data parallel over {world if not a.dp_emulate else a.dp_emulate} ranks: {scheme_words}; " + \
+                        ("SyncBN" if a.sync_bn else "per-rank BatchNorm statistics")
+        if a.dp_emulate:
+            workload += (f"; EMULATED: this is ONE rank's program of a {a.dp_emulate}-rank job on one GPU (collectives = device "
+                         "operations of the same bytes), value = that one rank's sequences/s, not a multi-GPU measurement")
         line = {
             "metric": "gait sequences/sec (train step)", "value": value, "unit": "sequences/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if a.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"PCAA V4 train step (enc+dec+disc fwd/bwd, WGAN-GP, Chamfer, 2x Adam), "
-                                   f"B={B}/GPU T={T} N={N} C={C} K={K}, BASELINE config[1]",
+            "config": {"workload": workload,
                        "global_batch": B * world, "precision": a.precision,
                        "parallelism": f"dp{world}", "sync_bn": bool(a.sync_bn), "finite_loss": loss_ok,
                        "hip_graph": bool(use_graph),
@@ -756,18 +859,20 @@ def main():
                        # single process, bf16: the decoder's wide weight gradients are consumed by a fused Adam kernel
                        "decoder_update": decoder_update,
                        # gradient / parameter exchanges of one step: number of collectives, payload bytes, and what a
-                       # ring moves per rank and direction for them (2 (w-1)/w x payload for an all-reduce; the
-                       # reduce-scatter + all-gather pair of --dp-mode zero moves the same)
-                       "dp": {"mode": a.dp_mode if (world > 1 or a.dp_force) else "none",
-                              "grad_compress": a.grad_compress if (world > 1 or a.dp_force) else "none",
+                       # ring moves per rank and direction for them (2 (w-1)/w x payload for an all-reduce, (w-1)/w for
+                       # an all-gather / reduce-scatter); `mode` is the scheme the timed steps RAN, `asked` the flag
+                       "dp": {"mode": dp_scheme if dp_on else "none", "asked": a.dp_mode if dp_on else "none",
+                              "grad_compress": a.grad_compress if dp_on else "none",
                               "collectives_per_step": comm["collectives"], "payload_bytes_per_step": comm["payload_bytes"],
-                              # (gather: its payload is almost all all-gathered operands -- (w-1)/w of it per rank)
-                              "ring_wire_bytes_per_rank": (2.0 * (world - 1) / world * comm["payload_bytes"]
-                                                           if a.dp_mode == "allreduce" else
-                                                           1.0 * (world - 1) / world * comm["payload_bytes"])},
+                              "ring_wire_bytes_per_rank": ((world - 1) / world) * (
+                                  2.0 * comm.get("allreduce_bytes", 0) + comm.get("gather_bytes", 0) + comm.get("scatter_bytes", 0))},
                        # time the host spends enqueueing one step (no synchronisation inside step())
                        "host_enqueue_ms_per_step": host_s / (a.steps * a.windows) * 1e3},
         }
+        if a.dp_emulate:
+            line["emulated"] = True
+            line["config"]["emulated_world"] = a.dp_emulate
+            line["config"]["parallelism"] = f"one rank of an emulated dp{a.dp_emulate}"
         if dp_legs is not None:
             line["dp_legs"] = {"note": "every exchange scheme of the data-parallel step, timed in this run (3 warm-up + "
                                        "`steps` steps, barrier + synchronize on both sides, max over ranks); exposed_comm_us = "
@@ -776,7 +881,16 @@ def main():
                                        "where every decoder bucket is back, + (ZeRO) the waits for the all-gathers of the "
                                        "updated decoder shards, + (SyncBN) every synchronous statistics all-reduce (HIP "
                                        "events, train.PCAATrainer.time_comm / exposed_comm_us); the line's `value` is the "
-                                       "leg marked is_default", "legs": dp_legs}
+                                       "leg marked is_default"
+                                       + ("; world = 1 here: these are FORCED 1-rank collectives (their fixed cost on one GPU), "
+                                          "not a measurement of any exchange scheme between GPUs" if world == 1 else ""),
+                               "legs": dp_legs}
+            # north_star names the RCCL all-reduce of gradients: that scheme's throughput beside `value` at top level
+            ar = [l for l in dp_legs if l["dp_mode"] == "allreduce" and not l["sync_bn"]
+                  and l["grad_buckets"] == ("bf16" if a.grad_compress == "bf16" else "fp32")]
+            if ar:
+                line["value_allreduce"] = ar[0]["value"]
+                line["ms_per_step_allreduce"] = ar[0]["ms_per_step"]
         if batcher_leg is not None:
             line["with_batcher"] = batcher_leg
         if sweep is not None:
@@ -790,6 +904,8 @@ def main():
             line["c5"] = c5
         if ref_default is not None:
             line["ref_default"] = ref_default
+        if dp_emulated is not None:
+            line["dp_emulated"] = dp_emulated
         if sections is not None:
             line["gpu_sections"] = sections
         if agg:

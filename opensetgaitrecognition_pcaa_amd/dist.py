@@ -57,3 +57,109 @@ def zero_slices(dec_start, total, world, chunks, rank):
     per = n // world
     return [(dec_start + c * n, dec_start + (c + 1) * n, dec_start + c * n + rank * per, dec_start + c * n + (rank + 1) * per)
             for c in range(chunks)]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The step's exchanges behind one small interface, so that a one-GPU box can run ONE RANK'S PROGRAM OF A WORLD OF W
+# (round 6: no multi-GPU node has been available in any round).
+# ----------------------------------------------------------------------------------------------------------------------
+class GroupExchange:
+    """The real thing: torch.distributed collectives on ``group`` (RCCL on the GPU, gloo in the CPU tests)."""
+
+    emulated = False
+
+    def __init__(self, group):
+        self.group = group
+        self.world = dist.get_world_size(group)
+
+    def all_reduce(self, t, async_op=False, tag=None):
+        return dist.all_reduce(t, group=self.group, async_op=async_op)
+
+    def all_gather_into_tensor(self, dst, src, async_op=False, tag=None):
+        return dist.all_gather_into_tensor(dst, src, group=self.group, async_op=async_op)
+
+
+class _StreamWork:
+    """What an emulated collective returns: ``wait()`` makes the CURRENT stream wait for it (like a c10d work's)."""
+
+    __slots__ = ("event",)
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class EmulatedExchange:
+    """One rank of a world of ``world`` ranks on ONE GPU, without peers: every collective becomes a device operation
+    that moves the bytes the rank's memory system would see and leaves the values the collective would leave IF EVERY
+    RANK HELD THIS RANK'S DATA (or, for the gathered operands, the peers' rows the caller staged with ``set_peers``):
+
+    * ``all_reduce(t)``: t *= world in place (reads and writes t once: what a ring all-reduce reads and writes per rank up
+      to the factor 2 (w-1)/w), the sum of ``world`` identical shards;
+    * ``all_gather_into_tensor(dst, src)``: own rows into slot 0, the other ``world - 1`` slots from the staged peers of
+      that ``tag`` (``set_peers``; shape [world - 1, *src.shape]) or, without any, copies of ``src``: (world - 1) x the
+      bytes arrive in ``dst``, as from the wire.
+
+    Like RCCL's, the operations run on a stream of their own that picks up behind the issuing stream; the returned work's
+    ``wait()`` orders the waiting stream behind them.  What is NOT emulated: the wire itself (latency, link bandwidth,
+    other ranks' skew) -- bench.py's ``scale_projection`` adds that from stated link figures -- and SyncBN."""
+
+    emulated = True
+
+    def __init__(self, world, device):
+        if world < 1:
+            raise ValueError("EmulatedExchange: world must be >= 1")
+        self.world = int(world)
+        self.group = None
+        self.stream = torch.cuda.Stream(device=device)
+        self.peers = {}
+        self.bytes_moved = 0
+
+    def set_peers(self, tag, rows):
+        """``rows`` [world - 1, *shape of the gathered source]: what the other ranks contribute to the gathers tagged ``tag``"""
+        self.peers[tag] = rows
+
+    def _issue(self, fn):
+        cur = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            fn()
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        return _StreamWork(done)
+
+    def all_reduce(self, t, async_op=False, tag=None):
+        t.record_stream(self.stream)
+        work = self._issue(lambda: t.mul_(self.world))
+        self.bytes_moved += 2 * t.numel() * t.element_size()
+        if async_op:
+            return work
+        work.wait()
+        return None
+
+    def all_gather_into_tensor(self, dst, src, async_op=False, tag=None):
+        n = src.shape[0]
+        if dst.shape[0] != n * self.world:
+            raise ValueError(f"EmulatedExchange.all_gather_into_tensor: dst has {dst.shape[0]} rows, want {n * self.world}")
+        peers = self.peers.get(tag)
+        if peers is not None and tuple(peers.shape) != (self.world - 1,) + tuple(src.shape):
+            raise ValueError(f"EmulatedExchange: peers of {tag!r} are {tuple(peers.shape)}, want "
+                             f"{(self.world - 1,) + tuple(src.shape)}")
+
+        def fn():
+            dst[:n].copy_(src)
+            rest = dst[n:].view((self.world - 1,) + tuple(src.shape)) if self.world > 1 else None
+            if rest is not None:
+                rest.copy_(peers if peers is not None else src.unsqueeze(0).expand_as(rest))
+        dst.record_stream(self.stream)
+        src.record_stream(self.stream)
+        work = self._issue(fn)
+        self.bytes_moved += 2 * dst.numel() * dst.element_size()
+        if async_op:
+            return work
+        work.wait()
+        return None

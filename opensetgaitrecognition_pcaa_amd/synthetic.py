@@ -13,7 +13,11 @@ import torch
 
 _BIG_FILLS = {}                      # (shape, seed, index) -> array, insertion-ordered: oldest evicted first
 _BIG_FILL_MIN = 1 << 22              # floats
-_BIG_FILL_BUDGET = 1 << 30           # floats kept in total (4 GB)
+import os as _os
+
+# floats kept in total (default 4 GB of host memory per process; PCAA_FILL_CACHE_FLOATS=0 turns the cache off, e.g. in
+# the rank processes of a multi-GPU bench)
+_BIG_FILL_BUDGET = int(_os.environ.get("PCAA_FILL_CACHE_FLOATS", 1 << 30))
 
 
 def fill_tensor_like(name: str, shape, seed: int, index: int) -> np.ndarray:
@@ -46,9 +50,11 @@ def fill_tensor_like(name: str, shape, seed: int, index: int) -> np.ndarray:
     out = rng.standard_normal(shape, dtype=np.float32)
     out *= np.float32(1.0 / math.sqrt(fan_in))
     n = out.size
-    if n >= _BIG_FILL_MIN:
+    if n >= _BIG_FILL_MIN and n <= _BIG_FILL_BUDGET:
         # the wide decoder matrices (up to 470 M floats, seconds of draws each) are asked for again and again by tests and
-        # bench legs that build the same architecture from the same seeds: keep the most recent ones (read-only)
+        # bench legs that build the same architecture from the same seeds: keep the most recent ones -- READ-ONLY: the array
+        # itself is handed out again, so an in-place edit by one caller would corrupt every later fill (numpy enforces it)
+        out.setflags(write=False)
         _BIG_FILLS[key] = out
         while sum(v.size for v in _BIG_FILLS.values()) > _BIG_FILL_BUDGET and len(_BIG_FILLS) > 1:
             _BIG_FILLS.pop(next(iter(_BIG_FILLS)))
@@ -63,9 +69,13 @@ def deterministic_fill_(module_or_state_dict, seed: int):
     sd = module_or_state_dict
     if isinstance(sd, torch.nn.Module):
         sd = sd.state_dict()
+    import warnings
     for i, (name, t) in enumerate(sd.items()):
         v = fill_tensor_like(name, t.shape, seed, i)
-        t.copy_(torch.from_numpy(v).to(t.dtype).reshape(t.shape))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", UserWarning)       # (cached fills are read-only arrays; they are only read here)
+            src = torch.from_numpy(v)
+        t.copy_(src.to(t.dtype).reshape(t.shape))
     return module_or_state_dict
 
 

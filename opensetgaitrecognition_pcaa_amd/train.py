@@ -204,7 +204,7 @@ class PCAATrainer:
 
     def __init__(self, config, n_classes=None, device="cuda", variant="v4", precision=None,
                  process_group=None, sync_bn=False, learn_centroids=False, dp_zero=False, grad_compress=None,
-                 force_collectives=False, fused_decoder_update=True, dp_gather=False):
+                 force_collectives=False, fused_decoder_update=True, dp_gather=False, emulate_world=0):
         """``fused_decoder_update`` (single process, every precision mode since round 5; "all" is the older spelling of
         True): the decoder's wide weight gradients are formed and consumed by one kernel per layer that applies Adam in
         place (pcaa_skinny_linear_wgrad_adam; the parity modes "fp32" / "fp16x3" use its fp32-product form) -- those
@@ -222,7 +222,11 @@ class PCAATrainer:
         (4 world B (in + out) bytes against 4 in out: ~10x less on the wire), and every rank forms the GLOBAL gradient
         inside the fused weight-gradient + Adam kernel (pcaa_skinny_linear_wgrad_adam_rows): the update stays 24 B per
         parameter and no Adam pass over the decoder follows the exchange.  Applies while world * B <= 512; mathematically
-        the all-reduce scheme's step (sum over ranks of dz_r^T x_r = stacked-rows product)."""
+        the all-reduce scheme's step (sum over ranks of dz_r^T x_r = stacked-rows product).
+        ``emulate_world=W`` (round 6; no process group): this process runs ONE RANK'S PROGRAM of a W-rank job on its own --
+        gradient scale 1/W, W * B stacked rows in the gathered update, every collective replaced by a device operation of
+        the same bytes on a stream of its own (dist.EmulatedExchange; peers' gathered rows can be staged there).  It
+        measures what the rank's GPU does at that world size; the wire is not in it."""
         self.cfg = dict(config)
         self.K = n_classes if n_classes is not None else len(config["TRAIN_CLASSES"])
         self.N = config["NMAX"]
@@ -237,11 +241,22 @@ class PCAATrainer:
         # SyncBN group: installed in functional for the duration of this trainer's train-mode work only
         # (_sync_bn()), so a later trainer or module call in the same process never all-reduces over it
         self._sync_bn_group = None
+        self._xchg = None               # the step's exchanges (dist.GroupExchange; emulate_world: dist.EmulatedExchange)
         if process_group is not None:
-            import torch.distributed as dist
-            self.world = dist.get_world_size(process_group)
+            if emulate_world:
+                raise ValueError("PCAATrainer: emulate_world runs without a process group")
+            self._xchg = pdist.GroupExchange(process_group)
+            self.world = self._xchg.world
             if sync_bn:
                 self._sync_bn_group = process_group
+        elif emulate_world:
+            if sync_bn or dp_zero:
+                raise ValueError("PCAATrainer: emulate_world covers the all-reduce and gathered-operand schemes without SyncBN")
+            self._xchg = pdist.EmulatedExchange(int(emulate_world), self.device)
+            self.world = int(emulate_world)
+            force_collectives = True
+        # what the LAST step did with the decoder's gradients: "none" (single process), "allreduce", "zero", "gather"
+        self.dp_scheme = "none"
         self._dp_zero_arg = bool(dp_zero)
         self._dp_gather = bool(dp_gather)
         if self._dp_gather and self._dp_zero_arg:
@@ -259,7 +274,8 @@ class PCAATrainer:
         # main stream, one pair around every place where that stream waits for an exchange: (1) from just before the
         # (synchronous) all-reduce of the encoder + head gradients to just after the waits for the decoder buckets;
         # (2) ZeRO: the waits for the all-gathers of the updated decoder shards (they come after the encoder's Adam);
-        # (3) SyncBN: each synchronous statistics all-reduce (functional._sync_stats).  The sum over a step's pairs is
+        # (3) SyncBN: each synchronous statistics all-reduce (functional._sync_stats); (4) the join with the side stream's
+        # decoder update, which is where a late all-gather of the gathered-operand scheme is paid.  The sum over a step's pairs is
         # what the step pays for communication it could not hide ("exposed"), measured where it is paid.
         # exposed_comm_us() turns the record into microseconds per step.
         self.time_comm = False
@@ -454,7 +470,7 @@ class PCAATrainer:
                 self._zero_g16 = [torch.empty(n // self.world, dtype=torch.bfloat16, device=self.device)
                                   for _ in range(self._zero_chunks)]      # this rank's slice of the bf16 sum
         self._g16_direct = set()
-        if self.grad_compress == "bf16" and self.pg is not None:
+        if self.grad_compress == "bf16" and self._xchg is not None:
             self._g16 = torch.zeros(self.flat_g.total, dtype=torch.bfloat16, device=self.device)
             # the wide decoder layers' weight gradients are produced as bf16 straight into the wire image
             # (ops.skinny_linear_wgrad with a bf16 destination): layer -> (offset, bf16 view in the stored shape)
@@ -511,13 +527,14 @@ class PCAATrainer:
             m.eval()
 
     # ------------------------------------------------------------------ one step
-    def _count(self, nbytes):
+    def _count(self, nbytes, kind="allreduce"):
+        """``kind``: "allreduce" (a ring moves 2 (w-1)/w of the payload per rank), "gather" / "scatter" ((w-1)/w of it)"""
         self.comm["collectives"] += 1
         self.comm["payload_bytes"] += int(nbytes)
+        self.comm[kind + "_bytes"] = self.comm.get(kind + "_bytes", 0) + int(nbytes)
 
     def _allreduce(self, t, async_op=False):
-        if self.pg is not None and (self.world > 1 or self._force_collectives) and t.numel():
-            import torch.distributed as dist
+        if self._collective() and t.numel():
             in_dec = (t.data_ptr() >= self.flat_g.g.data_ptr() + 4 * self._dec_start
                       and t.data_ptr() < self.flat_g.g.data_ptr() + 4 * self.flat_g.total)
             off = (t.data_ptr() - self.flat_g.g.data_ptr()) // 4 if in_dec else -1
@@ -530,15 +547,20 @@ class PCAATrainer:
                 if off not in self._g16_direct:          # else: the weight-gradient kernel wrote the bf16 image itself
                     g16.copy_(t)
                 self._count(2 * t.numel())
-                work = dist.all_reduce(g16, group=self.pg, async_op=async_op)
+                work = self._xchg.all_reduce(g16, async_op=async_op)
                 if not async_op:
                     t.copy_(g16)
                     return None
                 return _CompressedWork(work, t, g16)
             assert off not in self._g16_direct, "a bf16-direct gradient bucket reached the fp32 all-reduce"
             self._count(t.numel() * t.element_size())
-            return dist.all_reduce(t, group=self.pg, async_op=async_op)
+            return self._xchg.all_reduce(t, async_op=async_op)
         return None
+
+    def _collective(self):
+        """whether this trainer's steps issue collectives (a group of more than one rank, a forced 1-rank group, or the
+        emulation of a world)"""
+        return self._xchg is not None and (self.world > 1 or self._force_collectives)
 
     def _advance_g(self, supervise):
         """Begin optimizer_G's next step: the main count always, the supervised-only parameters' count on
@@ -717,7 +739,7 @@ class PCAATrainer:
 
         # (4) G-step forward: decoder + Chamfer (+ fused gradient)
         hproj = st.hproj if self.decoder_projection_head is not None else sup_fv
-        w16 = self._refresh_w16(mode, B, self.pg is not None and (self.world > 1 or self._force_collectives))
+        w16 = self._refresh_w16(mode, B, self._collective())
         rec, acts = F_hip.decoder_forward(dec, hproj, mode, images=w16)
         F_hip.mark("dec_fwd")
         rec4 = rec.view(B, self.C, self.T, self.N)
@@ -732,7 +754,7 @@ class PCAATrainer:
             ops.current_stream().wait_event(joined)
             joined = None
         dh = None
-        collective = self.pg is not None and (self.world > 1 or self._force_collectives)
+        collective = self._collective()
         # Data-parallel: a decoder layer's gradient goes onto the wire as soon as it exists.  The backward
         # produces the 118 M-parameter output layer FIRST (75 % of all gradient bytes), a quarter of a millisecond
         # before the decoder backward is over: its all-reduce is issued from the wgrad stream right behind its
@@ -778,8 +800,8 @@ class PCAATrainer:
         rows_all = self.world * B
         gather = (collective and self._dp_gather and not zero and mode == "bf16" and self.fused_decoder_update
                   and self._side is not None and ops.gathered_rows_alloc(rows_all) is not None)
+        self.dp_scheme = "zero" if zero else ("gather" if gather else ("allreduce" if collective else "none"))
         if gather:
-            import torch.distributed as dist
             R = ops.gathered_rows_alloc(rows_all)
 
             def gather_update(layer, Wv, mv, vv):
@@ -790,10 +812,10 @@ class PCAATrainer:
                                                   torch.zeros((R, x.shape[1]), dtype=torch.float32, device=self.device))
                     dz_all, x_all = self._gather_bufs[key]
                     works = []
-                    for dst, src in ((dz_all, dz2), (x_all, x)):
+                    for dst, src, which in ((dz_all, dz2, "dz"), (x_all, x, "x")):
                         src = src.contiguous()
-                        self._count(4 * rows_all * src.shape[1])
-                        works.append(dist.all_gather_into_tensor(dst[:rows_all], src, group=self.pg, async_op=True))
+                        self._count(4 * rows_all * src.shape[1], "gather")
+                        works.append(self._xchg.all_gather_into_tensor(dst[:rows_all], src, async_op=True, tag=(layer, which)))
                     deferred.append((dz_all, x_all, Wv, mv, vv, None, works))
                 return cb
 
@@ -859,10 +881,10 @@ class PCAATrainer:
                     # the exchange moves half the bytes; the updated parameters are gathered in fp32 as before
                     g16 = self._g16[lo:lo + n]
                     g16.copy_(fg.g[lo:lo + n])
-                    self._count(2 * n)
+                    self._count(2 * n, "scatter")
                     scatter.append(dist.reduce_scatter_tensor(self._zero_g16[c], g16, group=self.pg, async_op=True))
                 else:
-                    self._count(4 * n)
+                    self._count(4 * n, "scatter")
                     scatter.append(dist.reduce_scatter_tensor(self._zero_g[c], fg.g[lo:lo + n], group=self.pg, async_op=True))
             self._advance_g(supervise)
 
@@ -881,32 +903,26 @@ class PCAATrainer:
                             ops.adam_step_dev_(fg.p[lo:hi], self._zero_g[c], fg.m[lo:hi], fg.v[lo:hi], cfg["B1"], cfg["B2"],
                                                1e-8, fg.coef_dev, gs, self._side_adam_blocks)
                         self._zero_p[c].copy_(fg.p[lo:hi])
-                        self._count(4 * n)
+                        self._count(4 * n, "gather")
                         zero_gather.append(dist.all_gather_into_tensor(
                             fg.p[self._dec_start + c * n:self._dec_start + (c + 1) * n], self._zero_p[c],
                             group=self.pg, async_op=True))
-        elif gather and not early_buckets:
-            # every wide layer went out as gathered operands: what is left of the decoder region is its first layer and
-            # the biases -- one contiguous range in front of the wide weights (finalize), one small all-reduce
-            rest_hi = min(lo for lo, _ in fused_ranges) if fused_ranges else self.flat_g.total
-            if self._wg is not None:
+        elif gather or early_buckets:
+            # The wide layers are on the wire already, as gathered operands (no gradient exists) or as per-layer buckets.
+            # What is left of the decoder region -- its first layer and the biases in front of the wide weights
+            # (finalize), a wide layer neither scheme took, tail padding -- is the region MINUS those ranges, computed
+            # as such (round-5 advisor finding: the two branches this replaces each assumed which ranges the other
+            # scheme had covered): a few small all-reduces, issued once the wgrad stream's products are in.
+            covered = sorted(fused_ranges + [(lo, hi) for lo, hi, _ in early_buckets])
+            residual, a = [], self._dec_start
+            for lo, hi in covered + [(self.flat_g.total, self.flat_g.total)]:
+                if lo > a:
+                    residual.append((a, lo))
+                a = max(a, hi)
+            if residual and self._wg is not None:
                 ops.current_stream().wait_stream(self._wg)
-            if rest_hi > self._dec_start:
-                pending.append((self._dec_start, rest_hi,
-                                self._allreduce(self.flat_g.g[self._dec_start:rest_hi], async_op=True)))
-            tail_lo = max(hi for _, hi in fused_ranges) if fused_ranges else self.flat_g.total
-            if tail_lo < self.flat_g.total:
-                pending.append((tail_lo, self.flat_g.total,
-                                self._allreduce(self.flat_g.g[tail_lo:self.flat_g.total], async_op=True)))
-        elif early_buckets:
-            # per-layer buckets are on the wire already; what is left of the decoder region is its head
-            # (first layer): its weight gradient was written on the wgrad stream, its bias gradient on this one
-            rest_hi = min(lo for lo, _, _ in early_buckets)
-            if rest_hi > self._dec_start:
-                ops.current_stream().wait_stream(self._wg)
-                pending.append((self._dec_start, rest_hi,
-                                self._allreduce(self.flat_g.g[self._dec_start:rest_hi], async_op=True)))
-            pending = early_buckets + pending      # issue order = the order the collectives complete in
+            pending = early_buckets + [(lo, hi, self._allreduce(self.flat_g.g[lo:hi], async_op=True)) for lo, hi in residual]
+            # (issue order = the order the collectives of one communicator complete in)
         else:
             bounds = [self._dec_start]
             if collective and self._wg is not None:
@@ -1017,7 +1033,18 @@ class PCAATrainer:
                 step_events.append((ev_g0, ev_g1))
         elif early:
             self._adam_g(0, self._dec_start, supervise, gs)
+            ev_j0 = None
+            if ev_c0 is not None:
+                # the join with the side stream is where the main stream pays for a LATE exchange of the gathered-operand
+                # scheme (its all-gathers are waited for on the side stream only) -- and, in every scheme, for what of the
+                # decoder update did not fit beside the backward: timed in all of them, so the legs compare like with like
+                ev_j0 = torch.cuda.Event(enable_timing=True)
+                ev_j0.record()
             ops.current_stream().wait_event(done[0])      # next forward reads the updated decoder
+            if ev_j0 is not None:
+                ev_j1 = torch.cuda.Event(enable_timing=True)
+                ev_j1.record()
+                step_events.append((ev_j0, ev_j1))
         else:
             self._advance_g(supervise)
             self._adam_g(0, self.flat_g.total, supervise, gs)
@@ -1152,7 +1179,56 @@ def _wandb():
         return None
 
 
-def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=None, sync_bn=False, device="cuda"):
+class _EpochDraws:
+    """The loop's two host RNG draws (``z0 = np.random.normal(0, 1, (B, L))`` PCAA_ablation.py:915-925 and
+    ``alphas = torch.rand(size=(B, 1))`` :944-948) for a WHOLE EPOCH, made at its start: the same calls on the same two
+    global generators in the same order as the per-step draws of the reference (nothing else draws from either generator
+    between the epoch's order and its validation pass), written into pinned host buffers and moved with ONE asynchronous
+    copy each -- instead of two pageable, blocking ``.to(device)`` per step in front of every step's launches (round 5
+    VERDICT item 2; SURVEY section 7 "host-side RNG in the loop").  Data parallel: the draws are for the global batch,
+    rank 0's values are broadcast ONCE per epoch and every rank slices its rows."""
+
+    def __init__(self, L, device, process_group=None, rank=0, world=1):
+        self.L, self.dev, self.pg, self.rank, self.world = int(L), device, process_group, rank, world
+        self._z_host = self._a_host = None
+        self._copied = None
+
+    def draw(self, steps, gb):
+        if steps <= 0:
+            return None, None
+        if self._z_host is None or self._z_host.shape[0] < steps or self._z_host.shape[1] != gb:
+            pin = self.dev.type == "cuda"
+            self._z_host = torch.empty((steps, gb, self.L), dtype=torch.float32, pin_memory=pin)
+            self._a_host = torch.empty((steps, gb, 1), dtype=torch.float32, pin_memory=pin)
+        elif self._copied is not None:
+            self._copied.synchronize()                   # last epoch's copies have left the pinned buffers
+        z_np = self._z_host.numpy()
+        for i in range(steps):
+            # one call per step, as in the reference (the float64 -> float32 cast is the same rounding on either side of the copy)
+            z_np[i] = np.random.normal(0.0, 1.0, (gb, self.L))
+            torch.rand(size=(gb, 1), out=self._a_host[i])
+        z = self._z_host[:steps].to(self.dev, non_blocking=True)
+        a = self._a_host[:steps].to(self.dev, non_blocking=True)
+        if self.dev.type == "cuda":
+            self._copied = torch.cuda.Event()
+            self._copied.record()
+        if self.world > 1:
+            import torch.distributed as dist
+            src = dist.get_global_rank(self.pg, 0)
+            dist.broadcast(z, src=src, group=self.pg)
+            dist.broadcast(a, src=src, group=self.pg)
+            per = gb // self.world
+            z = z[:, self.rank * per:(self.rank + 1) * per]
+            a = a[:, self.rank * per:(self.rank + 1) * per]
+        return z, a
+
+
+def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=None, sync_bn=False, device="cuda",
+              timing=None):
+    """``timing``: a list that receives one dict per epoch -- wall-clock seconds of its train part (up to the point where
+    the epoch's predictions are on the host, i.e. every step has finished) and of its validation pass, and the number of
+    train steps (bench.py's ``loop`` leg)."""
+    import time
     from .datasets import MSRadarDataset
     from .constants import SPLIT
 
@@ -1212,25 +1288,28 @@ def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=
     history = []
     L = config["SUP_LATENT_DIM"]
     use_graph = world == 1 and trainer.prefers_graph(local_cfg["BATCH_SIZE"], nmax_points)
+    draws = _EpochDraws(L, dev, process_group, rank, world)
     for epoch in range(config["EPOCHS"]):
+        t_epoch = time.perf_counter()
         trainer.train()
         steps = []
         ys = []
-        for i, (pcs, gt_labels) in enumerate(loader_train):
+        # the first batch is fetched BEFORE the epoch's draws: creating / starting the loader's iterator is what consumes
+        # torch's global RNG for the epoch order (DataLoader: base seed at iter(), sampler seed at the first next())
+        batches = iter(loader_train)
+        first = next(batches, None)
+        n_steps = len(loader_train) if first is not None else 0
+        gb = first[0].shape[0] * world if first is not None else 0
+        z0_all, alphas_all = draws.draw(n_steps, gb)
+        for i, (pcs, gt_labels) in enumerate(itertools.chain([first] if first is not None else [], batches)):
             pcs = pcs.to(dev, non_blocking=True)
             gt_labels = gt_labels.to(dev, non_blocking=True)
-            # the reference's two host RNG draws, same generators, same order (:915-925, :944-948); data parallel:
-            # drawn for the global batch, rank 0's values broadcast, this rank's rows taken
-            gb = pcs.shape[0] * world
-            z0 = torch.from_numpy(np.random.normal(0.0, 1.0, (gb, L))).to(dev).float()
-            alphas = torch.rand(size=(gb, 1)).to(dev)
-            if world > 1:
-                import torch.distributed as dist
-                src = dist.get_global_rank(process_group, 0)
-                dist.broadcast(z0, src=src, group=process_group)
-                dist.broadcast(alphas, src=src, group=process_group)
-                z0 = z0[rank * pcs.shape[0]:(rank + 1) * pcs.shape[0]].contiguous()
-                alphas = alphas[rank * pcs.shape[0]:(rank + 1) * pcs.shape[0]].contiguous()
+            if i < n_steps and pcs.shape[0] * world == gb:
+                z0, alphas = z0_all[i], alphas_all[i]
+            else:
+                # (a loader that yields more, or other, batches than it announced: the reference's per-step draws)
+                z0, alphas = draws.draw(1, pcs.shape[0] * world)
+                z0, alphas = z0[0], alphas[0]
             supervise = i % config["SUPERVISION_FREQUENCY"] == 0
             if use_graph:
                 # replayed hipGraph (small shapes, where the host's enqueues bound the eager step): the outputs are
@@ -1256,6 +1335,7 @@ def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=
 
         y_hats = torch.cat([o["preds"] for o in steps]).cpu().numpy()
         ys = torch.cat(ys).cpu().numpy()
+        t_train = time.perf_counter()
 
         trainer.eval()
         v_rec, v_ce, v_hat, v_y = [], [], [], []
@@ -1284,6 +1364,10 @@ def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=
             dist.all_reduce(vals, group=process_group)
             record = {k: float(v) / world for k, v in zip(record, vals.tolist())}
         history.append(record)
+        if timing is not None:
+            # (every value of ``record`` is on the host: the validation pass has finished)
+            timing.append({"epoch": epoch, "train_steps": len(steps), "train_s": t_train - t_epoch,
+                           "valid_s": time.perf_counter() - t_train, "valid_batches": len(v_ce)})
         if rank == 0:                    # logging is rank 0's
             if log_fn is not None:
                 log_fn(record)

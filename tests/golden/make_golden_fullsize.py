@@ -52,7 +52,10 @@ def record(prefix, name, t, out):
         out[f"{prefix}{name}::samples"] = cs["samples"]
 
 
-def case(B, N):
+def case(B, N, extra=None):
+    """``extra``: a dict that receives the round-6 companion records (post-Adam strided rows of EVERY wide decoder weight
+    and the decoder's biases -- what the fused weight-gradient + Adam kernels write), kept out of the main file so that
+    the round-5 files stay byte-for-byte what they were."""
     mg.set_nfeatures(C)
     rconst.BATCH_SIZE = B
     cfg = dict(LR=1e-4, B1=0.9, B2=0.99, GP_WEIGHT=15, ADV_WEIGHT=1, SUP_LATENT_DIM=32)
@@ -127,23 +130,46 @@ def case(B, N):
         record("param.", k, named[k], rec)
     w5 = dec.state_dict()["dense5.weight"]
     rec["param.dense5_rows"] = np_(w5[:: w5.shape[0] // 16][:16, ::16])          # 16 strided rows, every 16th column
+    if extra is not None:
+        sd = dec.state_dict()
+        for i in range(1, 6):
+            w = sd[f"dense{i}.weight"]
+            extra[f"param.dense{i}_rows"] = np_(w[:: max(1, w.shape[0] // 16)][:16, ::16])
+            extra[f"param.dense{i}_rows_top"] = np_(w[:4, :256])                  # a contiguous corner as well (tile edges)
+            extra[f"param.dense{i}_rows_end"] = np_(w[-4:, -256:])
+            extra[f"param.G.dense{i}.bias"] = np_(sd[f"dense{i}.bias"])
+        extra["meta"] = rec["meta"]
+        extra["losses"] = rec["losses"]
     return rec
 
 
 def main():
     torch.manual_seed(0)
-    only = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]          # e.g. 64x32 16x150; default: all
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    params_only = "--params-only" in sys.argv[1:]       # round 6: write full_B*_N*_params.npz only, leave the main file alone
+    only = [tuple(int(v) for v in a.split("x")) for a in args]          # e.g. 64x32 16x150; default: all
     for B, N in only or ((64, 128), (128, 128), (64, 256), (64, 64), (64, 32), (16, 150)):
-        rec = case(B, N)
-        path = os.path.join(HERE, f"full_B{B}_N{N}.npz")
-        np.savez_compressed(path, **rec)
-        print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB, losses {rec['losses']}", flush=True)
+        extra = {}
+        rec = case(B, N, extra)
+        if params_only:
+            old = np.load(os.path.join(HERE, f"full_B{B}_N{N}.npz"))
+            # the companion must describe the SAME reference iteration as the committed main file
+            assert np.allclose(old["losses"], rec["losses"], rtol=1e-6, atol=0), (old["losses"], rec["losses"])
+            assert np.abs(old["param.dense5_rows"] - rec["param.dense5_rows"]).max() <= 1e-7
+        else:
+            path = os.path.join(HERE, f"full_B{B}_N{N}.npz")
+            np.savez_compressed(path, **rec)
+            print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB, losses {rec['losses']}", flush=True)
+        path = os.path.join(HERE, f"full_B{B}_N{N}_params.npz")
+        np.savez_compressed(path, **extra)
+        print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB", flush=True)
     prov = os.path.join(HERE, "PROVENANCE.json")
     with open(prov) as f:
         p = json.load(f)
     p.setdefault("scripts", {})["make_golden_fullsize.py"] = (
         "full_B{64,128}_N128.npz, full_B64_N{256,64,32}.npz, full_B16_N150.npz: one train_variant4 iteration of the "
-        "REFERENCE at the benchmarked shapes (bench.py's fills and input seeds)")
+        "REFERENCE at the benchmarked shapes (bench.py's fills and input seeds); full_B64_N128_params.npz (round 6, "
+        "--params-only): the same iteration's post-Adam decoder weights (strided rows + corners of every layer) and biases")
     with open(prov, "w") as f:
         json.dump(p, f, indent=1)
 

@@ -106,10 +106,13 @@ def ring_allreduce_bf16(grads):
     return out.view_as(grads[0])
 
 
+OUTLIER_CAP = 50.0
+
+
 def compare_record_l2(g, prefix, name, value, tol):
     """``value`` against a golden record in the relative-l2 sense of the full-size parity tests: a full tensor by
     ||a - b|| / ||b|| <= tol; a large one (l2, strided samples) by its l2 and by its samples, of which at most 1 % may lie
-    outside 4 tol of the samples' scale.  (Elementwise max-abs is the wrong gate at full size: a near-tie in one of
+    outside 4 tol of the samples' scale and none outside OUTLIER_CAP tol.  (Elementwise max-abs is the wrong gate at full size: a near-tie in one of
     Chamfer's 245 760 argmins resolved the other way moves single gradient elements by 1e-3 of the tensor's largest --
     between the reference's own contraction order and any other.)"""
     if f"{prefix}{name}::full" in g.files:
@@ -123,9 +126,17 @@ def compare_record_l2(g, prefix, name, value, tol):
     l2 = float(g[f"{prefix}{name}::l2"])
     assert abs(cs["l2"] - l2) <= tol * l2, f"{name}: l2 {cs['l2']} vs {l2}"
     scale = max(np.abs(ref_s).max(), l2 / np.sqrt(value.numel()))
-    bad = (np.abs(cs["samples"] - ref_s) > 4 * tol * scale).mean()
+    dev = np.abs(cs["samples"] - ref_s)
+    bad = (dev > 4 * tol * scale).mean()
     assert bad <= 0.01, f"{name}: {bad:.3%} of the samples differ"
+    # the allowed 1 % is for Chamfer's near-tie argmins (a few 1e-3 of the scale); it is not a licence for a corrupted
+    # tile edge or row: no sample at all may be further out than OUTLIER_CAP x tol of the scale (round-5 advisor finding)
+    worst = float(dev.max()) / scale
+    assert worst <= OUTLIER_CAP * tol, f"{name}: a sample is {worst:.3e} of the scale away (cap {OUTLIER_CAP * tol:.1e})"
     return abs(cs["l2"] - l2) / l2
+
+
+LABEL_REPORT = []      # one entry per check_step_against_full_golden call: the near-tie accounting of the label gate
 
 
 def full_golden(B, N):
@@ -136,7 +147,8 @@ def full_golden(B, N):
 
 def check_step_against_full_golden(g, losses, preds, sup_fvs, out_labels, grads_g, grads_d, tol=1e-4, gtol=5e-4, what=""):
     """The fp32-grade gates against a full-size golden: losses / embeddings / logits ``tol`` relative, argmax labels
-    bit-exact (a sample whose reference top-2 margin is below the tolerance is reported, not waved through), every
+    bit-exact (a sample whose reference top-2 margin is below the tolerance is excluded from that gate AND reported: the
+    count and how many of them differ are printed and appended to LABEL_REPORT), every
     recorded gradient ``gtol`` in the relative-l2 sense (compare_record_l2; large ones: l2 and 1 024 strided samples).
     ``grads_g`` {"E.<name>" / "GPH.<name>" / "G.<name>": tensor}, ``grads_d`` {"<name>": tensor}; a missing name is skipped."""
     ref = g["losses"]
@@ -146,6 +158,14 @@ def check_step_against_full_golden(g, losses, preds, sup_fvs, out_labels, grads_
     top2 = lg.topk(2, dim=1).values
     tied = (top2[:, 0] - top2[:, 1]) <= tol * lg.abs().max()
     same = preds.cpu() == torch.from_numpy(g["preds"])
+    # "flag the sample rather than silently accept a flip" -- the count of near-tied samples and how
+    # many of THOSE came out differently is printed with every call (pytest -s / -rP shows it; LABEL_REPORT keeps it for
+    # the caller), and a flip of any untied sample fails
+    n_tied, n_tied_diff = int(tied.sum()), int((~same[tied]).sum())
+    LABEL_REPORT.append({"what": what, "samples": int(same.numel()), "tied": n_tied, "tied_differ": n_tied_diff,
+                         "untied_differ": int((~same[~tied]).sum())})
+    print(f"[labels] {what or 'step'}: {same.numel()} samples, {n_tied} with a reference top-2 margin <= {tol:g} of scale "
+          f"({n_tied_diff} of them differ), untied differing: {int((~same[~tied]).sum())}")
     assert bool(same[~tied].all()), f"{what}: argmax labels must be bit-exact"
     fv = torch.from_numpy(g["sup_fvs"])
     assert (sup_fvs.cpu() - fv).abs().max().item() <= tol * fv.abs().max().item(), what

@@ -54,3 +54,30 @@ for K, N in zip(widths[:-1], widths[1:]):
     tot["fused"] = tot.get("fused", 0) + t_f
     del dz, x, W, m, v, dW
 print("totals (ms):", {k: round(t, 3) for k, t in tot.items()})
+
+# ---- round 6: the data-parallel update from GATHERED rows, pcaa_skinny_linear_wgrad_adam_rows, at the
+# row counts a world of 1 / 2 / 4 / 8 ranks x 64 sequences stacks (M = 64 .. 512), per wide decoder layer, alone on the GPU;
+# beside the single-process kernel at M = 64 above.  24 B per parameter whatever M is: the GB/s column says how much of
+# the HBM stream survives the longer contraction.
+print("\ngathered-rows update (pcaa_skinny_linear_wgrad_adam_rows), ms per layer [TB/s of 24 B/param]")
+rows_tot = {}
+for K, N in zip(widths[:-1], widths[1:]):
+    g = torch.Generator(device="cpu").manual_seed(N)
+    W = (torch.randn(N, K, generator=g) * 0.02).to(dev)
+    m, v = torch.zeros_like(W), torch.zeros_like(W)
+    c = StepCount(dev)
+    c.advance(1e-4, 0.9, 0.99)
+    n = N * K
+    cells = []
+    for Mr in (64, 128, 256, 512):
+        R = ops.gathered_rows_alloc(Mr)
+        dz = (torch.randn(R, N, generator=g) * 0.1).to(dev)
+        x = torch.randn(R, K, generator=g).to(dev)
+        t = timed(lambda: ops.skinny_linear_wgrad_adam_rows_(dz, x, Mr, W, m, v, 0.9, 0.99, 1e-8, c.coef_dev, 1.0 / (Mr // 64)), a.reps)
+        rows_tot[Mr] = rows_tot.get(Mr, 0) + t
+        cells.append(f"M={Mr}: {t:.3f} [{24 * n / t / 1e9:.2f}]")
+        del dz, x
+    print(f"[{K}->{N}] " + "   ".join(cells))
+    del W, m, v
+print("totals over the wide layers (ms):", {f"M={k}": round(t, 3) for k, t in rows_tot.items()},
+      "  single-process fused (M=64):", round(tot.get("fused", 0), 3))
