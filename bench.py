@@ -60,9 +60,10 @@ def parse():
     ap.add_argument("--classes", type=int, default=8)
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="train", choices=["train", "sweep", "infer"],
+    ap.add_argument("--workload", default="train", choices=["train", "sweep", "infer", "loop"],
                     help="train: BASELINE config[1] (default, the driver's line, with the other configs as extra keys); "
-                         "sweep / infer: config[3] / config[4] as a line of their own")
+                         "sweep / infer: config[3] / config[4] as a line of their own; loop: the drop-in train_variant4 loop "
+                         "alone (the default line's `loop` leg)")
     ap.add_argument("--dp-mode", default="auto", choices=["auto", "allreduce", "zero", "gather"],
                     help="data-parallel exchange of the decoder gradients: per-layer all-reduce buckets, reduce-scatter + "
                          "sharded Adam + all-gather (ZeRO-1), or gather: the wide layers all-gather their two small "
@@ -436,6 +437,59 @@ def leg_sections(tr, inputs, steps=10):
             "note": "median over %d steps of event intervals on the main stream; D-step: critic stream, hidden" % steps}
 
 
+def leg_loop(a, dev, N, steps=100, valid_batches=8, epochs=3):
+    """The drop-in loop itself (train.train_variant4 = the reference's PCAA_ablation.py:746-1122 call surface): `epochs`
+    epochs over a synthetic split of `steps` train batches and `valid_batches` validation batches resident in HBM as the
+    packed store the real-data path uses -- the device batcher's row gathers, the epoch's host RNG draws (z0, alphas: the
+    reference's generators, one pinned asynchronous copy per epoch), the step, the per-epoch statistics and the validation
+    pass.  Wall clock per epoch from inside the loop (its ``timing`` hook); the checkpoint writes after an improving
+    epoch are outside those intervals (630 MB of torch.save for the config[1] decoder)."""
+    import shutil
+    import tempfile
+    from opensetgaitrecognition_pcaa_amd import constants, functional as F_hip
+    from opensetgaitrecognition_pcaa_amd.datasets import SyntheticGaitDataset
+    from opensetgaitrecognition_pcaa_amd.train import train_variant4
+    B, C, K = a.batch, a.features, a.classes
+    saved = (constants.NFEATURES, F_hip.get_precision(), os.getcwd())
+    work = tempfile.mkdtemp(prefix="pcaa_loop_")
+    try:
+        constants.NFEATURES = C
+        F_hip.set_precision(a.precision)
+        os.chdir(work)
+        cfg = dict(constants.CONFIG)
+        cfg.update(MODEL_NAME="bench_loop", TRAIN_CLASSES=list(range(K)), NMAX=N, BATCH_SIZE=B, EPOCHS=epochs,
+                   CHECKPOINT_FREQUENCY=1, SUPERVISION_FREQUENCY=1, SUBSAMPLE_FACTOR=1.0, NOTES="")
+        make = lambda split: SyntheticGaitDataset(steps * B if split.value == "train" else valid_batches * B, K, N=N, C=C,
+                                                  seed=4400 + (0 if split.value == "train" else 1))
+        timing, records = [], []
+        import contextlib
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(sys.stderr):       # the loop prints its epoch records like the reference: stdout is the JSON line's
+            trainer, hist = train_variant4(cfg, wandb_mode="disabled", dataset_factory=make, device=str(dev), timing=timing,
+                                           log_fn=records.append)
+        torch.cuda.synchronize()
+        total_s = time.perf_counter() - t0
+        del trainer
+        torch.cuda.empty_cache()
+    finally:
+        os.chdir(saved[2])
+        constants.NFEATURES = saved[0]
+        F_hip.set_precision(saved[1])
+        shutil.rmtree(work, ignore_errors=True)
+    steady = timing[1:] or timing                       # epoch 0 carries lazy initialisation (first launches, allocator)
+    tr_s = statistics.median(t["train_s"] for t in steady)
+    va_s = statistics.median(t["valid_s"] for t in steady)
+    n = steady[0]["train_steps"]
+    return {"workload": f"train_variant4 (the drop-in loop): {epochs} epochs x {n} steps at B={B} N={N} C={C} + {valid_batches} "
+                        "validation batches per epoch, synthetic split as a packed store in HBM (DeviceBatcher), epoch order / z0 / "
+                        "alphas from the reference's host generators",
+            "train_steps_per_epoch": n, "epochs": epochs,
+            "train_ms_per_step": tr_s / n * 1e3, "value": n * B / tr_s, "unit": "sequences/s",
+            "value_with_validation": n * B / (tr_s + va_s), "valid_ms_per_batch": va_s / max(1, steady[0]["valid_batches"]) * 1e3,
+            "per_epoch": timing, "total_s_with_setup_and_checkpoints": total_s,
+            "finite": all(v == v for v in hist[-1].values())}
+
+
 XGMI_LINKS, XGMI_LINK_GBS = 7, 153.0      # per GPU: 7 point-to-point links x ~153 GB/s (MI355X_MICROARCH.md)
 
 
@@ -614,6 +668,11 @@ def main():
             raise SystemExit("bench.py: --workload sweep / infer are single-GPU workloads")
         dev = torch.device("cuda", int(os.environ.get("PCAA_BENCH_DEVICE", "0")))
         torch.cuda.set_device(dev)
+        if a.workload == "loop":
+            from opensetgaitrecognition_pcaa_amd import functional as F_hip
+            F_hip.set_precision(a.precision)
+            print(json.dumps(leg_loop(a, dev, a.points)), flush=True)
+            return None
         return workload_sweep(a, dev) if a.workload == "sweep" else workload_infer(a, dev)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -804,9 +863,11 @@ def main():
             del trl
             torch.cuda.empty_cache()
 
-    sweep = infer = c5 = ref_default = dp_emulated = None
+    sweep = infer = c5 = ref_default = dp_emulated = loop = None
     if single and not a.no_extra_legs and a.precision == "bf16":
         esteps = max(1, min(a.steps, 10))
+        # the drop-in loop itself (north_star: "keeping ... the train_AAE.py/PCAA_ablation.py training-loop API")
+        loop = leg_loop(a, dev, N)
         # BASELINE config[2] (8 x MI355X, global B=512) has never had a node to run on: one rank's program of a world of
         # 2 / 4 / 8 on this GPU, and the projection that follows from it under stated link figures
         dp_emulated = leg_dp_emulated(a, dev, N, steps=esteps)
@@ -906,6 +967,9 @@ def main():
             line["ref_default"] = ref_default
         if dp_emulated is not None:
             line["dp_emulated"] = dp_emulated
+        if loop is not None:
+            loop["vs_value"] = loop["value"] / value
+            line["loop"] = loop
         if sections is not None:
             line["gpu_sections"] = sections
         if agg:
