@@ -502,15 +502,19 @@ def leg_dp_emulated(a, dev, N, worlds=(2, 4, 8), steps=10, warmup=3):
     B, C, K, T = a.batch, a.features, a.classes, constants.NSTEPS
     inputs = make_inputs(B, T, N, C, K, dev)
 
-    def run(world, mode):
+    def run(world, mode, n_points=N, graph=False):
         aa = copy.copy(a)
         aa.dp_mode, aa.dp_force, aa.sync_bn = mode, False, False
         aa.grad_compress = "bf16" if a.precision == "bf16" else "none"
-        tr, _ = build_trainer(aa, N, dev, None, a.precision, fill="device", emulate_world=world)
+        tr, _ = build_trainer(aa, n_points, dev, None, a.precision, fill="device", emulate_world=world)
+        inp = inputs if n_points == N else make_inputs(B, T, n_points, C, K, dev)
         for _ in range(warmup):
-            tr.step(*inputs)
-        ms_list, out = time_single_gpu(lambda: tr.step(*inputs), steps, 3)
-        ent = {"world": world, "dp_mode": tr.dp_scheme, "ms_per_step": statistics.median(ms_list), "windows_ms_per_step": ms_list,
+            tr.step(*inp)
+        fn = (lambda: tr.step_graphed(*inp, warmup=0)) if graph else (lambda: tr.step(*inp))
+        fn()
+        ms_list, out = time_single_gpu(fn, steps, 3)
+        ent = {"world": world, "N": n_points, "hip_graph": bool(graph),
+               "dp_mode": tr.dp_scheme, "ms_per_step": statistics.median(ms_list), "windows_ms_per_step": ms_list,
                "steps": steps, "finite_loss": bool(torch.isfinite(out["tot_loss"]).item()),
                "collectives_per_step": tr.comm["collectives"], "payload_bytes_per_step": tr.comm["payload_bytes"],
                "gather_payload_bytes": tr.comm.get("gather_bytes", 0), "allreduce_payload_bytes": tr.comm.get("allreduce_bytes", 0)}
@@ -542,7 +546,13 @@ def leg_dp_emulated(a, dev, N, worlds=(2, 4, 8), steps=10, warmup=3):
                 "pessimistic_one_link_exposed": {"projected_ms_per_step": ent["ms_per_step"] + link_ms,
                                                  "projected_speedup_vs_1gpu": w * base["ms_per_step"] / (ent["ms_per_step"] + link_ms)}}
             legs.append(ent)
-    return {"label": "EMULATED on one GPU -- not a multi-GPU measurement",
+    # the data-parallel step at small N, where the eager step is bound by the host's enqueues (~2.5 ms): round 6 lets
+    # step_graphed capture it, collectives included (RCCL's are stream operations; here the emulated ones)
+    small = {"N": 32, "world": max(worlds),
+             "single_process_graph": run(0, "allreduce", 32, True)["ms_per_step"],
+             "eager": run(max(worlds), default_mode, 32, False)["ms_per_step"],
+             "graph": run(max(worlds), default_mode, 32, True)["ms_per_step"]}
+    return {"label": "EMULATED on one GPU -- not a multi-GPU measurement", "small_n_graph_vs_eager_ms": small,
             "what": "one rank's program of a W-rank weak-scaling job (B=%d per rank, N=%d): gradient scale 1/W, the fused decoder "
                     "update from 64 W stacked rows (pcaa_skinny_linear_wgrad_adam_rows), every collective replaced by a device "
                     "operation of the same bytes on its own stream (all-reduce: in-place scale, all-gather: own rows + W-1 staged "
@@ -715,7 +725,9 @@ def main():
             return float(t.item())
         return seconds
 
-    use_graph = a.graph == "on" or (a.graph == "auto" and world == 1 and tr.prefers_graph(B, N))
+    use_graph = (a.graph == "on" and tr.can_graph()) or (a.graph == "auto" and world == 1 and tr.prefers_graph(B, N))
+    if a.graph == "on" and not use_graph:
+        raise SystemExit("bench.py: --graph on, but this step cannot be captured (gloo collectives run on the host)")
     run_step = tr.step
     for _ in range(a.warmup):
         out = tr.step(pcs, gt, z0, al)

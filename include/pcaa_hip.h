@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PCAA_ABI_VERSION 15 /* pcaa_abi_version() of a library built from this header */
+#define PCAA_ABI_VERSION 16 /* pcaa_abi_version() of a library built from this header */
 
 #define PCAA_OK 0
 #define PCAA_ERR_INVALID_ARG 1
@@ -374,7 +374,8 @@ int pcaa_kvote(const double* lik, const long long* preds, double threshold, int 
  *   wgrad: dW[N][K] = dz^T . x
  * fwd/dgrad split the contraction into `nsplit` slabs in `ws` (>= nsplit*M*N resp. nsplit*M*K
  * floats) and reduce them deterministically; nsplit must come from pcaa_skinny_splits (kind 0
- * fwd, 1 dgrad).  pcaa_skinny_supported: M <= 64, N and K multiples of 64 and >= 128. */
+ * fwd, 1 dgrad; 2 / 3: the _exact forms) -- the deepest split whose grid still fits the chip's resident workgroups of
+ * that kernel in ONE round.  pcaa_skinny_supported: M <= 64, N and K multiples of 64 and >= 128. */
 int pcaa_skinny_supported(int M, int N, int K);
 int pcaa_skinny_splits(int kind, int M, int N, int K);
 int pcaa_skinny_linear_fwd(const float* x, long ldx, const float* W, long ldw, const float* bias, int act,
@@ -424,6 +425,22 @@ int pcaa_skinny_linear_wgrad_adam_rows(const float* dz, long lddz, const float* 
                                        const float* coef_dev, int rows_alloc, void* stream);
 /* (x is read in whole 64-row chunks: rows_alloc = the rows x is allocated for, >= the next of 64 / 128 / 256 / 512 above
  * M; the rows past M must hold finite values -- they meet zeros) */
+/* ABI 16 (round 6): the gathered update from PACKED operands -- what the data-parallel step exchanges since round 6.
+ * The reference has no multi-GPU path; this stands where a torch DDP port of PCAA_ablation.py:1018-1021 would all-reduce
+ * the decoder's gradient.  Every rank packs the two weight-gradient operands of a batch-skinny layer -- dz [rows, N] and
+ * x [rows, K], rows <= 64 -- into ONE chunk P[(N + K)][64] bf16: transposed (one 128-B row per column of dz, then per
+ * column of x), rounded to nearest even (the rounding the weight-gradient kernels apply in registers), zero behind `rows`.
+ * The ranks' chunks concatenate (one all-gather per layer, 2 (N + K) 64 bytes per rank); pcaa_skinny_linear_wgrad_adam_t16
+ * contracts over `chunks` <= 8 of them (chunk c at packed + c * chunk_stride elements, chunk_stride >=
+ * pcaa_packed_chunk_elems(N, K)) and applies Adam in place: W <- Adam(W, grad_scale * sum_c dz_c^T x_c), 24 B per
+ * parameter, bf16 products, fp32 accumulation.  Supersedes pcaa_skinny_linear_wgrad_adam_rows in the trainer (that entry
+ * takes fp32 row-major operands and needs no pack; it stays for callers that hold such operands). */
+long pcaa_packed_chunk_elems(int N, int K);
+int pcaa_pack_rows_t16(const float* dz, long lddz, int N, const float* x, long ldx, int K, int rows, void* chunk_bf16,
+                       void* stream);
+int pcaa_skinny_linear_wgrad_adam_t16(const void* packed_bf16, long chunk_stride, int chunks, float* W, float* exp_avg,
+                                      float* exp_avg_sq, long ldw, int N, int K, float beta1, float beta2, float eps,
+                                      float grad_scale, const float* coef_dev, void* stream);
 /* ABI 14: the bf16 IMAGE of a decoder weight (W16 [N, ldw] bf16: every element = the weight rounded to nearest even, the
  * conversion pcaa_skinny_linear_fwd / _dgrad apply in registers -- results are bit-identical).  _fwd_w16 / _dgrad_w16
  * stream the image instead of the fp32 matrix: half the bytes of the two passes that sit on the step's critical path.

@@ -272,7 +272,7 @@ template <bool F32 = false, bool W16 = false>
 __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, long ldx,
                                                          const typename std::conditional<W16, bf16_t, float>::type* __restrict__ W, long ldw,
                                                          float* __restrict__ slabs, long slab_stride, int M,
-                                                         int N, int K, int cps) {
+                                                         int N, int K, int cps, const float* __restrict__ bias, int act) {
   __shared__ __attribute__((aligned(16))) unsigned char sraw[2 * 64 * (F32 ? SPF * 4 : SP * 2)];
   __shared__ __attribute__((aligned(16))) unsigned char wraw[4 * 32 * (F32 ? SPF * 4 : SP * 2)];
   bf16_t (*sbuf)[64 * SP] = reinterpret_cast<bf16_t (*)[64 * SP]>(sraw);
@@ -351,6 +351,24 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
     }
     if (more) { if constexpr (F32) small_store_f32(st, sbuf32[(c + 1) & 1], tid); else small_store(st, sbuf[(c + 1) & 1], tid); }
     lds_barrier();
+  }
+  if (gridDim.y == 1) {
+    // no split (a contraction of one or two chunks, or more column groups than the chip holds workgroups): `slabs` is the
+    // output itself and the reduction kernel's epilogue -- bias, ELU, in its order of operations -- runs here: one launch
+    // less on the decoder's dependent chain (the 64 -> S/16 first layer)
+    const int col = n0 + l31;
+    if (col >= N) return;
+    const float b = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = acc[mf][r] + b;
+        if (act == PCAA_ACT_ELU) v = elu_f(v);
+        if (m < M) slabs[(long)m * N + col] = v;
+      }
+    return;
   }
   store_acc(acc, slabs + (long)blockIdx.y * slab_stride, N, M, n0 + l31, N, h);
 }
@@ -737,6 +755,143 @@ __global__ __launch_bounds__(256) void skinny_wgrad_adam_rows_kernel(const float
   }
 }
 
+// ------------------------------------------------------------------ round 6: the gathered update from PACKED operands
+// What round 5's rows kernel cost at the world sizes it exists for (tools/skinny_lab.py, the four wide layers of config[1],
+// alone on the GPU): M = 64: 0.77 ms, 256: 0.87, 512: 1.14 -- the x operand is fetched with 32 dword loads per lane and
+// 64-row chunk (8 batch rows x 4 k-steps, two 128-B lines per load) from a [512, K] fp32 matrix that no L2 holds
+// (15.7 MB at K = 7680), re-read by every one of the 120 row panels: 1.8 GB through the L2s per update at M = 512,
+// against 2.8 GB of HBM traffic for the weights themselves.
+// Here every rank PACKS its two operands once, right where the backward produced them, into the form the MFMA wants:
+// one 64-row chunk per rank, transposed and rounded to bf16 -- P_r[c][m], c = 0 .. N-1 the columns of dz (rows of W),
+// c = N .. N+K-1 the columns of x, m = the rank's batch row (zero behind its B rows) -- 128 B per column, so that a
+// lane's fragment of 8 contraction elements is ONE 16-B load instead of 8 dword loads, the bytes are half, and the
+// ranks' chunks concatenate: ONE all-gather per layer (was two) moves 2 (N + K) 64 bytes per rank (was 4 (N + K) B).
+// The contraction index of an MFMA is arbitrary as long as both operands agree: k-slot (s, h, e) of a chunk is batch
+// row 32 h + 8 s + e, i.e. lane-half h reads the 64 contiguous bytes [64 h, 64 h + 64) of its column.
+// The rounding is the rows kernel's own (fp32 -> bf16, nearest even, at the same point of the data flow), products and
+// fp32 accumulation are the same MFMAs: the update differs from the rows kernel's only in summation order.
+__global__ __launch_bounds__(256) void pack_rows_t16_kernel(const float* __restrict__ a, long lda, int wa,
+                                                            const float* __restrict__ b, long ldb, int wb, int rows,
+                                                            bf16_t* __restrict__ dst) {
+  // thread = one column: 64 coalesced dword reads down the rows, one 128-B row of the packed chunk out
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= wa + wb) return;
+  const float* src = c < wa ? a + c : b + (c - wa);
+  const long ld = c < wa ? lda : ldb;
+  uint4* out = reinterpret_cast<uint4*>(dst + (long)c * 64);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int m = 8 * q + e;
+      t[e] = m < rows ? src[(long)m * ld] : 0.f;
+    }
+    out[q] = __builtin_bit_cast(uint4, pack8(t));
+  }
+}
+
+template <int JL, bool FULLN, int NB>
+__global__ __launch_bounds__(256) void skinny_wgrad_adam_t16_kernel(const bf16_t* __restrict__ P, long chunk_stride, int MC,
+                                                                    float* __restrict__ W, float* __restrict__ mo,
+                                                                    float* __restrict__ vo, long ldw, int N, int K,
+                                                                    float b1, float b2, float eps, float grad_scale,
+                                                                    const float* __restrict__ coef) {
+  static_assert(NB == 2 || NB == 4, "fragment buffers: a ring of 2 or 4");
+  extern __shared__ __attribute__((aligned(16))) bf16x8 apan_t16[];            // [MC][row fragment i][k-step s][lane]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  const float step_size = coef[0], inv_bc2_sqrt = coef[1];
+  const int n0 = blockIdx.y * 128;
+  const int kb = (blockIdx.x * 4 + wave) * (32 * JL);
+  const int jn = kb < K ? min(JL, (K - kb) / 32) : 0;
+  // byte addressing through one buffer resource over all chunks (< 2^31 bytes: host-checked); an offset outside it
+  // reads zeros instead of faulting
+  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(P), 0,
+                                                                      (int)(unsigned)((long)MC * chunk_stride * 2), 0x00020000);
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  {
+    const int s = wave;                                    // wave w packs k-step w of all 4 row fragments of every chunk
+    for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned ncol = (unsigned)min(n0 + 32 * i + l31, N - 1);
+        const unsigned vo_ = ncol * 128u + (unsigned)h * 64u + (unsigned)s * 16u;
+        const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rP, vo_, (unsigned)((long)mc * chunk_stride * 2), 0);
+        apan_t16[((mc * 4 + i) * 4 + s) * 64 + lane] = __builtin_bit_cast(bf16x8, v);
+      }
+  }
+  // x fragments: column N + kb + 32 j + l31 of chunk mc, bytes [64 h + 16 s, + 16)
+  const unsigned xv = (unsigned)(N + min(kb, K - 32) + l31) * 128u + (unsigned)h * 64u;
+  auto load_x = [&](bf16x8 (&bf)[4], int mc, int j) __attribute__((always_inline)) {
+    const unsigned so = (unsigned)((long)mc * chunk_stride * 2) + 4096u * (unsigned)j;       // 32 columns x 128 B per j step
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      bf[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rP, xv + 16u * (unsigned)s, so, 0));
+  };
+  bf16x8 bcur[4], bnxt[4];
+  load_x(bcur, 0, 0);
+
+  const unsigned row0 = (unsigned)(n0 + 4 * h);
+  unsigned o0 = row0 * (unsigned)ldw + (unsigned)kb + l31;
+  float pw[NB][16], pm[NB][16], pv[NB][16];
+  const int nfrag = 4 * jn;
+  auto fetch = [&](int f, int b) {
+    if (f >= nfrag) return;
+    const unsigned base = o0 + 32u * (unsigned)(f >> 2);
+    const int i = f & 3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned rr = 32 * i + (r & 3) + 8 * (r >> 2);
+      if (FULLN || row0 + rr < (unsigned)N) {
+        const unsigned o = base + rr * (unsigned)ldw;
+        pw[b][r] = W[o]; pm[b][r] = mo[o]; pv[b][r] = vo[o];
+      }
+    }
+  };
+#pragma unroll
+  for (int f = 0; f < NB - 1; ++f) fetch(f, f);
+  __syncthreads();
+
+  for (int j = 0; j < jn; ++j) {
+    asm volatile("" : "+v"(o0) : : "memory");
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int mc = 0; mc < MC; ++mc) {
+      // the next chunk's x (behind the last chunk: the first chunk of the next column step; last step: a harmless re-read)
+      if (mc + 1 < MC) load_x(bnxt, mc + 1, j);
+      else load_x(bnxt, 0, min(j + 1, jn - 1));
+      const bf16x8* ap = apan_t16 + (mc * 16) * 64 + lane;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[(i * 4 + s) * 64], bcur[s], acc[i], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bcur[s] = bnxt[s];
+    }
+    const unsigned base = o0 + 32u * (unsigned)j;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = i % NB;
+      fetch(4 * j + i + NB - 1, (i + NB - 1) % NB);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned rr = 32 * i + (r & 3) + 8 * (r >> 2);
+        if (FULLN || row0 + rr < (unsigned)N) {
+          const unsigned o = base + rr * (unsigned)ldw;
+          adam_update(pw[b][r], pm[b][r], pv[b][r], acc[i][r] * grad_scale, b1, b2, eps, step_size, inv_bc2_sqrt);
+          W[o] = pw[b][r];
+          mo[o] = pm[b][r];
+          vo[o] = pv[b][r];
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ slab reduction (+ bias/ELU, or * ELU'(a_prev))
 __global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* __restrict__ slabs, int ns, long stride,
                                                             float* __restrict__ out, const float* __restrict__ bias,
@@ -757,8 +912,22 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* __restr
   }
 }
 
-// workgroups a forward / dgrad launch aims for (3 per CU: the split-K depth follows from it)
-int target_blocks() { return 768; }
+// Workgroups a forward / dgrad launch may hold RESIDENT at once: 256 CUs x the workgroups per CU the kernel's registers
+// and LDS admit (code-object metadata of this build: skinny_fwd_kernel<bf16> 140 VGPRs + 36 KB -> 3; <exact> 69.6 KB of LDS
+// -> 2; skinny_dgrad2_kernel<bf16> 186 VGPRs -> 2; <exact> 166 -> 3; the bf16-image forms 124 / 150 -> 4 / 3, priced as
+// their fp32-source siblings so that one split count serves both).  The split-K depth is the LARGEST that keeps the whole
+// grid inside that -- one round of workgroups, every CU streaming to the end.  Through round 5 the depth was rounded UP
+// from 768 for every kernel: the 7680 -> 15360 forward ran 840 workgroups on 768 slots and the dgrad 720 on 512, i.e. a
+// second, nearly empty round each (4.3 / 4.5 TB/s; profiles/r06_skinny_splits_ab.txt).
+int resident_blocks(int kind) {
+  switch (kind) {
+    case 0: return 768;      // forward, bf16 products
+    case 1: return 512;      // dgrad, bf16 products
+    case 2: return 512;      // forward, fp32 products
+    case 3: return 768;      // dgrad, fp32 products
+    default: return 512;
+  }
+}
 
 bool aligned16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
@@ -776,10 +945,15 @@ int reduce_launch(const float* ws, int ns, long stride, float* out, const float*
 // kind 0: forward (groups over N, contraction K); kind 1: dgrad (groups over K, contraction N)
 extern "C" int pcaa_skinny_splits(int kind, int M, int N, int K) {
   (void)M;
-  const int groups = (int)cdiv(kind == 0 ? N : K, 128);
-  const int chunks = (kind == 0 ? K : N) / CH;
+  const bool fwd = (kind & 1) == 0;
+  // column groups of one workgroup: 128 output columns forward; 256 input columns in the dgrad (two per lane)
+  const int groups = (int)cdiv(fwd ? N : K, fwd ? 128 : 256);
+  const int chunks = (fwd ? K : N) / CH;
   if (chunks < 1) return 1;
-  int ns = std::max(1, std::min(chunks, (target_blocks() + groups - 1) / groups));
+  static const bool legacy = getenv("PCAA_SKINNY_SPLITS_LEGACY") != nullptr;      // lab: the round 2-5 rule, for A/B runs
+  int ns;
+  if (legacy) ns = std::max(1, std::min(chunks, (768 + (int)cdiv(fwd ? N : K, 128) - 1) / (int)cdiv(fwd ? N : K, 128)));
+  else ns = std::max(1, std::min(chunks, resident_blocks(kind) / groups));
   const int cps = (int)cdiv(chunks, ns);
   return (int)cdiv(chunks, cps);
 }
@@ -806,16 +980,17 @@ static int skinny_fwd_impl(const float* x, long ldx, const void* Wv, int w16, lo
   const long stride = (long)M * N;
   PCAA_CHECK_ARG(ws_floats >= stride * nsplit, "pcaa_skinny_linear_fwd: workspace too small");
   hipStream_t s = as_stream(stream);
+  // one split: the kernel's own epilogue writes y (bias + activation); else slabs + the reduction launch
+  float* dst = nsplit == 1 ? y : ws;
+  const dim3 grid((unsigned)cdiv(N, 128), nsplit);
   if (w16)
-    hipLaunchKernelGGL((skinny_fwd_kernel<false, true>), dim3((unsigned)cdiv(N, 128), nsplit), dim3(256), 0, s, x, ldx,
-                       static_cast<const bf16_t*>(Wv), ldw, ws, stride, M, N, K, cps);
+    hipLaunchKernelGGL((skinny_fwd_kernel<false, true>), grid, dim3(256), 0, s, x, ldx, static_cast<const bf16_t*>(Wv), ldw,
+                       dst, stride, M, N, K, cps, bias, act);
   else if (exact)
-    hipLaunchKernelGGL(skinny_fwd_kernel<true>, dim3((unsigned)cdiv(N, 128), nsplit), dim3(256), 0, s, x, ldx, W, ldw, ws,
-                       stride, M, N, K, cps);
+    hipLaunchKernelGGL(skinny_fwd_kernel<true>, grid, dim3(256), 0, s, x, ldx, W, ldw, dst, stride, M, N, K, cps, bias, act);
   else
-    hipLaunchKernelGGL(skinny_fwd_kernel<false>, dim3((unsigned)cdiv(N, 128), nsplit), dim3(256), 0, s, x, ldx, W, ldw, ws,
-                       stride, M, N, K, cps);
-  reduce_launch(ws, nsplit, stride, y, bias, act, nullptr, 0, M, N, s);
+    hipLaunchKernelGGL(skinny_fwd_kernel<false>, grid, dim3(256), 0, s, x, ldx, W, ldw, dst, stride, M, N, K, cps, bias, act);
+  if (nsplit > 1) reduce_launch(ws, nsplit, stride, y, bias, act, nullptr, 0, M, N, s);
   PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_fwd");
 }
 
@@ -1051,4 +1226,74 @@ extern "C" int pcaa_skinny_linear_wgrad_adam_exact(const float* dz, long lddz, c
                                                    const float* coef_dev, void* stream) {
   return skinny_wgrad_adam_impl(dz, lddz, x, ldx, W, exp_avg, exp_avg_sq, ldw, M, N, K, beta1, beta2, eps, grad_scale,
                                 coef_dev, 1, stream);
+}
+
+// ------------------------------------------------------------------ packed (transposed bf16) gathered operands, round 6
+extern "C" long pcaa_packed_chunk_elems(int N, int K) { return ((long)N + K) * 64; }
+
+extern "C" int pcaa_pack_rows_t16(const float* dz, long lddz, int N, const float* x, long ldx, int K, int rows,
+                                  void* chunk_bf16, void* stream) {
+  PCAA_CHECK_ARG(dz && x && chunk_bf16, "pcaa_pack_rows_t16: null pointer");
+  PCAA_CHECK_ARG(rows >= 1 && rows <= 64 && N >= 1 && K >= 1, "pcaa_pack_rows_t16: unsupported shape rows=%d N=%d K=%d (rows <= 64)",
+                 rows, N, K);
+  PCAA_CHECK_ARG(lddz >= N && ldx >= K && ((uintptr_t)chunk_bf16 % 16) == 0, "pcaa_pack_rows_t16: bad leading dimensions / alignment");
+  hipLaunchKernelGGL(pack_rows_t16_kernel, dim3((unsigned)cdiv((long)N + K, 256)), dim3(256), 0, as_stream(stream), dz, lddz,
+                     N, x, ldx, K, rows, reinterpret_cast<bf16_t*>(chunk_bf16));
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_pack_rows_t16");
+}
+
+template <int NB>
+static int launch_wgrad_adam_t16(const bf16_t* P, long chunk_stride, int MC, float* W, float* exp_avg, float* exp_avg_sq,
+                                 long ldw, int N, int K, float beta1, float beta2, float eps, float grad_scale,
+                                 const float* coef_dev, hipStream_t st) {
+  const size_t lds = (size_t)MC * 4 * 4 * 64 * sizeof(bf16x8);
+  auto ntile = [&](int jl) { return cdiv(K, 4 * 32 * jl) * cdiv(N, 128); };
+  // columns per wave (32 JL).  Up to 2 chunks several workgroups share a CU and the single-process rule holds (>= 1024
+  // workgroups); from 4 chunks on the dz panels leave room for ONE workgroup per CU (64-128 KB of LDS), so 256 run at a
+  // time whatever the grid, and every workgroup pays a panel load (16 KB per chunk, from L2) + a barrier before its first
+  // MFMA: the widest JL that still gives every CU >= 1.5 workgroups amortises that prologue over 4 column steps
+  const int want = MC >= 4 ? 384 : 1024;
+  const int jl = ntile(4) >= want ? 4 : (ntile(2) >= want ? 2 : 1);
+  const bool full = N % 128 == 0;
+#define WT_LAUNCH(JL, FULL)                                                                                            \
+  do {                                                                                                                 \
+    auto kern = skinny_wgrad_adam_t16_kernel<JL, FULL, NB>;                                                            \
+    static size_t configured = 0;                                                                                      \
+    if (lds > configured) {                                                                                            \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        return 1;                                                                                                      \
+      configured = lds;                                                                                                \
+    }                                                                                                                  \
+    hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(K, 4 * 32 * JL), (unsigned)cdiv(N, 128)), dim3(256), lds, st, P, chunk_stride, \
+                       MC, W, exp_avg, exp_avg_sq, ldw, N, K, beta1, beta2, eps, grad_scale, coef_dev);                \
+  } while (0)
+  if (full) { if (jl == 4) WT_LAUNCH(4, true); else if (jl == 2) WT_LAUNCH(2, true); else WT_LAUNCH(1, true); }
+  else { if (jl == 4) WT_LAUNCH(4, false); else if (jl == 2) WT_LAUNCH(2, false); else WT_LAUNCH(1, false); }
+#undef WT_LAUNCH
+  return 0;
+}
+
+extern "C" int pcaa_skinny_linear_wgrad_adam_t16(const void* packed_bf16, long chunk_stride, int chunks, float* W,
+                                                 float* exp_avg, float* exp_avg_sq, long ldw, int N, int K, float beta1,
+                                                 float beta2, float eps, float grad_scale, const float* coef_dev,
+                                                 void* stream) {
+  PCAA_CHECK_ARG(packed_bf16 && W && exp_avg && exp_avg_sq && coef_dev, "pcaa_skinny_linear_wgrad_adam_t16: null pointer");
+  PCAA_CHECK_ARG(chunks >= 1 && chunks <= 8 && N >= 1 && K >= 32 && K % 32 == 0,
+                 "pcaa_skinny_linear_wgrad_adam_t16: unsupported shape chunks=%d N=%d K=%d (chunks <= 8, K %% 32 == 0)", chunks, N, K);
+  PCAA_CHECK_ARG(chunk_stride >= pcaa_packed_chunk_elems(N, K) && chunk_stride % 8 == 0 && ((uintptr_t)packed_bf16 % 16) == 0,
+                 "pcaa_skinny_linear_wgrad_adam_t16: chunk stride %ld below (N + K) * 64 or misaligned", chunk_stride);
+  PCAA_CHECK_ARG(ldw >= K && (long)N * ldw < (1L << 30) && (long)chunks * chunk_stride * 2 < (1L << 31),
+                 "pcaa_skinny_linear_wgrad_adam_t16: operands beyond 32-bit offsets");
+  hipStream_t st = as_stream(stream);
+  const bf16_t* P = reinterpret_cast<const bf16_t*>(packed_bf16);
+  // one workgroup per CU once the dz panels of >= 4 chunks fill the LDS: more fragments of W / exp_avg / exp_avg_sq in
+  // flight per wave then replace the second workgroup's (measured in tools/skinny_lab.py)
+  const int rc = chunks >= 4
+      ? launch_wgrad_adam_t16<4>(P, chunk_stride, chunks, W, exp_avg, exp_avg_sq, ldw, N, K, beta1, beta2, eps, grad_scale, coef_dev, st)
+      : launch_wgrad_adam_t16<2>(P, chunk_stride, chunks, W, exp_avg, exp_avg_sq, ldw, N, K, beta1, beta2, eps, grad_scale, coef_dev, st);
+  if (rc != 0) {
+    pcaa_set_error("pcaa_skinny_linear_wgrad_adam_t16: cannot raise the dynamic LDS limit");
+    return PCAA_ERR_LAUNCH;
+  }
+  PCAA_RETURN_LAUNCH_STATUS("pcaa_skinny_linear_wgrad_adam_t16");
 }

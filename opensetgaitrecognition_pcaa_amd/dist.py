@@ -71,6 +71,8 @@ class GroupExchange:
     def __init__(self, group):
         self.group = group
         self.world = dist.get_world_size(group)
+        # RCCL collectives are stream operations and can be recorded into a hipGraph; gloo's run on the host
+        self.capturable = dist.get_backend(group) == "nccl"
 
     def all_reduce(self, t, async_op=False, tag=None):
         return dist.all_reduce(t, group=self.group, async_op=async_op)
@@ -91,6 +93,11 @@ class _StreamWork:
         torch.cuda.current_stream().wait_event(self.event)
 
 
+class _NoWork:
+    def wait(self):
+        pass
+
+
 class EmulatedExchange:
     """One rank of a world of ``world`` ranks on ONE GPU, without peers: every collective becomes a device operation
     that moves the bytes the rank's memory system would see and leaves the values the collective would leave IF EVERY
@@ -100,13 +107,14 @@ class EmulatedExchange:
       to the factor 2 (w-1)/w), the sum of ``world`` identical shards;
     * ``all_gather_into_tensor(dst, src)``: own rows into slot 0, the other ``world - 1`` slots from the staged peers of
       that ``tag`` (``set_peers``; shape [world - 1, *src.shape]) or, without any, copies of ``src``: (world - 1) x the
-      bytes arrive in ``dst``, as from the wire.
+      bytes arrive in ``dst`` (contiguous, world x src), as from the wire.
 
     Like RCCL's, the operations run on a stream of their own that picks up behind the issuing stream; the returned work's
-    ``wait()`` orders the waiting stream behind them.  What is NOT emulated: the wire itself (latency, link bandwidth,
+    ``wait()`` orders the waiting stream behind them (under a hipGraph capture: on the issuing stream, see _issue).  What is NOT emulated: the wire itself (latency, link bandwidth,
     other ranks' skew) -- bench.py's ``scale_projection`` adds that from stated link figures -- and SyncBN."""
 
     emulated = True
+    capturable = True
 
     def __init__(self, world, device):
         if world < 1:
@@ -123,6 +131,15 @@ class EmulatedExchange:
 
     def _issue(self, fn):
         cur = torch.cuda.current_stream()
+        if torch.cuda.is_current_stream_capturing():
+            # Under a hipGraph capture the operation runs on the issuing stream itself and the work is a no-op: every
+            # consumer in PCAATrainer._step already orders itself behind the issuing stream (the side stream waits for
+            # the main and weight-gradient streams before it waits for the works).  The event pair of the eager form --
+            # record on the issuer, wait on the exchange stream, record there, wait on the consumer -- crashed
+            # hipStreamEndCapture on ROCm 7.2 (tools/lab/dp_graph_probe.py: with the events, with or without the
+            # operations: segfault; without the events: captured and replayed); RCCL's own collectives capture fine.
+            fn()
+            return _NoWork()
         ready = torch.cuda.Event()
         ready.record(cur)
         with torch.cuda.stream(self.stream):
@@ -133,7 +150,8 @@ class EmulatedExchange:
         return _StreamWork(done)
 
     def all_reduce(self, t, async_op=False, tag=None):
-        t.record_stream(self.stream)
+        if not torch.cuda.is_current_stream_capturing():
+            t.record_stream(self.stream)
         work = self._issue(lambda: t.mul_(self.world))
         self.bytes_moved += 2 * t.numel() * t.element_size()
         if async_op:
@@ -142,21 +160,22 @@ class EmulatedExchange:
         return None
 
     def all_gather_into_tensor(self, dst, src, async_op=False, tag=None):
-        n = src.shape[0]
-        if dst.shape[0] != n * self.world:
-            raise ValueError(f"EmulatedExchange.all_gather_into_tensor: dst has {dst.shape[0]} rows, want {n * self.world}")
+        if dst.numel() != src.numel() * self.world:
+            raise ValueError(f"EmulatedExchange.all_gather_into_tensor: dst {tuple(dst.shape)} is not {self.world} x src "
+                             f"{tuple(src.shape)}")
+        slots = dst.view((self.world,) + tuple(src.shape))
         peers = self.peers.get(tag)
         if peers is not None and tuple(peers.shape) != (self.world - 1,) + tuple(src.shape):
             raise ValueError(f"EmulatedExchange: peers of {tag!r} are {tuple(peers.shape)}, want "
                              f"{(self.world - 1,) + tuple(src.shape)}")
 
         def fn():
-            dst[:n].copy_(src)
-            rest = dst[n:].view((self.world - 1,) + tuple(src.shape)) if self.world > 1 else None
-            if rest is not None:
-                rest.copy_(peers if peers is not None else src.unsqueeze(0).expand_as(rest))
-        dst.record_stream(self.stream)
-        src.record_stream(self.stream)
+            slots[0].copy_(src)
+            if self.world > 1:
+                slots[1:].copy_(peers if peers is not None else src.unsqueeze(0).expand_as(slots[1:]))
+        if not torch.cuda.is_current_stream_capturing():
+            dst.record_stream(self.stream)
+            src.record_stream(self.stream)
         work = self._issue(fn)
         self.bytes_moved += 2 * dst.numel() * dst.element_size()
         if async_op:

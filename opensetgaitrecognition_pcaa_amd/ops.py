@@ -1168,7 +1168,7 @@ def skinny_linear_fwd(x, W, bias, act, exact=False, W16=None):
     if W.shape[1] != K:
         raise ValueError("skinny_linear_fwd: shape mismatch")
     lib = _lib.load()
-    ns = lib.pcaa_skinny_splits(0, M, N, K)
+    ns = lib.pcaa_skinny_splits(2 if exact else 0, M, N, K)
     ws = torch.empty(ns * M * N, dtype=torch.float32, device=x.device)
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
     if W16 is not None and not exact:
@@ -1203,7 +1203,7 @@ def skinny_linear_dgrad(dz, W, a_prev=None, out=None, accumulate=False, exact=Fa
         if out.numel() != M * K:
             raise ValueError("skinny_linear_dgrad: out size")
     lib = _lib.load()
-    ns = lib.pcaa_skinny_splits(1, M, N, K)
+    ns = lib.pcaa_skinny_splits(3 if exact else 1, M, N, K)
     ws = torch.empty(ns * M * K, dtype=torch.float32, device=dz.device)
     if W16 is not None and not exact:
         Wsrc, fn, wb = _w16_image(W16, W, "skinny_dgrad.W16"), lib.pcaa_skinny_linear_dgrad_w16, 2
@@ -1297,6 +1297,63 @@ def skinny_linear_wgrad_adam_rows_(dz_all, x_all, m, W, exp_avg, exp_avg_sq, bet
         _p(dz_all), dz_all.stride(0), _p(x_all), x_all.stride(0), _p(W), _p(exp_avg), _p(exp_avg_sq), K, int(m), N, K,
         float(beta1), float(beta2), float(eps), float(grad_scale), _p(coef_dev), R, _s()),
         "pcaa_skinny_linear_wgrad_adam_rows"), 2.0 * m * N * K, 4 * (6 * N * K + m * K + m * N))
+    return W
+
+
+PACK_ROWS = 64        # batch rows of one packed chunk (pcaa_pack_rows_t16)
+PACK_MAX_CHUNKS = 8   # chunks one pcaa_skinny_linear_wgrad_adam_t16 launch contracts over
+
+
+def packed_chunk_elems(N, K):
+    """bf16 elements of one rank's packed weight-gradient operands of an [N, K] layer: (N + K) columns x 64 rows"""
+    return int(_lib.load().pcaa_packed_chunk_elems(int(N), int(K)))
+
+
+def pack_rows_t16(dz, x, out=None):
+    """One rank's two weight-gradient operands of a batch-skinny layer -- dz [rows, N], x [rows, K], rows <= 64 -- as ONE
+    packed chunk [(N + K) * 64] bf16 (transposed: a 128-B row per column of dz, then of x; rounded to nearest even; zero
+    behind ``rows``): the form skinny_linear_wgrad_adam_t16_ contracts over and the data-parallel step all-gathers."""
+    _chk(dz, "pack_rows_t16.dz", torch.float32, 2)
+    _chk(x, "pack_rows_t16.x", torch.float32, 2)
+    rows, N = dz.shape
+    K = x.shape[1]
+    if x.shape[0] != rows or rows > PACK_ROWS:
+        raise ValueError(f"pack_rows_t16: dz {tuple(dz.shape)} / x {tuple(x.shape)}: equal row counts <= {PACK_ROWS}")
+    n = packed_chunk_elems(N, K)
+    if out is None:
+        out = torch.empty(n, dtype=torch.bfloat16, device=dz.device)
+    else:
+        _chk(out, "pack_rows_t16.out", torch.bfloat16)
+        if out.numel() != n:
+            raise ValueError(f"pack_rows_t16: out must hold {n} bf16 elements, got {out.numel()}")
+    check(_lib.load().pcaa_pack_rows_t16(_p(dz), dz.stride(0), N, _p(x), x.stride(0), K, rows, _p(out), _s()),
+          "pcaa_pack_rows_t16")
+    return out
+
+
+def skinny_linear_wgrad_adam_t16_(packed, chunks, W, exp_avg, exp_avg_sq, beta1, beta2, eps, coef_dev, grad_scale=1.0):
+    """The fused weight-gradient + Adam update from the ranks' PACKED operands (data parallel, round 6;
+    pcaa_skinny_linear_wgrad_adam_t16): ``packed`` [>= chunks, (N + K) * 64] bf16, one pack_rows_t16 chunk per rank
+    (a gathered buffer).  W[N,K] <- Adam(W, grad_scale * sum over the chunks of dz_c^T @ x_c) in place, bf16 products."""
+    if (not isinstance(packed, torch.Tensor) or not packed.is_cuda or packed.dtype != torch.bfloat16 or packed.dim() != 2
+            or packed.stride(1) != 1):
+        raise TypeError("skinny_linear_wgrad_adam_t16_: packed must be a [chunks, >= (N + K) * 64] bf16 tensor on the HIP "
+                        "device with contiguous rows")
+    for t, nm in ((W, "W"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, "skinny_wgrad_adam_t16." + nm, torch.float32, 2)
+        if tuple(t.shape) != tuple(W.shape):
+            raise ValueError(f"skinny_linear_wgrad_adam_t16_: {nm} must be {tuple(W.shape)}, got {tuple(t.shape)}")
+    N, K = W.shape
+    chunks = int(chunks)
+    if not 1 <= chunks <= min(PACK_MAX_CHUNKS, packed.shape[0]) or packed.shape[1] < packed_chunk_elems(N, K):
+        raise ValueError(f"skinny_linear_wgrad_adam_t16_: {chunks} chunks of an [{N},{K}] layer do not fit a packed buffer "
+                         f"{tuple(packed.shape)} (at most {PACK_MAX_CHUNKS} chunks of {packed_chunk_elems(N, K)} elements)")
+    _chk(coef_dev, "skinny_wgrad_adam_t16.coef", torch.float32)
+    m = chunks * PACK_ROWS
+    _skinny_timed(lambda: check(_lib.load().pcaa_skinny_linear_wgrad_adam_t16(
+        _p(packed), packed.stride(0), chunks, _p(W), _p(exp_avg), _p(exp_avg_sq), K, N, K, float(beta1), float(beta2),
+        float(eps), float(grad_scale), _p(coef_dev), _s()), "pcaa_skinny_linear_wgrad_adam_t16"),
+        2.0 * m * N * K, 24 * N * K + 2 * m * (N + K))
     return W
 
 

@@ -221,8 +221,11 @@ class PCAATrainer:
         weight-gradient operands -- dz [B, out] and x [B, in], all-gathered over the ranks -- instead of the gradient
         (4 world B (in + out) bytes against 4 in out: ~10x less on the wire), and every rank forms the GLOBAL gradient
         inside the fused weight-gradient + Adam kernel (pcaa_skinny_linear_wgrad_adam_rows): the update stays 24 B per
-        parameter and no Adam pass over the decoder follows the exchange.  Applies while world * B <= 512; mathematically
-        the all-reduce scheme's step (sum over ranks of dz_r^T x_r = stacked-rows product).
+        parameter and no Adam pass over the decoder follows the exchange.  Mathematically the all-reduce scheme's step
+        (sum over ranks of dz_r^T x_r = stacked-rows product).  Round 6: the two operands travel as ONE packed bf16 chunk
+        per rank and layer (ops.pack_rows_t16: transposed, 64 batch rows, the rounding the weight-gradient kernels apply
+        anyway) -- half the bytes, one all-gather per layer -- and pcaa_skinny_linear_wgrad_adam_t16 contracts over the
+        ranks' chunks.  Applies while world <= 8 and B <= 64 (else the all-reduce scheme runs; ``dp_scheme`` says which).
         ``emulate_world=W`` (round 6; no process group): this process runs ONE RANK'S PROGRAM of a W-rank job on its own --
         gradient scale 1/W, W * B stacked rows in the gathered update, every collective replaced by a device operation of
         the same bytes on a stream of its own (dist.EmulatedExchange; peers' gathered rows can be staged there).  It
@@ -261,7 +264,7 @@ class PCAATrainer:
         self._dp_gather = bool(dp_gather)
         if self._dp_gather and self._dp_zero_arg:
             raise ValueError("PCAATrainer: dp_gather and dp_zero are alternatives")
-        self._gather_bufs = {}          # (layer, rows_alloc) -> (dz_all, x_all): zero-initialised once, reused every step
+        self._gather_bufs = {}          # (layer, world) -> (gathered packed chunks [world, (N + K) * 64] bf16, own chunk)
         self._force_collectives = bool(force_collectives)
         self.fused_decoder_update = bool(fused_decoder_update)
         # the parity modes too (fp32-product kernels); tests that read the decoder's weight gradients pass False
@@ -794,29 +797,29 @@ class PCAATrainer:
                     updates[layer] = lambda dz2, x, t=(Wv, mv, vv, w16.get(layer)): deferred.append((dz2, x) + t + (None,))
                     fused_ranges.append((lo, hi))
         # Data parallel, dp_gather: the same fused update from the ranks' stacked rows.  A layer's callback runs where the
-        # backward has just formed dz2: the two all-gathers go out from there (the collective's own stream picks up behind
-        # what is enqueued here; this stream does not wait) and the update kernel follows on the Adam side stream once both
-        # are back -- no gradient bucket, no all-reduce, no separate Adam pass for these layers.
-        rows_all = self.world * B
+        # backward has just formed dz2: the operands are packed and their all-gather goes out from there (the collective's own
+        # stream picks up behind what is enqueued here; this stream does not wait) and the update kernel follows on the Adam
+        # side stream once it is back -- no gradient bucket, no all-reduce, no separate Adam pass for these layers.
+        # (round 6: the operands travel PACKED -- one transposed bf16 chunk of 64 batch rows per rank and layer, ops.pack_rows_t16
+        # -- half the bytes, one all-gather per layer instead of two, and 16-B fragment loads in the update kernel)
         gather = (collective and self._dp_gather and not zero and mode == "bf16" and self.fused_decoder_update
-                  and self._side is not None and ops.gathered_rows_alloc(rows_all) is not None)
+                  and self._side is not None and self.world <= ops.PACK_MAX_CHUNKS and B <= ops.PACK_ROWS)
         self.dp_scheme = "zero" if zero else ("gather" if gather else ("allreduce" if collective else "none"))
         if gather:
-            R = ops.gathered_rows_alloc(rows_all)
-
             def gather_update(layer, Wv, mv, vv):
                 def cb(dz2, x):
-                    key = (layer, R)
+                    key = (layer, self.world)
                     if key not in self._gather_bufs:
-                        self._gather_bufs[key] = (torch.zeros((R, dz2.shape[1]), dtype=torch.float32, device=self.device),
-                                                  torch.zeros((R, x.shape[1]), dtype=torch.float32, device=self.device))
-                    dz_all, x_all = self._gather_bufs[key]
-                    works = []
-                    for dst, src, which in ((dz_all, dz2, "dz"), (x_all, x, "x")):
-                        src = src.contiguous()
-                        self._count(4 * rows_all * src.shape[1], "gather")
-                        works.append(self._xchg.all_gather_into_tensor(dst[:rows_all], src, async_op=True, tag=(layer, which)))
-                    deferred.append((dz_all, x_all, Wv, mv, vv, None, works))
+                        ce = ops.packed_chunk_elems(Wv.shape[0], Wv.shape[1])
+                        self._gather_bufs[key] = (torch.zeros((self.world, ce), dtype=torch.bfloat16, device=self.device),
+                                                  torch.empty(ce, dtype=torch.bfloat16, device=self.device))
+                    packed_all, own = self._gather_bufs[key]
+                    ops.pack_rows_t16(dz2 if dz2.stride(1) == 1 else dz2.contiguous(), x if x.stride(1) == 1 else x.contiguous(),
+                                      out=own)
+                    self._count(2 * packed_all.numel(), "gather")
+                    # (flat views: gloo's all-gather wants output and input of the same rank)
+                    work = self._xchg.all_gather_into_tensor(packed_all.view(-1), own, async_op=True, tag=layer)
+                    deferred.append((packed_all, None, Wv, mv, vv, None, [work]))
                 return cb
 
             for layer, (lo, hi, Wv, mv, vv) in self._dec_fused.items():
@@ -953,12 +956,13 @@ class PCAATrainer:
                         self._side.wait_stream(self._wg)   # ... and the decoder weight gradients on the wgrad stream
                     for dz2, x, Wv, mv, vv, w16, works in deferred:
                         dz2.record_stream(self._side)
-                        x.record_stream(self._side)
+                        if x is not None:
+                            x.record_stream(self._side)
                         if works is not None:
                             for wk in works:
-                                wk.wait()               # this stream waits for the two all-gathers of THIS layer only
-                            ops.skinny_linear_wgrad_adam_rows_(dz2, x, rows_all, Wv, mv, vv, *self.betas_g(), 1e-8,
-                                                               self.flat_g.coef_dev, gs)
+                                wk.wait()               # this stream waits for the all-gather of THIS layer only
+                            ops.skinny_linear_wgrad_adam_t16_(dz2, self.world, Wv, mv, vv, *self.betas_g(), 1e-8,
+                                                              self.flat_g.coef_dev, gs)      # (dz2: the gathered packed chunks)
                             continue
                         ops.skinny_linear_wgrad_adam_(dz2, x, Wv, mv, vv, *self.betas_g(), 1e-8, self.flat_g.coef_dev, gs,
                                                       exact=exact_dec)
@@ -1067,10 +1071,19 @@ class PCAATrainer:
         """Whether step_graphed beats step for this shape on one GPU.  The eager step costs the host ~2.5 ms of
         enqueues (~120 launches); that only binds when the GPU needs less: measured (B=64, bf16, ms/step eager |
         graph) N=32: 2.56 | 2.34, N=64: 3.56 | 3.71, N=128: 6.51 | 6.66 -- replay wins below ~80 K points per step
-        and loses 2-4 % above (profiles/r02_graph_vs_eager.txt).  Single process, variants without autograd inside
-        the step only."""
-        return (self.world == 1 and self.variant in ("v4", "base", "v3") and self.device.type == "cuda"
+        and loses 2-4 % above (profiles/r02_graph_vs_eager.txt).  Variants without autograd inside the step only; single
+        process or an emulated world by default (see can_graph)."""
+        return (self.can_graph() and (self._xchg is None or self._xchg.emulated or os.environ.get("PCAA_GRAPH") == "on")
                 and B * self.T * N <= 80_000 and os.environ.get("PCAA_GRAPH", "auto") != "off")
+
+    def can_graph(self):
+        """Whether step_graphed can capture this trainer's step: no autograd inside it (variant 1's mean learner), and every
+        exchange a stream operation -- RCCL's collectives are (round 6: the data-parallel step replays as ONE graph launch
+        per rank, collectives included; at small N the eager DP step is bound by the host's ~2.5 ms of enqueues), gloo's
+        are host calls.  A real multi-rank group replays only on request (PCAA_GRAPH=on / bench.py --graph on): no node
+        with more than one GPU has been available to measure it on."""
+        return (self.variant in ("v4", "base", "v3") and self.device.type == "cuda"
+                and (self._xchg is None or self._xchg.capturable) and not self.time_comm)
 
     def step_graphed(self, pcs, gt, z0, alphas, supervise=True, warmup=2):
         """step() through a captured hipGraph.  The step is a fixed sequence of ~200 launches on four
@@ -1081,6 +1094,9 @@ class PCAATrainer:
         initialisation, allocator warm-up), the next one captures; every call performs exactly one real
         train step.  The returned tensors are the graph's static outputs: they are overwritten by the
         next replay (clone what must survive)."""
+        if not self.can_graph():
+            raise RuntimeError("PCAATrainer.step_graphed: this trainer's step cannot be captured (variant 1's autograd, a gloo "
+                               "process group, or time_comm's timing events): use step()")
         if not supervise and not self._sup_split:
             # the first unsupervised step changes the launch sequence of the supervised one as well
             self._sup_split = True
@@ -1287,7 +1303,7 @@ def _run_loop(config, variant, dataset_factory=None, log_fn=None, process_group=
     best_valid_accuracy = 0
     history = []
     L = config["SUP_LATENT_DIM"]
-    use_graph = world == 1 and trainer.prefers_graph(local_cfg["BATCH_SIZE"], nmax_points)
+    use_graph = trainer.prefers_graph(local_cfg["BATCH_SIZE"], nmax_points)
     draws = _EpochDraws(L, dev, process_group, rank, world)
     for epoch in range(config["EPOCHS"]):
         t_epoch = time.perf_counter()

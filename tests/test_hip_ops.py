@@ -508,6 +508,70 @@ def test_skinny_wgrad_adam_rows_gathered_update(M, N, K):
         ops.skinny_linear_wgrad_adam_rows_(dzb[:8], xb[:8], 600, W, m, v, 0.9, 0.99, 1e-8, c.coef_dev)
 
 
+@pytest.mark.parametrize("rows,N,K", [(64, 256, 128), (37, 192, 160), (5, 130, 96), (64, 1920, 960)])
+def test_pack_rows_t16_is_the_transposed_rounded_operand_pair(rows, N, K):
+    """Round 6: pcaa_pack_rows_t16 -- column c of dz, then of x, as one 128-B row of 64 bf16 batch rows (nearest even),
+    zeros behind ``rows``; strided sources (leading dimension > width) are honoured."""
+    dzf = _rand((rows, N + 8), 810, 0.3).to(DEV)
+    xf = _rand((rows, K + 4), 811, 1.0).to(DEV)
+    dz, x = dzf[:, :N], xf[:, :K]
+    assert dz.stride(0) == N + 8
+    from opensetgaitrecognition_pcaa_amd import _lib
+    out = torch.full((ops.packed_chunk_elems(N, K),), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.check(_lib.load().pcaa_pack_rows_t16(dz.data_ptr(), dz.stride(0), N, x.data_ptr(), x.stride(0), K, rows,
+                                              out.data_ptr(), torch.cuda.current_stream().cuda_stream), "pack")
+    want = torch.zeros((N + K, 64), dtype=torch.bfloat16, device=DEV)
+    want[:N, :rows] = dz.t().bfloat16()
+    want[N:, :rows] = x.t().bfloat16()
+    assert torch.equal(out.view(N + K, 64), want)
+    assert torch.equal(ops.pack_rows_t16(dz.contiguous(), x.contiguous()), out)
+    with pytest.raises(ValueError):
+        ops.pack_rows_t16(torch.zeros((65, N), device=DEV), torch.zeros((65, K), device=DEV))
+
+
+@pytest.mark.parametrize("chunks,rows,N,K", [(1, 64, 256, 128), (1, 37, 192, 160), (2, 64, 256, 128), (3, 16, 130, 96),
+                                             (4, 64, 960, 1920), (5, 64, 384, 512), (8, 64, 1920, 960), (8, 40, 128, 1024),
+                                             (8, 64, 3840, 1920)])
+def test_skinny_wgrad_adam_t16_packed_gathered_update(chunks, rows, N, K):
+    """Round 6 (the data-parallel decoder update from PACKED gathered operands): W <- Adam(W, s * sum_c dz_c^T x_c) over up
+    to 8 chunks of <= 64 rows.  The gradient it forms is the bf16-operand product with fp32 accumulation over all chunks --
+    checked through exp_avg = (1 - beta1) * grad after one step from zero moments against an fp64 product of the rounded
+    operands (1e-5 of the largest entry), and against the rows kernel of round 5 on the same stacked rows (the same
+    products in another summation order); chunks behind ``chunks`` in the buffer are not read."""
+    from opensetgaitrecognition_pcaa_amd.train import StepCount
+    W0 = _rand((N, K), 900, 0.05).to(DEV)
+    ce = ops.packed_chunk_elems(N, K)
+    packed = torch.full((chunks + 1, ce + 64), float("nan"), dtype=torch.bfloat16, device=DEV)[:, :ce]     # a strided buffer
+    dzs = [_rand((rows, N), 901 + 2 * c, 0.3).to(DEV) for c in range(chunks)]
+    xs = [_rand((rows, K), 902 + 2 * c, 1.0).to(DEV) for c in range(chunks)]
+    for c in range(chunks):
+        packed[c] = ops.pack_rows_t16(dzs[c], xs[c])
+    W, m, v = W0.clone(), torch.zeros_like(W0), torch.zeros_like(W0)
+    cnt = StepCount(DEV)
+    cnt.advance(1e-3, 0.9, 0.99)
+    ops.skinny_linear_wgrad_adam_t16_(packed, chunks, W, m, v, 0.9, 0.99, 1e-8, cnt.coef_dev, grad_scale=0.5)
+    torch.cuda.synchronize()
+    g64 = 0.5 * sum(dzs[c].bfloat16().double().t() @ xs[c].bfloat16().double() for c in range(chunks))
+    got = m.double() / 0.1
+    assert (got - g64).abs().max().item() <= 1e-5 * g64.abs().max().item() + 1e-7
+    assert torch.isfinite(W).all() and not torch.equal(W, W0)
+    # the rows kernel on the same rows stacked (rows < 64: zero rows in between change nothing)
+    M = chunks * 64
+    R = ops.gathered_rows_alloc(M)
+    dzb, xb = torch.zeros((R, N), device=DEV), torch.zeros((R, K), device=DEV)
+    for c in range(chunks):
+        dzb[64 * c:64 * c + rows] = dzs[c]
+        xb[64 * c:64 * c + rows] = xs[c]
+    Wr, mr, vr = W0.clone(), torch.zeros_like(W0), torch.zeros_like(W0)
+    cr = StepCount(DEV)
+    cr.advance(1e-3, 0.9, 0.99)
+    ops.skinny_linear_wgrad_adam_rows_(dzb, xb, M, Wr, mr, vr, 0.9, 0.99, 1e-8, cr.coef_dev, grad_scale=0.5)
+    assert (m - mr).abs().max().item() <= 2e-6 * mr.abs().max().item()
+    assert (W - Wr).abs().max().item() <= 2.1e-3 and (W - Wr).abs().mean().item() <= 1e-6
+    with pytest.raises(ValueError):
+        ops.skinny_linear_wgrad_adam_t16_(packed, chunks + 2, W, m, v, 0.9, 0.99, 1e-8, cnt.coef_dev)
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 256, 128), (37, 192, 160), (64, 960, 1920), (16, 4544, 2304)])
 def test_skinny_wgrad_bf16_output_is_the_rounded_fp32_gradient(M, N, K):
     """pcaa_skinny_linear_wgrad_bf16 (the data-parallel step's bf16 gradient buckets are produced directly): the same

@@ -81,3 +81,31 @@ for K, N in zip(widths[:-1], widths[1:]):
     del W, m, v
 print("totals over the wide layers (ms):", {f"M={k}": round(t, 3) for k, t in rows_tot.items()},
       "  single-process fused (M=64):", round(tot.get("fused", 0), 3))
+
+
+# ---- round 6: the same update from PACKED operands (pcaa_pack_rows_t16 chunks, one per rank; pcaa_skinny_linear_wgrad_adam_t16)
+print("\npacked-operand update (pcaa_skinny_linear_wgrad_adam_t16), ms per layer [TB/s of 24 B/param]; pack = one rank's pack launch")
+t16_tot, pack_tot = {}, 0.0
+for K, N in zip(widths[:-1], widths[1:]):
+    g = torch.Generator(device="cpu").manual_seed(N)
+    W = (torch.randn(N, K, generator=g) * 0.02).to(dev)
+    m, v = torch.zeros_like(W), torch.zeros_like(W)
+    c = StepCount(dev)
+    c.advance(1e-4, 0.9, 0.99)
+    n = N * K
+    dz = (torch.randn(64, N, generator=g) * 0.1).to(dev)
+    x = torch.randn(64, K, generator=g).to(dev)
+    own = ops.pack_rows_t16(dz, x)
+    t_p = timed(lambda: ops.pack_rows_t16(dz, x, out=own), a.reps)
+    pack_tot += t_p
+    cells = [f"pack {t_p * 1e3:.1f} us"]
+    for chunks in (1, 2, 4, 8):
+        packed = own.unsqueeze(0).repeat(chunks, 1).contiguous()
+        t = timed(lambda: ops.skinny_linear_wgrad_adam_t16_(packed, chunks, W, m, v, 0.9, 0.99, 1e-8, c.coef_dev, 1.0 / chunks), a.reps)
+        t16_tot[chunks] = t16_tot.get(chunks, 0) + t
+        cells.append(f"{chunks} x 64: {t:.3f} [{24 * n / t / 1e9:.2f}]")
+        del packed
+    print(f"[{K}->{N}] " + "   ".join(cells))
+    del W, m, v, dz, x
+print("totals over the wide layers (ms):", {f"{k} chunks": round(t, 3) for k, t in t16_tot.items()}, " packs:", round(pack_tot, 4),
+      "  rows kernel (round 5):", {f"M={k}": round(t, 3) for k, t in rows_tot.items()})
