@@ -953,7 +953,8 @@ extern "C" int pcaa_skinny_splits(int kind, int M, int N, int K) {
   static const bool legacy = getenv("PCAA_SKINNY_SPLITS_LEGACY") != nullptr;      // lab: the round 2-5 rule, for A/B runs
   int ns;
   if (legacy) ns = std::max(1, std::min(chunks, (768 + (int)cdiv(fwd ? N : K, 128) - 1) / (int)cdiv(fwd ? N : K, 128)));
-  else ns = std::max(1, std::min(chunks, resident_blocks(kind) / groups));
+  else ns = std::max(1, std::min(std::max(1, chunks / 2), resident_blocks(kind) / groups));   // (>= 2 chunks per workgroup: a
+  // one-chunk workgroup is all prologue -- the 1920 -> 3840 dgrad went 21 -> 32 us with 480 of them)
   const int cps = (int)cdiv(chunks, ns);
   return (int)cdiv(chunks, cps);
 }
