@@ -744,8 +744,8 @@ def linear_act_backward(x, a_out, lin, act, d_out, need_dx=True, dW_out=None, db
     the layer below): dx is multiplied by ELU'(x), i.e. it is the gradient w.r.t. that layer's
     pre-activation -- the caller passes it on with d_is_pre=True.
     ``update`` (skinny path only): callable ``update(dz, x)`` that forms the weight gradient AND applies the
-    optimizer to the weight in one kernel (ops.skinny_linear_wgrad_adam_); it is called after the layer's dgrad
-    -- which reads the weight it overwrites -- has been enqueued, and dW is returned as None."""
+    optimizer to the weight in one kernel (ops.skinny_linear_wgrad_adam_) LATER -- the callback itself must not touch the
+    weight: it is called before the layer's dgrad, which reads it -- and dW is returned as None."""
     M, K = x.shape
     N = lin.weight.shape[0]
     dz = ops.elu_bwd_from_out(d_out, a_out) if (act == ACT_ELU and not d_is_pre) else d_out
@@ -755,12 +755,16 @@ def linear_act_backward(x, a_out, lin, act, d_out, need_dx=True, dW_out=None, db
             raise RuntimeError("linear_act_backward: a fused weight update is only served by the skinny path")
         with _on_wgrad_stream(dz2):
             db = ops.colsum(dz2, out=db_out)
+        # the callback only NOTES the operands (single process: the kernels run later, on the Adam side stream, once the whole
+        # decoder backward -- whose dgrads read the weights they overwrite -- is enqueued) or packs and sends them (data
+        # parallel); nothing in it writes the weight, so it runs ahead of this layer's dgrad and the pack + all-gather of
+        # the data-parallel step leave while the dgrad streams the weight
+        update(dz2, x)
         dx = None
         if need_dx:
             dx = ops.skinny_linear_dgrad(dz2, lin.weight, a_prev=x if fuse_elu_in else None, out=dx_init,
                                          accumulate=dx_init is not None, exact=_skinny_exact(mode, M, N, K),
                                          W16=W16)
-        update(dz2, x)
         return None, db, dx
     exact = _skinny_exact(mode, M, N, K)
     if _skinny(mode, M, N, K) or exact:

@@ -814,11 +814,23 @@ class PCAATrainer:
                         self._gather_bufs[key] = (torch.zeros((self.world, ce), dtype=torch.bfloat16, device=self.device),
                                                   torch.empty(ce, dtype=torch.bfloat16, device=self.device))
                     packed_all, own = self._gather_bufs[key]
-                    ops.pack_rows_t16(dz2 if dz2.stride(1) == 1 else dz2.contiguous(), x if x.stride(1) == 1 else x.contiguous(),
-                                      out=own)
+                    dzc, xc = (dz2 if dz2.stride(1) == 1 else dz2.contiguous()), (x if x.stride(1) == 1 else x.contiguous())
                     self._count(2 * packed_all.numel(), "gather")
-                    # (flat views: gloo's all-gather wants output and input of the same rank)
-                    work = self._xchg.all_gather_into_tensor(packed_all.view(-1), own, async_op=True, tag=layer)
+
+                    def send():
+                        ops.pack_rows_t16(dzc, xc, out=own)
+                        # (flat views: gloo's all-gather wants output and input of the same rank)
+                        return self._xchg.all_gather_into_tensor(packed_all.view(-1), own, async_op=True, tag=layer)
+                    if self._wg is not None:
+                        # pack + all-gather leave from the weight-gradient stream (behind dz2, which this stream has just
+                        # formed): the main stream goes straight on to the layer's dgrad
+                        self._wg.wait_stream(ops.current_stream())
+                        with ops.on_stream(self._wg):
+                            dzc.record_stream(self._wg)
+                            xc.record_stream(self._wg)
+                            work = send()
+                    else:
+                        work = send()
                     deferred.append((packed_all, None, Wv, mv, vv, None, [work]))
                 return cb
 

@@ -498,6 +498,37 @@ def test_bench_multi_rank_branch_runs_on_two_gloo_ranks():
     # round 5: gathered operands instead of gradients -- 2 ranks x 64 rows x the layer widths against 157 M gradients
     assert by[("gather", "bf16", False)]["payload_bytes_per_step"] < 0.1 * by[("allreduce", "bf16", False)]["payload_bytes_per_step"]
     assert by[("gather", "bf16", False)]["is_default"], "bf16 mode: the gathered-operands scheme is the line's value"
+    # round 6: what `value` timed is said in the workload string itself, the scheme the steps RAN is
+    # reported (not the flag), and the all-reduce scheme's throughput -- the exchange north_star names -- stands at top level
+    assert "dp_gather" in d["config"]["workload"] and "per-rank BatchNorm" in d["config"]["workload"]
+    assert d["config"]["dp"]["asked"] == "gather" and all(l["dp_scheme_ran"] == l["dp_mode"] for l in legs)
+    assert d["value_allreduce"] == by[("allreduce", "bf16", False)]["value"] and d["ms_per_step_allreduce"] > 0
+    assert "emulated" not in d
+
+
+@pytest.mark.timeout(900)
+def test_bench_dp_emulate_line_is_labelled_and_never_claims_gpus():
+    """bench.py --dp-emulate 8: one rank's program of an 8-rank job on this GPU.  The line says so everywhere a reader
+    could take it for a multi-GPU number: `emulated`, n_gpus 1, the workload string, value = ONE rank's sequences/s."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--dp-emulate", "8", "--steps", "3", "--warmup", "2", "--windows", "2",
+           "--no-cpu-baseline", "--no-extra-legs", "--no-parity-mode", "--no-batcher-leg"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["emulated"] is True and d["n_gpus"] == 1 and d["config"]["emulated_world"] == 8
+    assert "EMULATED" in d["config"]["workload"] and "not a multi-GPU measurement" in d["config"]["workload"]
+    assert d["config"]["dp"]["mode"] == "gather" and d["config"]["decoder_update"] == "fused wgrad+adam"
+    assert abs(d["value"] - 64 / d["ms_per_step"] * 1e3) <= 1e-6 * d["value"], "one rank's sequences, not 8 x"
+    # 4 packed all-gathers (one per wide layer) + critic, encoder, decoder-rest all-reduces
+    assert d["config"]["dp"]["collectives_per_step"] >= 7
+    # a multi-rank launch refuses the flag
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dp-emulate", "8", "--dp-force", "--steps", "1"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "--dp-emulate" in bad.stderr
 
 
 @pytest.mark.timeout(900)
