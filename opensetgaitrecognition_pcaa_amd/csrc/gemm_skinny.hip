@@ -268,6 +268,13 @@ __global__ __launch_bounds__(256) void skinny_dgrad2_kernel(const float* __restr
 
 // ------------------------------------------------------------------ forward: y = x . W^T
 // grid (ceil(N/128), nsplit); wave w owns output columns (rows of W) [128 bx + 32 w, +32)
+// What bounds it (round 6, the 472 MB layer alone; profiles/r06_skinny_probes.txt): NOT the depth of the weight stream -- a
+// variant with two chunks of W per wave in flight (two register stages, x requested ahead of them so that its wait leaves
+// the younger W loads in flight across the barrier, 156 VGPRs, three workgroups per CU) timed 105.5 us against 105.6 -- but
+// the 64-row operand: at M = 64 / 32 / 8 / 1 rows the same weight stream takes 105.8 / 97.3 / 88.8 / 84.8 us (dgrad: 99.5 /
+// 89.9 / 85.5 / 83.4).  Every workgroup re-reads its x chunk (16 KB per 32 KB of weights: 236 MB from the L2s per pass),
+// writes a 32 KB slab, and the reduction reads them back.  Halving that (bf16 operands written by the producing reduction,
+// 8-wave workgroups) is worth ~15 us per big pass; not built.
 template <bool F32 = false, bool W16 = false>
 __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, long ldx,
                                                          const typename std::conditional<W16, bf16_t, float>::type* __restrict__ W, long ldw,
