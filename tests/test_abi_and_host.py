@@ -136,3 +136,63 @@ def test_steady_kernel_stats_keeps_only_the_timed_steps(tmp_path):
     g = out["gemm_bf16_v2_kernel<bf16>"]
     assert int(g["Calls"]) == 10 and float(g["AverageNs"]) == 250000.0, "warm-up launches must not be averaged in"
     assert "1030.8 TFLOP/s" in res.stderr and "0.412" in res.stderr
+
+
+def test_epoch_draws_are_the_reference_per_step_draws():
+    """Round 6: the loop draws a whole epoch's z0 / alphas at its start (train._EpochDraws) -- the values and the state both
+    generators are left in must be those of the reference's per-step calls (PCAA_ablation.py:915-925, 944-948):
+    ``np.random.normal(0, 1, (B, L))`` cast to float32 and ``torch.rand(size=(B, 1))``, step after step."""
+    from opensetgaitrecognition_pcaa_amd.train import _EpochDraws
+    steps, B, L = 7, 6, 32
+    np.random.seed(123)
+    torch.manual_seed(456)
+    ref_z = [torch.from_numpy(np.random.normal(0.0, 1.0, (B, L))).float() for _ in range(steps)]
+    np.random.seed(123)
+    torch.manual_seed(456)
+    ref_a = [torch.rand(size=(B, 1)) for _ in range(steps)]
+    # (the two generators are independent streams: the interleaving of the calls does not matter, their order within each does)
+    np.random.seed(123)
+    torch.manual_seed(456)
+    d = _EpochDraws(L, torch.device("cpu"))
+    z, a = d.draw(steps, B)
+    assert z.shape == (steps, B, L) and a.shape == (steps, B, 1) and z.dtype == a.dtype == torch.float32
+    for i in range(steps):
+        assert torch.equal(z[i], ref_z[i]) and torch.equal(a[i], ref_a[i]), i
+    # a second epoch continues both streams exactly where per-step draws would
+    np.random.seed(123)
+    torch.manual_seed(456)
+    for _ in range(steps):
+        np.random.normal(0.0, 1.0, (B, L))
+        torch.rand(size=(B, 1))
+    want_z, want_a = torch.from_numpy(np.random.normal(0.0, 1.0, (B, L))).float(), torch.rand(size=(B, 1))
+    np.random.seed(123)
+    torch.manual_seed(456)
+    d2 = _EpochDraws(L, torch.device("cpu"))
+    d2.draw(steps, B)
+    z2, a2 = d2.draw(1, B)
+    assert torch.equal(z2[0], want_z) and torch.equal(a2[0], want_a)
+    assert d.draw(0, B) == (None, None)
+
+
+def test_skinny_split_depth_keeps_the_grid_inside_one_round_of_resident_workgroups():
+    """Round 6: pcaa_skinny_splits -- a host-side function -- picks the deepest split whose grid fits the kernel's resident
+    workgroups (forward 768, dgrad 512 with bf16 products; 512 / 768 for the fp32-product forms), at least two chunks per
+    workgroup, no empty split; the config[1] decoder layers as the regression cases (the 7680 -> 15360 forward ran 840
+    workgroups on 768 slots through round 5)."""
+    lib = _lib.load()
+    S = 30 * 4 * 128
+    widths = [S // 16, S // 8, S // 4, S // 2, S]
+    slots = {0: 768, 1: 512, 2: 512, 3: 768}
+    for K, N in zip(widths[:-1], widths[1:]):
+        for kind in (0, 1, 2, 3):
+            fwd = kind % 2 == 0
+            groups = -(-(N if fwd else K) // (128 if fwd else 256))
+            chunks = (K if fwd else N) // 64
+            ns = lib.pcaa_skinny_splits(kind, 64, N, K)
+            cps = -(-chunks // ns)
+            assert 1 <= ns <= chunks and -(-chunks // cps) == ns, (kind, N, K, ns)          # no empty split
+            assert groups * ns <= slots[kind] or ns == 1, (kind, N, K, ns, groups)
+            assert cps >= 2 or chunks < 2, (kind, N, K, ns)
+    assert lib.pcaa_skinny_splits(0, 64, 15360, 7680) == 6 and lib.pcaa_skinny_splits(1, 64, 15360, 7680) == 16
+    assert lib.pcaa_skinny_splits(0, 64, 960, 64) == 1            # the first layer: one chunk, written by the kernel's own epilogue
+    assert lib.pcaa_packed_chunk_elems(15360, 7680) == (15360 + 7680) * 64
