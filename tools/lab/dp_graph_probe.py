@@ -10,8 +10,6 @@ if len(sys.argv) > 1:
     from opensetgaitrecognition_pcaa_amd.train import PCAATrainer
     from opensetgaitrecognition_pcaa_amd.utils import sample_distant_points
     case = sys.argv[1]
-    if ":" in case:
-        os.environ["PCAA_EMU_DEBUG"], case = case.split(":")
     B, N, C, K, T = 64, 32, 4, 8, constants.NSTEPS
     constants.NFEATURES = C
     cfg = dict(constants.CONFIG); cfg.update(NMAX=N, TRAIN_CLASSES=list(range(K)), BATCH_SIZE=B)
