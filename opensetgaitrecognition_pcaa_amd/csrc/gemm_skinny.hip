@@ -1139,6 +1139,10 @@ static int skinny_wgrad_adam_impl(const float* dz, long lddz, const float* x, lo
   PCAA_CHECK_ARG(lddz >= N && ldx >= K && ldw >= K, "pcaa_skinny_linear_wgrad_adam: bad leading dimensions");
   PCAA_CHECK_ARG((long)M * lddz < (1L << 31) && (long)M * ldx < (1L << 31) && (long)N * ldw < (1L << 30),
                  "pcaa_skinny_linear_wgrad_adam: operands beyond 32-bit offsets");
+  // (round 6, built and removed: the MFMA operands swapped -- the transposed tile, a lane holding four consecutive columns of
+  // ONE row, so that every access to W / exp_avg / exp_avg_sq is 16 B wide, 4 + 4 instructions per fragment and array instead
+  // of 16 + 16 -- bit-identical results, 0.99-1.03 ms against 0.79 on the same box: a wave instruction then touches a
+  // 32-B piece of 32 different lines instead of two whole lines; profiles/r06_wgrad_adam_swap_lab.txt)
   // measured alone on the four wide layers of the bench shape (tools/skinny_lab.py): 0.81 ms fused against 0.97 ms
   // (weight gradient 0.17 + Adam 0.80), 5.0 TB/s on the 7680 -> 15360 layer; a ring of 4 fragment buffers (three
   // fragments in flight) or 8 column steps per wave: 0.83 / 0.88 / 0.86 ms -- not kept
