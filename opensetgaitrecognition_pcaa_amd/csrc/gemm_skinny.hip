@@ -273,8 +273,10 @@ __global__ __launch_bounds__(256) void skinny_dgrad2_kernel(const float* __restr
 // the younger W loads in flight across the barrier, 156 VGPRs, three workgroups per CU) timed 105.5 us against 105.6 -- but
 // the 64-row operand: at M = 64 / 32 / 8 / 1 rows the same weight stream takes 105.8 / 97.3 / 88.8 / 84.8 us (dgrad: 99.5 /
 // 89.9 / 85.5 / 83.4).  Every workgroup re-reads its x chunk (16 KB per 32 KB of weights: 236 MB from the L2s per pass),
-// writes a 32 KB slab, and the reduction reads them back.  Halving that (bf16 operands written by the producing reduction,
-// 8-wave workgroups) is worth ~15 us per big pass; not built.
+// writes a 32 KB slab, and the reduction reads them back.  Halving the FIRST of the three -- the operands as bf16 images
+// written by the producing reduction / the Chamfer kernel, read instead of the fp32 operands, bit-identical results -- was
+// built and changed nothing in the step (profiles/r06_ab_dec_operand_images.txt; removed): what is left is the split-K's
+// own slab traffic and reduction launch.
 template <bool F32 = false, bool W16 = false>
 __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, long ldx,
                                                          const typename std::conditional<W16, bf16_t, float>::type* __restrict__ W, long ldw,
