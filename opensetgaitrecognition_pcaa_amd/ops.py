@@ -1357,9 +1357,11 @@ def skinny_linear_wgrad_adam_t16_(packed, chunks, W, exp_avg, exp_avg_sq, beta1,
     return W
 
 
-def total(x, scale=1.0):
+def total(x, scale=1.0, out=None):
     _chk(x, "sum.x", torch.float32)
-    out = torch.empty((), dtype=torch.float32, device=x.device)
+    out = torch.empty((), dtype=torch.float32, device=x.device) if out is None else _chk(out, "sum.out", torch.float32)
+    if out.numel() != 1:
+        raise ValueError("total: out must hold one float")
     check(_lib.load().pcaa_sum(_p(x), x.numel(), float(scale), _p(out), _s()), "pcaa_sum")
     return out
 
@@ -1569,13 +1571,17 @@ def disc_forward(x, label, params):
     return out
 
 
-def disc_backward(x, label, params, gout, want_dx=True, want_dlabel=False, want_params=True, grads_out=None):
+def disc_backward(x, label, params, gout, want_dx=True, want_dlabel=False, want_params=True, grads_out=None, dx_out=None):
     B, K = label.shape
     _chk(gout, "disc.gout", torch.float32)
     if gout.numel() != B:
         raise ValueError("disc_backward: gout size")
     dev = x.device
-    dx = torch.empty_like(x) if want_dx else None
+    if dx_out is not None:
+        _chk(dx_out, "disc.dx_out", torch.float32)
+        if tuple(dx_out.shape) != tuple(x.shape):
+            raise ValueError("disc_backward: dx_out must have x's shape")
+    dx = (dx_out if dx_out is not None else torch.empty_like(x)) if want_dx else None
     dl = torch.empty_like(label) if want_dlabel else None
     if want_params:
         grads = grads_out if grads_out is not None else [torch.empty_like(p) for p in params]
@@ -1609,14 +1615,16 @@ def disc_backward_backward(x, label, params, gout, gbar, want_dx=True, want_dlab
     return dx2, dl2, dgo, (grads if want_params else None)
 
 
-def disc_wgan_gp(z, fv, label, alphas, params, gp_weight, grads_out=None, want_dz=False):
+def disc_wgan_gp(z, fv, label, alphas, params, gp_weight, grads_out=None, want_dz=False, losses_out=None):
     for t, nm in ((z, "z"), (fv, "fv"), (label, "label"), (alphas, "alphas")):
         _chk(t, f"wgan.{nm}", torch.float32)
     B, K = label.shape
     if z.shape != (B, 32) or fv.shape != (B, 32) or alphas.numel() != B:
         raise ValueError("disc_wgan_gp: shapes")
     dev = z.device
-    losses = torch.empty(2, dtype=torch.float32, device=dev)
+    losses = torch.empty(2, dtype=torch.float32, device=dev) if losses_out is None else _chk(losses_out, "wgan.losses_out", torch.float32)
+    if losses.numel() != 2:
+        raise ValueError("disc_wgan_gp: losses_out must hold 2 floats")
     grads = grads_out if grads_out is not None else [torch.empty_like(p) for p in params]
     ws = disc_workspace(B, K, dev)
     dz = torch.empty_like(z) if want_dz else None

@@ -677,7 +677,8 @@ class PCAATrainer:
         # not depend on the critic, and join where the adversarial gradient enters the G backward.
         adv = float(cfg["ADV_WEIGHT"])
 
-        def critic_branch():
+        def critic_branch(outs=(None, None, None)):
+            """``outs``: (losses [2], loss_g [], dsup [B, L]) destinations allocated by the caller"""
             if self.variant == "v1":
                 # centroids from the mean learner (train-mode BatchNorm over the batch's one-hots, :170)
                 _, oh = ops.prior_sample(z0, self._zero_means, gt, self.K)
@@ -688,23 +689,23 @@ class PCAATrainer:
                     mus = self.mean_learner(oh)
                     z = z0 + mus.detach()
                     dl, _, dz = ops.disc_wgan_gp(z, sup_fv, oh, alphas.reshape(-1).contiguous(), self._d_params,
-                                                 cfg["GP_WEIGHT"], grads_out=self._d_grads, want_dz=True)
+                                                 cfg["GP_WEIGHT"], grads_out=self._d_grads, want_dz=True, losses_out=outs[0])
                     mus.backward(dz)
                 else:
                     with torch.no_grad():
                         z = z0 + self.mean_learner(oh)
                     dl, _ = ops.disc_wgan_gp(z, sup_fv, oh, alphas.reshape(-1).contiguous(), self._d_params,
-                                             cfg["GP_WEIGHT"], grads_out=self._d_grads)
+                                             cfg["GP_WEIGHT"], grads_out=self._d_grads, losses_out=outs[0])
             else:
                 z, oh = ops.prior_sample(z0, self.discriminator_means, gt, self.K)
                 dl, _ = ops.disc_wgan_gp(z, sup_fv, oh, alphas.reshape(-1).contiguous(), self._d_params,
-                                         cfg["GP_WEIGHT"], grads_out=self._d_grads)
+                                         cfg["GP_WEIGHT"], grads_out=self._d_grads, losses_out=outs[0])
             self._allreduce(self.flat_d.g)
             self.flat_d.adam(cfg["LR"], cfg["B1"], cfg["B2"], grad_scale=gs)
             synth = ops.disc_forward(sup_fv, oh, self._d_params)
-            lg = ops.total(synth, -adv / B)
+            lg = ops.total(synth, -adv / B, out=outs[1])
             gout = torch.full((B,), -adv / B, dtype=torch.float32, device=self.device)
-            ds, _, _ = ops.disc_backward(sup_fv, oh, self._d_params, gout, want_dx=True, want_params=False)
+            ds, _, _ = ops.disc_backward(sup_fv, oh, self._d_params, gout, want_dx=True, want_params=False, dx_out=outs[2])
             return dl, lg, ds
 
         joined = None
@@ -712,13 +713,19 @@ class PCAATrainer:
             main = ops.current_stream()
             fork = torch.cuda.Event()
             fork.record(main)
+            # The three results the main stream consumes are allocated HERE, from the main stream's pool, and written on the
+            # aux stream: a tensor allocated on the aux stream and handed to the main one (record_stream(main)) costs an
+            # event record ON THE MAIN STREAM when it is freed -- four of them were 18 us of the 40 us step boundary
+            # (round 6, probe: 40.1 -> 21.6 us without them).  This way the records fall on the aux stream.
+            outs = (torch.empty(2, dtype=torch.float32, device=self.device), torch.empty((), dtype=torch.float32, device=self.device),
+                    torch.empty_like(sup_fv))
+            for t in outs:
+                t.record_stream(self._aux)
             with ops.on_stream(self._aux):
                 self._aux.wait_event(fork)
-                d_losses, loss_g, dsup = critic_branch()
+                d_losses, loss_g, dsup = critic_branch(outs)
                 joined = torch.cuda.Event()
                 joined.record(self._aux)
-            for t in (d_losses[0], d_losses[1], loss_g, dsup):
-                t.record_stream(main)          # allocated on the aux stream, consumed on the main one
         else:
             d_losses, loss_g, dsup = critic_branch()
 
