@@ -738,14 +738,17 @@ def linear_act_forward(x, lin, act, mode="fp32", W16=None):
 
 
 def linear_act_backward(x, a_out, lin, act, d_out, need_dx=True, dW_out=None, db_out=None, dx_init=None,
-                        mode="fp32", d_is_pre=False, fuse_elu_in=False, update=None, W16=None):
+                        mode="fp32", d_is_pre=False, fuse_elu_in=False, update=None, W16=None, defer_db=None):
     """d_out is the gradient w.r.t. the layer output (d_is_pre: already w.r.t. its
     pre-activation).  Returns (dW, db, dx).  fuse_elu_in (skinny path only, x = ELU output of
     the layer below): dx is multiplied by ELU'(x), i.e. it is the gradient w.r.t. that layer's
     pre-activation -- the caller passes it on with d_is_pre=True.
     ``update`` (skinny path only): callable ``update(dz, x)`` that forms the weight gradient AND applies the
     optimizer to the weight in one kernel (ops.skinny_linear_wgrad_adam_) LATER -- the callback itself must not touch the
-    weight: it is called before the layer's dgrad, which reads it -- and dW is returned as None."""
+    weight: it is called before the layer's dgrad, which reads it -- and dW is returned as None.
+    ``defer_db`` (a list; with ``update`` and a ``db_out`` destination): the bias gradient's column sum is not launched here
+    but noted as (dz, db_out) for the caller to launch later (decoder_backward: all of them behind ONE hand-over to the
+    weight-gradient stream -- every hand-over is an event record on this stream, ~7 us of idle queue between two kernels)."""
     M, K = x.shape
     N = lin.weight.shape[0]
     dz = ops.elu_bwd_from_out(d_out, a_out) if (act == ACT_ELU and not d_is_pre) else d_out
@@ -753,8 +756,12 @@ def linear_act_backward(x, a_out, lin, act, d_out, need_dx=True, dW_out=None, db
     if update is not None:
         if not (_skinny(mode, M, N, K) or _skinny_exact(mode, M, N, K)):
             raise RuntimeError("linear_act_backward: a fused weight update is only served by the skinny path")
-        with _on_wgrad_stream(dz2):
-            db = ops.colsum(dz2, out=db_out)
+        if defer_db is not None and db_out is not None and _WGRAD_STREAM is not None:
+            defer_db.append(((dz2,), lambda dz2=dz2, db_out=db_out: ops.colsum(dz2, out=db_out)))
+            db = db_out
+        else:
+            with _on_wgrad_stream(dz2):
+                db = ops.colsum(dz2, out=db_out)
         # the callback only NOTES the operands (single process: the kernels run later, on the Adam side stream, once the whole
         # decoder backward -- whose dgrads read the weights they overwrite -- is enqueued) or packs and sends them (data
         # parallel); nothing in it writes the weight, so it runs ahead of this layer's dgrad and the pack + all-gather of
@@ -768,7 +775,14 @@ def linear_act_backward(x, a_out, lin, act, d_out, need_dx=True, dW_out=None, db
         return None, db, dx
     exact = _skinny_exact(mode, M, N, K)
     if _skinny(mode, M, N, K) or exact:
-        if dW_out is not None and db_out is not None:
+        if dW_out is not None and db_out is not None and defer_db is not None and _WGRAD_STREAM is not None:
+            # (decoder_backward's one hand-over to the weight-gradient stream takes this layer's two products as well)
+            def both(dz2=dz2, x=x, db_out=db_out, dW_out=dW_out, exact=exact):
+                ops.colsum(dz2, out=db_out)
+                ops.skinny_linear_wgrad(dz2, x, out=dW_out, exact=exact)
+            defer_db.append(((dz2, x), both))
+            db, dW = db_out, dW_out
+        elif dW_out is not None and db_out is not None:
             # the weight-gradient write stream (and the bias gradient) beside the dgrad read stream of the same layer
             with _on_wgrad_stream(dz2, x):
                 db = ops.colsum(dz2, out=db_out)
@@ -1222,6 +1236,7 @@ def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=Non
         dp[:, :d.shape[1]].copy_(d)
         d = dp
     pre = False           # d is w.r.t. the layer's pre-activation (ELU' already applied by the dgrad above)
+    defer_db = []         # (dz, db destination) of the layers whose update is fused: their column sums leave together below
     for i in range(4, -1, -1):
         lin = layers[i]
         nm = f"dense{i + 1}"
@@ -1232,7 +1247,8 @@ def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=Non
         dW, db, d = linear_act_backward(acts[i], acts[i + 1], lin, ACT_ELU if i < 4 else ACT_NONE, d,
                                         need_dx=(i > 0 or need_dz), dW_out=dW_out, db_out=db_out,
                                         dx_init=dz_init if i == 0 else None, mode=mode, d_is_pre=pre,
-                                        fuse_elu_in=fuse, update=(updates or {}).get(i + 1), W16=(images or {}).get(i + 1))
+                                        fuse_elu_in=fuse, update=(updates or {}).get(i + 1), W16=(images or {}).get(i + 1),
+                                        defer_db=defer_db if ((updates or {}).get(i + 1) is not None or after_layer is None) else None)
         pre = fuse
         if after_layer is not None:
             after_layer(i + 1)       # trainer hook: layer i+1's weight / bias gradients are enqueued
@@ -1242,6 +1258,10 @@ def decoder_backward(dec, acts, d_out, need_dz=True, grads_out=None, dz_init=Non
             db = db[:ref.bias.shape[0]]
             dW = dW[:ref.weight.shape[0], :ref.weight.shape[1]] if dW is not None else None
         g[nm + ".weight"], g[nm + ".bias"] = dW, db
+    if defer_db:
+        with _on_wgrad_stream(*[t for ts, _ in defer_db for t in ts]):
+            for _, launch in defer_db:
+                launch()
     return g, d
 
 
