@@ -163,7 +163,24 @@ def test_data_parallel_step_replays_as_a_hipgraph(kind):
     (the emulated world's device operations; a real RCCL group of one rank with forced collectives, the most a one-GPU box
     admits) -- performs the steps the eager data-parallel step performs.  N=32, where the eager step is bound by the host.
     Gate: the eager-vs-graph gate of tests/test_hip_modules.py (the two runs differ by the order of the fp64 statistics
-    atomics, which bf16 roundings and Adam's sign-like first steps amplify)."""
+    atomics, which bf16 roundings and Adam's sign-like first steps amplify).
+    The RCCL case runs in a CHILD process: a communicator created and destroyed inside the test runner leaves RCCL's
+    threads and streams behind in a process that goes on capturing and replaying graphs for two hundred more tests."""
+    if kind == "rccl1":
+        import os
+        import subprocess
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "rccl1"], capture_output=True, text=True, timeout=500,
+                             cwd=root, env=env)
+        assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+        assert "graph replay check ok" in res.stdout
+        return
+    _graph_replay_check(kind)
+
+
+def _graph_replay_check(kind):
     import torch.distributed as dist
     B, N, C, K = 64, 32, 4, 8
     pg = None
@@ -203,3 +220,12 @@ def test_data_parallel_step_replays_as_a_hipgraph(kind):
     finally:
         if pg is not None:
             dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    # child process of test_data_parallel_step_replays_as_a_hipgraph[rccl1]
+    import sys
+    from opensetgaitrecognition_pcaa_amd import functional as F_hip
+    F_hip.set_precision("fp32")
+    _graph_replay_check(sys.argv[1])
+    print("graph replay check ok", flush=True)
